@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz from the REFERENCE.
+
+Runs the reference-composed drivers in oracle/_ref/ (built by oracle/Makefile
+from the reference's own headers under /root/reference/src) on seeded
+synthetic inputs and stores {inputs, parameters, expected outputs} as small
+.npz fixtures. Only data is committed; no reference source.
+
+Run in the build container only (needs /root/reference):  python oracle/gen_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "_ref")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def hexf(x):
+    return float(x).hex()
+
+
+def run_ref(exe, args):
+    subprocess.check_call([os.path.join(REF, exe)] + [str(a) for a in args])
+
+
+def ref_func(mode, n, a0, a1, data, out_dtype=np.float64):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        if data is None:
+            fin = "-"
+        else:
+            np.ascontiguousarray(data, dtype=np.float64).tofile(fin)
+        run_ref("funcs_ref", [mode, n, hexf(a0), hexf(a1), fin, fout])
+        return np.fromfile(fout, dtype=out_dtype)
+
+
+def ref_euler_cart(u0, dl, dt, nsteps, gamma, theta, rk, bc):
+    rank = u0.ndim - 1
+    shape = list(u0.shape[:-1]) + [1] * (3 - rank)
+    dl3 = list(dl) + [1.0] * (3 - rank)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        np.ascontiguousarray(u0, dtype=np.float64).tofile(fin)
+        run_ref("euler_cart_ref", [rank, *shape, hexf(gamma), hexf(theta), rk, bc, hexf(dt), *map(hexf, dl3), nsteps, fin, fout])
+        return np.fromfile(fout).reshape(u0.shape)
+
+
+# ---- synthetic initial conditions (also used by tests and bench; keep in sync with mara3_amd/setups.py) ----
+def blast_ic(shape, gamma, radius=0.1, p_in=10.0, p_out=0.1):
+    """SURVEY.md §8(d) primary IC: rho=1, v=0, p = p_in inside r<radius of the centre else p_out, on [0,1]^rank."""
+    rank = len(shape)
+    axes = [(np.arange(n) + 0.5) / n for n in shape]
+    X = np.meshgrid(*axes, indexing="ij")
+    r2 = sum((x - 0.5) ** 2 for x in X)
+    p = np.where(r2 < radius * radius, p_in, p_out)
+    u = np.zeros(tuple(shape) + (5,))
+    u[..., 0] = 1.0
+    u[..., 4] = p / (gamma - 1.0)
+    return u
+
+
+def wave_ic(shape, gamma, seed=0):
+    """Smooth isentropic wave with all three velocity components non-zero plus seeded noise (periodic tests)."""
+    rng = np.random.default_rng(seed)
+    rank = len(shape)
+    axes = [(np.arange(n) + 0.5) / n for n in shape]
+    X = np.meshgrid(*axes, indexing="ij")
+    s = np.ones(shape)
+    for x in X:
+        s = s * np.sin(2 * np.pi * x)
+    d = 1.0 + 0.2 * s + 0.01 * rng.standard_normal(shape)
+    p = d ** gamma
+    v = [0.5 + 0.1 * s, -0.25 + 0.05 * np.cos(2 * np.pi * X[0]), 0.125 * np.ones(shape) + 0.01 * rng.standard_normal(shape)]
+    u = np.zeros(tuple(shape) + (5,))
+    u[..., 0] = d
+    for k in range(3):
+        u[..., 1 + k] = d * v[k]
+    u[..., 4] = 0.5 * d * (v[0] ** 2 + v[1] ** 2 + v[2] ** 2) + p / (gamma - 1.0)
+    return u
+
+
+def random_prims(rng, n):
+    P = np.empty((n, 5))
+    P[:, 0] = 10.0 ** rng.uniform(-3, 3, n)
+    P[:, 1:4] = rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-2, 2, (n, 1))
+    P[:, 4] = 10.0 ** rng.uniform(-4, 3, n)
+    return P
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20260101)
+
+    # ---- a1: plm_gradient, incl. sign changes, zeros, equal neighbours, signed zeros ----
+    n = 4096
+    y = rng.standard_normal((n, 3))
+    y[:256] = np.round(y[:256])                       # many exact ties / zeros
+    y[256:320, 1] = y[256:320, 0]                     # y0 == yl
+    y[320:384, 2] = y[320:384, 1]                     # yr == y0
+    y[384:400] = 0.0
+    y[400:416] = -0.0
+    y[416:432, 0] = -0.0
+    y[432:448] *= 1e-300
+    y[448:464] *= 1e300
+    plm = {}
+    for theta in (1.0, 1.2, 1.5, 1.8, 2.0, 0.0):
+        plm["g_%g" % theta] = ref_func("plm", n, theta, 0.0, y)
+    np.savez_compressed(os.path.join(OUT, "plm_gradient.npz"), y=y, **plm)
+
+    # ---- a2-a4: Euler per-cell / per-face functions ----
+    n = 4096
+    P = random_prims(rng, n)
+    Pr = random_prims(rng, n)
+    Pr[:512] = P[:512] * (1.0 + 1e-3 * rng.standard_normal((512, 5)))   # near-equal pairs
+    Pr[512:520] = P[512:520]                                             # identical pairs
+    P[520:530, 1:4] = 0.0                                                # static
+    P[530:534, 1:4] = -0.0
+    out = {"Pl": P, "Pr": Pr}
+    for gname, gamma in (("53", 5.0 / 3), ("43", 4.0 / 3), ("14", 1.4)):
+        U = ref_func("euler_p2c", n, gamma, 0.0, P).reshape(n, 5)
+        out["U_" + gname] = U
+        out["c2p_" + gname] = ref_func("euler_c2p", n, gamma, 0.0, U).reshape(n, 5)
+        for axis in range(3):
+            out["hlle_%s_%d" % (gname, axis)] = ref_func("euler_hlle", n, gamma, axis, np.hstack([P, Pr])).reshape(n, 5)
+            out["flux_%s_%d" % (gname, axis)] = ref_func("euler_flux", n, gamma, axis, P).reshape(n, 5)
+            out["lam_%s_%d" % (gname, axis)] = ref_func("euler_lam", n, gamma, axis, P).reshape(n, 2)
+    # temperature floor active: negative-pressure conserved states
+    Uneg = out["U_53"].copy()
+    Uneg[:, 4] *= rng.uniform(0.0, 1.2, n)
+    out["Uneg"] = Uneg
+    out["c2p_floor_53"] = ref_func("euler_c2p", n, 5.0 / 3, 1e-3, Uneg).reshape(n, 5)
+    out["c2p_nofloor_53"] = ref_func("euler_c2p", n, 5.0 / 3, 0.0, Uneg).reshape(n, 5)
+    np.savez_compressed(os.path.join(OUT, "euler_functions.npz"), **out)
+
+    # ---- integer work: a18 / a19 ----
+    ints = {}
+    for rank in (1, 2, 3):
+        ints["decomp_rank%d" % rank] = ref_func("decomp", 32, rank, 0, None, np.int64).reshape(32, rank)
+    for count in (4096, 4097, 1000, 640, 10, 7):
+        for nparts in range(1, 17):
+            ints["partition_%d_%d" % (count, nparts)] = ref_func("partition", nparts, count, 0, None, np.int64).reshape(nparts, 2)
+            if nparts <= count:
+                ints["blocks_%d_%d" % (count, nparts)] = ref_func("blocks", nparts, count, 0, None, np.int64).reshape(nparts, 2)
+    np.savez_compressed(os.path.join(OUT, "decomposition.npz"), **ints)
+
+    # ---- per-step: uniform cartesian Euler (configs 2 and 5 at fixture size) ----
+    def step_case(name, u0, dl, dt, nsteps_list, gamma, theta, rk, bc):
+        d = {"u0": u0, "dl": np.array(dl), "dt": dt, "gamma": gamma, "theta": theta, "rk": rk, "bc": bc,
+             "nsteps": np.array(nsteps_list)}
+        for ns in nsteps_list:
+            d["u_%d" % ns] = ref_euler_cart(u0, dl, dt, ns, gamma, theta, rk, bc)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(name, "ok")
+
+    g = 5.0 / 3
+    N = 64
+    step_case("euler2d_blast64_plm15_rk2", blast_ic((N, N), g), (1 / N, 1 / N), 0.3 / N / 6, [1, 2, 10], g, 1.5, 2, 0)
+    step_case("euler2d_blast64_plm20_rk1", blast_ic((N, N), g), (1 / N, 1 / N), 0.3 / N / 6, [1, 10], g, 2.0, 1, 0)
+    step_case("euler2d_blast64_pcm_rk1", blast_ic((N, N), g), (1 / N, 1 / N), 0.3 / N / 6, [1, 10], g, -1.0, 1, 0)
+    N = 128
+    step_case("euler2d_blast128_plm15_rk2", blast_ic((N, N), g, radius=0.25), (1 / N, 1 / N), 0.3 / N / 6, [10], g, 1.5, 2, 0)
+    step_case("euler2d_wave48x40_plm15_rk2_periodic", wave_ic((48, 40), 1.4, 1), (1 / 48, 1 / 40), 0.002, [1, 5], 1.4, 1.5, 2, 1)
+    step_case("euler2d_wave33x70_plm12_rk2_outflow", wave_ic((33, 70), 1.4, 2), (1 / 33, 1 / 70), 0.002, [3], 1.4, 1.2, 2, 0)
+    step_case("euler1d_wave200_plm15_rk2_periodic", wave_ic((200,), 1.4, 3), (1 / 200,), 0.001, [1, 10], 1.4, 1.5, 2, 1)
+    step_case("euler1d_blast128_plm15_rk2", blast_ic((128,), g), (1 / 128,), 0.3 / 128 / 6, [10], g, 1.5, 2, 0)
+    step_case("euler3d_blast24_plm15_rk2", blast_ic((24, 24, 24), g, radius=0.2), (1 / 24,) * 3, 0.3 / 24 / 6, [1, 4], g, 1.5, 2, 0)
+    step_case("euler3d_wave20x12x16_plm15_rk2_periodic", wave_ic((20, 12, 16), 1.4, 4), (1 / 20, 1 / 12, 1 / 16), 0.004, [2], 1.4, 1.5, 2, 1)
+
+    # ---- per-step: sedov newtonian=1 (config 1) ----
+    with tempfile.TemporaryDirectory() as d:
+        sed = {}
+        for ns in (1, 10, 100):
+            fv, f0, fn = (os.path.join(d, x) for x in ("v", "u0", "un"))
+            run_ref("sedov_ref", [256, hexf(100.0), ns, fv, f0, fn])
+            sed["vertices"] = np.fromfile(fv)
+            sed["u0"] = np.fromfile(f0).reshape(-1, 5)
+            sed["u_%d" % ns] = np.fromfile(fn).reshape(-1, 5)
+        np.savez_compressed(os.path.join(OUT, "sedov_newtonian_nr256.npz"), **sed)
+        print("sedov ok", sed["u0"].shape)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

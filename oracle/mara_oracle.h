@@ -1,0 +1,98 @@
+/*
+ * mara_oracle.h — TEST INFRASTRUCTURE. Not part of the product.
+ *
+ * Plain-C CPU restatement of the Mara3 per-step hot path, kept
+ * deliberately simple: flat loops over row-major array-of-structs fields, the
+ * same operation order as the reference expressions so that results are
+ * bit-identical to the reference compiled without FMA contraction.
+ *
+ * Parity status: PINNED — every function here is checked against outputs of
+ * the reference's own headers run in the build container (oracle/_ref drivers
+ * -> tests/golden/ (npz files); generator: oracle/gen_golden.py). Exceptions, which
+ * have no upstream counterpart and say so at their declaration: the Euler HLLC
+ * solver ("parity unpinned").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.
+ */
+#ifndef MARA_ORACLE_H
+#define MARA_ORACLE_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MO_BC_OUTFLOW = 0, MO_BC_PERIODIC = 1 };
+enum { MO_RIEMANN_HLLE = 0, MO_RIEMANN_HLLC = 1 };
+
+/* ---- per-cell / per-face functions ------------------------------------- */
+
+/* math_interpolation.hpp:85-94 */
+double mo_plm_gradient(double yl, double y0, double yr, double theta);
+
+/* physics_euler.hpp:555-575 */
+void mo_euler_recover_primitive(const double U[5], double gamma, double temperature_floor, double P[5]);
+/* physics_euler.hpp:209-220 */
+void mo_euler_to_conserved_density(const double P[5], double gamma, double U[5]);
+/* physics_euler.hpp:252-263 (axis selects unit_vector_t::on_axis, core_geometric.hpp:65-74) */
+void mo_euler_flux(const double P[5], const double U[5], int axis, double F[5]);
+/* physics_euler.hpp:276-284 ; lam[0] = minus, lam[1] = plus */
+void mo_euler_wavespeeds(const double P[5], int axis, double gamma, double lam[2]);
+/* physics_euler.hpp:614-631 */
+void mo_euler_riemann_hlle(const double Pl[5], const double Pr[5], int axis, double gamma, double F[5]);
+/* NO UPSTREAM COUNTERPART (parity unpinned): gamma-law generalisation of
+ * physics_iso2d.hpp:556-583,610-687 per Toro 3rd ed. eq. 10.61-10.73 */
+void mo_euler_riemann_hllc(const double Pl[5], const double Pr[5], int axis, double gamma, double F[5]);
+/* physics_euler.hpp:328-337 */
+void mo_euler_source_terms_radial(const double P[5], double r, double S[5]);
+
+/* array forms for the golden-vector tests (n independent items) */
+void mo_plm_gradient_n(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g);
+void mo_euler_recover_primitive_n(size_t n, const double* U, double gamma, double tfloor, double* P);
+void mo_euler_to_conserved_density_n(size_t n, const double* P, double gamma, double* U);
+void mo_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, int solver, double* F);
+
+/* ---- uniform cartesian Euler step (BASELINE configs 2 and 5) ------------ */
+
+typedef struct
+{
+    int    rank;            /* 1, 2 or 3 */
+    size_t shape[3];        /* cells per axis (unused axes = 1) */
+    double dl[3];           /* cell size per axis */
+    double gamma;
+    double plm_theta;       /* < 0 => piecewise constant */
+    int    riemann;         /* MO_RIEMANN_* */
+    int    bc;              /* MO_BC_* (same on every axis) */
+    int    rk_order;        /* 1 or 2 */
+    int    nthreads;        /* axis-0 slabs, app_parallel.hpp:75-103 */
+} mo_euler_cart_t;
+
+/* One stage: u1 = u0 - sum_axis diff(F)*(dt/dl). Fields: AoS [n0][n1][n2][5]. */
+int mo_euler_cart_advance(const mo_euler_cart_t* cfg, const double* u0, double dt, double* u1);
+/* nsteps full steps in place (RK1: advance; RK2: u*0.5 + advance(advance(u))*0.5,
+ * subprog_cloud.cpp:682-695). */
+int mo_euler_cart_run(const mo_euler_cart_t* cfg, double* u, double dt, int nsteps);
+
+/* ---- sedov: 1-D spherical Euler, PCM + HLLE + forward Euler ------------- */
+/* subprog_sedov.cpp:353-421. vertices[nz+1]; u = volume-integrated conserved AoS [nz][5]. */
+void mo_sedov_vertices(int nr, double outer_radius, size_t* nz_out, double* vertices /* may be NULL to query nz */);
+void mo_sedov_initial(size_t nz, const double* vertices, double gamma, double explosion_density,
+                      double explosion_pressure, double density_index, double* u);
+double mo_sedov_timestep(const double* vertices, double cfl);
+void mo_sedov_advance(size_t nz, const double* vertices, double gamma, double dt, const double* u0, double* u1);
+
+/* ---- integer / index work (bit-exact) ----------------------------------- */
+/* core_ndarray.hpp:820-836 : slab n of N over `count` rows -> [start, final) */
+void mo_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_);
+/* app_parallel.hpp:185-221 ; returns number of factors written (<= 64) */
+int  mo_prime_factors(unsigned long n, unsigned long* factors);
+/* app_parallel.hpp:119-131 */
+void mo_propose_block_decomposition(int rank, unsigned long nblocks, unsigned long* blocks_per_axis);
+/* app_parallel.hpp:148-179 : block b of B along an axis with n cells -> [start, final) */
+void mo_block_extent(size_t n, size_t nblocks, size_t b, size_t* start, size_t* final_);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+"""ctypes binding of the plain-C oracle (oracle/mara_oracle.c).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module. The product path (mara3_amd) never
+does; it fails loudly when its HIP library is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libmara_oracle.so")
+
+BC_OUTFLOW, BC_PERIODIC = 0, 1
+RIEMANN_HLLE, RIEMANN_HLLC = 0, 1
+
+
+def build():
+    """Compile the C oracle (and, where /root/reference exists, the reference-composed drivers)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+class _CartCfg(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int),
+        ("shape", C.c_size_t * 3),
+        ("dl", C.c_double * 3),
+        ("gamma", C.c_double),
+        ("plm_theta", C.c_double),
+        ("riemann", C.c_int),
+        ("bc", C.c_int),
+        ("rk_order", C.c_int),
+        ("nthreads", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        dp = C.POINTER(C.c_double)
+        _lib.mo_plm_gradient.restype = C.c_double
+        _lib.mo_plm_gradient.argtypes = [C.c_double] * 4
+        _lib.mo_plm_gradient_n.argtypes = [C.c_size_t, dp, dp, dp, C.c_double, dp]
+        _lib.mo_euler_recover_primitive_n.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp]
+        _lib.mo_euler_to_conserved_density_n.argtypes = [C.c_size_t, dp, C.c_double, dp]
+        _lib.mo_euler_riemann_n.argtypes = [C.c_size_t, dp, dp, C.c_int, C.c_double, C.c_int, dp]
+        _lib.mo_euler_cart_advance.argtypes = [C.POINTER(_CartCfg), dp, C.c_double, dp]
+        _lib.mo_euler_cart_run.argtypes = [C.POINTER(_CartCfg), dp, C.c_double, C.c_int]
+        _lib.mo_sedov_vertices.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_size_t), dp]
+        _lib.mo_sedov_initial.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+        _lib.mo_sedov_timestep.restype = C.c_double
+        _lib.mo_sedov_timestep.argtypes = [dp, C.c_double]
+        _lib.mo_sedov_advance.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, dp]
+        sp = C.POINTER(C.c_size_t)
+        _lib.mo_partition_rows.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
+        _lib.mo_block_extent.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
+        _lib.mo_prime_factors.argtypes = [C.c_ulong, C.POINTER(C.c_ulong)]
+        _lib.mo_propose_block_decomposition.argtypes = [C.c_int, C.c_ulong, C.POINTER(C.c_ulong)]
+    return _lib
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def plm_gradient(yl, y0, yr, theta):
+    yl, y0, yr = _f64(yl), _f64(y0), _f64(yr)
+    g = np.empty_like(y0)
+    lib().mo_plm_gradient_n(y0.size, _dp(yl), _dp(y0), _dp(yr), theta, _dp(g))
+    return g
+
+
+def euler_recover_primitive(U, gamma, tfloor=0.0):
+    U = _f64(U)
+    P = np.empty_like(U)
+    lib().mo_euler_recover_primitive_n(U.size // 5, _dp(U), gamma, tfloor, _dp(P))
+    return P
+
+
+def euler_to_conserved_density(P, gamma):
+    P = _f64(P)
+    U = np.empty_like(P)
+    lib().mo_euler_to_conserved_density_n(P.size // 5, _dp(P), gamma, _dp(U))
+    return U
+
+
+def euler_riemann(Pl, Pr, axis, gamma, solver=RIEMANN_HLLE):
+    Pl, Pr = _f64(Pl), _f64(Pr)
+    F = np.empty_like(Pl)
+    lib().mo_euler_riemann_n(Pl.size // 5, _dp(Pl), _dp(Pr), axis, gamma, solver, _dp(F))
+    return F
+
+
+def _cart_cfg(shape, dl, gamma, theta, riemann, bc, rk, nthreads):
+    rank = len(shape)
+    cfg = _CartCfg()
+    cfg.rank = rank
+    for a in range(3):
+        cfg.shape[a] = shape[a] if a < rank else 1
+        cfg.dl[a] = dl[a] if a < rank else 1.0
+    cfg.gamma, cfg.plm_theta = gamma, theta
+    cfg.riemann, cfg.bc, cfg.rk_order, cfg.nthreads = riemann, bc, rk, nthreads
+    return cfg
+
+
+def euler_cart_advance(u0, dl, dt, gamma, theta, riemann=RIEMANN_HLLE, bc=BC_OUTFLOW, nthreads=1):
+    """One stage on an AoS field u0[n0][n1][n2][5] (rank = u0.ndim - 1)."""
+    u0 = _f64(u0)
+    cfg = _cart_cfg(u0.shape[:-1], dl, gamma, theta, riemann, bc, 1, nthreads)
+    u1 = np.empty_like(u0)
+    rc = lib().mo_euler_cart_advance(C.byref(cfg), _dp(u0), dt, _dp(u1))
+    assert rc == 0
+    return u1
+
+
+def euler_cart_run(u, dl, dt, nsteps, gamma, theta, rk=2, riemann=RIEMANN_HLLE, bc=BC_OUTFLOW, nthreads=1):
+    """nsteps full steps; returns a new array."""
+    u = _f64(u).copy()
+    cfg = _cart_cfg(u.shape[:-1], dl, gamma, theta, riemann, bc, rk, nthreads)
+    rc = lib().mo_euler_cart_run(C.byref(cfg), _dp(u), dt, nsteps)
+    assert rc == 0
+    return u
+
+
+def sedov_vertices(nr=256, outer_radius=100.0):
+    nz = C.c_size_t()
+    lib().mo_sedov_vertices(nr, outer_radius, C.byref(nz), None)
+    v = np.empty(nz.value + 1)
+    lib().mo_sedov_vertices(nr, outer_radius, C.byref(nz), _dp(v))
+    return v
+
+
+def sedov_initial(vertices, gamma=4.0 / 3, explosion_density=1.0, explosion_pressure=1.0, density_index=0.0):
+    v = _f64(vertices)
+    u = np.empty((v.size - 1, 5))
+    lib().mo_sedov_initial(v.size - 1, _dp(v), gamma, explosion_density, explosion_pressure, density_index, _dp(u))
+    return u
+
+
+def sedov_timestep(vertices, cfl=0.4):
+    return lib().mo_sedov_timestep(_dp(_f64(vertices)), cfl)
+
+
+def sedov_advance(vertices, u0, dt, gamma=4.0 / 3):
+    v, u0 = _f64(vertices), _f64(u0)
+    u1 = np.empty_like(u0)
+    lib().mo_sedov_advance(u0.shape[0], _dp(v), gamma, dt, _dp(u0), _dp(u1))
+    return u1
+
+
+def partition_rows(count, nparts, part):
+    a, b = C.c_size_t(), C.c_size_t()
+    lib().mo_partition_rows(count, nparts, part, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def propose_block_decomposition(rank, nblocks):
+    out = (C.c_ulong * 3)()
+    lib().mo_propose_block_decomposition(rank, nblocks, out)
+    return tuple(out[i] for i in range(rank))
