@@ -1,0 +1,168 @@
+/*
+ * mara_hip.h — C ABI of libmara_hip.so, the MI355X (gfx950) engine for the
+ * per-time-step hot path of Mara3-style finite-volume Godunov hydro.
+ *
+ * What this boundary replaces. The reference (jzrake/Mara3) has no FFI; its
+ * innermost seam is the pure step function + array evaluator
+ *     advance(app_state, solution, dt) -> solution_t      src/subprog_cloud.cpp:511-584
+ *     next_solution(state) -> state                        src/subprog_cloud.cpp:676-697, src/subprog_sedov.cpp:394-421
+ *     `| mara::evaluate_on<N>()` / `| nd::to_shared()`     src/app_parallel.hpp:72-103
+ * Each entry point below cites the reference interface it stands in for.
+ * Everything is plain pointers and sizes; no C++ or torch types cross the ABI.
+ *
+ * Conventions
+ *  - All floating point is fp64. Return value 0 = success, negative = MH_E_*;
+ *    nothing throws across the ABI; mh_last_error() gives the message.
+ *  - HOST fields at the boundary are row-major array-of-structs exactly like
+ *    the reference's nd::shared_array<conserved_t, Rank>: cell (i,j[,k]) is
+ *    nq consecutive doubles in the logical order (rho|D, m1, m2, m3, E|tau)
+ *    (src/core_ndarray.hpp:777-792, src/physics_euler.hpp:46).
+ *  - DEVICE fields are struct-of-arrays planes with two ghost rows on each
+ *    side of axis 0 (the slab axis, src/core_ndarray.hpp:820-836):
+ *        plane q, row i in [-2, n0+2), transverse index t:  q*plane_stride + (i+2)*row_pitch + t
+ *    where row_pitch = n1 (2-D) or n1*n2 (3-D) and plane_stride = (n0+4)*row_pitch.
+ *    Ghost rows hold the boundary condition (outflow copies / periodic wrap)
+ *    or the neighbour rank's rows (slab decomposition); the stage kernels
+ *    keep physical ghosts up to date themselves.
+ *  - `stream` arguments are hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef MARA_HIP_H
+#define MARA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_VERSION 100
+
+enum mh_error
+{
+    MH_OK = 0,
+    MH_E_INVALID = -1,       /* bad argument / unsupported combination */
+    MH_E_HIP = -2,           /* HIP runtime error (see mh_last_error) */
+    MH_E_NOMEM = -3,
+    MH_E_STATE = -4,         /* call order (e.g. step before upload) */
+    MH_E_PHYSICS = -5        /* status word non-zero after a step (negative density/pressure, NaN) */
+};
+
+enum mh_system   { MH_SYSTEM_EULER = 0, MH_SYSTEM_ISO2D = 1, MH_SYSTEM_SRHD = 2 };
+enum mh_riemann  { MH_RIEMANN_HLLE = 0, MH_RIEMANN_HLLC = 1 };
+/* boundary kinds. On axis 0 each side is set separately because a slab cut is
+ * MH_BC_EXTERNAL (ghost rows are written by the caller's halo exchange). */
+enum mh_bc       { MH_BC_OUTFLOW = 0, MH_BC_PERIODIC = 1, MH_BC_EXTERNAL = 2, MH_BC_REFLECT = 3 };
+/* arithmetic contract: STRICT = no FMA contraction, IEEE division/sqrt: bit-identical
+ * to the reference built for baseline x86-64. FAST = contraction allowed and shared
+ * reciprocals; validated to the 1e-12 L1 bound of BASELINE.json, not bit-exact. */
+enum mh_arith    { MH_ARITH_STRICT = 0, MH_ARITH_FAST = 1 };
+
+/* status bits accumulated on the device by a stage (reference error contract:
+ * src/physics_srhd.hpp:430-449, src/subprog_binary_scheme.cpp:726-752) */
+enum mh_status
+{
+    MH_STATUS_NEG_DENSITY = 1, MH_STATUS_NEG_PRESSURE = 2, MH_STATUS_C2P_FAILED = 4, MH_STATUS_NAN = 8
+};
+
+/* ------------------------------------------------------------------------ */
+/* Uniform cartesian Euler (BASELINE configs 2 and 5): stateless launchers.   */
+/* Replaces one `advance` evaluation of the composition in                    */
+/* src/subprog_cloud.cpp:511-584 specialised to mara::euler on a cartesian    */
+/* grid: recover_primitive (src/physics_euler.hpp:555-575), plm_gradient      */
+/* (src/math_interpolation.hpp:85-94), riemann_hlle (src/physics_euler.hpp:   */
+/* 614-631), flux difference, and the RK combine of                           */
+/* src/subprog_cloud.cpp:682-695 fused into the second stage.                 */
+/* ------------------------------------------------------------------------ */
+typedef struct
+{
+    int    rank;            /* 2 or 3 (1-D: use rank 2 with n1 = 1 is NOT supported; see mh_sedov_*) */
+    int    n[3];            /* LOCAL cells per axis on this device (axis 0 = slab axis) */
+    double dl[3];           /* cell sizes */
+    double gamma;           /* gamma-law index */
+    double plm_theta;       /* < 0: piecewise constant */
+    int    riemann;         /* enum mh_riemann */
+    int    bc_lo0, bc_hi0;  /* enum mh_bc on the low / high side of axis 0 */
+    int    bc_transverse;   /* MH_BC_OUTFLOW or MH_BC_PERIODIC on axes 1 (and 2) */
+    int    arith;           /* enum mh_arith */
+    int    chunk_rows;      /* rows marched per wave (0 = default) */
+} mh_euler_cart_desc;
+
+/* number of doubles one SoA device field of this description occupies (5 planes incl. ghost rows) */
+size_t mh_euler_cart_field_doubles(const mh_euler_cart_desc* d);
+
+/*
+ * One Runge-Kutta stage over rows [row_begin, row_end) of axis 0:
+ *     stage_weight == 1.0 :  u_out = u_in - sum_axis diff(F)*(dt/dl)                      (RK1 / first RK2 stage)
+ *     otherwise           :  u_out = u_base*(1-w) + (u_in - sum_axis diff(F)*(dt/dl))*w    (w = 0.5: RK2 combine,
+ *                            src/subprog_cloud.cpp:693 `s0*0.5 + s2*0.5`; u_out may alias u_base)
+ * All pointers are DEVICE SoA fields (layout above). Ghost rows of u_in must be valid.
+ * Physical ghost rows of u_out (bc OUTFLOW / PERIODIC) are written by the same launch.
+ * status (device, may be NULL): int32[2] = {OR of mh_status bits, unused}.
+ */
+int mh_euler_cart_stage(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                        double dt, double stage_weight, int row_begin, int row_end, int32_t* status, void* stream);
+
+/* Fill the physical ghost rows of a field (after an upload). External sides are left untouched. */
+int mh_euler_cart_fill_ghosts(const mh_euler_cart_desc* d, double* u, void* stream);
+
+/* Host-layout conversion on the device: AoS [n0][row_pitch][5] (no ghosts) <-> SoA field with ghosts.
+ * Replaces nothing in the reference (its arrays are AoS throughout); this is the boundary's layout shim. */
+int mh_aos_to_soa(const double* aos_dev, double* soa_dev, int nq, int n0, size_t row_pitch, void* stream);
+int mh_soa_to_aos(const double* soa_dev, double* aos_dev, int nq, int n0, size_t row_pitch, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Context API for compiled hosts (owns device memory and streams).           */
+/* Mirrors the solution_t value that the reference's drivers thread through   */
+/* `next` (src/subprog_cloud.cpp:676-697): upload once, step many, download   */
+/* when a task is due.                                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct mh_ctx mh_ctx;
+
+int  mh_create(mh_ctx** ctx, int device_id);
+void mh_destroy(mh_ctx* ctx);
+const char* mh_last_error(const mh_ctx* ctx);      /* ctx may be NULL: last error of the calling thread */
+
+int  mh_euler_cart_configure(mh_ctx* ctx, const mh_euler_cart_desc* d, int rk_order);
+int  mh_upload(mh_ctx* ctx, const double* u_aos_host, size_t ncell);     /* host AoS -> device SoA (+ ghosts) */
+int  mh_download(mh_ctx* ctx, double* u_aos_host, size_t ncell);         /* device SoA -> host AoS */
+/* nsteps full time steps (all RK stages) with fixed dt, like the reference's cloud/sedov drivers. */
+int  mh_step(mh_ctx* ctx, double dt, int nsteps);
+int  mh_synchronize(mh_ctx* ctx);
+/* OR of mh_status bits since the last call (reads back 4 bytes; synchronises). */
+int  mh_status_word(mh_ctx* ctx, int32_t* status);
+/* Raw device pointer of the current solution field (SoA with ghosts) and of the scratch field, for halo exchange. */
+double* mh_field_ptr(mh_ctx* ctx, int which /* 0 = current solution, 1 = stage scratch */);
+/* Average kernel time in ms of the stage launches since the last reset, measured with HIP events
+ * on the context's stream (enable before stepping). */
+int  mh_profile_enable(mh_ctx* ctx, int on);
+int  mh_profile_read(mh_ctx* ctx, double* avg_stage_ms, int* nlaunches);
+
+/* ------------------------------------------------------------------------ */
+/* Per-function device entry points (parity tests call these through the ABI) */
+/* inputs/outputs are DEVICE arrays of n items, AoS rows of 5 (or 3 / 1)      */
+/* ------------------------------------------------------------------------ */
+int mh_plm_gradient_n(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g, int arith, void* stream);
+int mh_euler_recover_primitive_n(size_t n, const double* U, double gamma, double temperature_floor, double* P, int arith, void* stream);
+int mh_euler_to_conserved_n(size_t n, const double* P, double gamma, double* U, int arith, void* stream);
+int mh_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, int riemann, double* F, int arith, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Integer / index work (host side, bit-exact with the reference)             */
+/* ------------------------------------------------------------------------ */
+/* nd::partition_shape, src/core_ndarray.hpp:820-836: rows [start, final) of slab `part` of `nparts` */
+void mh_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_);
+/* mara::propose_block_decomposition<Rank>, src/app_parallel.hpp:119-131 */
+int  mh_propose_block_decomposition(int rank, unsigned long nblocks, unsigned long* blocks_per_axis);
+
+/* device utilities used by bench / tests without torch */
+int  mh_device_count(void);
+int  mh_malloc(void** ptr, size_t bytes);
+int  mh_free(void* ptr);
+int  mh_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int  mh_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int  mh_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of libmara_hip.so (C ABI: include/mara_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmara_hip.so")
+
+# enums of include/mara_hip.h
+OK = 0
+RIEMANN_HLLE, RIEMANN_HLLC = 0, 1
+BC_OUTFLOW, BC_PERIODIC, BC_EXTERNAL, BC_REFLECT = 0, 1, 2, 3
+ARITH_STRICT, ARITH_FAST = 0, 1
+STATUS_NEG_DENSITY, STATUS_NEG_PRESSURE, STATUS_C2P_FAILED, STATUS_NAN = 1, 2, 4, 8
+
+
+class MaraHipError(RuntimeError):
+    pass
+
+
+class EulerCartDesc(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int),
+        ("n", C.c_int * 3),
+        ("dl", C.c_double * 3),
+        ("gamma", C.c_double),
+        ("plm_theta", C.c_double),
+        ("riemann", C.c_int),
+        ("bc_lo0", C.c_int),
+        ("bc_hi0", C.c_int),
+        ("bc_transverse", C.c_int),
+        ("arith", C.c_int),
+        ("chunk_rows", C.c_int),
+    ]
+
+
+# every symbol include/mara_hip.h declares: (name, restype, argtypes)
+_vp, _dp, _sz, _i, _d = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
+_descp = C.POINTER(EulerCartDesc)
+SYMBOLS = [
+    ("mh_euler_cart_field_doubles", _sz, [_descp]),
+    ("mh_euler_cart_stage", _i, [_descp, _dp, _dp, _dp, _d, _d, _i, _i, _vp, _vp]),
+    ("mh_euler_cart_fill_ghosts", _i, [_descp, _dp, _vp]),
+    ("mh_aos_to_soa", _i, [_dp, _dp, _i, _i, _sz, _vp]),
+    ("mh_soa_to_aos", _i, [_dp, _dp, _i, _i, _sz, _vp]),
+    ("mh_create", _i, [C.POINTER(_vp), _i]),
+    ("mh_destroy", None, [_vp]),
+    ("mh_last_error", C.c_char_p, [_vp]),
+    ("mh_euler_cart_configure", _i, [_vp, _descp, _i]),
+    ("mh_upload", _i, [_vp, _vp, _sz]),
+    ("mh_download", _i, [_vp, _vp, _sz]),
+    ("mh_step", _i, [_vp, _d, _i]),
+    ("mh_synchronize", _i, [_vp]),
+    ("mh_status_word", _i, [_vp, C.POINTER(C.c_int32)]),
+    ("mh_field_ptr", _vp, [_vp, _i]),
+    ("mh_profile_enable", _i, [_vp, _i]),
+    ("mh_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
+    ("mh_plm_gradient_n", _i, [_sz, _dp, _dp, _dp, _d, _dp, _i, _vp]),
+    ("mh_euler_recover_primitive_n", _i, [_sz, _dp, _d, _d, _dp, _i, _vp]),
+    ("mh_euler_to_conserved_n", _i, [_sz, _dp, _d, _dp, _i, _vp]),
+    ("mh_euler_riemann_n", _i, [_sz, _dp, _dp, _i, _d, _i, _dp, _i, _vp]),
+    ("mh_partition_rows", None, [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
+    ("mh_device_count", _i, []),
+    ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
+    ("mh_free", _i, [_vp]),
+    ("mh_memcpy_h2d", _i, [_vp, _vp, _sz]),
+    ("mh_memcpy_d2h", _i, [_vp, _vp, _sz]),
+    ("mh_device_synchronize", _i, []),
+]
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libmara_hip.so. Raises MaraHipError if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MaraHipError(
+            "libmara_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mara3_amd/csrc`. mara3_amd has no CPU fallback." % _LIB_PATH)
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:
+        raise MaraHipError("cannot load %s: %s" % (_LIB_PATH, e))
+    for name, restype, argtypes in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise MaraHipError("libmara_hip.so does not export %s" % name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != OK:
+        msg = load_library().mh_last_error(ctx)
+        raise MaraHipError("mara_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

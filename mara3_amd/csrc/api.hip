@@ -1,0 +1,433 @@
+// C ABI of libmara_hip.so (see include/mara_hip.h for the contract and the
+// reference interfaces each entry point stands in for).
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "launch.hpp"
+#include "euler_device.hpp"
+
+namespace mh {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error("HIP error %d (%s) in %s", (int) e, hipGetErrorString(e), what);
+    return MH_E_HIP;
+}
+
+static int check_desc(const mh_euler_cart_desc* d)
+{
+    if (! d) { set_error("null descriptor"); return MH_E_INVALID; }
+    if (d->rank != 2) { set_error("mh_euler_cart: rank %d not supported by this build (2 only)", d->rank); return MH_E_INVALID; }
+    if (d->n[0] < 2 || d->n[1] < 2) { set_error("mh_euler_cart: need at least 2 cells per axis"); return MH_E_INVALID; }
+    if (d->riemann != MH_RIEMANN_HLLE && d->riemann != MH_RIEMANN_HLLC) { set_error("unknown riemann solver %d", d->riemann); return MH_E_INVALID; }
+    if (d->bc_transverse != MH_BC_OUTFLOW && d->bc_transverse != MH_BC_PERIODIC) { set_error("transverse bc must be outflow or periodic"); return MH_E_INVALID; }
+    for (int bc : {d->bc_lo0, d->bc_hi0})
+        if (bc != MH_BC_OUTFLOW && bc != MH_BC_PERIODIC && bc != MH_BC_EXTERNAL) { set_error("axis-0 bc must be outflow, periodic or external"); return MH_E_INVALID; }
+    if ((d->bc_lo0 == MH_BC_PERIODIC) != (d->bc_hi0 == MH_BC_PERIODIC)) { set_error("periodic axis-0 bc must be set on both sides"); return MH_E_INVALID; }
+    if (d->arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (!(d->gamma > 1.0)) { set_error("gamma must be > 1"); return MH_E_INVALID; }
+    return MH_OK;
+}
+
+static size_t row_pitch_of(const mh_euler_cart_desc* d) { return d->rank == 3 ? (size_t) d->n[1] * d->n[2] : (size_t) d->n[1]; }
+
+// ---- per-function kernels (one thread per item; AoS rows) ----------------
+__global__ void plm_kernel(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] = plm_gradient(yl[i], y0[i], yr[i], theta);
+}
+__device__ inline State5 load5(const double* p) { State5 s; for (int q = 0; q < 5; ++q) s[q] = p[q]; return s; }
+__device__ inline void store5(double* p, const State5& s) { for (int q = 0; q < 5; ++q) p[q] = s[q]; }
+
+__global__ void c2p_kernel(size_t n, const double* U, double gamma, double tfloor, double* P)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(P + 5 * i, recover_primitive(load5(U + 5 * i), gamma, tfloor));
+}
+__global__ void p2c_kernel(size_t n, const double* P, double gamma, double* U)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(U + 5 * i, to_conserved_density(load5(P + 5 * i), gamma));
+}
+template<int RIEMANN, int AXIS>
+__global__ void riemann_kernel(size_t n, const double* Pl, const double* Pr, double gamma, double* F)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(F + 5 * i, riemann<RIEMANN, AXIS>(load5(Pl + 5 * i), load5(Pr + 5 * i), gamma));
+}
+
+} // namespace mh
+
+using namespace mh;
+
+struct mh_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool configured = false, uploaded = false;
+    mh_euler_cart_desc desc;
+    int rk_order = 2;
+    size_t field_doubles = 0;
+    double* field[2] = {nullptr, nullptr};   // [0] current solution, [1] stage scratch
+    double* staging = nullptr;               // AoS staging for upload/download
+    size_t staging_doubles = 0;
+    int32_t* status = nullptr;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::string error;
+};
+
+static int ctx_fail(mh_ctx* c, int code)
+{
+    if (c) c->error = g_error;
+    return code;
+}
+
+extern "C" {
+
+const char* mh_last_error(const mh_ctx* ctx)
+{
+    return ctx && ! ctx->error.empty() ? ctx->error.c_str() : g_error.c_str();
+}
+
+size_t mh_euler_cart_field_doubles(const mh_euler_cart_desc* d)
+{
+    if (! d) return 0;
+    return (size_t) 5 * (d->n[0] + 4) * row_pitch_of(d);
+}
+
+int mh_euler_cart_stage(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                        double dt, double stage_weight, int row_begin, int row_end, int32_t* status, void* stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    if (! u_in || ! u_out || u_in == u_out) { set_error("stage: u_in and u_out must be distinct device fields"); return MH_E_INVALID; }
+    if (stage_weight != 1.0 && ! u_base) { set_error("stage: combine needs u_base"); return MH_E_INVALID; }
+    if (row_begin < 0 || row_end > d->n[0] || row_begin > row_end) { set_error("stage: bad row range [%d,%d)", row_begin, row_end); return MH_E_INVALID; }
+    MH_HIP_TRY(euler2d_stage_launch(d, u_in, u_base, u_out, dt, stage_weight, row_begin, row_end, status, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_euler_cart_fill_ghosts(const mh_euler_cart_desc* d, double* u, void* stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    MH_HIP_TRY(fill_ghost_rows_launch(u, 5, d->n[0], row_pitch_of(d), d->bc_lo0, d->bc_hi0, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_aos_to_soa(const double* aos_dev, double* soa_dev, int nq, int n0, size_t row_pitch, void* stream)
+{
+    MH_HIP_TRY(aos_to_soa_launch(aos_dev, soa_dev, nq, n0, row_pitch, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_soa_to_aos(const double* soa_dev, double* aos_dev, int nq, int n0, size_t row_pitch, void* stream)
+{
+    MH_HIP_TRY(soa_to_aos_launch(soa_dev, aos_dev, nq, n0, row_pitch, (hipStream_t) stream));
+    return MH_OK;
+}
+
+// ---- context -------------------------------------------------------------
+int mh_create(mh_ctx** out, int device_id)
+{
+    if (! out) return MH_E_INVALID;
+    int count = 0;
+    MH_HIP_TRY(hipGetDeviceCount(&count));
+    if (device_id < 0 || device_id >= count) { set_error("device %d not available (%d visible)", device_id, count); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(device_id));
+    mh_ctx* c = new mh_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    e = hipMalloc((void**) &c->status, 2 * sizeof(int32_t));
+    if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipMalloc(status)"); }
+    hipMemsetAsync(c->status, 0, 2 * sizeof(int32_t), c->stream);
+    *out = c;
+    return MH_OK;
+}
+
+static void release_fields(mh_ctx* c)
+{
+    for (auto& f : c->field) { if (f) hipFree(f); f = nullptr; }
+    if (c->staging) hipFree(c->staging);
+    c->staging = nullptr;
+    c->staging_doubles = 0;
+}
+
+void mh_destroy(mh_ctx* c)
+{
+    if (! c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    release_fields(c);
+    if (c->status) hipFree(c->status);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mh_euler_cart_configure(mh_ctx* c, const mh_euler_cart_desc* d, int rk_order)
+{
+    if (! c) return MH_E_INVALID;
+    if (int rc = check_desc(d)) return ctx_fail(c, rc);
+    if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    release_fields(c);
+    c->desc = *d;
+    c->rk_order = rk_order;
+    c->field_doubles = mh_euler_cart_field_doubles(d);
+    for (auto& f : c->field)
+    {
+        hipError_t e = hipMalloc((void**) &f, c->field_doubles * sizeof(double));
+        if (e != hipSuccess) { release_fields(c); set_error("hipMalloc of %zu bytes failed", c->field_doubles * sizeof(double)); return ctx_fail(c, MH_E_NOMEM); }
+        hipMemsetAsync(f, 0, c->field_doubles * sizeof(double), c->stream);
+    }
+    c->configured = true;
+    c->uploaded = false;
+    return MH_OK;
+}
+
+static int ensure_staging(mh_ctx* c, size_t doubles)
+{
+    if (c->staging_doubles >= doubles) return MH_OK;
+    if (c->staging) hipFree(c->staging);
+    c->staging = nullptr;
+    c->staging_doubles = 0;
+    if (hipMalloc((void**) &c->staging, doubles * sizeof(double)) != hipSuccess) { set_error("hipMalloc(staging) failed"); return MH_E_NOMEM; }
+    c->staging_doubles = doubles;
+    return MH_OK;
+}
+
+int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
+{
+    if (! c || ! c->configured) { set_error("upload before configure"); return ctx_fail(c, MH_E_STATE); }
+    const mh_euler_cart_desc* d = &c->desc;
+    const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
+    if (ncell != expect || ! u_aos_host) { set_error("upload: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_staging(c, ncell * 5)) return ctx_fail(c, rc);
+    MH_HIP_TRY(hipMemcpyAsync(c->staging, u_aos_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    MH_HIP_TRY(aos_to_soa_launch(c->staging, c->field[0], 5, d->n[0], row_pitch_of(d), c->stream));
+    MH_HIP_TRY(fill_ghost_rows_launch(c->field[0], 5, d->n[0], row_pitch_of(d), d->bc_lo0, d->bc_hi0, c->stream));
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    return MH_OK;
+}
+
+int mh_download(mh_ctx* c, double* u_aos_host, size_t ncell)
+{
+    if (! c || ! c->uploaded) { set_error("download before upload"); return ctx_fail(c, MH_E_STATE); }
+    const mh_euler_cart_desc* d = &c->desc;
+    const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
+    if (ncell != expect || ! u_aos_host) { set_error("download: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_staging(c, ncell * 5)) return ctx_fail(c, rc);
+    MH_HIP_TRY(soa_to_aos_launch(c->field[0], c->staging, 5, d->n[0], row_pitch_of(d), c->stream));
+    MH_HIP_TRY(hipMemcpyAsync(u_aos_host, c->staging, ncell * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MH_OK;
+}
+
+static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, double* out, double dt, double w)
+{
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (c->profile)
+    {
+        hipEventCreate(&ev.first);
+        hipEventCreate(&ev.second);
+        hipEventRecord(ev.first, c->stream);
+    }
+    hipError_t e = euler2d_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
+    if (c->profile)
+    {
+        hipEventRecord(ev.second, c->stream);
+        c->events.push_back(ev);
+    }
+    return e;
+}
+
+int mh_step(mh_ctx* c, double dt, int nsteps)
+{
+    if (! c || ! c->uploaded) { set_error("step before upload"); return ctx_fail(c, MH_E_STATE); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    for (int s = 0; s < nsteps; ++s)
+    {
+        if (c->rk_order == 1)
+        {
+            MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+            std::swap(c->field[0], c->field[1]);
+        }
+        else
+        {
+            // u1 = advance(u0); u = u0*0.5 + advance(u1)*0.5 written in place over u0
+            MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+            MH_HIP_TRY(timed_stage(c, c->field[1], c->field[0], c->field[0], dt, 0.5));
+        }
+    }
+    return MH_OK;
+}
+
+int mh_synchronize(mh_ctx* c)
+{
+    if (! c) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(c->device));
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MH_OK;
+}
+
+int mh_status_word(mh_ctx* c, int32_t* status)
+{
+    if (! c || ! status) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(c->device));
+    int32_t h[2] = {0, 0};
+    MH_HIP_TRY(hipMemcpyAsync(h, c->status, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP_TRY(hipMemsetAsync(c->status, 0, sizeof h, c->stream));
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    *status = h[0];
+    return MH_OK;
+}
+
+double* mh_field_ptr(mh_ctx* c, int which)
+{
+    if (! c || which < 0 || which > 1) return nullptr;
+    return c->field[which];
+}
+
+int mh_profile_enable(mh_ctx* c, int on)
+{
+    if (! c) return MH_E_INVALID;
+    for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    c->events.clear();
+    c->profile = on != 0;
+    return MH_OK;
+}
+
+int mh_profile_read(mh_ctx* c, double* avg_stage_ms, int* nlaunches)
+{
+    if (! c) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(c->device));
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    for (auto& ev : c->events)
+    {
+        float ms = 0.f;
+        MH_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+    }
+    if (avg_stage_ms) *avg_stage_ms = c->events.empty() ? 0.0 : total / c->events.size();
+    if (nlaunches) *nlaunches = (int) c->events.size();
+    return MH_OK;
+}
+
+// ---- per-function entry points --------------------------------------------
+static dim3 grid1(size_t n) { return dim3((unsigned) ((n + 255) / 256)); }
+
+int mh_plm_gradient_n(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g, int arith, void* stream)
+{
+    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(plm_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, yl, y0, yr, theta, g);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_euler_recover_primitive_n(size_t n, const double* U, double gamma, double tfloor, double* P, int arith, void* stream)
+{
+    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(c2p_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, U, gamma, tfloor, P);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_euler_to_conserved_n(size_t n, const double* P, double gamma, double* U, int arith, void* stream)
+{
+    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(p2c_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, gamma, U);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, int riemann_kind, double* F, int arith, void* stream)
+{
+    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (axis < 0 || axis > 2 || (riemann_kind != MH_RIEMANN_HLLE && riemann_kind != MH_RIEMANN_HLLC)) { set_error("bad axis/solver"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    hipStream_t s = (hipStream_t) stream;
+#define MH_LAUNCH_R(R, A) hipLaunchKernelGGL((riemann_kernel<R, A>), grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F)
+    switch (riemann_kind * 3 + axis)
+    {
+        case 0: MH_LAUNCH_R(0, 0); break;
+        case 1: MH_LAUNCH_R(0, 1); break;
+        case 2: MH_LAUNCH_R(0, 2); break;
+        case 3: MH_LAUNCH_R(1, 0); break;
+        case 4: MH_LAUNCH_R(1, 1); break;
+        case 5: MH_LAUNCH_R(1, 2); break;
+    }
+#undef MH_LAUNCH_R
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+// ---- integer work ----------------------------------------------------------
+void mh_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_)
+{
+    *start  = (part + 0) * count / nparts;
+    *final_ = (part + 1) * count / nparts;
+}
+
+static void factorize(int num, std::vector<int>& out)
+{
+    // smallest-divisor-first recursion, the order of mara::parallel::detail::prime_factors
+    int d = 2;
+    for (; ; ++d)
+    {
+        if (num % d == 0) break;
+        if (d * d > num) { d = num; break; }
+    }
+    if (d == num || num / d == 1) { out.push_back(d == num ? num : d); return; }
+    factorize(d, out);
+    factorize(num / d, out);
+}
+
+int mh_propose_block_decomposition(int rank, unsigned long nblocks, unsigned long* blocks_per_axis)
+{
+    if (rank < 1 || rank > 3 || nblocks < 1 || ! blocks_per_axis) return MH_E_INVALID;
+    std::vector<int> f;
+    factorize((int) nblocks, f);
+    for (int g = 0; g < rank; ++g)
+    {
+        size_t a, b;
+        mh_partition_rows(f.size(), (size_t) rank, (size_t) g, &a, &b);
+        int prod = 1;
+        for (size_t k = a; k < b; ++k) prod *= f[k];
+        blocks_per_axis[g] = (unsigned long) prod;
+    }
+    return MH_OK;
+}
+
+// ---- device utilities -------------------------------------------------------
+int mh_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+int mh_malloc(void** ptr, size_t bytes) { MH_HIP_TRY(hipMalloc(ptr, bytes)); return MH_OK; }
+int mh_free(void* ptr) { MH_HIP_TRY(hipFree(ptr)); return MH_OK; }
+int mh_memcpy_h2d(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MH_OK; }
+int mh_memcpy_d2h(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MH_OK; }
+int mh_device_synchronize(void) { MH_HIP_TRY(hipDeviceSynchronize()); return MH_OK; }
+
+} // extern "C"

@@ -1,0 +1,316 @@
+// 2-D uniform-cartesian Euler Runge-Kutta stage for gfx950 (MI355X).
+//
+// Replaces one evaluation of the lazily-composed `advance` expression
+// (src/subprog_cloud.cpp:511-584, specialised to mara::euler on a cartesian
+// grid; see oracle/ref_drivers/euler_cart_ref.cpp for the reference-header
+// form) plus, when stage_weight != 1, the RK combine of
+// src/subprog_cloud.cpp:682-695.
+//
+// Design (HBM-bound stencil with ~800 fp64 issue slots per cell, no MFMA):
+//  * One 64-lane wavefront owns a strip of 60 columns (+2 halo lanes on each
+//    side) and MARCHES along axis 0 over `chunk_rows` rows. Lanes run along
+//    axis 1, the contiguous axis, so every plane access is one coalesced 512 B
+//    row segment.
+//  * Along the march direction everything a cell needs lives in the lane's
+//    registers: primitives of rows r..r+2, the PLM slope of row r and the
+//    flux through face r-1/2, which is reused from the previous iteration -
+//    each axis-0 face flux is computed exactly once.
+//  * Along axis 1 the neighbours' primitives, face states and fluxes move
+//    between lanes with DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1):
+//    each axis-1 face flux is also computed once, by the lane on its right,
+//    and handed to the lane on its left.
+//  * Only the conserved planes are read (once, + 4/chunk_rows and 4/60 halo
+//    re-reads that hit in L2) and written; primitives, slopes and fluxes never
+//    touch memory. The second RK2 stage also streams the step-start field
+//    and writes the averaged result in place.
+//  * Boundary conditions need no branches in the row loop: axis-1 ghosts are
+//    clamped / wrapped column indices computed once per wave; axis-0 ghosts are
+//    two stored rows per side, refreshed by whichever wave writes the edge rows.
+//
+// Algorithmic HBM bytes per cell per stage: 80 (first stage) / 120 (second
+// stage of RK2) => 200 B per zone-update for RK2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "euler_device.hpp"
+#include "launch.hpp"
+
+namespace mh {
+
+static constexpr int WAVE = 64;
+static constexpr int HALO = 2;
+static constexpr int STRIP = WAVE - 2 * HALO;   // 60 output columns per wave
+static constexpr int WAVES_PER_BLOCK = 4;
+
+struct Stage2dParams
+{
+    const double* u_in;
+    const double* u_base;
+    double*       u_out;
+    int32_t*      status;
+    long   plane_stride;     // doubles between planes
+    int    n0, n1;           // local rows, columns
+    int    row_begin, row_end;
+    int    chunk_rows;
+    int    nstrips, nchunks;
+    int    bc_lo0, bc_hi0, bc1;
+    double gamma, theta, cx, cy, weight;
+};
+
+// value of the lane on the left (lane-1) / right (lane+1); edge lanes keep their own value
+__device__ inline double from_left(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double from_right(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline State5 from_left(const State5& s)
+{
+    State5 r;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) r[q] = from_left(s[q]);
+    return r;
+}
+__device__ inline State5 from_right(const State5& s)
+{
+    State5 r;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) r[q] = from_right(s[q]);
+    return r;
+}
+
+__device__ inline State5 load_row(const double* base, long plane_stride, long offset)
+{
+    State5 U;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) U[q] = base[q * plane_stride + offset];
+    return U;
+}
+
+template<int RIEMANN, bool PLM, bool COMBINE>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK)
+void euler2d_stage_kernel(Stage2dParams p)
+{
+    // ---- which (chunk, strip) does this wave own? XCD-aware: consecutive work
+    // items (neighbouring strips, then neighbouring chunks) go to the same XCD so
+    // that halo re-reads hit in that XCD's L2 (blocks are dealt round-robin over 8 XCDs).
+    const int nblocks = gridDim.x;
+    int b = blockIdx.x;
+    {
+        const int per_xcd = nblocks >> 3;
+        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
+    }
+    const int w = b * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (w >= p.nstrips * p.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = w / p.nstrips;
+    const int strip = w - chunk * p.nstrips;
+
+    const int r0 = p.row_begin + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, p.row_end);
+
+    // ---- column of this lane, with the axis-1 boundary condition folded into the index
+    const int col = strip * STRIP - HALO + lane;
+    int jc = col;
+    if (p.bc1 == 1) { jc = jc < 0 ? jc + p.n1 : (jc >= p.n1 ? jc - p.n1 : jc); jc = min(max(jc, 0), p.n1 - 1); }
+    else            { jc = min(max(jc, 0), p.n1 - 1); }
+    const bool writes = lane >= HALO && lane < WAVE - HALO && col < p.n1;
+
+    const long pitch = p.n1;
+    const double* in = p.u_in + jc;                  // row r lives at (r + 2) * pitch
+    auto row_off = [pitch] (int r) { return (long) (r + HALO) * pitch; };
+
+    const double gamma = p.gamma, theta = p.theta;
+
+    // ---- prologue: rows r0-2 .. r0+1
+    State5 Ua = load_row(in, p.plane_stride, row_off(r0 - 2));
+    State5 Ub = load_row(in, p.plane_stride, row_off(r0 - 1));
+    State5 U0 = load_row(in, p.plane_stride, row_off(r0));
+    State5 U1 = load_row(in, p.plane_stride, row_off(r0 + 1));
+    State5 U2 = load_row(in, p.plane_stride, row_off(r0 + 2));   // first prefetch
+
+    State5 P0, P1, G0, Fx_lo;
+    {
+        const State5 Pa = recover_primitive(Ua, gamma, 0.0);
+        const State5 Pb = recover_primitive(Ub, gamma, 0.0);
+        P0 = recover_primitive(U0, gamma, 0.0);
+        P1 = recover_primitive(U1, gamma, 0.0);
+        if constexpr (PLM)
+        {
+            const State5 Gb = plm_gradient(Pa, Pb, P0, theta);
+            G0 = plm_gradient(Pb, P0, P1, theta);
+            Fx_lo = riemann<RIEMANN, 0>(face_plus(Pb, Gb), face_minus(P0, G0), gamma);
+        }
+        else
+        {
+            Fx_lo = riemann<RIEMANN, 0>(Pb, P0, gamma);
+        }
+    }
+
+    int32_t bad = 0;
+
+    for (int r = r0; r < r1; ++r)
+    {
+        // prefetch row r+3 (clamped to the stored ghost range; the value is unused past the chunk end)
+        const int rp = min(r + 3, p.n0 + 1);
+        const State5 U3 = load_row(in, p.plane_stride, row_off(rp));
+        State5 Ubase;
+        if constexpr (COMBINE) Ubase = load_row(p.u_base + jc, p.plane_stride, row_off(r));
+
+        // ---- axis 0: flux through face r+1/2
+        const State5 P2 = recover_primitive(U2, gamma, 0.0);
+        State5 G1, Fx_hi;
+        if constexpr (PLM)
+        {
+            G1 = plm_gradient(P0, P1, P2, theta);
+            Fx_hi = riemann<RIEMANN, 0>(face_plus(P0, G0), face_minus(P1, G1), gamma);
+        }
+        else
+        {
+            Fx_hi = riemann<RIEMANN, 0>(P0, P1, gamma);
+        }
+
+        // ---- axis 1: this lane computes the flux through its LEFT face (between lane-1 and lane)
+        State5 Fy_lo, Fy_hi;
+        if constexpr (PLM)
+        {
+            const State5 Gy = plm_gradient(from_left(P0), P0, from_right(P0), theta);
+            const State5 SL = from_left(face_plus(P0, Gy));       // left neighbour's right-going face state
+            Fy_lo = riemann<RIEMANN, 1>(SL, face_minus(P0, Gy), gamma);
+        }
+        else
+        {
+            Fy_lo = riemann<RIEMANN, 1>(from_left(P0), P0, gamma);
+        }
+        Fy_hi = from_right(Fy_lo);
+
+        // ---- conservative update (+ RK combine)
+        State5 Un;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+        {
+            const double lx = (Fx_hi[q] - Fx_lo[q]) * p.cx;
+            const double ly = (Fy_hi[q] - Fy_lo[q]) * p.cy;
+            const double u1 = U0[q] - (lx + ly);
+            if constexpr (COMBINE) Un[q] = Ubase[q] * (1.0 - p.weight) + u1 * p.weight;
+            else                   Un[q] = u1;
+        }
+        if (!(Un[0] > 0.0)) bad |= 1;          // catches <= 0 and NaN
+
+        if (writes)
+        {
+            double* out = p.u_out + col;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(r)] = Un[q];
+
+            // keep the physical axis-0 ghost rows of the output current
+            if (r < HALO)
+            {
+                if (p.bc_lo0 == 0 && r == 0)
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                    {
+                        out[q * p.plane_stride + row_off(-1)] = Un[q];
+                        out[q * p.plane_stride + row_off(-2)] = Un[q];
+                    }
+                }
+                if (p.bc_hi0 == 1)
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(p.n0 + r)] = Un[q];
+                }
+            }
+            if (r >= p.n0 - HALO)
+            {
+                if (p.bc_hi0 == 0 && r == p.n0 - 1)
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                    {
+                        out[q * p.plane_stride + row_off(p.n0)] = Un[q];
+                        out[q * p.plane_stride + row_off(p.n0 + 1)] = Un[q];
+                    }
+                }
+                if (p.bc_lo0 == 1)
+                {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(r - p.n0)] = Un[q];
+                }
+            }
+        }
+
+        // ---- rotate the register window
+        U0 = U1; U1 = U2; U2 = U3;
+        P0 = P1; P1 = P2;
+        if constexpr (PLM) G0 = G1;
+        Fx_lo = Fx_hi;
+    }
+
+    if (p.status)
+    {
+        const bool any_bad = __any(writes && bad);
+        if (any_bad && lane == 0) atomicOr(p.status, 1);
+    }
+}
+
+template<int RIEMANN, bool PLM, bool COMBINE>
+static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
+{
+    const int nwaves = p.nstrips * p.nchunks;
+    const int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL((euler2d_stage_kernel<RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
+{
+    Stage2dParams p;
+    p.u_in = u_in;
+    p.u_base = u_base;
+    p.u_out = u_out;
+    p.status = status;
+    p.n0 = d->n[0];
+    p.n1 = d->n[1];
+    p.plane_stride = (long) (p.n0 + 2 * HALO) * p.n1;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 64;
+    p.nstrips = (p.n1 + STRIP - 1) / STRIP;
+    p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    p.bc_lo0 = d->bc_lo0;
+    p.bc_hi0 = d->bc_hi0;
+    p.bc1 = d->bc_transverse;
+    p.gamma = d->gamma;
+    p.theta = d->plm_theta;
+    p.cx = dt / d->dl[0];
+    p.cy = dt / d->dl[1];
+    p.weight = weight;
+    if (p.nchunks <= 0) return hipSuccess;
+
+    const bool plm = d->plm_theta >= 0.0;
+    const bool combine = weight != 1.0;
+    const int key = (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
+    switch (key)
+    {
+        case 0: return launch<0, false, false>(p, stream);
+        case 1: return launch<0, false, true >(p, stream);
+        case 2: return launch<0, true,  false>(p, stream);
+        case 3: return launch<0, true,  true >(p, stream);
+        case 4: return launch<1, false, false>(p, stream);
+        case 5: return launch<1, false, true >(p, stream);
+        case 6: return launch<1, true,  false>(p, stream);
+        case 7: return launch<1, true,  true >(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+} // namespace mh

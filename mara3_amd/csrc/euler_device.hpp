@@ -1,0 +1,211 @@
+// Device-side gamma-law Euler physics and PLM reconstruction for gfx950.
+//
+// Operation order follows the reference expressions exactly (SURVEY.md §8a,
+// Appendix B) so that, compiled with -ffp-contract=off, every result is
+// bit-identical to the reference built for baseline x86-64:
+//   plm_gradient                      src/math_interpolation.hpp:85-94
+//   euler::recover_primitive          src/physics_euler.hpp:555-575
+//   primitive_t::to_conserved_density src/physics_euler.hpp:209-220
+//   primitive_t::flux                 src/physics_euler.hpp:252-263
+//   primitive_t::wavespeeds           src/physics_euler.hpp:276-284
+//   euler::riemann_hlle               src/physics_euler.hpp:614-631
+//   unit_vector_t::project            src/core_geometric.hpp:85-89
+// The HLLC solver has no upstream Euler counterpart; it is the gamma-law form
+// of src/physics_iso2d.hpp:556-583,610-687 (Toro 3rd ed. §10.6).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mh {
+
+struct State5
+{
+    double v[5];
+    __host__ __device__ double& operator[](int i) { return v[i]; }
+    __host__ __device__ const double& operator[](int i) const { return v[i]; }
+};
+
+// std::max / std::min semantics (the reference uses those, not fmax/fmin)
+__host__ __device__ inline double std_max(double a, double b) { return (a < b) ? b : a; }
+__host__ __device__ inline double std_min(double a, double b) { return (b < a) ? b : a; }
+
+__host__ __device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
+{
+    const double a = (y0 - yl) * theta;
+    const double b = (yr - yl) * 0.5;
+    const double c = (yr - y0) * theta;
+    const double sa = copysign(1.0, a);
+    const double sb = copysign(1.0, b);
+    const double sc = copysign(1.0, c);
+    const double m = std_min(std_min(fabs(a), fabs(b)), fabs(c));
+    return 0.25 * fabs(sa + sb) * (sa + sc) * m;
+}
+
+__host__ __device__ inline State5 plm_gradient(const State5& l, const State5& c, const State5& r, double theta)
+{
+    State5 g;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) g[q] = plm_gradient(l[q], c[q], r[q], theta);
+    return g;
+}
+
+__host__ __device__ inline State5 recover_primitive(const State5& U, double gamma, double temperature_floor)
+{
+    const double p_squared = U[1] * U[1] + U[2] * U[2] + U[3] * U[3];
+    const double d = U[0];
+    State5 P;
+    P[0] = d;
+    P[1] = U[1] / d;
+    P[2] = U[2] / d;
+    P[3] = U[3] / d;
+    P[4] = (U[4] - 0.5 * p_squared / d) * (gamma - 1.0);
+    if (P[4] < 0.0 && temperature_floor > 0.0) P[4] = temperature_floor * d;
+    return P;
+}
+
+__host__ __device__ inline State5 to_conserved_density(const State5& P, double gamma)
+{
+    const double d = P[0];
+    const double vsq = P[1] * P[1] + P[2] * P[2] + P[3] * P[3];
+    State5 U;
+    U[0] = d;
+    U[1] = d * P[1];
+    U[2] = d * P[2];
+    U[3] = d * P[3];
+    U[4] = 0.5 * d * vsq + P[4] / (gamma - 1);
+    return U;
+}
+
+// nhat = on_axis(AXIS): components are the literal 1.0 / 0.0 of the reference;
+// the products with 0.0 are kept (they are not no-ops for -0.0, inf and NaN).
+template<int AXIS> struct Normal
+{
+    static constexpr double n1 = AXIS == 0 ? 1.0 : 0.0;
+    static constexpr double n2 = AXIS == 1 ? 1.0 : 0.0;
+    static constexpr double n3 = AXIS == 2 ? 1.0 : 0.0;
+};
+
+template<int AXIS> __host__ __device__ inline double velocity_along(const State5& P)
+{
+    using N = Normal<AXIS>;
+    return P[1] * N::n1 + P[2] * N::n2 + P[3] * N::n3;
+}
+
+template<int AXIS> __host__ __device__ inline State5 flux(const State5& P, const State5& U, double vn)
+{
+    using N = Normal<AXIS>;
+    const double p = P[4];
+    State5 F;
+    F[0] = vn * U[0];
+    F[1] = vn * U[1] + p * N::n1;
+    F[2] = vn * U[2] + p * N::n2;
+    F[3] = vn * U[3] + p * N::n3;
+    F[4] = vn * U[4] + p * vn;
+    return F;
+}
+
+template<int AXIS> __host__ __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, double gamma)
+{
+    const State5 Ul = to_conserved_density(Pl, gamma);
+    const State5 Ur = to_conserved_density(Pr, gamma);
+    const double csl = sqrt(gamma * Pl[4] / Pl[0]);
+    const double vl = velocity_along<AXIS>(Pl);
+    const double csr = sqrt(gamma * Pr[4] / Pr[0]);
+    const double vr = velocity_along<AXIS>(Pr);
+    const State5 Fl = flux<AXIS>(Pl, Ul, vl);
+    const State5 Fr = flux<AXIS>(Pr, Ur, vr);
+    const double ap = std_max(0.0, std_max(vl + csl, vr + csr));
+    const double am = std_min(0.0, std_min(vl - csl, vr - csr));
+    const double den = ap - am;
+    State5 F;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) F[q] = (Fl[q] * ap - Fr[q] * am - (Ul[q] - Ur[q]) * ap * am) / den;
+    return F;
+}
+
+template<int AXIS> __host__ __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, double gamma)
+{
+    using N = Normal<AXIS>;
+    const double nh[3] = {N::n1, N::n2, N::n3};
+    const State5 Ul = to_conserved_density(Pl, gamma);
+    const State5 Ur = to_conserved_density(Pr, gamma);
+    const double ul = velocity_along<AXIS>(Pl);
+    const double ur = velocity_along<AXIS>(Pr);
+    const State5 Fl = flux<AXIS>(Pl, Ul, ul);
+    const State5 Fr = flux<AXIS>(Pr, Ur, ur);
+    const double dl = Pl[0], dr = Pr[0], pl = Pl[4], pr = Pr[4];
+    const double dbar = 0.5 * (dl + dr);
+    const double al = sqrt(gamma * pl / dl);
+    const double ar = sqrt(gamma * pr / dr);
+    const double abar = 0.5 * (al + ar);
+    const double ppvrs = 0.5 * (pl + pr) - 0.5 * (ur - ul) * dbar * abar;
+    const double pstar = std_max(0.0, ppvrs);
+    const double gfac = (gamma + 1.0) / (2.0 * gamma);
+    const double ql = pstar <= pl ? 1.0 : sqrt(1.0 + gfac * (pstar / pl - 1.0));
+    const double qr = pstar <= pr ? 1.0 : sqrt(1.0 + gfac * (pstar / pr - 1.0));
+    const double sl = ul - al * ql;
+    const double sr = ur + ar * qr;
+    const double den = dl * (sl - ul) - dr * (sr - ur);
+    const double sstar = (pr - pl + ul * dl * (sl - ul) - ur * dr * (sr - ur)) / den;
+
+    State5 F;
+    if (0.0 <= sl)
+    {
+        F = Fl;
+    }
+    else if (sl <= 0.0 && 0.0 <= sstar)
+    {
+        const double fac = dl * (sl - ul) / (sl - sstar);
+        State5 Us;
+        Us[0] = fac;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Us[1 + k] = fac * (sstar * nh[k] + (Pl[1 + k] - nh[k] * ul));
+        Us[4] = fac * (Ul[4] / dl + (sstar - ul) * (sstar + pl / (dl * (sl - ul))));
+#pragma unroll
+        for (int q = 0; q < 5; ++q) F[q] = Fl[q] + (Us[q] - Ul[q]) * sl;
+    }
+    else if (sstar <= 0.0 && 0.0 <= sr)
+    {
+        const double fac = dr * (sr - ur) / (sr - sstar);
+        State5 Us;
+        Us[0] = fac;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Us[1 + k] = fac * (sstar * nh[k] + (Pr[1 + k] - nh[k] * ur));
+        Us[4] = fac * (Ur[4] / dr + (sstar - ur) * (sstar + pr / (dr * (sr - ur))));
+#pragma unroll
+        for (int q = 0; q < 5; ++q) F[q] = Fr[q] + (Us[q] - Ur[q]) * sr;
+    }
+    else if (sr <= 0.0)
+    {
+        F = Fr;
+    }
+    else
+    {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) F[q] = __builtin_nan("");
+    }
+    return F;
+}
+
+template<int RIEMANN, int AXIS> __host__ __device__ inline State5 riemann(const State5& Pl, const State5& Pr, double gamma)
+{
+    if constexpr (RIEMANN == 1) return riemann_hllc<AXIS>(Pl, Pr, gamma);
+    else                        return riemann_hlle<AXIS>(Pl, Pr, gamma);
+}
+
+// face states: PL = P + G*0.5, PR = P - G*0.5 (src/subprog_cloud.cpp:566-568)
+__host__ __device__ inline State5 face_plus(const State5& P, const State5& G)
+{
+    State5 S;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) S[q] = P[q] + G[q] * 0.5;
+    return S;
+}
+__host__ __device__ inline State5 face_minus(const State5& P, const State5& G)
+{
+    State5 S;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) S[q] = P[q] - G[q] * 0.5;
+    return S;
+}
+
+} // namespace mh

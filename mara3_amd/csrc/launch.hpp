@@ -1,0 +1,22 @@
+// Internal launcher declarations shared by the translation units of libmara_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mara_hip.h"
+
+namespace mh {
+
+hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
+
+hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream);
+hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, size_t row_pitch, hipStream_t stream);
+hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, size_t row_pitch, hipStream_t stream);
+
+// thread-local error text for the C ABI
+void set_error(const char* fmt, ...);
+int  hip_fail(hipError_t e, const char* what);
+
+} // namespace mh
+
+#define MH_HIP_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return mh::hip_fail(_e, #call); } while (0)

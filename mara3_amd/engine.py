@@ -1,0 +1,142 @@
+"""Python host mirror of the reference's step interface for the uniform-cartesian Euler path.
+
+`EulerCartSolver` plays the role of the reference's (solution_t, advance, next_solution) triple
+(src/subprog_cloud.cpp:511-584, :676-697): upload a host AoS field once, call `step(dt, n)`, download
+when a task is due. All compute happens in libmara_hip.so through the C ABI; this class owns no arithmetic.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib as L
+
+
+class EulerCartSolver:
+    def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
+                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0):
+        self.lib = L.load_library()
+        self.shape = tuple(int(n) for n in shape)
+        rank = len(self.shape)
+        d = L.EulerCartDesc()
+        d.rank = rank
+        for a in range(3):
+            d.n[a] = self.shape[a] if a < rank else 1
+            d.dl[a] = dl[a] if a < rank else 1.0
+        d.gamma = gamma
+        d.plm_theta = plm_theta
+        d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
+        bcs = {"outflow": L.BC_OUTFLOW, "periodic": L.BC_PERIODIC, "external": L.BC_EXTERNAL}
+        d.bc_transverse = bcs[bc]
+        d.bc_lo0 = bcs[bc_lo0 or bc]
+        d.bc_hi0 = bcs[bc_hi0 or bc]
+        d.arith = L.ARITH_STRICT
+        d.chunk_rows = chunk_rows
+        self.desc = d
+        self.rk_order = rk_order
+        self.ctx = C.c_void_p()
+        L.check(self.lib.mh_create(C.byref(self.ctx), device))
+        L.check(self.lib.mh_euler_cart_configure(self.ctx, C.byref(d), rk_order), self.ctx)
+        self.ncell = int(np.prod(self.shape))
+
+    def close(self):
+        if self.ctx:
+            self.lib.mh_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, u_aos):
+        u = np.ascontiguousarray(u_aos, dtype=np.float64)
+        assert u.shape == self.shape + (5,), (u.shape, self.shape)
+        L.check(self.lib.mh_upload(self.ctx, u.ctypes.data_as(C.c_void_p), self.ncell), self.ctx)
+
+    def download(self):
+        u = np.empty(self.shape + (5,), dtype=np.float64)
+        L.check(self.lib.mh_download(self.ctx, u.ctypes.data_as(C.c_void_p), self.ncell), self.ctx)
+        return u
+
+    def step(self, dt, nsteps=1):
+        L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
+
+    def synchronize(self):
+        L.check(self.lib.mh_synchronize(self.ctx), self.ctx)
+
+    def status(self):
+        s = C.c_int32()
+        L.check(self.lib.mh_status_word(self.ctx, C.byref(s)), self.ctx)
+        return s.value
+
+    def profile(self, on=True):
+        L.check(self.lib.mh_profile_enable(self.ctx, 1 if on else 0), self.ctx)
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int()
+        L.check(self.lib.mh_profile_read(self.ctx, C.byref(ms), C.byref(n)), self.ctx)
+        return ms.value, n.value
+
+
+class DeviceArray:
+    """A raw device allocation made through the C ABI (tests of the per-function entry points)."""
+
+    def __init__(self, host):
+        self.lib = L.load_library()
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        self.shape = host.shape
+        self.nbytes = host.nbytes
+        self.ptr = C.c_void_p()
+        L.check(self.lib.mh_malloc(C.byref(self.ptr), max(self.nbytes, 8)))
+        if self.nbytes:
+            L.check(self.lib.mh_memcpy_h2d(self.ptr, host.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    @classmethod
+    def empty(cls, shape):
+        return cls(np.zeros(shape))
+
+    def get(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        L.check(self.lib.mh_device_synchronize())
+        if self.nbytes:
+            L.check(self.lib.mh_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.mh_free(self.ptr)
+        except Exception:
+            pass
+
+
+def plm_gradient(yl, y0, yr, theta):
+    lib = L.load_library()
+    a, b, c = DeviceArray(yl), DeviceArray(y0), DeviceArray(yr)
+    g = DeviceArray.empty(a.shape)
+    L.check(lib.mh_plm_gradient_n(int(np.prod(a.shape)), a.ptr, b.ptr, c.ptr, theta, g.ptr, L.ARITH_STRICT, None))
+    return g.get()
+
+
+def euler_recover_primitive(U, gamma, tfloor=0.0):
+    lib = L.load_library()
+    u = DeviceArray(U)
+    p = DeviceArray.empty(u.shape)
+    L.check(lib.mh_euler_recover_primitive_n(int(np.prod(u.shape)) // 5, u.ptr, gamma, tfloor, p.ptr, L.ARITH_STRICT, None))
+    return p.get()
+
+
+def euler_to_conserved(P, gamma):
+    lib = L.load_library()
+    p = DeviceArray(P)
+    u = DeviceArray.empty(p.shape)
+    L.check(lib.mh_euler_to_conserved_n(int(np.prod(p.shape)) // 5, p.ptr, gamma, u.ptr, L.ARITH_STRICT, None))
+    return u.get()
+
+
+def euler_riemann(Pl, Pr, axis, gamma, solver="hlle"):
+    lib = L.load_library()
+    a, b = DeviceArray(Pl), DeviceArray(Pr)
+    f = DeviceArray.empty(a.shape)
+    kind = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[solver]
+    L.check(lib.mh_euler_riemann_n(int(np.prod(a.shape)) // 5, a.ptr, b.ptr, axis, gamma, kind, f.ptr, L.ARITH_STRICT, None))
+    return f.get()
