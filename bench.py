@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — zone-updates/s of the 2-D Euler PLM+HLLC RK2 sweep at 4096^2 (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--riemann hllc|hlle] [--n 4096]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One process per GPU. The global 4096^2 grid is cut into axis-0 slabs with the reference's partition formula
+(strong scaling: total work fixed), ghost rows travel as RCCL send/recv. A "step" is one full RK2 time step
+of the whole grid; inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line with the
+contract keys plus `roofline` (dominant kernel: the second, combining RK2 stage) and, at N=1, `cpu_baseline`
+(the parity-pinned plain-C restatement of the reference's thread-slab CPU path, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+BYTES_STAGE1 = 2 * 5 * 8       # read U, write U1                      
+BYTES_STAGE2 = 3 * 5 * 8       # read U1, read U0, write U (in place)
+BYTES_STEP = BYTES_STAGE1 + BYTES_STAGE2   # 200 B per zone-update
+
+
+def cpu_baseline(n, gamma, theta, riemann, budget_s=15.0):
+    """Time the oracle (test infrastructure, used here ONLY as the reported CPU baseline) on the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import mara_oracle
+    from mara3_amd import setups
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    kind = mara_oracle.RIEMANN_HLLC if riemann == "hllc" else mara_oracle.RIEMANN_HLLE
+    dl = (1.0 / n, 1.0 / n)
+    dt = setups.baseline_dt(n)
+    u = setups.blast_ic((n, n), gamma)
+    t0 = time.perf_counter()
+    u = mara_oracle.euler_cart_run(u, dl, dt, 1, gamma, theta, 2, kind, mara_oracle.BC_OUTFLOW, nthreads=cores)
+    t1 = time.perf_counter() - t0
+    steps = max(1, min(50, int(budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    mara_oracle.euler_cart_run(u, dl, dt, steps, gamma, theta, 2, kind, mara_oracle.BC_OUTFLOW, nthreads=cores)
+    t = time.perf_counter() - t0
+    out = {"value": n * n * steps / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+           "sample": "%d RK2 steps of the same %dx%d PLM+%s workload, oracle/mara_oracle.c with %d slab threads"
+                     % (steps, n, n, riemann.upper(), cores)}
+    return out
+
+
+def cpu_reference(gamma, theta):
+    """If the reference-composed driver was prebuilt (oracle/_ref), time Mara3's own lazy-array path (1 thread)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from mara3_amd import setups
+    exe = os.path.join(ROOT, "oracle", "_ref", "euler_cart_ref")
+    if not os.path.exists(exe):
+        return None
+    n, steps = 512, 4
+    u = setups.blast_ic((n, n), gamma)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        u.tofile(fin)
+        hx = lambda x: float(x).hex()
+        args = [exe, "2", str(n), str(n), "1", hx(gamma), hx(theta), "2", "0", hx(setups.baseline_dt(n)),
+                hx(1.0 / n), hx(1.0 / n), hx(1.0)]
+        try:
+            t0 = time.perf_counter()
+            subprocess.check_call(args + ["0", fin, fout])
+            tz = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            subprocess.check_call(args + [str(steps), fin, fout])
+            t = time.perf_counter() - t0 - tz
+        except Exception:
+            return None
+    return {"value": n * n * steps / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "reference",
+            "sample": "%d RK2 steps at %dx%d PLM+HLLE, reference headers composed as in oracle/ref_drivers/euler_cart_ref.cpp" % (steps, n, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--riemann", default="hllc", choices=["hllc", "hlle"])
+    ap.add_argument("--theta", type=float, default=1.5)
+    ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mara3_amd
+    from mara3_amd import setups
+    from mara3_amd.slab import SlabEulerStepper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    mara3_amd.load_library()           # fails loudly if the HIP library is missing
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n, gamma = args.n, 5.0 / 3
+    dl = (1.0 / n, 1.0 / n)
+    dt = setups.baseline_dt(n)
+    st = SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+                          device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows)
+    st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    st.step(dt, args.warmup)
+    fence()
+    st.timers = []
+    t0 = time.perf_counter()
+    st.step(dt, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timers, st.timers = st.timers, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status = st.status()
+
+    # per-launch durations of the bulk stage launches on this rank (HIP events on the launch stream)
+    dur = {1.0: [], 0.5: []}
+    for w, e0, e1 in timers:
+        dur[w].append(e0.elapsed_time(e1))
+    avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
+    avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
+    rows_bulk = st.n0 - 2 * st.edge_rows
+    cells_launch = rows_bulk * n
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * n * args.steps / elapsed / 1e6
+        ach2 = cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9
+        ach1 = cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and world == 1 and n == 4096:
+            try:
+                traffic = json.load(open(pmc)).get("stage2_%s_bytes_per_launch" % args.riemann)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "zone-updates/sec (Mcells/s) whole node, 2D Euler %d^2 PLM+%s RK2" % (n, args.riemann.upper()),
+            "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
+                                   % (n, n, args.theta, args.riemann.upper()),
+                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage" % world,
+                       "arith": "strict (bit-exact with the reference CPU path)", "status_word": status},
+            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "euler2d_stage_kernel<%s,PLM,COMBINE> (second RK2 stage)" % args.riemann,
+                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": len(dur[0.5])},
+            "roofline_stage1": {"achieved": ach1, "frac": ach1 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1,
+                                "avg_launch_ms": avg1, "launches": len(dur[1.0])},
+            "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
+                              "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del st
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(n, gamma, args.theta, args.riemann)
+            ref = cpu_reference(gamma, args.theta)
+            if ref:
+                out["cpu_reference"] = ref
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,13 +17,16 @@
  *    the reference's nd::shared_array<conserved_t, Rank>: cell (i,j[,k]) is
  *    nq consecutive doubles in the logical order (rho|D, m1, m2, m3, E|tau)
  *    (src/core_ndarray.hpp:777-792, src/physics_euler.hpp:46).
- *  - DEVICE fields are struct-of-arrays planes with two ghost rows on each
- *    side of axis 0 (the slab axis, src/core_ndarray.hpp:820-836):
- *        plane q, row i in [-2, n0+2), transverse index t:  q*plane_stride + (i+2)*row_pitch + t
- *    where row_pitch = n1 (2-D) or n1*n2 (3-D) and plane_stride = (n0+4)*row_pitch.
+ *  - DEVICE fields are row-interleaved struct-of-arrays with two ghost rows on
+ *    each side of axis 0 (the slab axis, src/core_ndarray.hpp:820-836):
+ *        row i in [-2, n0+2), variable q, transverse index t:  ((i+2)*nq + q)*row_pitch + t
+ *    where row_pitch = n1 (2-D) or n1*n2 (3-D). Every variable of a row is a
+ *    contiguous, coalescable run of row_pitch doubles, and the two ghost rows
+ *    of a side (all variables) are ONE contiguous block of 2*nq*row_pitch
+ *    doubles - one message per neighbour in a slab decomposition.
  *    Ghost rows hold the boundary condition (outflow copies / periodic wrap)
- *    or the neighbour rank's rows (slab decomposition); the stage kernels
- *    keep physical ghosts up to date themselves.
+ *    or the neighbour rank's rows; the stage kernels keep physical ghosts up
+ *    to date themselves.
  *  - `stream` arguments are hipStream_t passed as void* (NULL = default stream).
  */
 #ifndef MARA_HIP_H
@@ -87,7 +90,7 @@ typedef struct
     int    chunk_rows;      /* rows marched per wave (0 = default) */
 } mh_euler_cart_desc;
 
-/* number of doubles one SoA device field of this description occupies (5 planes incl. ghost rows) */
+/* number of doubles one device field of this description occupies: (n0+4) * 5 * row_pitch */
 size_t mh_euler_cart_field_doubles(const mh_euler_cart_desc* d);
 
 /*

@@ -47,7 +47,8 @@ struct Stage2dParams
     const double* u_base;
     double*       u_out;
     int32_t*      status;
-    long   plane_stride;     // doubles between planes
+    long   plane_stride;     // doubles between planes of one row
+    long   row_stride;       // doubles between consecutive rows
     int    n0, n1;           // local rows, columns
     int    row_begin, row_end;
     int    chunk_rows;
@@ -123,9 +124,9 @@ void euler2d_stage_kernel(Stage2dParams p)
     else            { jc = min(max(jc, 0), p.n1 - 1); }
     const bool writes = lane >= HALO && lane < WAVE - HALO && col < p.n1;
 
-    const long pitch = p.n1;
-    const double* in = p.u_in + jc;                  // row r lives at (r + 2) * pitch
-    auto row_off = [pitch] (int r) { return (long) (r + HALO) * pitch; };
+    const long row_stride = p.row_stride;
+    const double* in = p.u_in + jc;                  // row r, plane q lives at (r + 2) * row_stride + q * plane_stride
+    auto row_off = [row_stride] (int r) { return (long) (r + HALO) * row_stride; };
 
     const double gamma = p.gamma, theta = p.theta;
 
@@ -280,7 +281,8 @@ hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
     p.status = status;
     p.n0 = d->n[0];
     p.n1 = d->n[1];
-    p.plane_stride = (long) (p.n0 + 2 * HALO) * p.n1;
+    p.plane_stride = p.n1;
+    p.row_stride = 5L * p.n1;
     p.row_begin = row_begin;
     p.row_end = row_end;
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 64;

@@ -1,6 +1,7 @@
-// Layout shims at the boundary: host-order array-of-structs <-> device
-// struct-of-arrays planes with two ghost rows per side of axis 0, and the
-// physical ghost-row fill used after an upload.
+// Layout shims at the boundary: host-order array-of-structs <-> the device
+// layout (row-interleaved struct-of-arrays: for each axis-0 row, nq contiguous
+// plane-rows; two ghost rows per side of axis 0), and the physical ghost-row
+// fill used after an upload.
 //
 // The reference keeps every field as row-major AoS (src/core_ndarray.hpp:777-792)
 // and builds ghost zones on the fly with extend_zero_gradient /
@@ -16,14 +17,16 @@ static constexpr int HALO = 2;
 // (L2 merges them: each 64-lane wave touches nq*512 contiguous bytes), SoA side is fully coalesced.
 template<bool TO_SOA>
 __global__ __launch_bounds__(256)
-void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int nq, size_t ncell, size_t plane_stride, size_t ghost_offset)
+void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int nq, size_t ncell, size_t row_pitch)
 {
     for (size_t c = (size_t) blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t) gridDim.x * blockDim.x)
     {
+        const size_t row = c / row_pitch, t = c - row * row_pitch;
+        const size_t base = (row + HALO) * nq * row_pitch + t;
         for (int q = 0; q < nq; ++q)
         {
-            if (TO_SOA) dst[q * plane_stride + ghost_offset + c] = src[c * nq + q];
-            else        dst[c * nq + q] = src[q * plane_stride + ghost_offset + c];
+            if (TO_SOA) dst[base + q * row_pitch] = src[c * nq + q];
+            else        dst[c * nq + q] = src[base + q * row_pitch];
         }
     }
 }
@@ -31,7 +34,6 @@ void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, 
 __global__ __launch_bounds__(256)
 void fill_ghost_rows_kernel(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0)
 {
-    const size_t plane_stride = (size_t) (n0 + 2 * HALO) * row_pitch;
     const size_t total = (size_t) nq * HALO * row_pitch;
 
     for (size_t m = (size_t) blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (size_t) gridDim.x * blockDim.x)
@@ -39,8 +41,7 @@ void fill_ghost_rows_kernel(double* u, int nq, int n0, size_t row_pitch, int bc_
         const size_t t = m % row_pitch;
         const int g = (int) ((m / row_pitch) % HALO);     // ghost layer 0,1
         const int q = (int) (m / (row_pitch * HALO));
-        double* plane = u + q * plane_stride;
-        auto at = [=] (int row) -> double& { return plane[(size_t) (row + HALO) * row_pitch + t]; };
+        auto at = [=] (int row) -> double& { return u[((size_t) (row + HALO) * nq + q) * row_pitch + t]; };
 
         if (bc_lo0 == MH_BC_OUTFLOW)  at(-1 - g) = at(0);
         if (bc_lo0 == MH_BC_PERIODIC) at(-1 - g) = at(n0 - 1 - g);
@@ -59,7 +60,7 @@ hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, siz
 {
     const size_t ncell = (size_t) n0 * row_pitch;
     hipLaunchKernelGGL(transpose_kernel<true>, dim3(grid_for(ncell)), dim3(256), 0, stream,
-                       aos, soa, nq, ncell, (size_t) (n0 + 2 * HALO) * row_pitch, (size_t) HALO * row_pitch);
+                       aos, soa, nq, ncell, row_pitch);
     return hipGetLastError();
 }
 
@@ -67,7 +68,7 @@ hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, siz
 {
     const size_t ncell = (size_t) n0 * row_pitch;
     hipLaunchKernelGGL(transpose_kernel<false>, dim3(grid_for(ncell)), dim3(256), 0, stream,
-                       soa, aos, nq, ncell, (size_t) (n0 + 2 * HALO) * row_pitch, (size_t) HALO * row_pitch);
+                       soa, aos, nq, ncell, row_pitch);
     return hipGetLastError();
 }
 

@@ -1,0 +1,224 @@
+"""Slab decomposition of the structured grid over the GPUs of one node, one process per GPU.
+
+The cut is exactly the reference's thread-slab formula (nd::partition_shape, src/core_ndarray.hpp:820-836,
+used by mara::evaluate_on<N>, src/app_parallel.hpp:75-103): rank n of N owns axis-0 rows
+[n*Ni/N, (n+1)*Ni/N). The reference never exchanges anything (its slabs share one address space); here each
+Runge-Kutta stage is followed by a two-row ghost exchange with the axis-0 neighbours as point-to-point
+send/recv (RCCL over xGMI under torch.distributed's "nccl" backend), issued as ONE group per stage and
+overlapped with the interior update, which runs on the main stream while the edge rows and the exchange run
+on a second, high-priority stream.
+
+This module owns no arithmetic. The stage kernel is libmara_hip.so's mh_euler_cart_stage (C ABI); tests may
+inject another `stage_fn` to exercise the exchange logic on CPU with the gloo backend.
+"""
+import ctypes as C
+import torch
+import torch.distributed as dist
+from . import _lib as L
+
+HALO = 2
+NQ = 5
+
+
+def partition_rows(count, nparts, part):
+    """Rows [start, final) of slab `part` (calls the C ABI's host-side mh_partition_rows)."""
+    lib = L.load_library()
+    a, b = C.c_size_t(), C.c_size_t()
+    lib.mh_partition_rows(count, nparts, part, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class HipStage:
+    """Default stage function: launches the HIP kernel on the current torch stream through the C ABI."""
+
+    def __init__(self, desc):
+        self.lib = L.load_library()
+        self.desc = desc
+        self.status = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def __call__(self, u_in, u_base, u_out, dt, weight, row_ranges):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        base = C.c_void_p(u_base.data_ptr()) if u_base is not None else None
+        for (a, b) in row_ranges:
+            if b > a:
+                L.check(self.lib.mh_euler_cart_stage(C.byref(self.desc), C.c_void_p(u_in.data_ptr()), base,
+                                                      C.c_void_p(u_out.data_ptr()), dt, weight, a, b,
+                                                      C.c_void_p(self.status.data_ptr()), stream))
+
+
+class TorchDistExchange:
+    """Ghost-row exchange with the axis-0 neighbours over torch.distributed (nccl = RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, rank, world, periodic, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.lo = rank - 1 if rank > 0 else (world - 1 if periodic and world > 1 else None)
+        self.hi = rank + 1 if rank < world - 1 else (0 if periodic and world > 1 else None)
+
+    def start(self, field, n0):
+        """Post the sends of the two edge row-blocks and the receives into the two ghost row-blocks."""
+        ops = []
+        # field: [n0 + 4, NQ, pitch]; row-blocks are contiguous: one message per neighbour
+        if self.lo is not None:
+            ops.append(dist.P2POp(dist.isend, field[HALO:2 * HALO], self.lo, self.group, tag=1))
+        if self.hi is not None:
+            ops.append(dist.P2POp(dist.isend, field[n0:n0 + HALO], self.hi, self.group, tag=2))
+        # receive order mirrors the neighbours' send order (low rows first), which matters when lo == hi
+        if self.hi is not None:
+            ops.append(dist.P2POp(dist.irecv, field[n0 + HALO:n0 + 2 * HALO], self.hi, self.group, tag=1))
+        if self.lo is not None:
+            ops.append(dist.P2POp(dist.irecv, field[0:HALO], self.lo, self.group, tag=2))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def finish(reqs):
+        for r in reqs:
+            r.wait()
+
+
+class SlabEulerStepper:
+    """One rank's share of a uniform-cartesian 2-D Euler run: fields, stages, ghost exchange.
+
+    global_shape = (N0, N1); this rank owns rows partition_rows(N0, world, rank). `bc` is the physical boundary
+    condition ("outflow" | "periodic") of the global domain. Fields live on `device` in the library's device
+    layout [n0 + 4, 5, n1] (include/mara_hip.h)."""
+
+    def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
+                 rank=0, world=1, device="cuda", stage_fn=None, exchange=None, overlap=True, chunk_rows=0,
+                 edge_chunk_rows=8):
+        self.global_shape = tuple(global_shape)
+        self.rank, self.world = rank, world
+        self.row0, self.row1 = partition_rows(global_shape[0], world, rank)
+        self.n0, self.n1 = self.row1 - self.row0, global_shape[1]
+        if self.n0 < 2 * HALO and world > 1:
+            raise ValueError("slab of %d rows is thinner than two ghost layers" % self.n0)
+        self.rk_order = rk_order
+        self.device = torch.device(device)
+        periodic = bc == "periodic"
+        self.exchange = exchange if exchange is not None else TorchDistExchange(rank, world, periodic)
+        has_lo = getattr(self.exchange, "lo", None) is not None
+        has_hi = getattr(self.exchange, "hi", None) is not None
+
+        d = L.EulerCartDesc()
+        d.rank = 2
+        d.n[0], d.n[1], d.n[2] = self.n0, self.n1, 1
+        d.dl[0], d.dl[1], d.dl[2] = dl[0], dl[1], 1.0
+        d.gamma, d.plm_theta = gamma, plm_theta
+        d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
+        phys = L.BC_PERIODIC if periodic else L.BC_OUTFLOW
+        d.bc_transverse = phys
+        d.bc_lo0 = L.BC_EXTERNAL if has_lo else phys
+        d.bc_hi0 = L.BC_EXTERNAL if has_hi else phys
+        d.arith = L.ARITH_STRICT
+        d.chunk_rows = chunk_rows
+        self.desc = d
+        self.edge_desc = L.EulerCartDesc.from_buffer_copy(d)
+        self.edge_desc.chunk_rows = edge_chunk_rows
+        self.has_neighbours = has_lo or has_hi
+        self.edge_rows = edge_chunk_rows if self.has_neighbours else 0
+        if 2 * self.edge_rows > self.n0:
+            self.edge_rows = max(HALO, self.n0 // 2) if self.has_neighbours else 0
+
+        if stage_fn is None:
+            if self.device.type != "cuda":
+                raise L.MaraHipError("SlabEulerStepper has no CPU path: pass device='cuda' (tests inject stage_fn)")
+            self.stage = HipStage(self.desc)
+            self.edge_stage = HipStage(self.edge_desc)
+            self.edge_stage.status = self.stage.status
+        else:
+            self.stage = self.edge_stage = stage_fn
+        self.overlap = overlap and self.has_neighbours and self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap else None
+
+        self.timers = None   # list of (stage_weight, start_event, end_event) when enabled
+        shape = (self.n0 + 2 * HALO, NQ, self.n1)
+        self.u = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.scratch = torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    # ---- data movement ---------------------------------------------------
+    def load_slab(self, u_aos_slab):
+        """u_aos_slab: host/any tensor or ndarray [n0][n1][5] of this rank's rows (reference host order)."""
+        t = torch.as_tensor(u_aos_slab, dtype=torch.float64).to(self.device)
+        assert tuple(t.shape) == (self.n0, self.n1, NQ), (tuple(t.shape), (self.n0, self.n1, NQ))
+        self.u[HALO:HALO + self.n0] = t.permute(0, 2, 1)
+        self.fill_ghosts(self.u)
+
+    def slab(self):
+        """This rank's rows as a host-order AoS tensor [n0][n1][5] on the compute device."""
+        return self.u[HALO:HALO + self.n0].permute(0, 2, 1).contiguous()
+
+    def fill_ghosts(self, f):
+        """Physical ghost rows from the interior; neighbour ghost rows by exchange (initial condition only)."""
+        self.fill_ghosts_physical_only(f)
+        if self.has_neighbours:
+            self.exchange.finish(self.exchange.start(f, self.n0))
+
+    def fill_ghosts_physical_only(self, f):
+        n0 = self.n0
+        d = self.desc
+        if d.bc_lo0 == L.BC_OUTFLOW:
+            f[0:HALO] = f[HALO:HALO + 1]
+        if d.bc_hi0 == L.BC_OUTFLOW:
+            f[n0 + HALO:n0 + 2 * HALO] = f[n0 + HALO - 1:n0 + HALO]
+        if d.bc_lo0 == L.BC_PERIODIC:
+            f[0:HALO] = f[n0:n0 + HALO]
+        if d.bc_hi0 == L.BC_PERIODIC:
+            f[n0 + HALO:n0 + 2 * HALO] = f[HALO:2 * HALO]
+
+    # ---- one Runge-Kutta stage + ghost exchange ------------------------------
+    def _launch_main(self, u_in, u_base, u_out, dt, weight, rows):
+        """The bulk launch on the main stream, optionally bracketed by events (bench.py's roofline leg)."""
+        if self.timers is None:
+            self.stage(u_in, u_base, u_out, dt, weight, rows)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.stage(u_in, u_base, u_out, dt, weight, rows)
+        e1.record()
+        self.timers.append((weight, e0, e1))
+
+    def compute_stage(self, u_in, u_base, u_out, dt, weight):
+        """All rows of one stage, no exchange (single-process multi-slab tests drive the exchange themselves)."""
+        n0, e = self.n0, self.edge_rows
+        if e:
+            self.edge_stage(u_in, u_base, u_out, dt, weight, [(0, e), (n0 - e, n0)])
+        self.stage(u_in, u_base, u_out, dt, weight, [(e, n0 - e)])
+
+    def _stage(self, u_in, u_base, u_out, dt, weight):
+        n0, e = self.n0, self.edge_rows
+        if not self.has_neighbours:
+            self._launch_main(u_in, u_base, u_out, dt, weight, [(0, n0)])
+            return
+        if self.overlap:
+            main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.edge_stage(u_in, u_base, u_out, dt, weight, [(0, e), (n0 - e, n0)])
+                reqs = self.exchange.start(u_out, n0)
+            self._launch_main(u_in, u_base, u_out, dt, weight, [(e, n0 - e)])
+            with torch.cuda.stream(self.side):
+                self.exchange.finish(reqs)
+            main.wait_stream(self.side)
+        else:
+            self.edge_stage(u_in, u_base, u_out, dt, weight, [(0, e), (n0 - e, n0)])
+            reqs = self.exchange.start(u_out, n0)
+            self._launch_main(u_in, u_base, u_out, dt, weight, [(e, n0 - e)])
+            self.exchange.finish(reqs)
+
+    def step(self, dt, nsteps=1):
+        """nsteps full time steps. RK1: u <- advance(u). RK2: u <- u*0.5 + advance(advance(u))*0.5
+        (src/subprog_cloud.cpp:682-695), the combine fused into the second stage and written in place."""
+        for _ in range(nsteps):
+            if self.rk_order == 1:
+                self._stage(self.u, None, self.scratch, dt, 1.0)
+                self.u, self.scratch = self.scratch, self.u
+            else:
+                self._stage(self.u, None, self.scratch, dt, 1.0)
+                self._stage(self.scratch, self.u, self.u, dt, 0.5)
+
+    def status(self):
+        st = getattr(self.stage, "status", None)
+        if st is None:
+            return 0
+        v = int(st[0].item())
+        st.zero_()
+        return v

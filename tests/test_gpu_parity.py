@@ -155,3 +155,84 @@ def test_baseline_size_properties(eng, oracle):
         # (c) symmetry of density under i -> n-1-i and j -> n-1-j
         d = got[..., 0]
         assert np.allclose(d, d[::-1, :], rtol=1e-11, atol=0) and np.allclose(d, d[:, ::-1], rtol=1e-11, atol=0)
+
+
+class _LocalExchange:
+    """Single-process stand-in for the RCCL exchange: copies edge rows between sibling slabs on one GPU."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi           # neighbour indices or None (only their None-ness is used by the stepper)
+
+    def start(self, field, n0):
+        return []
+
+    @staticmethod
+    def finish(reqs):
+        pass
+
+
+@pytest.mark.parametrize("bc", ["outflow", "periodic"])
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_slabs_on_one_gpu_bit_identical_to_single_domain(eng, oracle, bc, nslabs):
+    """The real HIP stage with MH_BC_EXTERNAL sides and split edge/interior row ranges: the union of the slabs
+    must equal the single-domain result bit for bit (SURVEY.md §8e determinism requirement)."""
+    import torch
+    from mara3_amd import setups
+    from mara3_amd.slab import SlabEulerStepper, HALO
+    shape, gamma = (150, 130), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    dt = 1e-3
+    u0 = setups.wave_ic(shape, gamma, seed=21)
+    periodic = bc == "periodic"
+    sts = []
+    for r in range(nslabs):
+        lo = r - 1 if r > 0 else (nslabs - 1 if periodic else None)
+        hi = r + 1 if r < nslabs - 1 else (0 if periodic else None)
+        st = SlabEulerStepper(shape, dl, gamma, 1.5, "hlle", 2, bc, rank=r, world=nslabs, device="cuda",
+                              exchange=_LocalExchange(lo, hi), overlap=False, chunk_rows=16, edge_chunk_rows=4)
+        st.nbr = (lo, hi)
+        st.load_slab(u0[st.row0:st.row1])
+        sts.append(st)
+
+    def exchange(field_of):
+        for st in sts:
+            lo, hi = st.nbr
+            f = field_of(st)
+            if lo is not None:
+                g = field_of(sts[lo])
+                f[0:HALO] = g[sts[lo].n0:sts[lo].n0 + HALO]
+            if hi is not None:
+                g = field_of(sts[hi])
+                f[st.n0 + HALO:st.n0 + 2 * HALO] = g[HALO:2 * HALO]
+
+    exchange(lambda s: s.u)
+    nsteps = 3
+    for _ in range(nsteps):
+        for st in sts:
+            st.compute_stage(st.u, None, st.scratch, dt, 1.0)
+        exchange(lambda s: s.scratch)
+        for st in sts:
+            st.compute_stage(st.scratch, st.u, st.u, dt, 0.5)
+        exchange(lambda s: s.u)
+    torch.cuda.synchronize()
+    got = np.concatenate([st.slab().cpu().numpy() for st in sts], axis=0)
+    obc = oracle.BC_PERIODIC if periodic else oracle.BC_OUTFLOW
+    want = oracle.euler_cart_run(u0, dl, dt, nsteps, gamma, 1.5, 2, oracle.RIEMANN_HLLE, obc)
+    assert bits_equal(got, want), np.abs(got - want).max()
+
+
+def test_stepper_world1_equals_context_api(eng):
+    import torch
+    from mara3_amd import setups
+    from mara3_amd.slab import SlabEulerStepper
+    shape, gamma = (128, 192), 5.0 / 3
+    dl = (1.0 / 128, 1.0 / 192)
+    u0 = setups.blast_ic(shape, gamma, radius=0.3)
+    st = SlabEulerStepper(shape, dl, gamma, 1.5, "hllc", 2, "outflow")
+    st.load_slab(u0)
+    st.step(1e-3, 4)
+    s = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, "outflow")
+    s.upload(u0)
+    s.step(1e-3, 4)
+    assert bits_equal(st.slab().cpu().numpy(), s.download())
+    assert st.status() == 0
