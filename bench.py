@@ -26,17 +26,37 @@ BYTES_STAGE2 = 3 * 5 * 8       # read U1, read U0, write U (in place)
 BYTES_STEP = BYTES_STAGE1 + BYTES_STAGE2   # 200 B per zone-update
 
 
+def host_cores():
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (the GPU box gives a 1-GPU job a share)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return min(cores, int(os.environ.get("MARA_BENCH_CPU_THREADS", "64")))
+
+
 def cpu_baseline(n, gamma, theta, riemann, budget_s=15.0):
     """Time the oracle (test infrastructure, used here ONLY as the reported CPU baseline) on the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import mara_oracle
     from mara3_amd import setups
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     kind = mara_oracle.RIEMANN_HLLC if riemann == "hllc" else mara_oracle.RIEMANN_HLLE
     dl = (1.0 / n, 1.0 / n)
     dt = setups.baseline_dt(n)
@@ -93,6 +113,7 @@ def main():
     ap.add_argument("--riemann", default="hllc", choices=["hllc", "hlle"])
     ap.add_argument("--theta", type=float, default=1.5)
     ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--arith", default="strict", choices=["strict", "fast"])
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -122,7 +143,7 @@ def main():
     dl = (1.0 / n, 1.0 / n)
     dt = setups.baseline_dt(n)
     st = SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
-                          device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows)
+                          device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=args.arith)
     st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
 
     def fence():

@@ -6,8 +6,10 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <type_traits>
 #include "launch.hpp"
 #include "euler_device.hpp"
+#include "euler_device_fast.hpp"
 
 namespace mh {
 
@@ -39,7 +41,7 @@ static int check_desc(const mh_euler_cart_desc* d)
     for (int bc : {d->bc_lo0, d->bc_hi0})
         if (bc != MH_BC_OUTFLOW && bc != MH_BC_PERIODIC && bc != MH_BC_EXTERNAL) { set_error("axis-0 bc must be outflow, periodic or external"); return MH_E_INVALID; }
     if ((d->bc_lo0 == MH_BC_PERIODIC) != (d->bc_hi0 == MH_BC_PERIODIC)) { set_error("periodic axis-0 bc must be set on both sides"); return MH_E_INVALID; }
-    if (d->arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (d->arith != MH_ARITH_STRICT && d->arith != MH_ARITH_FAST) { set_error("unknown arith mode %d", d->arith); return MH_E_INVALID; }
     if (!(d->gamma > 1.0)) { set_error("gamma must be > 1"); return MH_E_INVALID; }
     return MH_OK;
 }
@@ -47,29 +49,44 @@ static int check_desc(const mh_euler_cart_desc* d)
 static size_t row_pitch_of(const mh_euler_cart_desc* d) { return d->rank == 3 ? (size_t) d->n[1] * d->n[2] : (size_t) d->n[1]; }
 
 // ---- per-function kernels (one thread per item; AoS rows) ----------------
+template<class A>
 __global__ void plm_kernel(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g)
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) g[i] = plm_gradient(yl[i], y0[i], yr[i], theta);
+    if (i >= n) return;
+    if constexpr (std::is_same<A, FastArith>::value) g[i] = fast::plm_gradient(yl[i], y0[i], yr[i], theta);
+    else                                             g[i] = plm_gradient(yl[i], y0[i], yr[i], theta);
 }
 __device__ inline State5 load5(const double* p) { State5 s; for (int q = 0; q < 5; ++q) s[q] = p[q]; return s; }
 __device__ inline void store5(double* p, const State5& s) { for (int q = 0; q < 5; ++q) p[q] = s[q]; }
 
+template<class A>
 __global__ void c2p_kernel(size_t n, const double* U, double gamma, double tfloor, double* P)
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) store5(P + 5 * i, recover_primitive(load5(U + 5 * i), gamma, tfloor));
+    if (i >= n) return;
+    if constexpr (std::is_same<A, FastArith>::value) store5(P + 5 * i, fast::recover_primitive(load5(U + 5 * i), fast::make_gamma_law(gamma), tfloor));
+    else                                             store5(P + 5 * i, recover_primitive(load5(U + 5 * i), gamma, tfloor));
 }
+template<class A>
 __global__ void p2c_kernel(size_t n, const double* P, double gamma, double* U)
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) store5(U + 5 * i, to_conserved_density(load5(P + 5 * i), gamma));
+    if (i >= n) return;
+    if constexpr (std::is_same<A, FastArith>::value)
+    {
+        State5 Uc, F;
+        double vn, cs;
+        fast::face_quantities<0>(load5(P + 5 * i), fast::make_gamma_law(gamma), Uc, F, vn, cs);
+        store5(U + 5 * i, Uc);
+    }
+    else store5(U + 5 * i, to_conserved_density(load5(P + 5 * i), make_gamma_law(gamma)));
 }
-template<int RIEMANN, int AXIS>
+template<class A, int RIEMANN, int AXIS>
 __global__ void riemann_kernel(size_t n, const double* Pl, const double* Pr, double gamma, double* F)
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) store5(F + 5 * i, riemann<RIEMANN, AXIS>(load5(Pl + 5 * i), load5(Pr + 5 * i), gamma));
+    if (i < n) store5(F + 5 * i, A::template flux<RIEMANN, AXIS>(load5(Pl + 5 * i), load5(Pr + 5 * i), A::gamma_law(gamma)));
 }
 
 } // namespace mh
@@ -339,38 +356,42 @@ static dim3 grid1(size_t n) { return dim3((unsigned) ((n + 255) / 256)); }
 
 int mh_plm_gradient_n(size_t n, const double* yl, const double* y0, const double* yr, double theta, double* g, int arith, void* stream)
 {
-    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (arith != MH_ARITH_STRICT && arith != MH_ARITH_FAST) { set_error("unknown arith mode"); return MH_E_INVALID; }
     if (n == 0) return MH_OK;
-    hipLaunchKernelGGL(plm_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, yl, y0, yr, theta, g);
+    if (arith == MH_ARITH_FAST) hipLaunchKernelGGL(plm_kernel<FastArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, yl, y0, yr, theta, g);
+    else                        hipLaunchKernelGGL(plm_kernel<StrictArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, yl, y0, yr, theta, g);
     MH_HIP_TRY(hipGetLastError());
     return MH_OK;
 }
 
 int mh_euler_recover_primitive_n(size_t n, const double* U, double gamma, double tfloor, double* P, int arith, void* stream)
 {
-    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (arith != MH_ARITH_STRICT && arith != MH_ARITH_FAST) { set_error("unknown arith mode"); return MH_E_INVALID; }
     if (n == 0) return MH_OK;
-    hipLaunchKernelGGL(c2p_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, U, gamma, tfloor, P);
+    if (arith == MH_ARITH_FAST) hipLaunchKernelGGL(c2p_kernel<FastArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, U, gamma, tfloor, P);
+    else                        hipLaunchKernelGGL(c2p_kernel<StrictArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, U, gamma, tfloor, P);
     MH_HIP_TRY(hipGetLastError());
     return MH_OK;
 }
 
 int mh_euler_to_conserved_n(size_t n, const double* P, double gamma, double* U, int arith, void* stream)
 {
-    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (arith != MH_ARITH_STRICT && arith != MH_ARITH_FAST) { set_error("unknown arith mode"); return MH_E_INVALID; }
     if (n == 0) return MH_OK;
-    hipLaunchKernelGGL(p2c_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, gamma, U);
+    if (arith == MH_ARITH_FAST) hipLaunchKernelGGL(p2c_kernel<FastArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, gamma, U);
+    else                        hipLaunchKernelGGL(p2c_kernel<StrictArith>, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, gamma, U);
     MH_HIP_TRY(hipGetLastError());
     return MH_OK;
 }
 
 int mh_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, int riemann_kind, double* F, int arith, void* stream)
 {
-    if (arith != MH_ARITH_STRICT) { set_error("only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (arith != MH_ARITH_STRICT && arith != MH_ARITH_FAST) { set_error("unknown arith mode"); return MH_E_INVALID; }
     if (axis < 0 || axis > 2 || (riemann_kind != MH_RIEMANN_HLLE && riemann_kind != MH_RIEMANN_HLLC)) { set_error("bad axis/solver"); return MH_E_INVALID; }
     if (n == 0) return MH_OK;
     hipStream_t s = (hipStream_t) stream;
-#define MH_LAUNCH_R(R, A) hipLaunchKernelGGL((riemann_kernel<R, A>), grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F)
+#define MH_LAUNCH_R(R, AX) do { if (arith == MH_ARITH_FAST) hipLaunchKernelGGL((riemann_kernel<FastArith, R, AX>), grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F); \
+                              else hipLaunchKernelGGL((riemann_kernel<StrictArith, R, AX>), grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F); } while (0)
     switch (riemann_kind * 3 + axis)
     {
         case 0: MH_LAUNCH_R(0, 0); break;

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "euler_device.hpp"
+#include "euler_device_fast.hpp"
 #include "launch.hpp"
 
 namespace mh {
@@ -40,6 +41,9 @@ static constexpr int WAVE = 64;
 static constexpr int HALO = 2;
 static constexpr int STRIP = WAVE - 2 * HALO;   // 60 output columns per wave
 static constexpr int WAVES_PER_BLOCK = 4;
+#ifndef MH_MIN_WAVES
+#define MH_MIN_WAVES 2
+#endif
 
 struct Stage2dParams
 {
@@ -57,19 +61,19 @@ struct Stage2dParams
     double gamma, theta, cx, cy, weight;
 };
 
-// value of the lane on the left (lane-1) / right (lane+1); edge lanes keep their own value
+// value of the lane on the left (lane-1) / right (lane+1); the edge lane reads 0 (its result is never used)
 __device__ inline double from_left(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ inline double from_right(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ inline State5 from_left(const State5& s)
@@ -95,8 +99,8 @@ __device__ inline State5 load_row(const double* base, long plane_stride, long of
     return U;
 }
 
-template<int RIEMANN, bool PLM, bool COMBINE>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK)
+template<class A, int RIEMANN, bool PLM, bool COMBINE>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, A::min_waves_per_simd)
 void euler2d_stage_kernel(Stage2dParams p)
 {
     // ---- which (chunk, strip) does this wave own? XCD-aware: consecutive work
@@ -129,6 +133,7 @@ void euler2d_stage_kernel(Stage2dParams p)
     auto row_off = [row_stride] (int r) { return (long) (r + HALO) * row_stride; };
 
     const double gamma = p.gamma, theta = p.theta;
+    const typename A::Gamma gl = A::gamma_law(gamma);
 
     // ---- prologue: rows r0-2 .. r0+1
     State5 Ua = load_row(in, p.plane_stride, row_off(r0 - 2));
@@ -139,19 +144,19 @@ void euler2d_stage_kernel(Stage2dParams p)
 
     State5 P0, P1, G0, Fx_lo;
     {
-        const State5 Pa = recover_primitive(Ua, gamma, 0.0);
-        const State5 Pb = recover_primitive(Ub, gamma, 0.0);
-        P0 = recover_primitive(U0, gamma, 0.0);
-        P1 = recover_primitive(U1, gamma, 0.0);
+        const State5 Pa = A::c2p(Ua, gl);
+        const State5 Pb = A::c2p(Ub, gl);
+        P0 = A::c2p(U0, gl);
+        P1 = A::c2p(U1, gl);
         if constexpr (PLM)
         {
-            const State5 Gb = plm_gradient(Pa, Pb, P0, theta);
-            G0 = plm_gradient(Pb, P0, P1, theta);
-            Fx_lo = riemann<RIEMANN, 0>(face_plus(Pb, Gb), face_minus(P0, G0), gamma);
+            const State5 Gb = A::plm(Pa, Pb, P0, theta);
+            G0 = A::plm(Pb, P0, P1, theta);
+            Fx_lo = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P0, G0), gl);
         }
         else
         {
-            Fx_lo = riemann<RIEMANN, 0>(Pb, P0, gamma);
+            Fx_lo = A::template flux<RIEMANN, 0>(Pb, P0, gl);
         }
     }
 
@@ -166,29 +171,29 @@ void euler2d_stage_kernel(Stage2dParams p)
         if constexpr (COMBINE) Ubase = load_row(p.u_base + jc, p.plane_stride, row_off(r));
 
         // ---- axis 0: flux through face r+1/2
-        const State5 P2 = recover_primitive(U2, gamma, 0.0);
+        const State5 P2 = A::c2p(U2, gl);
         State5 G1, Fx_hi;
         if constexpr (PLM)
         {
-            G1 = plm_gradient(P0, P1, P2, theta);
-            Fx_hi = riemann<RIEMANN, 0>(face_plus(P0, G0), face_minus(P1, G1), gamma);
+            G1 = A::plm(P0, P1, P2, theta);
+            Fx_hi = A::template flux<RIEMANN, 0>(A::plus(P0, G0), A::minus(P1, G1), gl);
         }
         else
         {
-            Fx_hi = riemann<RIEMANN, 0>(P0, P1, gamma);
+            Fx_hi = A::template flux<RIEMANN, 0>(P0, P1, gl);
         }
 
         // ---- axis 1: this lane computes the flux through its LEFT face (between lane-1 and lane)
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM)
         {
-            const State5 Gy = plm_gradient(from_left(P0), P0, from_right(P0), theta);
-            const State5 SL = from_left(face_plus(P0, Gy));       // left neighbour's right-going face state
-            Fy_lo = riemann<RIEMANN, 1>(SL, face_minus(P0, Gy), gamma);
+            const State5 Gy = A::plm(from_left(P0), P0, from_right(P0), theta);
+            const State5 SL = from_left(A::plus(P0, Gy));       // left neighbour's right-going face state
+            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P0, Gy), gl);
         }
         else
         {
-            Fy_lo = riemann<RIEMANN, 1>(from_left(P0), P0, gamma);
+            Fy_lo = A::template flux<RIEMANN, 1>(from_left(P0), P0, gl);
         }
         Fy_hi = from_right(Fy_lo);
 
@@ -197,10 +202,8 @@ void euler2d_stage_kernel(Stage2dParams p)
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double lx = (Fx_hi[q] - Fx_lo[q]) * p.cx;
-            const double ly = (Fy_hi[q] - Fy_lo[q]) * p.cy;
-            const double u1 = U0[q] - (lx + ly);
-            if constexpr (COMBINE) Un[q] = Ubase[q] * (1.0 - p.weight) + u1 * p.weight;
+            const double u1 = A::update2(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+            if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
         if (!(Un[0] > 0.0)) bad |= 1;          // catches <= 0 and NaN
@@ -262,12 +265,12 @@ void euler2d_stage_kernel(Stage2dParams p)
     }
 }
 
-template<int RIEMANN, bool PLM, bool COMBINE>
+template<class A, int RIEMANN, bool PLM, bool COMBINE>
 static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
 {
     const int nwaves = p.nstrips * p.nchunks;
     const int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    hipLaunchKernelGGL((euler2d_stage_kernel<RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
+    hipLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -285,7 +288,7 @@ hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
     p.row_stride = 5L * p.n1;
     p.row_begin = row_begin;
     p.row_end = row_end;
-    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 64;
+    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     p.nstrips = (p.n1 + STRIP - 1) / STRIP;
     p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
     p.bc_lo0 = d->bc_lo0;
@@ -300,17 +303,25 @@ hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
 
     const bool plm = d->plm_theta >= 0.0;
     const bool combine = weight != 1.0;
-    const int key = (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
+    const int key = (d->arith == MH_ARITH_FAST ? 8 : 0) | (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
     switch (key)
     {
-        case 0: return launch<0, false, false>(p, stream);
-        case 1: return launch<0, false, true >(p, stream);
-        case 2: return launch<0, true,  false>(p, stream);
-        case 3: return launch<0, true,  true >(p, stream);
-        case 4: return launch<1, false, false>(p, stream);
-        case 5: return launch<1, false, true >(p, stream);
-        case 6: return launch<1, true,  false>(p, stream);
-        case 7: return launch<1, true,  true >(p, stream);
+        case 0:  return launch<StrictArith, 0, false, false>(p, stream);
+        case 1:  return launch<StrictArith, 0, false, true >(p, stream);
+        case 2:  return launch<StrictArith, 0, true,  false>(p, stream);
+        case 3:  return launch<StrictArith, 0, true,  true >(p, stream);
+        case 4:  return launch<StrictArith, 1, false, false>(p, stream);
+        case 5:  return launch<StrictArith, 1, false, true >(p, stream);
+        case 6:  return launch<StrictArith, 1, true,  false>(p, stream);
+        case 7:  return launch<StrictArith, 1, true,  true >(p, stream);
+        case 8:  return launch<FastArith, 0, false, false>(p, stream);
+        case 9:  return launch<FastArith, 0, false, true >(p, stream);
+        case 10: return launch<FastArith, 0, true,  false>(p, stream);
+        case 11: return launch<FastArith, 0, true,  true >(p, stream);
+        case 12: return launch<FastArith, 1, false, false>(p, stream);
+        case 13: return launch<FastArith, 1, false, true >(p, stream);
+        case 14: return launch<FastArith, 1, true,  false>(p, stream);
+        case 15: return launch<FastArith, 1, true,  true >(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -12,23 +12,103 @@
 //   unit_vector_t::project            src/core_geometric.hpp:85-89
 // The HLLC solver has no upstream Euler counterpart; it is the gamma-law form
 // of src/physics_iso2d.hpp:556-583,610-687 (Toro 3rd ed. §10.6).
+//
+// Two instruction-count optimisations keep every finite result bit-identical:
+//  * shared-denominator division (struct Recip): x/d for several x and one d runs
+//    the exact v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup sequence
+//    hipcc emits for `x / d`, but the reciprocal refinement (rcp + 4 fma) is done
+//    once per denominator. If a numerator would make v_div_scale rescale the
+//    denominator differently (extreme exponents), that lane recomputes it.
+//  * plm_gradient takes the minimum with v_min_f64 on |.| operands. For finite
+//    arguments this equals std::min; only the NaN pattern differs (std::min is
+//    not commutative for NaN), and a NaN state is reported through the status
+//    word in any case.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace mh {
 
+// ---- IEEE fp64 division with a shared denominator -------------------------
+struct Recip
+{
+    double den;   // the denominator as given
+    double ds;    // v_div_scale'd denominator the reciprocal was refined for
+    double r;     // refined reciprocal of ds
+};
+
+__device__ inline double refine_rcp(double ds)
+{
+    double r = __builtin_amdgcn_rcp(ds);
+    double e = __builtin_fma(-ds, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-ds, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// num0: a representative numerator (only its exponent class matters; 1.0 covers every normal-range numerator)
+__device__ inline Recip make_recip(double den, double num0)
+{
+    bool flag;
+    Recip R;
+    R.den = den;
+    R.ds = __builtin_amdgcn_div_scale(num0, den, false, &flag);
+    R.r = refine_rcp(R.ds);
+    return R;
+}
+
+// N quotients x[k] / R.den in place. One cold fallback per group instead of one per quotient.
+template<int N>
+__device__ inline void divide_group(double (&x)[N], const Recip& R)
+{
+    double ds[N], ns[N];
+    bool flag[N];
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+    {
+        bool unused;
+        ds[k] = __builtin_amdgcn_div_scale(x[k], R.den, false, &unused);
+        ns[k] = __builtin_amdgcn_div_scale(x[k], R.den, true, &flag[k]);
+        same = same && (__double_as_longlong(ds[k]) == __double_as_longlong(R.ds));
+    }
+    if (__builtin_expect(same, 1))
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+        {
+            const double q = ns[k] * R.r;
+            const double rem = __builtin_fma(-R.ds, q, ns[k]);
+            const double res = __builtin_amdgcn_div_fmas(rem, R.r, q, flag[k]);
+            x[k] = __builtin_amdgcn_div_fixup(res, R.den, x[k]);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = x[k] / R.den;
+    }
+}
+
+__device__ inline double divide(double num, const Recip& R)
+{
+    double x[1] = {num};
+    divide_group<1>(x, R);
+    return x[0];
+}
+
 struct State5
 {
     double v[5];
-    __host__ __device__ double& operator[](int i) { return v[i]; }
-    __host__ __device__ const double& operator[](int i) const { return v[i]; }
+    __device__ double& operator[](int i) { return v[i]; }
+    __device__ const double& operator[](int i) const { return v[i]; }
 };
 
 // std::max / std::min semantics (the reference uses those, not fmax/fmin)
-__host__ __device__ inline double std_max(double a, double b) { return (a < b) ? b : a; }
-__host__ __device__ inline double std_min(double a, double b) { return (b < a) ? b : a; }
+__device__ inline double std_max(double a, double b) { return (a < b) ? b : a; }
+__device__ inline double std_min(double a, double b) { return (b < a) ? b : a; }
 
-__host__ __device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
+__device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
 {
     const double a = (y0 - yl) * theta;
     const double b = (yr - yl) * 0.5;
@@ -36,11 +116,11 @@ __host__ __device__ inline double plm_gradient(double yl, double y0, double yr, 
     const double sa = copysign(1.0, a);
     const double sb = copysign(1.0, b);
     const double sc = copysign(1.0, c);
-    const double m = std_min(std_min(fabs(a), fabs(b)), fabs(c));
+    const double m = __builtin_fmin(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), __builtin_fabs(c));
     return 0.25 * fabs(sa + sb) * (sa + sc) * m;
 }
 
-__host__ __device__ inline State5 plm_gradient(const State5& l, const State5& c, const State5& r, double theta)
+__device__ inline State5 plm_gradient(const State5& l, const State5& c, const State5& r, double theta)
 {
     State5 g;
 #pragma unroll
@@ -48,21 +128,38 @@ __host__ __device__ inline State5 plm_gradient(const State5& l, const State5& c,
     return g;
 }
 
-__host__ __device__ inline State5 recover_primitive(const State5& U, double gamma, double temperature_floor)
+__device__ inline State5 recover_primitive(const State5& U, double gamma, double temperature_floor)
 {
     const double p_squared = U[1] * U[1] + U[2] * U[2] + U[3] * U[3];
     const double d = U[0];
+    const Recip Rd = make_recip(d, 1.0);
     State5 P;
+    double x[4] = {U[1], U[2], U[3], 0.5 * p_squared};
+    divide_group<4>(x, Rd);
     P[0] = d;
-    P[1] = U[1] / d;
-    P[2] = U[2] / d;
-    P[3] = U[3] / d;
-    P[4] = (U[4] - 0.5 * p_squared / d) * (gamma - 1.0);
+    P[1] = x[0];
+    P[2] = x[1];
+    P[3] = x[2];
+    P[4] = (U[4] - x[3]) * (gamma - 1.0);
     if (P[4] < 0.0 && temperature_floor > 0.0) P[4] = temperature_floor * d;
     return P;
 }
 
-__host__ __device__ inline State5 to_conserved_density(const State5& P, double gamma)
+// gamma-law constants prepared once per kernel: gm1 = make_recip(gamma - 1, 1.0)
+struct GammaLaw
+{
+    double gamma;
+    Recip  gm1;
+};
+__device__ inline GammaLaw make_gamma_law(double gamma)
+{
+    GammaLaw g;
+    g.gamma = gamma;
+    g.gm1 = make_recip(gamma - 1, 1.0);
+    return g;
+}
+
+__device__ inline State5 to_conserved_with(const State5& P, double p_over_gm1)
 {
     const double d = P[0];
     const double vsq = P[1] * P[1] + P[2] * P[2] + P[3] * P[3];
@@ -71,8 +168,22 @@ __host__ __device__ inline State5 to_conserved_density(const State5& P, double g
     U[1] = d * P[1];
     U[2] = d * P[2];
     U[3] = d * P[3];
-    U[4] = 0.5 * d * vsq + P[4] / (gamma - 1);
+    U[4] = 0.5 * d * vsq + p_over_gm1;
     return U;
+}
+
+__device__ inline State5 to_conserved_density(const State5& P, const GammaLaw& g)
+{
+    return to_conserved_with(P, divide(P[4], g.gm1));
+}
+
+// both sides of a face share one division group for p / (gamma - 1)
+__device__ inline void to_conserved_pair(const State5& Pl, const State5& Pr, const GammaLaw& g, State5& Ul, State5& Ur)
+{
+    double x[2] = {Pl[4], Pr[4]};
+    divide_group<2>(x, g.gm1);
+    Ul = to_conserved_with(Pl, x[0]);
+    Ur = to_conserved_with(Pr, x[1]);
 }
 
 // nhat = on_axis(AXIS): components are the literal 1.0 / 0.0 of the reference;
@@ -84,13 +195,13 @@ template<int AXIS> struct Normal
     static constexpr double n3 = AXIS == 2 ? 1.0 : 0.0;
 };
 
-template<int AXIS> __host__ __device__ inline double velocity_along(const State5& P)
+template<int AXIS> __device__ inline double velocity_along(const State5& P)
 {
     using N = Normal<AXIS>;
     return P[1] * N::n1 + P[2] * N::n2 + P[3] * N::n3;
 }
 
-template<int AXIS> __host__ __device__ inline State5 flux(const State5& P, const State5& U, double vn)
+template<int AXIS> __device__ inline State5 flux(const State5& P, const State5& U, double vn)
 {
     using N = Normal<AXIS>;
     const double p = P[4];
@@ -103,10 +214,11 @@ template<int AXIS> __host__ __device__ inline State5 flux(const State5& P, const
     return F;
 }
 
-template<int AXIS> __host__ __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, double gamma)
+template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const GammaLaw& g)
 {
-    const State5 Ul = to_conserved_density(Pl, gamma);
-    const State5 Ur = to_conserved_density(Pr, gamma);
+    const double gamma = g.gamma;
+    State5 Ul, Ur;
+    to_conserved_pair(Pl, Pr, g, Ul, Ur);
     const double csl = sqrt(gamma * Pl[4] / Pl[0]);
     const double vl = velocity_along<AXIS>(Pl);
     const double csr = sqrt(gamma * Pr[4] / Pr[0]);
@@ -115,19 +227,21 @@ template<int AXIS> __host__ __device__ inline State5 riemann_hlle(const State5& 
     const State5 Fr = flux<AXIS>(Pr, Ur, vr);
     const double ap = std_max(0.0, std_max(vl + csl, vr + csr));
     const double am = std_min(0.0, std_min(vl - csl, vr - csr));
-    const double den = ap - am;
-    State5 F;
+    State5 N;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = (Fl[q] * ap - Fr[q] * am - (Ul[q] - Ur[q]) * ap * am) / den;
-    return F;
+    for (int q = 0; q < 5; ++q) N[q] = Fl[q] * ap - Fr[q] * am - (Ul[q] - Ur[q]) * ap * am;
+    const Recip Rden = make_recip(ap - am, 1.0);
+    divide_group<5>(N.v, Rden);
+    return N;
 }
 
-template<int AXIS> __host__ __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, double gamma)
+template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, const GammaLaw& g)
 {
     using N = Normal<AXIS>;
     const double nh[3] = {N::n1, N::n2, N::n3};
-    const State5 Ul = to_conserved_density(Pl, gamma);
-    const State5 Ur = to_conserved_density(Pr, gamma);
+    const double gamma = g.gamma;
+    State5 Ul, Ur;
+    to_conserved_pair(Pl, Pr, g, Ul, Ur);
     const double ul = velocity_along<AXIS>(Pl);
     const double ur = velocity_along<AXIS>(Pr);
     const State5 Fl = flux<AXIS>(Pl, Ul, ul);
@@ -186,21 +300,21 @@ template<int AXIS> __host__ __device__ inline State5 riemann_hllc(const State5& 
     return F;
 }
 
-template<int RIEMANN, int AXIS> __host__ __device__ inline State5 riemann(const State5& Pl, const State5& Pr, double gamma)
+template<int RIEMANN, int AXIS> __device__ inline State5 riemann(const State5& Pl, const State5& Pr, const GammaLaw& g)
 {
-    if constexpr (RIEMANN == 1) return riemann_hllc<AXIS>(Pl, Pr, gamma);
-    else                        return riemann_hlle<AXIS>(Pl, Pr, gamma);
+    if constexpr (RIEMANN == 1) return riemann_hllc<AXIS>(Pl, Pr, g);
+    else                        return riemann_hlle<AXIS>(Pl, Pr, g);
 }
 
 // face states: PL = P + G*0.5, PR = P - G*0.5 (src/subprog_cloud.cpp:566-568)
-__host__ __device__ inline State5 face_plus(const State5& P, const State5& G)
+__device__ inline State5 face_plus(const State5& P, const State5& G)
 {
     State5 S;
 #pragma unroll
     for (int q = 0; q < 5; ++q) S[q] = P[q] + G[q] * 0.5;
     return S;
 }
-__host__ __device__ inline State5 face_minus(const State5& P, const State5& G)
+__device__ inline State5 face_minus(const State5& P, const State5& G)
 {
     State5 S;
 #pragma unroll

@@ -11,7 +11,7 @@ from . import _lib as L
 
 class EulerCartSolver:
     def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
-                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0):
+                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict"):
         self.lib = L.load_library()
         self.shape = tuple(int(n) for n in shape)
         rank = len(self.shape)
@@ -27,7 +27,7 @@ class EulerCartSolver:
         d.bc_transverse = bcs[bc]
         d.bc_lo0 = bcs[bc_lo0 or bc]
         d.bc_hi0 = bcs[bc_hi0 or bc]
-        d.arith = L.ARITH_STRICT
+        d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
         d.chunk_rows = chunk_rows
         self.desc = d
         self.rk_order = rk_order
@@ -109,34 +109,37 @@ class DeviceArray:
             pass
 
 
-def plm_gradient(yl, y0, yr, theta):
+_ARITH = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}
+
+
+def plm_gradient(yl, y0, yr, theta, arith="strict"):
     lib = L.load_library()
     a, b, c = DeviceArray(yl), DeviceArray(y0), DeviceArray(yr)
     g = DeviceArray.empty(a.shape)
-    L.check(lib.mh_plm_gradient_n(int(np.prod(a.shape)), a.ptr, b.ptr, c.ptr, theta, g.ptr, L.ARITH_STRICT, None))
+    L.check(lib.mh_plm_gradient_n(int(np.prod(a.shape)), a.ptr, b.ptr, c.ptr, theta, g.ptr, _ARITH[arith], None))
     return g.get()
 
 
-def euler_recover_primitive(U, gamma, tfloor=0.0):
+def euler_recover_primitive(U, gamma, tfloor=0.0, arith="strict"):
     lib = L.load_library()
     u = DeviceArray(U)
     p = DeviceArray.empty(u.shape)
-    L.check(lib.mh_euler_recover_primitive_n(int(np.prod(u.shape)) // 5, u.ptr, gamma, tfloor, p.ptr, L.ARITH_STRICT, None))
+    L.check(lib.mh_euler_recover_primitive_n(int(np.prod(u.shape)) // 5, u.ptr, gamma, tfloor, p.ptr, _ARITH[arith], None))
     return p.get()
 
 
-def euler_to_conserved(P, gamma):
+def euler_to_conserved(P, gamma, arith="strict"):
     lib = L.load_library()
     p = DeviceArray(P)
     u = DeviceArray.empty(p.shape)
-    L.check(lib.mh_euler_to_conserved_n(int(np.prod(p.shape)) // 5, p.ptr, gamma, u.ptr, L.ARITH_STRICT, None))
+    L.check(lib.mh_euler_to_conserved_n(int(np.prod(p.shape)) // 5, p.ptr, gamma, u.ptr, _ARITH[arith], None))
     return u.get()
 
 
-def euler_riemann(Pl, Pr, axis, gamma, solver="hlle"):
+def euler_riemann(Pl, Pr, axis, gamma, solver="hlle", arith="strict"):
     lib = L.load_library()
     a, b = DeviceArray(Pl), DeviceArray(Pr)
     f = DeviceArray.empty(a.shape)
     kind = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[solver]
-    L.check(lib.mh_euler_riemann_n(int(np.prod(a.shape)) // 5, a.ptr, b.ptr, axis, gamma, kind, f.ptr, L.ARITH_STRICT, None))
+    L.check(lib.mh_euler_riemann_n(int(np.prod(a.shape)) // 5, a.ptr, b.ptr, axis, gamma, kind, f.ptr, _ARITH[arith], None))
     return f.get()

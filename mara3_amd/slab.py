@@ -84,7 +84,7 @@ class SlabEulerStepper:
 
     def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
                  rank=0, world=1, device="cuda", stage_fn=None, exchange=None, overlap=True, chunk_rows=0,
-                 edge_chunk_rows=8):
+                 edge_chunk_rows=8, arith="strict"):
         self.global_shape = tuple(global_shape)
         self.rank, self.world = rank, world
         self.row0, self.row1 = partition_rows(global_shape[0], world, rank)
@@ -108,7 +108,7 @@ class SlabEulerStepper:
         d.bc_transverse = phys
         d.bc_lo0 = L.BC_EXTERNAL if has_lo else phys
         d.bc_hi0 = L.BC_EXTERNAL if has_hi else phys
-        d.arith = L.ARITH_STRICT
+        d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
         d.chunk_rows = chunk_rows
         self.desc = d
         self.edge_desc = L.EulerCartDesc.from_buffer_copy(d)

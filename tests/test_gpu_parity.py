@@ -236,3 +236,69 @@ def test_stepper_world1_equals_context_api(eng):
     s.step(1e-3, 4)
     assert bits_equal(st.slab().cpu().numpy(), s.download())
     assert st.status() == 0
+
+
+# ---- MH_ARITH_FAST: same scheme, FMA / shared reciprocals; tolerance = north_star's L1 <= 1e-12 ----------
+
+def test_fast_plm_equals_strict_as_numbers(eng):
+    g = golden("plm_gradient")
+    y = g["y"]
+    for key in g.files:
+        if key.startswith("g_"):
+            got = eng.plm_gradient(y[:, 0].copy(), y[:, 1].copy(), y[:, 2].copy(), float(key[2:]), arith="fast")
+            assert np.array_equal(got, g[key]), key          # identical values; only the sign of an exact zero may differ
+
+
+def test_fast_functions_within_a_few_ulp(eng):
+    g = golden("euler_functions")
+    gamma = 5.0 / 3
+    U = eng.euler_to_conserved(g["Pl"], gamma, arith="fast")
+    assert (np.abs(U - g["U_53"]) <= 1e-15 * np.abs(g["U_53"]).max(axis=1, keepdims=True)).all()
+    P = eng.euler_recover_primitive(g["U_53"], gamma, arith="fast")
+    want = g["c2p_53"]
+    # pressure is a difference of two energies: scale its error by the total energy
+    scale = np.abs(want).copy()
+    scale[:, 4] = np.maximum(scale[:, 4], (gamma - 1) * np.abs(g["U_53"][:, 4]))
+    assert (np.abs(P - want) <= 4e-15 * scale + 1e-300).all()
+    for solver in ("hlle", "hllc"):
+        for axis in range(3):
+            Ff = eng.euler_riemann(g["Pl"][:512], g["Pr"][:512], axis, gamma, solver, arith="fast")
+            Fs = eng.euler_riemann(g["Pl"][:512], g["Pr"][:512], axis, gamma, solver, arith="strict")
+            scale = np.abs(Fs).max(axis=1, keepdims=True)
+            assert (np.abs(Ff - Fs) <= 1e-12 * scale).all(), (solver, axis, (np.abs(Ff - Fs) / scale).max())
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_fast_euler2d_steps_within_l1_tolerance(eng, case):
+    g = golden(case)
+    bc = "periodic" if int(g["bc"]) == 1 else "outflow"
+    for ns in g["nsteps"]:
+        s = eng.EulerCartSolver(g["u0"].shape[:2], g["dl"], float(g["gamma"]), float(g["theta"]), "hlle", int(g["rk"]), bc, arith="fast")
+        s.upload(g["u0"])
+        s.step(float(g["dt"]), int(ns))
+        got = s.download()
+        want = g["u_%d" % ns]
+        assert l1(got, want) <= L1_TOL, (case, ns, l1(got, want))
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+
+
+def test_fast_baseline_size_l1_vs_strict(eng):
+    """BASELINE config 2 at full size: FAST against the bit-exact STRICT path after 10 RK2 steps, L1 <= 1e-12."""
+    from mara3_amd import setups
+    n, gamma = 4096, 5.0 / 3
+    dl = (1.0 / n, 1.0 / n)
+    dt = setups.baseline_dt(n)
+    u0 = setups.blast_ic((n, n), gamma)
+    for riemann in ("hlle", "hllc"):
+        out = {}
+        for arith in ("strict", "fast"):
+            s = eng.EulerCartSolver((n, n), dl, gamma, 1.5, riemann, 2, "outflow", arith=arith)
+            s.upload(u0)
+            s.step(dt, 10)
+            out[arith] = s.download()
+            assert s.status() == 0
+            s.close()
+        err = l1(out["fast"], out["strict"])
+        assert err <= L1_TOL, (riemann, err)
+        for q in (0, 4):
+            assert abs(out["fast"][..., q].sum() - u0[..., q].sum()) <= 1e-11 * abs(u0[..., q].sum())
