@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--riemann", default="hllc", choices=["hllc", "hlle"])
     ap.add_argument("--theta", type=float, default=1.5)
     ap.add_argument("--chunk-rows", type=int, default=0)
-    ap.add_argument("--arith", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--arith", default="fast", choices=["strict", "fast"], help="arithmetic contract of the headline value")
+    ap.add_argument("--single-arith", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -142,9 +143,6 @@ def main():
     n, gamma = args.n, 5.0 / 3
     dl = (1.0 / n, 1.0 / n)
     dt = setups.baseline_dt(n)
-    st = SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
-                          device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=args.arith)
-    st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
 
     def fence():
         torch.cuda.synchronize()
@@ -152,60 +150,85 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    st.step(dt, args.warmup)
-    fence()
-    st.timers = []
-    t0 = time.perf_counter()
-    st.step(dt, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timers, st.timers = st.timers, None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    status = st.status()
+    def run_mode(arith):
+        """W untimed + K timed steps of the whole (slab-decomposed) grid in one arithmetic mode."""
+        st = SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+                              device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=arith)
+        st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
+        st.step(dt, args.warmup)
+        fence()
+        st.timers = []
+        t0 = time.perf_counter()
+        st.step(dt, args.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        timers, st.timers = st.timers, None
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        dur = {1.0: [], 0.5: []}
+        for w, e0, e1 in timers:       # HIP events on the stream the bulk stage launches ran on
+            dur[w].append(e0.elapsed_time(e1))
+        cells_launch = (st.n0 - 2 * st.edge_rows) * n
+        avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
+        avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
+        value = n * n * args.steps / elapsed / 1e6
+        res = {
+            "value": value, "ms_per_step": elapsed / args.steps * 1e3, "status_word": st.status(),
+            "roofline": {"bound": "hbm", "achieved": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, args.riemann),
+                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": len(dur[0.5])},
+            "roofline_stage1": {"achieved": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9,
+                                "frac": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1, "avg_launch_ms": avg1, "launches": len(dur[1.0])},
+            "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
+                              "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
+        }
+        return res, st.u[2:2 + st.n0].clone()
 
-    # per-launch durations of the bulk stage launches on this rank (HIP events on the launch stream)
-    dur = {1.0: [], 0.5: []}
-    for w, e0, e1 in timers:
-        dur[w].append(e0.elapsed_time(e1))
-    avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
-    avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
-    rows_bulk = st.n0 - 2 * st.edge_rows
-    cells_launch = rows_bulk * n
+    primary = args.arith
+    other = "strict" if primary == "fast" else "fast"
+    res, u_primary = run_mode(primary)
+    res_other, u_other = (None, None) if args.single_arith else run_mode(other)
+    l1 = None
+    if u_other is not None:
+        s = (u_primary - u_other).abs().sum()
+        if world > 1:
+            dist.all_reduce(s)
+        l1 = float(s.item()) / (n * n * 5)
+    del u_primary, u_other
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n * n * args.steps / elapsed / 1e6
-        ach2 = cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9
-        ach1 = cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9
-        traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and world == 1 and n == 4096:
             try:
-                traffic = json.load(open(pmc)).get("stage2_%s_bytes_per_launch" % args.riemann)
+                table = json.load(open(pmc))
+                res["roofline"]["traffic"] = table.get("stage2_%s_%s_bytes_per_launch" % (primary, args.riemann))
+                if res_other:
+                    res_other["roofline"]["traffic"] = table.get("stage2_%s_%s_bytes_per_launch" % (other, args.riemann))
             except Exception:
-                traffic = None
+                pass
+        arith_note = {"strict": "strict: bit-identical to the reference CPU path (tests/test_gpu_parity.py, golden vectors from reference headers)",
+                      "fast": "fast: FMA + shared reciprocals, conserved-variable L1 <= 1e-12 vs the reference CPU path (tests/test_gpu_parity.py::test_fast_*)"}
         out = {
             "metric": "zone-updates/sec (Mcells/s) whole node, 2D Euler %d^2 PLM+%s RK2" % (n, args.riemann.upper()),
-            "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": res["value"], "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
                        "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage" % world,
-                       "arith": "strict (bit-exact with the reference CPU path)", "status_word": status},
-            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "euler2d_stage_kernel<%s,PLM,COMBINE> (second RK2 stage)" % args.riemann,
-                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": len(dur[0.5])},
-            "roofline_stage1": {"achieved": ach1, "frac": ach1 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1,
-                                "avg_launch_ms": avg1, "launches": len(dur[1.0])},
-            "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
-                              "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
+                       "arith": arith_note[primary], "status_word": res["status_word"]},
+            "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
+        if res_other:
+            out["arith_" + other] = {"note": arith_note[other], "value": res_other["value"], "ms_per_step": res_other["ms_per_step"],
+                                     "roofline": res_other["roofline"], "roofline_step": res_other["roofline_step"],
+                                     "status_word": res_other["status_word"]}
+            out["l1_fast_vs_strict_after_%d_steps" % (args.steps + args.warmup)] = l1
         if world == 1 and not args.no_cpu_baseline:
-            del st
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(n, gamma, args.theta, args.riemann)
             ref = cpu_reference(gamma, args.theta)

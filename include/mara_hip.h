@@ -113,6 +113,10 @@ int mh_euler_cart_fill_ghosts(const mh_euler_cart_desc* d, double* u, void* stre
 int mh_aos_to_soa(const double* aos_dev, double* soa_dev, int nq, int n0, size_t row_pitch, void* stream);
 int mh_soa_to_aos(const double* soa_dev, double* aos_dev, int nq, int n0, size_t row_pitch, void* stream);
 
+/* Measurement aid: copies ndoubles doubles with the stage kernels' access shape (8 B per lane). Used to
+ * calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count (MI355X_MICROARCH.md, HBM section). */
+int mh_calib_stream_copy(const double* src_dev, double* dst_dev, size_t ndoubles, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* Context API for compiled hosts (owns device memory and streams).           */
 /* Mirrors the solution_t value that the reference's drivers thread through   */

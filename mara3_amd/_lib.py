@@ -42,6 +42,7 @@ SYMBOLS = [
     ("mh_euler_cart_fill_ghosts", _i, [_descp, _dp, _vp]),
     ("mh_aos_to_soa", _i, [_dp, _dp, _i, _i, _sz, _vp]),
     ("mh_soa_to_aos", _i, [_dp, _dp, _i, _i, _sz, _vp]),
+    ("mh_calib_stream_copy", _i, [_dp, _dp, _sz, _vp]),
     ("mh_create", _i, [C.POINTER(_vp), _i]),
     ("mh_destroy", None, [_vp]),
     ("mh_last_error", C.c_char_p, [_vp]),

@@ -159,6 +159,12 @@ int mh_soa_to_aos(const double* soa_dev, double* aos_dev, int nq, int n0, size_t
     return MH_OK;
 }
 
+int mh_calib_stream_copy(const double* src_dev, double* dst_dev, size_t ndoubles, void* stream)
+{
+    MH_HIP_TRY(stream_copy_launch(src_dev, dst_dev, ndoubles, (hipStream_t) stream));
+    return MH_OK;
+}
+
 // ---- context -------------------------------------------------------------
 int mh_create(mh_ctx** out, int device_id)
 {

@@ -11,6 +11,7 @@ hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
 
 hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream);
 hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, size_t row_pitch, hipStream_t stream);
+hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStream_t stream);
 hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, size_t row_pitch, hipStream_t stream);
 
 // thread-local error text for the C ABI

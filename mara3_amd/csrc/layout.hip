@@ -50,6 +50,15 @@ void fill_ghost_rows_kernel(double* u, int nq, int n0, size_t row_pitch, int bc_
     }
 }
 
+// Known-byte-count stream with the stage kernels' access shape (8 B per lane, 512 B per wave instruction):
+// calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 for this pattern.
+__global__ __launch_bounds__(256)
+void stream_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
 static int grid_for(size_t n)
 {
     size_t b = (n + 255) / 256;
@@ -69,6 +78,12 @@ hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, siz
     const size_t ncell = (size_t) n0 * row_pitch;
     hipLaunchKernelGGL(transpose_kernel<false>, dim3(grid_for(ncell)), dim3(256), 0, stream,
                        soa, aos, nq, ncell, row_pitch);
+    return hipGetLastError();
+}
+
+hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, n);
     return hipGetLastError();
 }
 
