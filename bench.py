@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — zone-updates/s of the 2-D Euler PLM+HLLC RK2 sweep at 4096^2 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--riemann hllc|hlle] [--n 4096]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--riemann hllc|hlle] [--grid 4096]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="cells per axis of the global grid")
     ap.add_argument("--riemann", default="hllc", choices=["hllc", "hlle"])
     ap.add_argument("--theta", type=float, default=1.5)
     ap.add_argument("--chunk-rows", type=int, default=0)
@@ -128,6 +128,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "MARA_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N>1 code path on a one-GPU box
+        local_rank = int(os.environ["MARA_BENCH_FORCE_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))

@@ -49,10 +49,13 @@ class HipStage:
 class TorchDistExchange:
     """Ghost-row exchange with the axis-0 neighbours over torch.distributed (nccl = RCCL on GPUs, gloo on CPU)."""
 
-    def __init__(self, rank, world, periodic, group=None):
+    def __init__(self, rank, world, periodic, group=None, self_exchange=False):
+        """self_exchange: with a periodic domain on ONE rank, wrap around by sending to oneself instead of letting the
+        kernel copy the rows locally - exercises the whole send/recv + overlap machinery on a single GPU."""
         self.rank, self.world, self.group = rank, world, group
-        self.lo = rank - 1 if rank > 0 else (world - 1 if periodic and world > 1 else None)
-        self.hi = rank + 1 if rank < world - 1 else (0 if periodic and world > 1 else None)
+        wrap = periodic and (world > 1 or self_exchange)
+        self.lo = rank - 1 if rank > 0 else (world - 1 if wrap else None)
+        self.hi = rank + 1 if rank < world - 1 else (0 if wrap else None)
 
     def start(self, field, n0):
         """Post the sends of the two edge row-blocks and the receives into the two ghost row-blocks."""

@@ -1,0 +1,46 @@
+"""GPU test of the RCCL point-to-point path on ONE GPU: a periodic domain whose wrap-around is done by the
+rank sending its two edge row-blocks to ITSELF (ncclSend/ncclRecv to self inside one group). This drives the
+real mara3_amd.slab exchange code - message layout, group ordering when both neighbours are the same rank,
+MH_BC_EXTERNAL sides, edge/interior launch split and the two-stream overlap - and must equal the kernel's own
+local periodic handling bit for bit. (The 8-GPU run itself is the driver's; world_size > 1 is covered on CPU
+by tests/test_slab_gloo.py.)"""
+import os
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("riemann,arith", [("hlle", "strict"), ("hllc", "fast")])
+def test_self_exchange_equals_local_periodic(nccl_world1, overlap, riemann, arith):
+    from mara3_amd import setups
+    from mara3_amd.slab import SlabEulerStepper, TorchDistExchange
+    from mara3_amd import _lib as L
+    shape, gamma = (256, 300), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=3)
+    ref = SlabEulerStepper(shape, dl, gamma, 1.5, riemann, 2, "periodic", arith=arith)
+    ref.load_slab(u0)
+    ref.step(1e-3, 6)
+    st = SlabEulerStepper(shape, dl, gamma, 1.5, riemann, 2, "periodic", arith=arith, overlap=overlap,
+                          exchange=TorchDistExchange(0, 1, True, self_exchange=True))
+    assert st.has_neighbours and st.desc.bc_lo0 == L.BC_EXTERNAL and st.desc.bc_hi0 == L.BC_EXTERNAL
+    st.load_slab(u0)
+    st.step(1e-3, 6)
+    torch.cuda.synchronize()
+    assert torch.equal(st.slab(), ref.slab())
+    assert st.status() == 0
