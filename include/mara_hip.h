@@ -130,6 +130,22 @@ void mh_destroy(mh_ctx* ctx);
 const char* mh_last_error(const mh_ctx* ctx);      /* ctx may be NULL: last error of the calling thread */
 
 int  mh_euler_cart_configure(mh_ctx* ctx, const mh_euler_cart_desc* d, int rk_order);
+
+/* `sedov` sub-program (BASELINE config 1): 1-D spherical blast, piecewise constant + HLLE + forward Euler,
+ * volume-integrated conserved variables, reflecting inner / zero-gradient outer boundary.
+ * Replaces SedovProblem<HydroSystem>::next_solution (src/subprog_sedov.cpp:394-421). vertices_host[nz+1]
+ * are the radial vertices (src/subprog_sedov.cpp:366-371); geometry factors are built host-side with the
+ * reference's libm calls. After this call mh_upload / mh_step / mh_download act on the sedov state
+ * (AoS [nz][5], volume-integrated); mh_step(ctx, dt, n) takes dt = cfl*(r1 - r0) from the caller (:404-405). */
+typedef struct
+{
+    int    nz;              /* radial zones */
+    double gamma;           /* 4/3 in the reference (#define at src/subprog_sedov.cpp:48) */
+    int    system;          /* MH_SYSTEM_EULER (newtonian=1); MH_SYSTEM_SRHD: not yet */
+    int    arith;           /* MH_ARITH_STRICT */
+} mh_sedov_desc;
+int  mh_sedov_configure(mh_ctx* ctx, const mh_sedov_desc* d, const double* vertices_host);
+
 int  mh_upload(mh_ctx* ctx, const double* u_aos_host, size_t ncell);     /* host AoS -> device SoA (+ ghosts) */
 int  mh_download(mh_ctx* ctx, double* u_aos_host, size_t ncell);         /* device SoA -> host AoS */
 /* nsteps full time steps (all RK stages) with fixed dt, like the reference's cloud/sedov drivers. */

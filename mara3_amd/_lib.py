@@ -33,6 +33,10 @@ class EulerCartDesc(C.Structure):
     ]
 
 
+class SedovDesc(C.Structure):
+    _fields_ = [("nz", C.c_int), ("gamma", C.c_double), ("system", C.c_int), ("arith", C.c_int)]
+
+
 # every symbol include/mara_hip.h declares: (name, restype, argtypes)
 _vp, _dp, _sz, _i, _d = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
 _descp = C.POINTER(EulerCartDesc)
@@ -47,6 +51,7 @@ SYMBOLS = [
     ("mh_destroy", None, [_vp]),
     ("mh_last_error", C.c_char_p, [_vp]),
     ("mh_euler_cart_configure", _i, [_vp, _descp, _i]),
+    ("mh_sedov_configure", _i, [_vp, C.POINTER(SedovDesc), _vp]),
     ("mh_upload", _i, [_vp, _vp, _sz]),
     ("mh_download", _i, [_vp, _vp, _sz]),
     ("mh_step", _i, [_vp, _d, _i]),

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 #include <type_traits>
@@ -98,7 +99,10 @@ struct mh_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     bool configured = false, uploaded = false;
+    enum { KIND_NONE, KIND_EULER_CART, KIND_SEDOV } kind = KIND_NONE;
     mh_euler_cart_desc desc;
+    mh_sedov_desc sedov;
+    double* geom = nullptr;                  // sedov: dv[nz], da[nz+1], rc[nz]
     int rk_order = 2;
     size_t field_doubles = 0;
     double* field[2] = {nullptr, nullptr};   // [0] current solution, [1] stage scratch
@@ -187,6 +191,8 @@ int mh_create(mh_ctx** out, int device_id)
 static void release_fields(mh_ctx* c)
 {
     for (auto& f : c->field) { if (f) hipFree(f); f = nullptr; }
+    if (c->geom) hipFree(c->geom);
+    c->geom = nullptr;
     if (c->staging) hipFree(c->staging);
     c->staging = nullptr;
     c->staging_doubles = 0;
@@ -220,8 +226,62 @@ int mh_euler_cart_configure(mh_ctx* c, const mh_euler_cart_desc* d, int rk_order
         if (e != hipSuccess) { release_fields(c); set_error("hipMalloc of %zu bytes failed", c->field_doubles * sizeof(double)); return ctx_fail(c, MH_E_NOMEM); }
         hipMemsetAsync(f, 0, c->field_doubles * sizeof(double), c->stream);
     }
+    c->kind = mh_ctx::KIND_EULER_CART;
     c->configured = true;
     c->uploaded = false;
+    return MH_OK;
+}
+
+int mh_sedov_configure(mh_ctx* c, const mh_sedov_desc* d, const double* vertices_host)
+{
+    if (! c) return MH_E_INVALID;
+    if (! d || ! vertices_host || d->nz < 2) { set_error("sedov: need a descriptor, vertices and nz >= 2"); return ctx_fail(c, MH_E_INVALID); }
+    if (d->system != MH_SYSTEM_EULER) { set_error("sedov: only the newtonian (mara::euler) system is built"); return ctx_fail(c, MH_E_INVALID); }
+    if (d->arith != MH_ARITH_STRICT) { set_error("sedov: only MH_ARITH_STRICT is built"); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    release_fields(c);
+    const int n = d->nz;
+    // geometry exactly as the reference builds it, on the host (src/subprog_sedov.cpp:166-181, :408)
+    std::vector<double> geom((size_t) 3 * n + 1);
+    double* dv = geom.data();
+    double* da = dv + n;
+    double* rc = da + n + 1;
+    const double* v = vertices_host;
+    for (int i = 0; i < n; ++i)
+    {
+        dv[i] = (std::pow(v[i + 1], 3) - std::pow(v[i], 3)) / 3;
+        rc[i] = (v[i] + v[i + 1]) * 0.5;
+    }
+    for (int i = 0; i <= n; ++i) da[i] = v[i] * v[i];
+    if (hipMalloc((void**) &c->geom, geom.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(geom) failed"); return ctx_fail(c, MH_E_NOMEM); }
+    MH_HIP_TRY(hipMemcpy(c->geom, geom.data(), geom.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->field_doubles = (size_t) 5 * n;
+    for (auto& f : c->field)
+        if (hipMalloc((void**) &f, c->field_doubles * sizeof(double)) != hipSuccess) { release_fields(c); set_error("hipMalloc(field) failed"); return ctx_fail(c, MH_E_NOMEM); }
+    c->sedov = *d;
+    c->kind = mh_ctx::KIND_SEDOV;
+    c->configured = true;
+    c->uploaded = false;
+    return MH_OK;
+}
+
+// sedov fields are tiny: transpose AoS [nz][5] <-> SoA [5][nz] on the host
+static int sedov_transfer(mh_ctx* c, double* host_aos, size_t ncell, bool to_device)
+{
+    const size_t n = (size_t) c->sedov.nz;
+    if (ncell != n || ! host_aos) { set_error("sedov: expected %zu cells, got %zu", n, ncell); return MH_E_INVALID; }
+    std::vector<double> soa(5 * n);
+    if (to_device)
+    {
+        for (size_t i = 0; i < n; ++i) for (int q = 0; q < 5; ++q) soa[q * n + i] = host_aos[5 * i + q];
+        MH_HIP_TRY(hipMemcpy(c->field[0], soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    else
+    {
+        MH_HIP_TRY(hipStreamSynchronize(c->stream));
+        MH_HIP_TRY(hipMemcpy(soa.data(), c->field[0], soa.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) for (int q = 0; q < 5; ++q) host_aos[5 * i + q] = soa[q * n + i];
+    }
     return MH_OK;
 }
 
@@ -239,6 +299,13 @@ static int ensure_staging(mh_ctx* c, size_t doubles)
 int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
 {
     if (! c || ! c->configured) { set_error("upload before configure"); return ctx_fail(c, MH_E_STATE); }
+    if (c->kind == mh_ctx::KIND_SEDOV)
+    {
+        MH_HIP_TRY(hipSetDevice(c->device));
+        if (int rc = sedov_transfer(c, const_cast<double*>(u_aos_host), ncell, true)) return ctx_fail(c, rc);
+        c->uploaded = true;
+        return MH_OK;
+    }
     const mh_euler_cart_desc* d = &c->desc;
     const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
     if (ncell != expect || ! u_aos_host) { set_error("upload: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
@@ -255,6 +322,12 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
 int mh_download(mh_ctx* c, double* u_aos_host, size_t ncell)
 {
     if (! c || ! c->uploaded) { set_error("download before upload"); return ctx_fail(c, MH_E_STATE); }
+    if (c->kind == mh_ctx::KIND_SEDOV)
+    {
+        MH_HIP_TRY(hipSetDevice(c->device));
+        if (int rc = sedov_transfer(c, u_aos_host, ncell, false)) return ctx_fail(c, rc);
+        return MH_OK;
+    }
     const mh_euler_cart_desc* d = &c->desc;
     const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
     if (ncell != expect || ! u_aos_host) { set_error("download: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
@@ -288,6 +361,20 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
 {
     if (! c || ! c->uploaded) { set_error("step before upload"); return ctx_fail(c, MH_E_STATE); }
     MH_HIP_TRY(hipSetDevice(c->device));
+    if (c->kind == mh_ctx::KIND_SEDOV)
+    {
+        // forward Euler only (src/subprog_sedov.cpp:414)
+        const int n = c->sedov.nz;
+        const double* dv = c->geom;
+        const double* da = dv + n;
+        const double* rc = da + n + 1;
+        for (int s = 0; s < nsteps; ++s)
+        {
+            MH_HIP_TRY(sedov_stage_launch(c->field[0], c->field[1], dv, da, rc, n, c->sedov.gamma, dt, c->stream));
+            std::swap(c->field[0], c->field[1]);
+        }
+        return MH_OK;
+    }
     for (int s = 0; s < nsteps; ++s)
     {
         if (c->rk_order == 1)

@@ -77,6 +77,46 @@ class EulerCartSolver:
         return ms.value, n.value
 
 
+class SedovSolver:
+    """Host mirror of SedovProblem<mara::euler> (src/subprog_sedov.cpp): vertices + volume-integrated conserved state."""
+
+    def __init__(self, vertices, gamma=4.0 / 3, device=0):
+        self.lib = L.load_library()
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+        self.nz = self.vertices.size - 1
+        d = L.SedovDesc(nz=self.nz, gamma=gamma, system=0, arith=L.ARITH_STRICT)
+        self.ctx = C.c_void_p()
+        L.check(self.lib.mh_create(C.byref(self.ctx), device))
+        L.check(self.lib.mh_sedov_configure(self.ctx, C.byref(d), self.vertices.ctypes.data_as(C.c_void_p)), self.ctx)
+
+    def timestep(self, cfl=0.4):
+        return cfl * (self.vertices[1] - self.vertices[0])      # src/subprog_sedov.cpp:404-405
+
+    def upload(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape == (self.nz, 5)
+        L.check(self.lib.mh_upload(self.ctx, u.ctypes.data_as(C.c_void_p), self.nz), self.ctx)
+
+    def download(self):
+        u = np.empty((self.nz, 5))
+        L.check(self.lib.mh_download(self.ctx, u.ctypes.data_as(C.c_void_p), self.nz), self.ctx)
+        return u
+
+    def step(self, dt, nsteps=1):
+        L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
+
+    def close(self):
+        if self.ctx:
+            self.lib.mh_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceArray:
     """A raw device allocation made through the C ABI (tests of the per-function entry points)."""
 

@@ -1,0 +1,59 @@
+// Shared helpers of the compiled hosts: wall-clock timing of a step (the reference's
+// mara::time_execution, src/app_performance.hpp:76-82, which produces its `kzps`
+// figure), a throwing wrapper around the C ABI, and a raw binary state dump (the
+// HDF5 checkpoint format is out of scope this round).
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <sys/stat.h>
+#include "mara_hip.h"
+
+namespace host {
+
+inline void check(int rc, const mh_ctx* ctx, const char* what)
+{
+    if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(ctx));
+}
+
+template<typename F> double time_ms(F&& f)
+{
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    f();
+    return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+}
+
+// negative density etc. cannot throw on the device: map the status word to the reference's exception
+inline void throw_on_status(mh_ctx* ctx)
+{
+    int32_t status = 0;
+    check(mh_status_word(ctx, &status), ctx, "mh_status_word");
+    if (status & MH_STATUS_NEG_DENSITY) throw std::runtime_error("negative density in updated state");
+    if (status & MH_STATUS_NAN) throw std::runtime_error("nan in updated state");
+}
+
+// <outdir>/<name>: [int64 rank][int64 shape...][int64 nq][f64 time][int64 iteration][f64 vertices (1-D only)...][f64 data...]
+inline void dump_state(const std::string& outdir, const std::string& name, const std::vector<long>& shape, long nq,
+                       double time, long iteration, const std::vector<double>& vertices, const std::vector<double>& data)
+{
+    if (! outdir.empty()) mkdir(outdir.c_str(), 0755);
+    const std::string path = outdir.empty() ? name : outdir + "/" + name;
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (! f) throw std::runtime_error("cannot write " + path);
+    long rank = (long) shape.size();
+    std::fwrite(&rank, sizeof rank, 1, f);
+    std::fwrite(shape.data(), sizeof(long), shape.size(), f);
+    std::fwrite(&nq, sizeof nq, 1, f);
+    std::fwrite(&time, sizeof time, 1, f);
+    std::fwrite(&iteration, sizeof iteration, 1, f);
+    long nv = (long) vertices.size();
+    std::fwrite(&nv, sizeof nv, 1, f);
+    std::fwrite(vertices.data(), sizeof(double), vertices.size(), f);
+    std::fwrite(data.data(), sizeof(double), data.size(), f);
+    std::fclose(f);
+    std::printf("write %s\n", path.c_str());
+}
+
+} // namespace host

@@ -1,0 +1,101 @@
+// `sedov` sub-program on the MI355X engine: same options, initial condition, time
+// step, boundary conditions and run loop as the reference's subprog_sedov
+// (src/subprog_sedov.cpp; options :55-70, vertices :366-371, IC :353-363 and
+// :373-380, dt :404-405, loop :626-645, message :588-595), with the state resident
+// on the device and `next_solution` (:394-421) replaced by mh_step. Only the
+// newtonian (mara::euler) system is available this round.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "app_config.hpp"
+#include "app_subprogram.hpp"
+#include "host_common.hpp"
+
+namespace {
+
+constexpr double gamma_law_index = 4. / 3;   // src/subprog_sedov.cpp:48
+constexpr double cfl_number = 0.4;           // :49
+
+mara::config_t config_template()
+{
+    return mara::config_t()
+    .item("restart", "")
+    .item("outdir", "data")
+    .item("nr", 256)
+    .item("tfinal", 1.0)
+    .item("outer_radius", 100.0)
+    .item("explosion_pressure", 1.0)
+    .item("explosion_density", 1.0)
+    .item("density_index", 0.0)
+    .item("newtonian", 0)
+    .item("device", 0);
+}
+
+class subprog_sedov : public mara::sub_program_t
+{
+public:
+    int main(int argc, const char* argv[]) override
+    {
+        auto cfg = config_template().update(argc, argv);
+        if (! cfg.get_string("restart").empty()) throw std::invalid_argument("sedov: restart needs the HDF5 checkpoint reader (out of scope)");
+        if (cfg.get_int("newtonian") == 0) throw std::invalid_argument("sedov: run with newtonian=1 (the SRHD system is not built yet)");
+        cfg.pretty_print(stdout, "config");
+
+        // vertices: 10^linspace(-0.5, log10(R), int(decades*nr)+1)
+        const double decades = std::log10(cfg.get_double("outer_radius"));
+        const std::size_t count = std::size_t(int(decades * cfg.get_int("nr")) + 1);
+        std::vector<double> v(count);
+        for (std::size_t i = 0; i < count; ++i) v[i] = std::pow(10.0, -0.5 + (decades - -0.5) * i / (count - 1));
+        const std::size_t nz = count - 1;
+
+        // initial condition: to_conserved_density(P(r_c)) * dv   (:353-363, :380; physics_euler.hpp:209-220)
+        std::vector<double> u(5 * nz);
+        const double dindex = cfg.get_double("density_index");
+        for (std::size_t i = 0; i < nz; ++i)
+        {
+            const double r = (v[i] + v[i + 1]) * 0.5;
+            const double d = r < 1.0 ? cfg.get_double("explosion_density") : std::pow(r, -dindex);
+            const double p = r < 1.0 ? cfg.get_double("explosion_pressure") : std::pow(r, -dindex) * 1e-6;
+            const double dv = (std::pow(v[i + 1], 3) - std::pow(v[i], 3)) / 3;
+            const double U[5] = {d, d * 0.0, d * 0.0, d * 0.0, 0.5 * d * (0.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0) + p / (gamma_law_index - 1)};
+            for (int q = 0; q < 5; ++q) u[5 * i + q] = U[q] * dv;
+        }
+
+        mh_ctx* ctx = nullptr;
+        host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
+        mh_sedov_desc d = {int(nz), gamma_law_index, MH_SYSTEM_EULER, MH_ARITH_STRICT};
+        host::check(mh_sedov_configure(ctx, &d, v.data()), ctx, "mh_sedov_configure");
+        host::check(mh_upload(ctx, u.data(), nz), ctx, "mh_upload");
+
+        const double dt = cfl_number * (v[1] - v[0]);
+        const double tfinal = cfg.get_double("tfinal");
+        double time = 0.0;
+        long iteration = 0;
+
+        while (time < tfinal)
+        {
+            const double ms = host::time_ms([&] {
+                host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
+                host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+            });
+            time += dt;
+            iteration += 1;
+            if (iteration % 100 == 0)
+            {
+                host::throw_on_status(ctx);
+                std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, count / ms);   // counts vertices, like the reference (:592)
+            }
+        }
+        host::throw_on_status(ctx);
+        host::check(mh_download(ctx, u.data(), nz), ctx, "mh_download");
+        host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nz)}, 5, time, iteration, v, u);
+        mh_destroy(ctx);
+        return 0;
+    }
+
+    std::string name() const override { return "sedov"; }
+};
+
+} // namespace
+
+std::unique_ptr<mara::sub_program_t> make_subprog_sedov() { return std::make_unique<subprog_sedov>(); }

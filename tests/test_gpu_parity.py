@@ -302,3 +302,20 @@ def test_fast_baseline_size_l1_vs_strict(eng):
         assert err <= L1_TOL, (riemann, err)
         for q in (0, 4):
             assert abs(out["fast"][..., q].sum() - u0[..., q].sum()) <= 1e-11 * abs(u0[..., q].sum())
+
+
+def test_sedov_newtonian_bit_exact_vs_reference(eng):
+    """BASELINE config 1: `mara sedov newtonian=1 nr=256` (512 zones, PCM + HLLE + forward Euler, gamma = 4/3,
+    CFL 0.4) after 1, 10 and 100 steps against vectors from the reference headers."""
+    g = golden("sedov_newtonian_nr256")
+    s = eng.SedovSolver(g["vertices"])
+    s.upload(g["u0"])
+    assert bits_equal(s.download(), g["u0"])
+    dt = s.timestep()
+    done = 0
+    for n in (1, 10, 100):
+        s.step(dt, n - done)
+        done = n
+        got = s.download()
+        assert l1(got, g["u_%d" % n]) <= L1_TOL
+        assert bits_equal(got, g["u_%d" % n]), n
