@@ -37,7 +37,7 @@ def test_sedov_subprogram_matches_reference(tmp_path):
     g = golden("sedov_newtonian_nr256")
     dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
     for nsteps in (10, 100):
-        stdout = run(["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % ((nsteps - 0.5) * dt), "outdir=out%d" % nsteps], str(tmp_path))
+        stdout = run(["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % float((nsteps - 0.5) * dt), "outdir=out%d" % nsteps], str(tmp_path))
         d = read_dump(os.path.join(tmp_path, "out%d" % nsteps, "final.bin"))
         assert d["iteration"] == nsteps
         assert bits_equal(d["vertices"], g["vertices"])
@@ -57,7 +57,7 @@ def test_sedov_subprogram_option_errors(tmp_path):
 def test_euler2d_subprogram_matches_reference(tmp_path):
     g = golden("euler2d_blast64_plm15_rk2")
     dt = float(g["dt"])
-    run(["euler2d", "n=64", "tfinal=%r" % (9.5 * dt), "riemann=hlle", "plm_theta=1.5", "rk_order=2", "steps_per_call=3"], str(tmp_path))
+    run(["euler2d", "n=64", "tfinal=%r" % float(9.5 * dt), "riemann=hlle", "plm_theta=1.5", "rk_order=2", "steps_per_call=3"], str(tmp_path))
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     assert d["iteration"] == 10
     assert bits_equal(d["data"], g["u_10"])
