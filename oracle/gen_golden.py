@@ -91,8 +91,77 @@ def random_prims(rng, n):
     return P
 
 
+def ref_srhd(mode, n, a0, a1, data):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        np.ascontiguousarray(data, dtype=np.float64).tofile(fin)
+        run_ref("funcs_srhd_ref", [mode, n, hexf(a0), hexf(a1), fin, fout])
+        return np.fromfile(fout)
+
+
+def ref_cloud(nr, num_decades, rk, method, theta, nsteps):
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "c")
+        run_ref("cloud_ref", [nr, hexf(num_decades), rk, method, hexf(theta), nsteps, prefix])
+        rv, qv = np.fromfile(prefix + ".rv.f64"), np.fromfile(prefix + ".qv.f64")
+        n0, n1 = rv.size - 1, qv.size - 1
+        meta = np.fromfile(prefix + ".meta.f64")
+        return dict(rv=rv, qv=qv, u0=np.fromfile(prefix + ".u0.f64").reshape(n0, n1, 5),
+                    un=np.fromfile(prefix + ".un.f64").reshape(n0, n1, 5),
+                    inflow=np.fromfile(prefix + ".inflow.f64").reshape(nsteps, n1, 5), dt=meta[0], tfloor=meta[1],
+                    rk=rk, method=method, theta=theta, nsteps=nsteps)
+
+
+def random_srhd_prims(rng, n):
+    P = np.empty((n, 5))
+    P[:, 0] = 10.0 ** rng.uniform(-3, 2, n)
+    u = 10.0 ** rng.uniform(-3, 1.3, n)                       # |gamma-beta| up to ~20
+    dirs = rng.standard_normal((n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    P[:, 1:4] = dirs * u[:, None]
+    P[:, 4] = P[:, 0] * 10.0 ** rng.uniform(-6, 1, n)         # cold to relativistically hot
+    return P
+
+
+def gen_srhd(rng):
+    n = 4096
+    g = 4.0 / 3
+    P, Pr = random_srhd_prims(rng, n), random_srhd_prims(rng, n)
+    Pr[:512] = P[:512] * (1.0 + 1e-3 * rng.standard_normal((512, 5)))
+    P[512:520, 1:4] = 0.0
+    out = {"Pl": P, "Pr": Pr}
+    U = ref_srhd("p2c", n, g, 0, P).reshape(n, 5)
+    out["U"] = U
+    r = ref_srhd("c2p", n, g, 0.0, U).reshape(n, 6)
+    out["c2p"], out["c2p_threw"] = r[:, :5], r[:, 5]
+    # floor-active and failing cases: scale tau down so that the recovered pressure is tiny / negative
+    Ubad = U.copy()
+    Ubad[:, 4] *= rng.uniform(0.0, 1.0, n) ** 4
+    out["Ubad"] = Ubad
+    for name, floor in (("floor", 1e-8), ("nofloor", 0.0)):
+        r = ref_srhd("c2p", n, g, floor, Ubad).reshape(n, 6)
+        out["c2p_bad_" + name], out["c2p_bad_" + name + "_threw"] = r[:, :5], r[:, 5]
+    for axis in range(3):
+        out["hlle_%d" % axis] = ref_srhd("hlle", n, g, axis, np.hstack([P, Pr])).reshape(n, 5)
+        out["lam_%d" % axis] = ref_srhd("lam", n, g, axis, P).reshape(n, 2)
+    rr = 10.0 ** rng.uniform(0, 2, n)
+    qq = rng.uniform(1e-3, np.pi - 1e-3, n)
+    out["src_r"], out["src_q"] = rr, qq
+    out["src"] = ref_srhd("src", n, g, 0, np.hstack([P, rr[:, None], qq[:, None]])).reshape(n, 5)
+    np.savez_compressed(os.path.join(OUT, "srhd_functions.npz"), **out)
+    print("srhd functions ok; c2p throws:", int(out["c2p_threw"].sum()), int(out["c2p_bad_floor_threw"].sum()), int(out["c2p_bad_nofloor_threw"].sum()))
+
+    for name, args in (("cloud_nr32_plm_rk2", (32, 1.0, 2, 2, 1.2, 3)), ("cloud_nr32_plm_rk1", (32, 1.0, 1, 2, 1.2, 4)),
+                       ("cloud_nr24_pcm_rk1", (24, 1.0, 1, 1, 1.2, 4)), ("cloud_nr20x2dec_plm_rk2", (20, 2.0, 2, 2, 1.5, 2)),
+                       ("cloud_nr70_plm_rk2", (70, 1.0, 2, 2, 1.2, 2))):
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **ref_cloud(*args))
+        print(name, "ok")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "srhd":
+        return gen_srhd(np.random.default_rng(20260202))
     rng = np.random.default_rng(20260101)
 
     # ---- a1: plm_gradient, incl. sign changes, zeros, equal neighbours, signed zeros ----

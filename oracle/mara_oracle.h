@@ -82,6 +82,33 @@ void mo_sedov_initial(size_t nz, const double* vertices, double gamma, double ex
 double mo_sedov_timestep(const double* vertices, double cfl);
 void mo_sedov_advance(size_t nz, const double* vertices, double gamma, double dt, const double* u0, double* u1);
 
+/* ---- mara::srhd and the `cloud` stage (mara_oracle_srhd.c) ------------------ */
+enum { MO_C2P_NOT_CONVERGED = 4, MO_C2P_NEG_DENSITY = 1, MO_C2P_NEG_PRESSURE = 2, MO_C2P_NAN = 8 };
+/* physics_srhd.hpp:364-451 ; returns failure bits where the reference throws */
+int  mo_srhd_recover_primitive(const double U[5], double gamma, double temperature_floor, double P[5]);
+/* physics_srhd.hpp:213-227 */
+void mo_srhd_to_conserved_density(const double P[5], double gamma, double U[5]);
+/* physics_srhd.hpp:259-270 */
+void mo_srhd_flux(const double P[5], const double U[5], int axis, double F[5]);
+/* physics_srhd.hpp:283-295 */
+void mo_srhd_wavespeeds(const double P[5], int axis, double gamma, double lam[2]);
+/* physics_srhd.hpp:466-483 */
+void mo_srhd_riemann_hlle(const double Pl[5], const double Pr[5], int axis, double gamma, double F[5]);
+/* physics_srhd.hpp:309-326 */
+void mo_srhd_source_terms(const double P[5], double r, double theta, double gamma, double S[5]);
+void mo_srhd_recover_primitive_n(size_t n, const double* U, double gamma, double tfloor, double* P, int* status);
+void mo_srhd_to_conserved_density_n(size_t n, const double* P, double gamma, double* U);
+void mo_srhd_riemann_hlle_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, double* F);
+void mo_srhd_source_terms_n(size_t n, const double* P, const double* r, const double* theta, double gamma, double* S);
+/* subprog_cloud.cpp:260-290 : dAr[(nr+1)*nq], dAq[nr*(nq+1)], dv[nr*nq] */
+void mo_cloud_geometry(size_t nr, size_t nq, const double* rv, const double* qv, double* dAr, double* dAq, double* dv);
+/* subprog_cloud.cpp:511-584 ; u = cell-integrated conserved AoS [nr][nq][5]; inflow [nq][5] primitives */
+int  mo_cloud_advance(size_t nr, size_t nq, const double* rv, const double* qv, const double* inflow,
+                      double gamma, double plm_theta, double temperature_floor, double dt, const double* u0, double* u1);
+/* subprog_cloud.cpp:676-697 ; inflow [nsteps][nq][5] */
+int  mo_cloud_run(size_t nr, size_t nq, const double* rv, const double* qv, const double* inflow, double gamma,
+                  double plm_theta, double temperature_floor, int rk_order, double dt, int nsteps, double* u);
+
 /* ---- integer / index work (bit-exact) ----------------------------------- */
 /* core_ndarray.hpp:820-836 : slab n of N over `count` rows -> [start, final) */
 void mo_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_);

@@ -58,6 +58,14 @@ def lib():
         _lib.mo_sedov_timestep.restype = C.c_double
         _lib.mo_sedov_timestep.argtypes = [dp, C.c_double]
         _lib.mo_sedov_advance.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, dp]
+        ip = C.POINTER(C.c_int)
+        _lib.mo_srhd_recover_primitive_n.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, ip]
+        _lib.mo_srhd_to_conserved_density_n.argtypes = [C.c_size_t, dp, C.c_double, dp]
+        _lib.mo_srhd_riemann_hlle_n.argtypes = [C.c_size_t, dp, dp, C.c_int, C.c_double, dp]
+        _lib.mo_srhd_source_terms_n.argtypes = [C.c_size_t, dp, dp, dp, C.c_double, dp]
+        _lib.mo_cloud_geometry.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, dp, dp]
+        _lib.mo_cloud_advance.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
+        _lib.mo_cloud_run.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, dp]
         sp = C.POINTER(C.c_size_t)
         _lib.mo_partition_rows.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
         _lib.mo_block_extent.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
@@ -170,3 +178,51 @@ def propose_block_decomposition(rank, nblocks):
     out = (C.c_ulong * 3)()
     lib().mo_propose_block_decomposition(rank, nblocks, out)
     return tuple(out[i] for i in range(rank))
+
+
+# ---- mara::srhd and the cloud stage ------------------------------------------------------------------------
+def srhd_recover_primitive(U, gamma=4.0 / 3, tfloor=0.0):
+    """Returns (P, status) with status bits C2P_* where the reference throws."""
+    U = _f64(U)
+    P = np.empty_like(U)
+    st = np.zeros(U.size // 5, dtype=np.int32)
+    lib().mo_srhd_recover_primitive_n(U.size // 5, _dp(U), gamma, tfloor, _dp(P), st.ctypes.data_as(C.POINTER(C.c_int)))
+    return P, st
+
+
+def srhd_to_conserved_density(P, gamma=4.0 / 3):
+    P = _f64(P)
+    U = np.empty_like(P)
+    lib().mo_srhd_to_conserved_density_n(P.size // 5, _dp(P), gamma, _dp(U))
+    return U
+
+
+def srhd_riemann_hlle(Pl, Pr, axis, gamma=4.0 / 3):
+    Pl, Pr = _f64(Pl), _f64(Pr)
+    F = np.empty_like(Pl)
+    lib().mo_srhd_riemann_hlle_n(Pl.size // 5, _dp(Pl), _dp(Pr), axis, gamma, _dp(F))
+    return F
+
+
+def srhd_source_terms(P, r, theta, gamma=4.0 / 3):
+    P, r, theta = _f64(P), _f64(r), _f64(theta)
+    S = np.empty_like(P)
+    lib().mo_srhd_source_terms_n(P.size // 5, _dp(P), _dp(r), _dp(theta), gamma, _dp(S))
+    return S
+
+
+def cloud_geometry(rv, qv):
+    rv, qv = _f64(rv), _f64(qv)
+    nr, nq = rv.size - 1, qv.size - 1
+    dAr, dAq, dv = np.empty((nr + 1, nq)), np.empty((nr, nq + 1)), np.empty((nr, nq))
+    lib().mo_cloud_geometry(nr, nq, _dp(rv), _dp(qv), _dp(dAr), _dp(dAq), _dp(dv))
+    return dAr, dAq, dv
+
+
+def cloud_run(u, rv, qv, inflow, dt, nsteps, rk=1, theta=1.2, tfloor=1e-8, gamma=4.0 / 3):
+    """u: [nr][nq][5] cell-integrated conserved; inflow: [nsteps][nq][5]. Returns (u_new, status)."""
+    u, rv, qv, inflow = _f64(u).copy(), _f64(rv), _f64(qv), _f64(inflow)
+    nr, nq = u.shape[0], u.shape[1]
+    assert inflow.shape == (nsteps, nq, 5)
+    st = lib().mo_cloud_run(nr, nq, _dp(rv), _dp(qv), _dp(inflow), gamma, theta, tfloor, rk, dt, nsteps, _dp(u))
+    return u, st
