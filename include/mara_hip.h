@@ -54,7 +54,7 @@ enum mh_system   { MH_SYSTEM_EULER = 0, MH_SYSTEM_ISO2D = 1, MH_SYSTEM_SRHD = 2 
 enum mh_riemann  { MH_RIEMANN_HLLE = 0, MH_RIEMANN_HLLC = 1 };
 /* boundary kinds. On axis 0 each side is set separately because a slab cut is
  * MH_BC_EXTERNAL (ghost rows are written by the caller's halo exchange). */
-enum mh_bc       { MH_BC_OUTFLOW = 0, MH_BC_PERIODIC = 1, MH_BC_EXTERNAL = 2, MH_BC_REFLECT = 3 };
+enum mh_bc       { MH_BC_OUTFLOW = 0, MH_BC_PERIODIC = 1, MH_BC_EXTERNAL = 2, MH_BC_REFLECT = 3, MH_BC_INFLOW = 4 };
 /* arithmetic contract: STRICT = no FMA contraction, IEEE division/sqrt: bit-identical
  * to the reference built for baseline x86-64. FAST = contraction allowed and shared
  * reciprocals; validated to the 1e-12 L1 bound of BASELINE.json, not bit-exact. */
@@ -146,6 +146,40 @@ typedef struct
 } mh_sedov_desc;
 int  mh_sedov_configure(mh_ctx* ctx, const mh_sedov_desc* d, const double* vertices_host);
 
+/* `cloud` sub-program (BASELINE config 4): 2-D axisymmetric spherical-polar SRHD, PCM/PLM + HLLE, RK1/RK2,
+ * cell-integrated conserved variables (D, S_r, S_theta, S_phi, tau). Replaces CloudProblem::advance and
+ * next_solution (src/subprog_cloud.cpp:511-584, :676-697). Axis 0 = radius (the slab axis), axis 1 = polar angle.
+ * Inner radial boundary: nozzle inflow given as PRIMITIVES per polar cell (src/subprog_cloud.cpp:466-493; the
+ * host evaluates the jet model at the step-start time and passes the row); outer: zero-gradient; poles: zero
+ * slope in the pole cells and zero flux through the pole faces (:563, :573).                                  */
+typedef struct
+{
+    int    nr, nq;              /* LOCAL radial rows on this device, polar cells */
+    int    nr_global;           /* radial cells of the whole grid (vertex array has nr_global + 1 entries) */
+    int    row_offset;          /* global index of local row 0 (nd::partition_shape slab) */
+    double gamma;               /* 4/3 in the reference (#define at src/subprog_cloud.cpp:52) */
+    double plm_theta;           /* < 0: reconstruct_method 1 (piecewise constant) */
+    double temperature_floor;   /* recover_primitive's floor (0 = none) */
+    int    bc_lo0, bc_hi0;      /* MH_BC_INFLOW / MH_BC_OUTFLOW on physical sides, MH_BC_EXTERNAL on slab cuts */
+    int    arith;               /* MH_ARITH_STRICT */
+    int    chunk_rows;          /* rows marched per wave (0 = default) */
+} mh_cloud_desc;
+
+/* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] */
+size_t mh_cloud_geometry_doubles(const mh_cloud_desc* d);
+/* Host side: fill that block from the vertex arrays with the reference's libm calls
+ * (dmu_j = -cos q_{j+1} - -cos q_j, sin q_j, cot = tan(pi/2 - (q_j + q_{j+1})/2); src/subprog_cloud.cpp:260-290,
+ * src/physics_srhd.hpp:314). */
+int  mh_cloud_pack_geometry(const mh_cloud_desc* d, const double* r_vertices, const double* q_vertices, double* geom_host);
+/* One stage over local rows [row_begin, row_end) (stateless launcher; all pointers DEVICE; inflow_dev = [5][nq]). */
+int  mh_cloud_stage(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in,
+                    const double* u_base, double* u_out, double dt, double stage_weight, int row_begin, int row_end,
+                    int32_t* status, void* stream);
+/* Context form (single device, both radial sides physical). After mh_cloud_configure, mh_upload / mh_step /
+ * mh_download act on the cloud state (AoS [nr][nq][5]); mh_cloud_set_inflow takes host AoS [nq][5] primitives. */
+int  mh_cloud_configure(mh_ctx* ctx, const mh_cloud_desc* d, const double* r_vertices_host, const double* q_vertices_host, int rk_order);
+int  mh_cloud_set_inflow(mh_ctx* ctx, const double* inflow_prims_host);
+
 int  mh_upload(mh_ctx* ctx, const double* u_aos_host, size_t ncell);     /* host AoS -> device SoA (+ ghosts) */
 int  mh_download(mh_ctx* ctx, double* u_aos_host, size_t ncell);         /* device SoA -> host AoS */
 /* nsteps full time steps (all RK stages) with fixed dt, like the reference's cloud/sedov drivers. */
@@ -168,6 +202,14 @@ int mh_plm_gradient_n(size_t n, const double* yl, const double* y0, const double
 int mh_euler_recover_primitive_n(size_t n, const double* U, double gamma, double temperature_floor, double* P, int arith, void* stream);
 int mh_euler_to_conserved_n(size_t n, const double* P, double gamma, double* U, int arith, void* stream);
 int mh_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, int riemann, double* F, int arith, void* stream);
+
+/* mara::srhd (src/physics_srhd.hpp): recover_primitive :364-451 (status[i] = OR of mh_status bits where the
+ * reference throws), to_conserved_density :213-227, riemann_hlle :466-483, spherical_geometry_source_terms :309-326
+ * (cot_theta[i] = tan(pi/2 - theta_i) evaluated by the caller, as the host does for the cloud geometry). */
+int mh_srhd_recover_primitive_n(size_t n, const double* U, double gamma, double temperature_floor, double* P, int32_t* status, void* stream);
+int mh_srhd_to_conserved_n(size_t n, const double* P, double gamma, double* U, void* stream);
+int mh_srhd_riemann_hlle_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, double* F, void* stream);
+int mh_srhd_source_terms_n(size_t n, const double* P, const double* r, const double* cot_theta, double gamma, double* S, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Integer / index work (host side, bit-exact with the reference)             */

@@ -8,7 +8,7 @@ _LIB_PATH = os.path.join(_HERE, "libmara_hip.so")
 # enums of include/mara_hip.h
 OK = 0
 RIEMANN_HLLE, RIEMANN_HLLC = 0, 1
-BC_OUTFLOW, BC_PERIODIC, BC_EXTERNAL, BC_REFLECT = 0, 1, 2, 3
+BC_OUTFLOW, BC_PERIODIC, BC_EXTERNAL, BC_REFLECT, BC_INFLOW = 0, 1, 2, 3, 4
 ARITH_STRICT, ARITH_FAST = 0, 1
 STATUS_NEG_DENSITY, STATUS_NEG_PRESSURE, STATUS_C2P_FAILED, STATUS_NAN = 1, 2, 4, 8
 
@@ -37,6 +37,12 @@ class SedovDesc(C.Structure):
     _fields_ = [("nz", C.c_int), ("gamma", C.c_double), ("system", C.c_int), ("arith", C.c_int)]
 
 
+class CloudDesc(C.Structure):
+    _fields_ = [("nr", C.c_int), ("nq", C.c_int), ("nr_global", C.c_int), ("row_offset", C.c_int), ("gamma", C.c_double),
+                ("plm_theta", C.c_double), ("temperature_floor", C.c_double), ("bc_lo0", C.c_int), ("bc_hi0", C.c_int),
+                ("arith", C.c_int), ("chunk_rows", C.c_int)]
+
+
 # every symbol include/mara_hip.h declares: (name, restype, argtypes)
 _vp, _dp, _sz, _i, _d = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
 _descp = C.POINTER(EulerCartDesc)
@@ -52,6 +58,11 @@ SYMBOLS = [
     ("mh_last_error", C.c_char_p, [_vp]),
     ("mh_euler_cart_configure", _i, [_vp, _descp, _i]),
     ("mh_sedov_configure", _i, [_vp, C.POINTER(SedovDesc), _vp]),
+    ("mh_cloud_geometry_doubles", _sz, [C.POINTER(CloudDesc)]),
+    ("mh_cloud_pack_geometry", _i, [C.POINTER(CloudDesc), _vp, _vp, _vp]),
+    ("mh_cloud_stage", _i, [C.POINTER(CloudDesc), _dp, _dp, _dp, _dp, _dp, _d, _d, _i, _i, _vp, _vp]),
+    ("mh_cloud_configure", _i, [_vp, C.POINTER(CloudDesc), _vp, _vp, _i]),
+    ("mh_cloud_set_inflow", _i, [_vp, _vp]),
     ("mh_upload", _i, [_vp, _vp, _sz]),
     ("mh_download", _i, [_vp, _vp, _sz]),
     ("mh_step", _i, [_vp, _d, _i]),
@@ -64,6 +75,10 @@ SYMBOLS = [
     ("mh_euler_recover_primitive_n", _i, [_sz, _dp, _d, _d, _dp, _i, _vp]),
     ("mh_euler_to_conserved_n", _i, [_sz, _dp, _d, _dp, _i, _vp]),
     ("mh_euler_riemann_n", _i, [_sz, _dp, _dp, _i, _d, _i, _dp, _i, _vp]),
+    ("mh_srhd_recover_primitive_n", _i, [_sz, _dp, _d, _d, _dp, _vp, _vp]),
+    ("mh_srhd_to_conserved_n", _i, [_sz, _dp, _d, _dp, _vp]),
+    ("mh_srhd_riemann_hlle_n", _i, [_sz, _dp, _dp, _i, _d, _dp, _vp]),
+    ("mh_srhd_source_terms_n", _i, [_sz, _dp, _dp, _dp, _d, _dp, _vp]),
     ("mh_partition_rows", None, [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
     ("mh_device_count", _i, []),

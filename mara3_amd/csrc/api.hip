@@ -11,6 +11,7 @@
 #include "launch.hpp"
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
+#include "srhd_device.hpp"
 
 namespace mh {
 
@@ -90,6 +91,31 @@ __global__ void riemann_kernel(size_t n, const double* Pl, const double* Pr, dou
     if (i < n) store5(F + 5 * i, A::template flux<RIEMANN, AXIS>(load5(Pl + 5 * i), load5(Pr + 5 * i), A::gamma_law(gamma)));
 }
 
+__global__ void srhd_c2p_kernel(size_t n, const double* U, double gamma, double tfloor, double* P, int32_t* status)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    State5 Pi;
+    status[i] = srhd::recover_primitive(load5(U + 5 * i), srhd::make_gamma(gamma), tfloor, Pi);
+    store5(P + 5 * i, Pi);
+}
+__global__ void srhd_p2c_kernel(size_t n, const double* P, double gamma, double* U)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(U + 5 * i, srhd::to_conserved_density(load5(P + 5 * i), srhd::make_gamma(gamma)));
+}
+template<int AXIS>
+__global__ void srhd_hlle_kernel(size_t n, const double* Pl, const double* Pr, double gamma, double* F)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(F + 5 * i, srhd::riemann_hlle<AXIS>(load5(Pl + 5 * i), load5(Pr + 5 * i), srhd::make_gamma(gamma)));
+}
+__global__ void srhd_src_kernel(size_t n, const double* P, const double* r, const double* cotq, double gamma, double* S)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store5(S + 5 * i, srhd::source_terms(load5(P + 5 * i), r[i], cotq[i], srhd::make_gamma(gamma)));
+}
+
 } // namespace mh
 
 using namespace mh;
@@ -99,9 +125,11 @@ struct mh_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     bool configured = false, uploaded = false;
-    enum { KIND_NONE, KIND_EULER_CART, KIND_SEDOV } kind = KIND_NONE;
+    enum { KIND_NONE, KIND_EULER_CART, KIND_SEDOV, KIND_CLOUD } kind = KIND_NONE;
     mh_euler_cart_desc desc;
     mh_sedov_desc sedov;
+    mh_cloud_desc cloud;
+    double* inflow = nullptr;                // cloud: [5][nq] inner-ghost primitives
     double* geom = nullptr;                  // sedov: dv[nz], da[nz+1], rc[nz]
     int rk_order = 2;
     size_t field_doubles = 0;
@@ -193,6 +221,8 @@ static void release_fields(mh_ctx* c)
     for (auto& f : c->field) { if (f) hipFree(f); f = nullptr; }
     if (c->geom) hipFree(c->geom);
     c->geom = nullptr;
+    if (c->inflow) hipFree(c->inflow);
+    c->inflow = nullptr;
     if (c->staging) hipFree(c->staging);
     c->staging = nullptr;
     c->staging_doubles = 0;
@@ -265,6 +295,95 @@ int mh_sedov_configure(mh_ctx* c, const mh_sedov_desc* d, const double* vertices
     return MH_OK;
 }
 
+static int check_cloud(const mh_cloud_desc* d)
+{
+    if (! d) { set_error("null descriptor"); return MH_E_INVALID; }
+    if (d->nr < 2 || d->nq < 3) { set_error("cloud: need nr >= 2 and nq >= 3"); return MH_E_INVALID; }
+    if (d->row_offset < 0 || d->row_offset + d->nr > d->nr_global) { set_error("cloud: slab [%d,%d) outside the global grid of %d rows", d->row_offset, d->row_offset + d->nr, d->nr_global); return MH_E_INVALID; }
+    if (d->arith != MH_ARITH_STRICT) { set_error("cloud: only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (d->bc_lo0 != MH_BC_INFLOW && d->bc_lo0 != MH_BC_EXTERNAL) { set_error("cloud: bc_lo0 must be inflow or external"); return MH_E_INVALID; }
+    if (d->bc_hi0 != MH_BC_OUTFLOW && d->bc_hi0 != MH_BC_EXTERNAL) { set_error("cloud: bc_hi0 must be outflow or external"); return MH_E_INVALID; }
+    if ((d->bc_lo0 == MH_BC_INFLOW) != (d->row_offset == 0) || (d->bc_hi0 == MH_BC_OUTFLOW) != (d->row_offset + d->nr == d->nr_global)) { set_error("cloud: physical boundary flags do not match the slab position"); return MH_E_INVALID; }
+    if (!(d->gamma > 1.0)) { set_error("gamma must be > 1"); return MH_E_INVALID; }
+    return MH_OK;
+}
+
+size_t mh_cloud_geometry_doubles(const mh_cloud_desc* d)
+{
+    return d ? (size_t) (d->nr_global + 1) + d->nq + (d->nq + 1) + d->nq : 0;
+}
+
+int mh_cloud_pack_geometry(const mh_cloud_desc* d, const double* rv, const double* qv, double* out)
+{
+    if (! d || ! rv || ! qv || ! out) { set_error("cloud geometry: null argument"); return MH_E_INVALID; }
+    double* prv = out;
+    double* dmu = prv + d->nr_global + 1;
+    double* sinq = dmu + d->nq;
+    double* cotq = sinq + d->nq + 1;
+    for (int i = 0; i <= d->nr_global; ++i) prv[i] = rv[i];
+    for (int j = 0; j < d->nq; ++j)
+    {
+        dmu[j] = -std::cos(qv[j + 1]) - -std::cos(qv[j]);
+        cotq[j] = std::tan(M_PI_2 - (qv[j] + qv[j + 1]) * 0.5);
+    }
+    for (int j = 0; j <= d->nq; ++j) sinq[j] = std::sin((qv[j] + qv[j]) * 0.5);
+    return MH_OK;
+}
+
+int mh_cloud_stage(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in,
+                   const double* u_base, double* u_out, double dt, double stage_weight, int row_begin, int row_end,
+                   int32_t* status, void* stream)
+{
+    if (int rc = check_cloud(d)) return rc;
+    if (! geom_dev || ! u_in || ! u_out || u_in == u_out) { set_error("cloud stage: bad field pointers"); return MH_E_INVALID; }
+    if (d->bc_lo0 == MH_BC_INFLOW && ! inflow_dev) { set_error("cloud stage: inflow row missing"); return MH_E_INVALID; }
+    if (stage_weight != 1.0 && ! u_base) { set_error("cloud stage: combine needs u_base"); return MH_E_INVALID; }
+    if (row_begin < 0 || row_end > d->nr || row_begin > row_end) { set_error("cloud stage: bad row range"); return MH_E_INVALID; }
+    MH_HIP_TRY(cloud_stage_launch(d, geom_dev, inflow_dev, u_in, u_base, u_out, dt, stage_weight, row_begin, row_end, status, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_cloud_configure(mh_ctx* c, const mh_cloud_desc* d, const double* rv, const double* qv, int rk_order)
+{
+    if (! c) return MH_E_INVALID;
+    if (int rc = check_cloud(d)) return ctx_fail(c, rc);
+    if (d->bc_lo0 != MH_BC_INFLOW || d->bc_hi0 != MH_BC_OUTFLOW) { set_error("cloud context: single-device form needs both radial sides physical"); return ctx_fail(c, MH_E_INVALID); }
+    if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    release_fields(c);
+    std::vector<double> geom(mh_cloud_geometry_doubles(d));
+    if (int rc = mh_cloud_pack_geometry(d, rv, qv, geom.data())) return ctx_fail(c, rc);
+    if (hipMalloc((void**) &c->geom, geom.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(geom) failed"); return ctx_fail(c, MH_E_NOMEM); }
+    MH_HIP_TRY(hipMemcpy(c->geom, geom.data(), geom.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (hipMalloc((void**) &c->inflow, (size_t) 5 * d->nq * sizeof(double)) != hipSuccess) { release_fields(c); set_error("hipMalloc(inflow) failed"); return ctx_fail(c, MH_E_NOMEM); }
+    MH_HIP_TRY(hipMemset(c->inflow, 0, (size_t) 5 * d->nq * sizeof(double)));
+    c->field_doubles = (size_t) 5 * (d->nr + 4) * d->nq;
+    for (auto& f : c->field)
+    {
+        if (hipMalloc((void**) &f, c->field_doubles * sizeof(double)) != hipSuccess) { release_fields(c); set_error("hipMalloc(field) failed"); return ctx_fail(c, MH_E_NOMEM); }
+        MH_HIP_TRY(hipMemset(f, 0, c->field_doubles * sizeof(double)));
+    }
+    c->cloud = *d;
+    c->rk_order = rk_order;
+    c->kind = mh_ctx::KIND_CLOUD;
+    c->configured = true;
+    c->uploaded = false;
+    return MH_OK;
+}
+
+int mh_cloud_set_inflow(mh_ctx* c, const double* inflow_aos)
+{
+    if (! c || c->kind != mh_ctx::KIND_CLOUD || ! inflow_aos) { set_error("set_inflow: not a cloud context"); return ctx_fail(c, MH_E_STATE); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    const size_t nq = (size_t) c->cloud.nq;
+    std::vector<double> soa(5 * nq);
+    for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_aos[5 * j + q];
+    // stream-ordered after the stages already queued; the staging vector is consumed before return
+    MH_HIP_TRY(hipStreamSynchronize(c->stream));
+    MH_HIP_TRY(hipMemcpy(c->inflow, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MH_OK;
+}
+
 // sedov fields are tiny: transpose AoS [nz][5] <-> SoA [5][nz] on the host
 static int sedov_transfer(mh_ctx* c, double* host_aos, size_t ncell, bool to_device)
 {
@@ -307,13 +426,16 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
         return MH_OK;
     }
     const mh_euler_cart_desc* d = &c->desc;
-    const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
+    const bool cloud = c->kind == mh_ctx::KIND_CLOUD;
+    const int n0 = cloud ? c->cloud.nr : d->n[0];
+    const size_t pitch = cloud ? (size_t) c->cloud.nq : row_pitch_of(d);
+    const size_t expect = (size_t) n0 * pitch;
     if (ncell != expect || ! u_aos_host) { set_error("upload: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
     MH_HIP_TRY(hipSetDevice(c->device));
     if (int rc = ensure_staging(c, ncell * 5)) return ctx_fail(c, rc);
     MH_HIP_TRY(hipMemcpyAsync(c->staging, u_aos_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    MH_HIP_TRY(aos_to_soa_launch(c->staging, c->field[0], 5, d->n[0], row_pitch_of(d), c->stream));
-    MH_HIP_TRY(fill_ghost_rows_launch(c->field[0], 5, d->n[0], row_pitch_of(d), d->bc_lo0, d->bc_hi0, c->stream));
+    MH_HIP_TRY(aos_to_soa_launch(c->staging, c->field[0], 5, n0, pitch, c->stream));
+    if (! cloud) MH_HIP_TRY(fill_ghost_rows_launch(c->field[0], 5, n0, pitch, d->bc_lo0, d->bc_hi0, c->stream));
     MH_HIP_TRY(hipStreamSynchronize(c->stream));
     c->uploaded = true;
     return MH_OK;
@@ -329,11 +451,14 @@ int mh_download(mh_ctx* c, double* u_aos_host, size_t ncell)
         return MH_OK;
     }
     const mh_euler_cart_desc* d = &c->desc;
-    const size_t expect = (size_t) d->n[0] * row_pitch_of(d);
+    const bool cloud = c->kind == mh_ctx::KIND_CLOUD;
+    const int n0 = cloud ? c->cloud.nr : d->n[0];
+    const size_t pitch = cloud ? (size_t) c->cloud.nq : row_pitch_of(d);
+    const size_t expect = (size_t) n0 * pitch;
     if (ncell != expect || ! u_aos_host) { set_error("download: expected %zu cells, got %zu", expect, ncell); return ctx_fail(c, MH_E_INVALID); }
     MH_HIP_TRY(hipSetDevice(c->device));
     if (int rc = ensure_staging(c, ncell * 5)) return ctx_fail(c, rc);
-    MH_HIP_TRY(soa_to_aos_launch(c->field[0], c->staging, 5, d->n[0], row_pitch_of(d), c->stream));
+    MH_HIP_TRY(soa_to_aos_launch(c->field[0], c->staging, 5, n0, pitch, c->stream));
     MH_HIP_TRY(hipMemcpyAsync(u_aos_host, c->staging, ncell * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     MH_HIP_TRY(hipStreamSynchronize(c->stream));
     return MH_OK;
@@ -372,6 +497,24 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
         {
             MH_HIP_TRY(sedov_stage_launch(c->field[0], c->field[1], dv, da, rc, n, c->sedov.gamma, dt, c->stream));
             std::swap(c->field[0], c->field[1]);
+        }
+        return MH_OK;
+    }
+    if (c->kind == mh_ctx::KIND_CLOUD)
+    {
+        const mh_cloud_desc* d = &c->cloud;
+        for (int s = 0; s < nsteps; ++s)
+        {
+            if (c->rk_order == 1)
+            {
+                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[0], nullptr, c->field[1], dt, 1.0, 0, d->nr, c->status, c->stream));
+                std::swap(c->field[0], c->field[1]);
+            }
+            else
+            {
+                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[0], nullptr, c->field[1], dt, 1.0, 0, d->nr, c->status, c->stream));
+                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[1], c->field[0], c->field[0], dt, 0.5, 0, d->nr, c->status, c->stream));
+            }
         }
         return MH_OK;
     }
@@ -495,6 +638,42 @@ int mh_euler_riemann_n(size_t n, const double* Pl, const double* Pr, int axis, d
         case 5: MH_LAUNCH_R(1, 2); break;
     }
 #undef MH_LAUNCH_R
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_srhd_recover_primitive_n(size_t n, const double* U, double gamma, double tfloor, double* P, int32_t* status, void* stream)
+{
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(srhd_c2p_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, U, gamma, tfloor, P, status);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_srhd_to_conserved_n(size_t n, const double* P, double gamma, double* U, void* stream)
+{
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(srhd_p2c_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, gamma, U);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_srhd_riemann_hlle_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, double* F, void* stream)
+{
+    if (axis < 0 || axis > 2) { set_error("bad axis"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    hipStream_t s = (hipStream_t) stream;
+    if (axis == 0) hipLaunchKernelGGL(srhd_hlle_kernel<0>, grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F);
+    if (axis == 1) hipLaunchKernelGGL(srhd_hlle_kernel<1>, grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F);
+    if (axis == 2) hipLaunchKernelGGL(srhd_hlle_kernel<2>, grid1(n), dim3(256), 0, s, n, Pl, Pr, gamma, F);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_srhd_source_terms_n(size_t n, const double* P, const double* r, const double* cot_theta, double gamma, double* S, void* stream)
+{
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(srhd_src_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, r, cot_theta, gamma, S);
     MH_HIP_TRY(hipGetLastError());
     return MH_OK;
 }

@@ -1,0 +1,294 @@
+// `cloud` sub-program stage on gfx950: 2-D axisymmetric spherical-polar SRHD
+// (BASELINE config 4). Replaces one evaluation of CloudProblem::advance
+// (src/subprog_cloud.cpp:511-584) and, with stage_weight != 1, the RK combine
+// of next_solution (:682-695):
+//     p0 = recover_primitive(u0 / dv)                                   :533
+//     s0 = spherical_geometry_source_terms(p0, r_c, theta_c) * dv       :534
+//     lr = diff_r( hlle_r(PL, PR) * (-dAr) ),  lq = diff_q( hlle_q(PL, PR) * (-dAq) )   :572-573
+//     u1 = u0 + (lr + lq + s0) * dt                                     :574
+// Geometry (:260-290): dAr = ((r_i r_i) dmu_j) 2 pi, dAq = ((r_c dr) sin q_j) 2 pi,
+// dv = (((r^3_{i+1} - r^3_i) dmu_j) 2 pi) / 3. The theta-dependent factors
+// (dmu_j = -cos q_{j+1} - -cos q_j, sin q_j, cot theta_c) come from the host,
+// which evaluates them with the same libm as the reference; products are formed
+// here in the reference's order.
+// Boundary conditions: inner radial ghost = nozzle-inflow PRIMITIVES (:466-493),
+// outer = copy of the last row (:503-509), radial ghost slopes = edge slope * 0
+// (extend_zeros on G, :563); polar: slopes of the two pole cells = neighbour's
+// slope * 0, and the pole-face fluxes = neighbouring face flux * 0 (:573).
+//
+// Same wave-marching structure as euler2d.hip: a wavefront owns 60 polar columns
+// and marches radially; radial fluxes are reused between iterations, polar
+// neighbours move through DPP wave shifts. Conserved variables are
+// cell-integrated; device layout as in include/mara_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "launch.hpp"
+#include "euler_device.hpp"
+#include "srhd_device.hpp"
+
+namespace mh {
+
+static constexpr int CWAVE = 64;
+static constexpr int CHALO = 2;
+static constexpr int CSTRIP = CWAVE - 2 * CHALO;
+static constexpr int CWAVES_PER_BLOCK = 4;
+
+struct CloudParams
+{
+    const double* u_in;
+    const double* u_base;
+    double*       u_out;
+    const double* rv;          // radial vertices of the GLOBAL grid (device)
+    const double* dmu;         // [nq]   -cos q_{j+1} - -cos q_j
+    const double* sinq;        // [nq+1] sin q_j
+    const double* cotq;        // [nq]   tan(pi/2 - theta_c)
+    const double* inflow;      // [5][nq] primitives of the inner ghost row
+    int32_t*      status;
+    long   plane_stride, row_stride;
+    int    n0, n1;             // local radial rows, polar columns
+    int    row_offset;         // global index of local row 0
+    int    row_begin, row_end, chunk_rows, nstrips, nchunks;
+    int    bc_lo0, bc_hi0;     // MH_BC_INFLOW / MH_BC_OUTFLOW (physical) or MH_BC_EXTERNAL (slab cut)
+    double gamma, theta, tfloor, dt, weight;
+};
+
+__device__ inline double dpp_left(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double dpp_right(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline State5 dpp_left(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp_left(s[q]); return r; }
+__device__ inline State5 dpp_right(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp_right(s[q]); return r; }
+__device__ inline State5 times_zero(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = s[q] * 0.0; return r; }
+
+// wave-uniform radial geometry of global row i
+struct RowGeom
+{
+    double rr_lo, rr_hi;     // r_i r_i, r_{i+1} r_{i+1}   ((r + r) * 0.5 == r exactly)
+    double d3;               // r_{i+1}^3 - r_i^3          (its axis-1 midpoint (x + x) * 0.5 == x exactly)
+    double rcdr;             // ((r_i + r_{i+1}) * 0.5) * (r_{i+1} - r_i)
+    double rc;               // (r_i + r_{i+1}) * 0.5
+};
+__device__ inline RowGeom row_geometry(const double* rv, int i)
+{
+    const double r0 = rv[i], r1 = rv[i + 1];
+    RowGeom g;
+    g.rr_lo = r0 * r0;
+    g.rr_hi = r1 * r1;
+    g.d3 = r1 * r1 * r1 - r0 * r0 * r0;
+    g.rc = (r0 + r1) * 0.5;
+    g.rcdr = g.rc * (r1 - r0);
+    return g;
+}
+
+struct ColGeom { double dmu, sin_lo, sin_hi, cot; };
+
+__device__ inline double cell_volume(const RowGeom& rg, const ColGeom& cg, const Recip& three)
+{
+    return divide(rg.d3 * cg.dmu * 2 * M_PI, three);
+}
+
+template<bool PLM, bool COMBINE>
+__global__ __launch_bounds__(CWAVE * CWAVES_PER_BLOCK, 2)
+void cloud_stage_kernel(CloudParams p)
+{
+    int b = blockIdx.x;
+    {
+        const int per_xcd = gridDim.x >> 3;
+        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
+    }
+    const int w = b * CWAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (w >= p.nstrips * p.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = w / p.nstrips;
+    const int strip = w - chunk * p.nstrips;
+    const int r0 = p.row_begin + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, p.row_end);
+
+    const int col = strip * CSTRIP - CHALO + lane;
+    const int jc = min(max(col, 0), p.n1 - 1);
+    const bool writes = lane >= CHALO && lane < CWAVE - CHALO && col < p.n1;
+    const bool pole_lo = col == 0, pole_hi = col == p.n1 - 1;
+
+    const srhd::Gamma g = srhd::make_gamma(p.gamma);
+    const Recip three = make_recip(3.0, 1.0);
+    const double theta = p.theta, tfloor = p.tfloor;
+    const ColGeom cg = {p.dmu[jc], p.sinq[jc], p.sinq[jc + 1], p.cotq[jc]};
+
+    const long row_stride = p.row_stride, plane = p.plane_stride;
+    const double* in = p.u_in + jc;
+    auto row_off = [row_stride] (int r) { return (long) (r + CHALO) * row_stride; };
+    int bad = 0;
+
+    // primitive of a stored row (real row, or a ghost row received from the neighbouring slab)
+    auto prim_of_row = [&] (int r) -> State5
+    {
+        const RowGeom rg = row_geometry(p.rv, p.row_offset + r);
+        double x[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) x[q] = in[q * plane + row_off(r)];
+        divide_group<5>(x, make_recip(cell_volume(rg, cg, three), 1.0));
+        State5 U, P;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) U[q] = x[q];
+        const int st = srhd::recover_primitive(U, g, tfloor, P);
+        if (r >= 0 && r < p.n0) bad |= st;
+        return P;
+    };
+    // primitive of row r with the physical boundary conditions applied
+    auto prim_bc = [&] (int r, const State5& last) -> State5
+    {
+        if (r < 0 && p.bc_lo0 != MH_BC_EXTERNAL)
+        {
+            State5 P;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) P[q] = p.inflow[(long) q * p.n1 + jc];
+            return P;
+        }
+        if (r >= p.n0 && p.bc_hi0 != MH_BC_EXTERNAL) return last;     // zero-gradient outer: copy of the last real row
+        return prim_of_row(r);
+    };
+    const bool phys_lo = p.bc_lo0 != MH_BC_EXTERNAL, phys_hi = p.bc_hi0 != MH_BC_EXTERNAL;
+
+    // ---- prologue
+    State5 P0, P1, G0, Fx_lo;
+    {
+        State5 dummy = {};
+        const State5 Pb = prim_bc(r0 - 1, dummy);
+        P0 = prim_of_row(r0);
+        P1 = prim_bc(r0 + 1, P0);
+        if constexpr (PLM)
+        {
+            G0 = plm_gradient(Pb, P0, P1, theta);
+            State5 Gb;
+            if (r0 == 0 && phys_lo) Gb = times_zero(G0);                       // extend_zeros on G
+            else                    Gb = plm_gradient(prim_bc(r0 - 2, dummy), Pb, P0, theta);
+            Fx_lo = srhd::riemann_hlle<0>(face_plus(Pb, Gb), face_minus(P0, G0), g);
+        }
+        else
+        {
+            Fx_lo = srhd::riemann_hlle<0>(Pb, P0, g);
+        }
+    }
+
+    for (int r = r0; r < r1; ++r)
+    {
+        // ---- radial face r+1/2
+        const State5 P2 = prim_bc(r + 2, P1);
+        State5 G1, Fx_hi;
+        if constexpr (PLM)
+        {
+            if (r + 1 == p.n0 && phys_hi) G1 = times_zero(G0);
+            else                          G1 = plm_gradient(P0, P1, P2, theta);
+            Fx_hi = srhd::riemann_hlle<0>(face_plus(P0, G0), face_minus(P1, G1), g);
+        }
+        else
+        {
+            Fx_hi = srhd::riemann_hlle<0>(P0, P1, g);
+        }
+
+        // ---- polar faces: this lane computes its LEFT face; pole faces carry the neighbouring flux times zero
+        State5 Fy_lo, Fy_hi;
+        if constexpr (PLM)
+        {
+            const State5 Graw = plm_gradient(dpp_left(P0), P0, dpp_right(P0), theta);
+            const State5 Gl = dpp_left(Graw), Gr = dpp_right(Graw);
+            State5 Gy;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Gy[q] = pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]);
+            const State5 SL = dpp_left(face_plus(P0, Gy));
+            Fy_lo = srhd::riemann_hlle<1>(SL, face_minus(P0, Gy), g);
+        }
+        else
+        {
+            Fy_lo = srhd::riemann_hlle<1>(dpp_left(P0), P0, g);
+        }
+        Fy_hi = dpp_right(Fy_lo);
+        if (pole_lo) Fy_lo = times_zero(Fy_hi);
+        if (pole_hi) Fy_hi = times_zero(Fy_lo);
+
+        // ---- geometry, source terms, update
+        const RowGeom rg = row_geometry(p.rv, p.row_offset + r);
+        const double dv = cell_volume(rg, cg, three);
+        const double nAr_lo = -(rg.rr_lo * cg.dmu * 2 * M_PI);
+        const double nAr_hi = -(rg.rr_hi * cg.dmu * 2 * M_PI);
+        const double nAq_lo = -(rg.rcdr * cg.sin_lo * 2 * M_PI);
+        const double nAq_hi = -(rg.rcdr * cg.sin_hi * 2 * M_PI);
+        const State5 S = srhd::source_terms(P0, rg.rc, cg.cot, g);
+
+        State5 Un;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+        {
+            const double lr = Fx_hi[q] * nAr_hi - Fx_lo[q] * nAr_lo;
+            const double lq = Fy_hi[q] * nAq_hi - Fy_lo[q] * nAq_lo;
+            const double s0 = S[q] * dv;
+            const double u0 = in[q * plane + row_off(r)];
+            const double u1 = u0 + (lr + lq + s0) * p.dt;
+            if constexpr (COMBINE) Un[q] = p.u_base[jc + q * plane + row_off(r)] * (1.0 - p.weight) + u1 * p.weight;
+            else                   Un[q] = u1;
+        }
+        if (writes)
+        {
+            double* out = p.u_out + col;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) out[q * plane + row_off(r)] = Un[q];
+        }
+
+        P0 = P1; P1 = P2;
+        if constexpr (PLM) G0 = G1;
+        Fx_lo = Fx_hi;
+    }
+
+    if (p.status)
+    {
+        const int mine = writes ? bad : 0;
+        if (__any(mine != 0)) atomicOr(p.status, mine);
+    }
+}
+
+hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev,
+                              const double* u_in, const double* u_base, double* u_out, double dt, double weight,
+                              int row_begin, int row_end, int32_t* status, hipStream_t stream)
+{
+    CloudParams p;
+    p.u_in = u_in; p.u_base = u_base; p.u_out = u_out;
+    p.n0 = d->nr; p.n1 = d->nq;
+    // geom_dev: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq]
+    p.rv = geom_dev;
+    p.dmu = p.rv + d->nr_global + 1;
+    p.sinq = p.dmu + d->nq;
+    p.cotq = p.sinq + d->nq + 1;
+    p.inflow = inflow_dev;
+    p.status = status;
+    p.plane_stride = d->nq;
+    p.row_stride = 5L * d->nq;
+    p.row_offset = d->row_offset;
+    p.row_begin = row_begin; p.row_end = row_end;
+    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
+    p.nstrips = (p.n1 + CSTRIP - 1) / CSTRIP;
+    p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    p.bc_lo0 = d->bc_lo0; p.bc_hi0 = d->bc_hi0;
+    p.gamma = d->gamma; p.theta = d->plm_theta; p.tfloor = d->temperature_floor;
+    p.dt = dt; p.weight = weight;
+    if (p.nchunks <= 0) return hipSuccess;
+    const int nwaves = p.nstrips * p.nchunks;
+    const dim3 grid((nwaves + CWAVES_PER_BLOCK - 1) / CWAVES_PER_BLOCK), block(CWAVE * CWAVES_PER_BLOCK);
+    const bool plm = d->plm_theta >= 0.0, combine = weight != 1.0;
+    if (plm && combine)       hipLaunchKernelGGL((cloud_stage_kernel<true, true>), grid, block, 0, stream, p);
+    else if (plm)             hipLaunchKernelGGL((cloud_stage_kernel<true, false>), grid, block, 0, stream, p);
+    else if (combine)         hipLaunchKernelGGL((cloud_stage_kernel<false, true>), grid, block, 0, stream, p);
+    else                      hipLaunchKernelGGL((cloud_stage_kernel<false, false>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace mh

@@ -17,6 +17,10 @@ hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, siz
 hipError_t sedov_stage_launch(const double* u0, double* u1, const double* dv, const double* da, const double* rc,
                               int n, double gamma, double dt, hipStream_t stream);
 
+hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev,
+                              const double* u_in, const double* u_base, double* u_out, double dt, double weight,
+                              int row_begin, int row_end, int32_t* status, hipStream_t stream);
+
 // thread-local error text for the C ABI
 void set_error(const char* fmt, ...);
 int  hip_fail(hipError_t e, const char* what);

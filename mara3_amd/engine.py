@@ -117,6 +117,61 @@ class SedovSolver:
             pass
 
 
+class CloudSolver:
+    """Host mirror of CloudProblem's (solution_t, advance, next_solution) (src/subprog_cloud.cpp): vertices,
+    cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
+
+    def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0):
+        self.lib = L.load_library()
+        self.rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
+        self.qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
+        self.nr, self.nq = self.rv.size - 1, self.qv.size - 1
+        d = L.CloudDesc(nr=self.nr, nq=self.nq, nr_global=self.nr, row_offset=0, gamma=gamma, plm_theta=plm_theta,
+                        temperature_floor=temperature_floor, bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith=L.ARITH_STRICT,
+                        chunk_rows=chunk_rows)
+        self.ctx = C.c_void_p()
+        L.check(self.lib.mh_create(C.byref(self.ctx), device))
+        L.check(self.lib.mh_cloud_configure(self.ctx, C.byref(d), self.rv.ctypes.data_as(C.c_void_p),
+                                            self.qv.ctypes.data_as(C.c_void_p), rk_order), self.ctx)
+
+    def timestep(self, cfl=0.4):
+        return (self.rv[1] - self.rv[0]) / 1.0 * cfl            # src/subprog_cloud.cpp:678-679
+
+    def set_inflow(self, prims):
+        p = np.ascontiguousarray(prims, dtype=np.float64)
+        assert p.shape == (self.nq, 5)
+        L.check(self.lib.mh_cloud_set_inflow(self.ctx, p.ctypes.data_as(C.c_void_p)), self.ctx)
+
+    def upload(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape == (self.nr, self.nq, 5)
+        L.check(self.lib.mh_upload(self.ctx, u.ctypes.data_as(C.c_void_p), self.nr * self.nq), self.ctx)
+
+    def download(self):
+        u = np.empty((self.nr, self.nq, 5))
+        L.check(self.lib.mh_download(self.ctx, u.ctypes.data_as(C.c_void_p), self.nr * self.nq), self.ctx)
+        return u
+
+    def step(self, dt, nsteps=1):
+        L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
+
+    def status(self):
+        s = C.c_int32()
+        L.check(self.lib.mh_status_word(self.ctx, C.byref(s)), self.ctx)
+        return s.value
+
+    def close(self):
+        if self.ctx:
+            self.lib.mh_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceArray:
     """A raw device allocation made through the C ABI (tests of the per-function entry points)."""
 
@@ -183,3 +238,38 @@ def euler_riemann(Pl, Pr, axis, gamma, solver="hlle", arith="strict"):
     kind = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[solver]
     L.check(lib.mh_euler_riemann_n(int(np.prod(a.shape)) // 5, a.ptr, b.ptr, axis, gamma, kind, f.ptr, _ARITH[arith], None))
     return f.get()
+
+
+def srhd_recover_primitive(U, gamma=4.0 / 3, tfloor=0.0):
+    lib = L.load_library()
+    u = DeviceArray(U)
+    p = DeviceArray.empty(u.shape)
+    n = int(np.prod(u.shape)) // 5
+    st = DeviceArray(np.zeros(max(n, 1)))          # int32 words in an 8-byte-per-item buffer
+    L.check(lib.mh_srhd_recover_primitive_n(n, u.ptr, gamma, tfloor, p.ptr, st.ptr, None))
+    status = st.get().view(np.int32)[:n].copy()
+    return p.get(), status
+
+
+def srhd_to_conserved(P, gamma=4.0 / 3):
+    lib = L.load_library()
+    p = DeviceArray(P)
+    u = DeviceArray.empty(p.shape)
+    L.check(lib.mh_srhd_to_conserved_n(int(np.prod(p.shape)) // 5, p.ptr, gamma, u.ptr, None))
+    return u.get()
+
+
+def srhd_riemann_hlle(Pl, Pr, axis, gamma=4.0 / 3):
+    lib = L.load_library()
+    a, b = DeviceArray(Pl), DeviceArray(Pr)
+    f = DeviceArray.empty(a.shape)
+    L.check(lib.mh_srhd_riemann_hlle_n(int(np.prod(a.shape)) // 5, a.ptr, b.ptr, axis, gamma, f.ptr, None))
+    return f.get()
+
+
+def srhd_source_terms(P, r, cot_theta, gamma=4.0 / 3):
+    lib = L.load_library()
+    p, rr, cc = DeviceArray(P), DeviceArray(r), DeviceArray(cot_theta)
+    s = DeviceArray.empty(p.shape)
+    L.check(lib.mh_srhd_source_terms_n(int(np.prod(p.shape)) // 5, p.ptr, rr.ptr, cc.ptr, gamma, s.ptr, None))
+    return s.get()
