@@ -10,6 +10,7 @@ int main(int argc, const char* argv[])
     std::map<std::string, std::unique_ptr<mara::sub_program_t>> programs;
     programs["sedov"] = make_subprog_sedov();
     programs["euler2d"] = make_subprog_euler2d();
+    programs["cloud"] = make_subprog_cloud();
 
     if (argc == 1)
     {

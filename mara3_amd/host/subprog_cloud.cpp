@@ -1,0 +1,186 @@
+// `cloud` sub-program on the MI355X engine: 2-D axisymmetric jet-cloud interaction in spherical-polar
+// coordinates, special-relativistic (mara::srhd). Same options, grid, units, initial condition, time step,
+// nozzle boundary condition, run loop and iteration message as the reference's subprog_cloud
+// (src/subprog_cloud.cpp: options :60-87, units :319-332, IC and grid :610-662, dt :678-679, nozzle
+// :466-493, loop :916-936, message :856-861). CloudProblem::advance / next_solution (:511-584, :676-697)
+// are replaced by mh_step; the state stays on the device between tasks. Checkpoint / diagnostics / time
+// series (HDF5) are out of scope this round: the final state is dumped as raw binary.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "app_config.hpp"
+#include "app_subprogram.hpp"
+#include "host_common.hpp"
+#include "models.hpp"
+
+namespace {
+
+constexpr double gamma_law_index = 4. / 3;      // src/subprog_cloud.cpp:52
+constexpr double light_speed_cgs = 2.998e10;    // :53
+constexpr double solar_mass_cgs = 1.989e33;     // :54
+
+mara::config_t config_template()
+{
+    return mara::config_t()
+    .item("restart", "")
+    .item("outdir", "data")
+    .item("nr", 256)
+    .item("tfinal", 1.0)
+    .item("num_decades", 2.0)
+    .item("inner_radius", 3e08)
+    .item("cloud_cutoff", 3e10)
+    .item("cloud_mass", 2e-2)
+    .item("density_index", 2.0)
+    .item("density_index2", 6.0)
+    .item("jet_delay_time", 1.0)
+    .item("jet_total_energy", 1e50)
+    .item("jet_duration", 1.0)
+    .item("jet_gamma_beta", 10.0)
+    .item("jet_opening_angle", 0.1)
+    .item("jet_structure_exp", 2.0)
+    .item("cfl_number", 0.4)
+    .item("rk_order", 1)
+    .item("reconstruct_method", 2)
+    .item("plm_theta", 1.2)
+    .item("temperature_floor", 1e-8)
+    .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
+    .item("write_inflow", 0)         // also dump the nozzle row of the first step (tests)
+    .item("device", 0);
+}
+
+// conserved density of a primitive state, mara::srhd::primitive_t::to_conserved_density (src/physics_srhd.hpp:213-227);
+// host-side because the initial condition is built on the host, as in the reference (:658)
+void to_conserved_density(const double P[5], double U[5])
+{
+    const double W = std::sqrt(1.0 + (P[1] * P[1] + P[2] * P[2] + P[3] * P[3]));
+    const double h = (P[0] + P[4] * (1.0 + 1.0 / (gamma_law_index - 1.0))) / P[0];
+    const double D = P[0] * W;
+    U[0] = D;
+    U[1] = D * P[1] * h;
+    U[2] = D * P[2] * h;
+    U[3] = D * P[3] * h;
+    U[4] = D * h * W - P[4] - D;
+}
+
+class subprog_cloud : public mara::sub_program_t
+{
+public:
+    int main(int argc, const char* argv[]) override
+    {
+        auto cfg = config_template().update(argc, argv);
+        if (! cfg.get_string("restart").empty()) throw std::invalid_argument("cloud: restart needs the HDF5 checkpoint reader (out of scope)");
+        cfg.pretty_print(stdout, "config");
+
+        model::cloud_and_envelop envelop;
+        envelop.inner_radius = cfg.get_double("inner_radius");
+        envelop.cloud_index = cfg.get_double("density_index");
+        model::power_law_atmosphere atmosphere;
+        atmosphere.r0 = cfg.get_double("inner_radius");
+        atmosphere.rc = cfg.get_double("cloud_cutoff");
+        atmosphere.n1 = cfg.get_double("density_index");
+        atmosphere.n2 = cfg.get_double("density_index2");
+        atmosphere = atmosphere.with_total_mass(cfg.get_double("cloud_mass") * solar_mass_cgs);
+        model::jet_nozzle jet;
+        jet.r0 = cfg.get_double("inner_radius");
+        jet.Ej = cfg.get_double("jet_total_energy");
+        jet.tj = cfg.get_double("jet_duration");
+        jet.as = cfg.get_double("jet_structure_exp");
+        jet.qj = cfg.get_double("jet_opening_angle");
+        jet.G0 = cfg.get_double("jet_gamma_beta");
+
+        // reference units (:319-332): length = r0, mass = total atmosphere mass, time = r0 / c
+        const double ref_length = atmosphere.r0;
+        const double ref_mass = atmosphere.total_mass();
+        const double ref_time = atmosphere.r0 / light_speed_cgs;
+        const double ref_density = ref_mass / std::pow(ref_length, 3);
+
+        // grid (:645-651): r = 10^linspace(0, decades, int(decades*nr)+1), theta = linspace(0, pi, nr+1)
+        const int nr_opt = cfg.get_int("nr");
+        const double num_decades = cfg.get_double("num_decades");
+        const std::size_t nrv = std::size_t(int(num_decades * nr_opt) + 1), nqv = std::size_t(nr_opt + 1);
+        std::vector<double> rv(nrv), qv(nqv);
+        for (std::size_t i = 0; i < nrv; ++i) rv[i] = std::pow(10.0, 0.0 + (num_decades - 0.0) * i / (nrv - 1));
+        for (std::size_t j = 0; j < nqv; ++j) qv[j] = 0.0 + (M_PI - 0.0) * j / (nqv - 1);
+        const int nr = int(nrv - 1), nq = int(nqv - 1);
+
+        // initial condition (:626-660): primitive from the envelop model at the centroid radius, times the cell volume
+        std::vector<double> u(std::size_t(5) * nr * nq);
+        const double jet_delay_time = cfg.get_double("jet_delay_time");
+        for (int i = 0; i < nr; ++i)
+        {
+            const double rc = (rv[i] + rv[i + 1]) * 0.5;
+            const double r_cm = rc * ref_length;
+            const double density = envelop.density_at(r_cm, jet_delay_time) / ref_density;
+            const double gamma_beta = envelop.gamma_beta_at(r_cm, jet_delay_time);
+            const double P[5] = {density, gamma_beta, 0.0, 0.0, density * 1e-6};
+            double U[5];
+            to_conserved_density(P, U);
+            const double d3 = rv[i + 1] * rv[i + 1] * rv[i + 1] - rv[i] * rv[i] * rv[i];
+            for (int j = 0; j < nq; ++j)
+            {
+                const double dmj = -std::cos(qv[j + 1]) - -std::cos(qv[j]);
+                const double dv = ((d3 + d3) * 0.5) * ((dmj + dmj) * 0.5) * 2 * M_PI / 3.0;      // cell_volumes (:276-283)
+                for (int q = 0; q < 5; ++q) u[(std::size_t(i) * nq + j) * 5 + q] = U[q] * dv;
+            }
+        }
+
+        mh_cloud_desc d = {};
+        d.nr = nr; d.nq = nq; d.nr_global = nr; d.row_offset = 0;
+        d.gamma = gamma_law_index;
+        d.plm_theta = cfg.get_int("reconstruct_method") == 1 ? -1.0 : cfg.get_double("plm_theta");
+        if (cfg.get_int("reconstruct_method") != 1 && cfg.get_int("reconstruct_method") != 2) throw std::invalid_argument("reconstruct_method must be 1 or 2");
+        d.temperature_floor = cfg.get_double("temperature_floor");
+        d.bc_lo0 = MH_BC_INFLOW; d.bc_hi0 = MH_BC_OUTFLOW;
+        d.arith = MH_ARITH_STRICT;
+
+        mh_ctx* ctx = nullptr;
+        host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
+        host::check(mh_cloud_configure(ctx, &d, rv.data(), qv.data(), cfg.get_int("rk_order")), ctx, "mh_cloud_configure");
+        host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+
+        const double dt = (rv[1] - rv[0]) / 1.0 * cfg.get_double("cfl_number");
+        const double tfinal = cfg.get_double("tfinal");
+        const long max_steps = cfg.get_int("max_steps");
+        double time = 0.0;
+        long iteration = 0;
+        std::vector<double> inflow(std::size_t(5) * nq, 0.0), inflow_first;
+
+        while (time < tfinal && (max_steps == 0 || iteration < max_steps))
+        {
+            // nozzle row at the step-start time (:466-493); both RK stages use it (:524)
+            const double t_seconds = time * ref_time;
+            for (int j = 0; j < nq; ++j)
+            {
+                const double q = (qv[j] + qv[j + 1]) * 0.5;
+                inflow[5 * j + 0] = jet.density_at_base() / ref_density;
+                inflow[5 * j + 1] = jet.gamma_beta(q, t_seconds) + jet.gamma_beta(M_PI - q, t_seconds);
+            }
+            if (iteration == 0) inflow_first = inflow;
+            const double ms = host::time_ms([&] {
+                host::check(mh_cloud_set_inflow(ctx, inflow.data()), ctx, "mh_cloud_set_inflow");
+                host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
+                host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+            });
+            time += dt;
+            iteration += 1;
+            int32_t status = 0;
+            host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
+            if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");
+            std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
+        }
+        host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
+        std::vector<double> vertices(rv);
+        vertices.insert(vertices.end(), qv.begin(), qv.end());
+        host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nr), long(nq)}, 5, time, iteration, vertices, u);
+        if (cfg.get_int("write_inflow"))
+            host::dump_state(cfg.get_string("outdir"), "inflow0.bin", {long(nq)}, 5, 0.0, 0, {}, inflow_first);
+        mh_destroy(ctx);
+        return 0;
+    }
+
+    std::string name() const override { return "cloud"; }
+};
+
+} // namespace
+
+std::unique_ptr<mara::sub_program_t> make_subprog_cloud() { return std::make_unique<subprog_cloud>(); }

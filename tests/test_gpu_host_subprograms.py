@@ -61,3 +61,22 @@ def test_euler2d_subprogram_matches_reference(tmp_path):
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     assert d["iteration"] == 10
     assert bits_equal(d["data"], g["u_10"])
+
+
+@pytest.mark.parametrize("case,args", [
+    ("cloud_nr32_plm_rk2", ["nr=32", "num_decades=1", "rk_order=2", "max_steps=3"]),
+    ("cloud_nr24_pcm_rk1", ["nr=24", "num_decades=1", "rk_order=1", "reconstruct_method=1", "max_steps=4"]),
+    ("cloud_nr20x2dec_plm_rk2", ["nr=20", "num_decades=2", "rk_order=2", "plm_theta=1.5", "max_steps=2"]),
+])
+def test_cloud_subprogram_matches_reference(tmp_path, case, args):
+    """`mara_hip cloud`: grid, units, envelope-model initial condition, nozzle row and the device steps must
+    reproduce the reference-composed run (oracle/ref_drivers/cloud_ref.cpp) bit for bit."""
+    g = golden(case)
+    stdout = run(["cloud", "tfinal=1e9", "write_inflow=1"] + args, str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert d["iteration"] == int(g["nsteps"])
+    assert bits_equal(d["vertices"], np.concatenate([g["rv"], g["qv"]]))
+    inflow = read_dump(os.path.join(tmp_path, "data", "inflow0.bin"))["data"]
+    assert bits_equal(inflow, g["inflow"][0])
+    assert bits_equal(d["data"], g["un"]), np.abs(d["data"] - g["un"]).max()
+    assert "kzps=" in stdout
