@@ -211,6 +211,20 @@ int mh_srhd_to_conserved_n(size_t n, const double* P, double gamma, double* U, v
 int mh_srhd_riemann_hlle_n(size_t n, const double* Pl, const double* Pr, int axis, double gamma, double* F, void* stream);
 int mh_srhd_source_terms_n(size_t n, const double* P, const double* r, const double* cot_theta, double gamma, double* S, void* stream);
 
+/* mara::iso2d (src/physics_iso2d.hpp), AoS rows of 3 in the logical order (Sigma, x, y); x = positions [n][2]:
+ * to_conserved_per_area :249-258, recover_primitive(U) :351-362 (threw[i] = 1 where the reference throws on
+ * negative density), to_conserved_angmom_per_area :263-272, recover_primitive(Q, x) :376-390, flux :299-307,
+ * wavespeeds + max_wavespeed :320-337 (out rows = minus, plus, max), riemann_hlle :488-506 / riemann_hllc
+ * :556-583,:610-712 (contact[i] = s_star, threw[i] = 1 where interface_flux throws). axis in {0, 1}. */
+int mh_iso2d_to_conserved_n(size_t n, const double* P, double* U, void* stream);
+int mh_iso2d_recover_primitive_n(size_t n, const double* U, double* P, int32_t* threw, void* stream);
+int mh_iso2d_to_conserved_angmom_n(size_t n, const double* P, const double* x, double* Q, void* stream);
+int mh_iso2d_recover_primitive_angmom_n(size_t n, const double* Q, const double* x, double* P, int32_t* threw, void* stream);
+int mh_iso2d_flux_n(size_t n, const double* P, const double* cs2, int axis, double* F, void* stream);
+int mh_iso2d_wavespeeds_n(size_t n, const double* P, const double* cs2, int axis, double* lam, void* stream);
+int mh_iso2d_riemann_n(size_t n, const double* Pl, const double* Pr, const double* cs2l, const double* cs2r, int axis, int riemann,
+                       double* F, double* contact, int32_t* threw, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* Integer / index work (host side, bit-exact with the reference)             */
 /* ------------------------------------------------------------------------ */

@@ -79,6 +79,13 @@ SYMBOLS = [
     ("mh_srhd_to_conserved_n", _i, [_sz, _dp, _d, _dp, _vp]),
     ("mh_srhd_riemann_hlle_n", _i, [_sz, _dp, _dp, _i, _d, _dp, _vp]),
     ("mh_srhd_source_terms_n", _i, [_sz, _dp, _dp, _dp, _d, _dp, _vp]),
+    ("mh_iso2d_to_conserved_n", _i, [_sz, _dp, _dp, _vp]),
+    ("mh_iso2d_recover_primitive_n", _i, [_sz, _dp, _dp, _vp, _vp]),
+    ("mh_iso2d_to_conserved_angmom_n", _i, [_sz, _dp, _dp, _dp, _vp]),
+    ("mh_iso2d_recover_primitive_angmom_n", _i, [_sz, _dp, _dp, _dp, _vp, _vp]),
+    ("mh_iso2d_flux_n", _i, [_sz, _dp, _dp, _i, _dp, _vp]),
+    ("mh_iso2d_wavespeeds_n", _i, [_sz, _dp, _dp, _i, _dp, _vp]),
+    ("mh_iso2d_riemann_n", _i, [_sz, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _vp, _vp]),
     ("mh_partition_rows", None, [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
     ("mh_device_count", _i, []),

@@ -12,6 +12,7 @@
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
 #include "srhd_device.hpp"
+#include "iso2d_device.hpp"
 
 namespace mh {
 
@@ -114,6 +115,47 @@ __global__ void srhd_src_kernel(size_t n, const double* P, const double* r, cons
 {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) store5(S + 5 * i, srhd::source_terms(load5(P + 5 * i), r[i], cotq[i], srhd::make_gamma(gamma)));
+}
+
+// ---- iso2d per-function kernels; mode selects the function, AXIS the face normal -------------------------
+__device__ inline iso2d::State3 load3(const double* p) { iso2d::State3 s; for (int q = 0; q < 3; ++q) s[q] = p[q]; return s; }
+__device__ inline void store3(double* p, const iso2d::State3& s) { for (int q = 0; q < 3; ++q) p[q] = s[q]; }
+
+enum { ISO_P2C, ISO_C2P, ISO_P2Q, ISO_Q2P, ISO_FLUX, ISO_LAM, ISO_HLLE, ISO_HLLC };
+
+template<int AXIS>
+__global__ void iso2d_kernel(int mode, size_t n, const double* a, const double* b, const double* c, const double* d,
+                             double* out, double* out2, int32_t* flag)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    iso2d::State3 R;
+    bool threw = false;
+    switch (mode)
+    {
+        case ISO_P2C: R = iso2d::to_conserved(load3(a + 3 * i)); break;
+        case ISO_C2P: threw = iso2d::recover_primitive(load3(a + 3 * i), R); break;
+        case ISO_P2Q: R = iso2d::to_conserved_angmom(load3(a + 3 * i), b[2 * i], b[2 * i + 1]); break;
+        case ISO_Q2P: threw = iso2d::recover_primitive_angmom(load3(a + 3 * i), b[2 * i], b[2 * i + 1], R); break;
+        case ISO_FLUX: R = iso2d::flux<AXIS>(load3(a + 3 * i), c[i]); break;
+        case ISO_LAM:
+        {
+            const iso2d::State3 P = load3(a + 3 * i);
+            const double cs = sqrt(c[i]), vn = iso2d::velocity_along<AXIS>(P);
+            R[0] = vn - cs; R[1] = vn + cs; R[2] = iso2d::max_wavespeed(P, c[i]);
+            break;
+        }
+        case ISO_HLLE: R = iso2d::riemann_hlle<AXIS>(load3(a + 3 * i), load3(b + 3 * i), c[i], d[i]); break;
+        case ISO_HLLC:
+        {
+            double contact;
+            threw = iso2d::riemann_hllc<AXIS>(load3(a + 3 * i), load3(b + 3 * i), c[i], d[i], R, contact);
+            if (out2) out2[i] = contact;
+            break;
+        }
+    }
+    store3(out + 3 * i, R);
+    if (flag) flag[i] = threw ? 1 : 0;
 }
 
 } // namespace mh
@@ -676,6 +718,36 @@ int mh_srhd_source_terms_n(size_t n, const double* P, const double* r, const dou
     hipLaunchKernelGGL(srhd_src_kernel, grid1(n), dim3(256), 0, (hipStream_t) stream, n, P, r, cot_theta, gamma, S);
     MH_HIP_TRY(hipGetLastError());
     return MH_OK;
+}
+
+static int iso2d_launch(int mode, int axis, size_t n, const double* a, const double* b, const double* c, const double* d,
+                        double* out, double* out2, int32_t* flag, void* stream)
+{
+    if (axis < 0 || axis > 1) { set_error("iso2d: axis must be 0 or 1"); return MH_E_INVALID; }
+    if (n == 0) return MH_OK;
+    if (axis == 0) hipLaunchKernelGGL(iso2d_kernel<0>, grid1(n), dim3(256), 0, (hipStream_t) stream, mode, n, a, b, c, d, out, out2, flag);
+    else           hipLaunchKernelGGL(iso2d_kernel<1>, grid1(n), dim3(256), 0, (hipStream_t) stream, mode, n, a, b, c, d, out, out2, flag);
+    MH_HIP_TRY(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_iso2d_to_conserved_n(size_t n, const double* P, double* U, void* stream)
+{ return iso2d_launch(ISO_P2C, 0, n, P, nullptr, nullptr, nullptr, U, nullptr, nullptr, stream); }
+int mh_iso2d_recover_primitive_n(size_t n, const double* U, double* P, int32_t* threw, void* stream)
+{ return iso2d_launch(ISO_C2P, 0, n, U, nullptr, nullptr, nullptr, P, nullptr, threw, stream); }
+int mh_iso2d_to_conserved_angmom_n(size_t n, const double* P, const double* x, double* Q, void* stream)
+{ return iso2d_launch(ISO_P2Q, 0, n, P, x, nullptr, nullptr, Q, nullptr, nullptr, stream); }
+int mh_iso2d_recover_primitive_angmom_n(size_t n, const double* Q, const double* x, double* P, int32_t* threw, void* stream)
+{ return iso2d_launch(ISO_Q2P, 0, n, Q, x, nullptr, nullptr, P, nullptr, threw, stream); }
+int mh_iso2d_flux_n(size_t n, const double* P, const double* cs2, int axis, double* F, void* stream)
+{ return iso2d_launch(ISO_FLUX, axis, n, P, nullptr, cs2, nullptr, F, nullptr, nullptr, stream); }
+int mh_iso2d_wavespeeds_n(size_t n, const double* P, const double* cs2, int axis, double* lam, void* stream)
+{ return iso2d_launch(ISO_LAM, axis, n, P, nullptr, cs2, nullptr, lam, nullptr, nullptr, stream); }
+int mh_iso2d_riemann_n(size_t n, const double* Pl, const double* Pr, const double* cs2l, const double* cs2r, int axis, int riemann_kind,
+                       double* F, double* contact, int32_t* threw, void* stream)
+{
+    if (riemann_kind != MH_RIEMANN_HLLE && riemann_kind != MH_RIEMANN_HLLC) { set_error("iso2d: unknown riemann solver"); return MH_E_INVALID; }
+    return iso2d_launch(riemann_kind == MH_RIEMANN_HLLC ? ISO_HLLC : ISO_HLLE, axis, n, Pl, Pr, cs2l, cs2r, F, contact, threw, stream);
 }
 
 // ---- integer work ----------------------------------------------------------

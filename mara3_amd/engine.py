@@ -273,3 +273,64 @@ def srhd_source_terms(P, r, cot_theta, gamma=4.0 / 3):
     s = DeviceArray.empty(p.shape)
     L.check(lib.mh_srhd_source_terms_n(int(np.prod(p.shape)) // 5, p.ptr, rr.ptr, cc.ptr, gamma, s.ptr, None))
     return s.get()
+
+
+# ---- mara::iso2d per-function entry points ---------------------------------------------------------------------
+def _flags(n):
+    return DeviceArray(np.zeros(max(n, 1)))
+
+
+def _read_flags(arr, n):
+    return arr.get().view(np.int32)[:n].copy()
+
+
+def iso2d_to_conserved(P):
+    lib = L.load_library()
+    p = DeviceArray(P); u = DeviceArray.empty(p.shape)
+    L.check(lib.mh_iso2d_to_conserved_n(int(np.prod(p.shape)) // 3, p.ptr, u.ptr, None))
+    return u.get()
+
+
+def iso2d_recover_primitive(U):
+    lib = L.load_library()
+    u = DeviceArray(U); p = DeviceArray.empty(u.shape); n = int(np.prod(u.shape)) // 3; f = _flags(n)
+    L.check(lib.mh_iso2d_recover_primitive_n(n, u.ptr, p.ptr, f.ptr, None))
+    return p.get(), _read_flags(f, n)
+
+
+def iso2d_to_conserved_angmom(P, x):
+    lib = L.load_library()
+    p, xx = DeviceArray(P), DeviceArray(x); q = DeviceArray.empty(p.shape)
+    L.check(lib.mh_iso2d_to_conserved_angmom_n(int(np.prod(p.shape)) // 3, p.ptr, xx.ptr, q.ptr, None))
+    return q.get()
+
+
+def iso2d_recover_primitive_angmom(Q, x):
+    lib = L.load_library()
+    q, xx = DeviceArray(Q), DeviceArray(x); p = DeviceArray.empty(q.shape); n = int(np.prod(q.shape)) // 3; f = _flags(n)
+    L.check(lib.mh_iso2d_recover_primitive_angmom_n(n, q.ptr, xx.ptr, p.ptr, f.ptr, None))
+    return p.get(), _read_flags(f, n)
+
+
+def iso2d_flux(P, cs2, axis):
+    lib = L.load_library()
+    p, c = DeviceArray(P), DeviceArray(cs2); f = DeviceArray.empty(p.shape)
+    L.check(lib.mh_iso2d_flux_n(int(np.prod(p.shape)) // 3, p.ptr, c.ptr, axis, f.ptr, None))
+    return f.get()
+
+
+def iso2d_wavespeeds(P, cs2, axis):
+    lib = L.load_library()
+    p, c = DeviceArray(P), DeviceArray(cs2); f = DeviceArray.empty(p.shape)
+    L.check(lib.mh_iso2d_wavespeeds_n(int(np.prod(p.shape)) // 3, p.ptr, c.ptr, axis, f.ptr, None))
+    return f.get()
+
+
+def iso2d_riemann(Pl, Pr, cs2l, cs2r, axis, solver="hlle"):
+    lib = L.load_library()
+    a, b, c, d = DeviceArray(Pl), DeviceArray(Pr), DeviceArray(cs2l), DeviceArray(cs2r)
+    n = int(np.prod(a.shape)) // 3
+    F = DeviceArray.empty(a.shape); contact = DeviceArray.empty((max(n, 1),)); f = _flags(n)
+    kind = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[solver]
+    L.check(lib.mh_iso2d_riemann_n(n, a.ptr, b.ptr, c.ptr, d.ptr, axis, kind, F.ptr, contact.ptr, f.ptr, None))
+    return F.get(), contact.get()[:n], _read_flags(f, n)

@@ -158,8 +158,58 @@ def gen_srhd(rng):
         print(name, "ok")
 
 
+def ref_iso2d(mode, n, axis, data):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        np.ascontiguousarray(data, dtype=np.float64).tofile(fin)
+        run_ref("funcs_iso2d_ref", [mode, n, axis, fin, fout])
+        return np.fromfile(fout)
+
+
+def gen_iso2d(rng):
+    n = 4096
+    def prims(n):
+        P = np.empty((n, 3))
+        P[:, 0] = 10.0 ** rng.uniform(-4, 2, n)
+        P[:, 1:] = rng.standard_normal((n, 2)) * 10.0 ** rng.uniform(-2, 1.5, (n, 1))
+        return P
+    Pl, Pr = prims(n), prims(n)
+    Pr[:512] = Pl[:512] * (1.0 + 1e-3 * rng.standard_normal((512, 3)))
+    # the reference's own known-answer test, src/physics_test.cpp:143-153: contact speed exactly 0
+    Pl[0], Pr[0] = (1.0, 0.0, 0.0), (2.0, 0.0, 0.0)
+    cs2l, cs2r = 10.0 ** rng.uniform(-3, 1, n), 10.0 ** rng.uniform(-3, 1, n)
+    cs2r[:512] = cs2l[:512] * (1.0 + 1e-3 * rng.standard_normal(512))
+    cs2l[0], cs2r[0] = 1.0, 0.5
+    x = rng.standard_normal((n, 2)) * 10.0 ** rng.uniform(-2, 1, (n, 1))
+    x[1], x[2] = (1.0, 2.0), (1e-8, 1e-8)                       # src/physics_test.cpp:115-141
+    out = {"Pl": Pl, "Pr": Pr, "cs2l": cs2l, "cs2r": cs2r, "x": x}
+    out["U"] = ref_iso2d("p2c", n, 0, Pl).reshape(n, 3)
+    r = ref_iso2d("c2p", n, 0, out["U"]).reshape(n, 4)
+    out["c2p"], out["c2p_threw"] = r[:, :3], r[:, 3]
+    Uneg = out["U"].copy()
+    Uneg[::7, 0] *= -1.0
+    out["Uneg"] = Uneg
+    r = ref_iso2d("c2p", n, 0, Uneg).reshape(n, 4)
+    out["c2p_neg"], out["c2p_neg_threw"] = r[:, :3], r[:, 3]
+    out["Q"] = ref_iso2d("p2q", n, 0, np.hstack([Pl, x])).reshape(n, 3)
+    r = ref_iso2d("q2p", n, 0, np.hstack([out["Q"], x])).reshape(n, 4)
+    out["q2p"], out["q2p_threw"] = r[:, :3], r[:, 3]
+    both = np.hstack([Pl, Pr, cs2l[:, None], cs2r[:, None]])
+    for axis in range(2):
+        out["flux_%d" % axis] = ref_iso2d("flux", n, axis, np.hstack([Pl, cs2l[:, None]])).reshape(n, 3)
+        out["lam_%d" % axis] = ref_iso2d("lam", n, axis, np.hstack([Pl, cs2l[:, None]])).reshape(n, 3)
+        out["hlle_%d" % axis] = ref_iso2d("hlle", n, axis, both).reshape(n, 3)
+        r = ref_iso2d("hllc", n, axis, both).reshape(n, 5)
+        out["hllc_%d" % axis], out["hllc_contact_%d" % axis], out["hllc_threw_%d" % axis] = r[:, :3], r[:, 3], r[:, 4]
+    assert out["hllc_contact_0"][0] == 0.0
+    np.savez_compressed(os.path.join(OUT, "iso2d_functions.npz"), **out)
+    print("iso2d ok; c2p_neg throws", int(out["c2p_neg_threw"].sum()), "hllc throws", int(out["hllc_threw_0"].sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "iso2d":
+        return gen_iso2d(np.random.default_rng(20260303))
     if len(sys.argv) > 1 and sys.argv[1] == "srhd":
         return gen_srhd(np.random.default_rng(20260202))
     rng = np.random.default_rng(20260101)

@@ -109,6 +109,24 @@ int  mo_cloud_advance(size_t nr, size_t nq, const double* rv, const double* qv, 
 int  mo_cloud_run(size_t nr, size_t nq, const double* rv, const double* qv, const double* inflow, double gamma,
                   double plm_theta, double temperature_floor, int rk_order, double dt, int nsteps, double* u);
 
+/* ---- mara::iso2d (mara_oracle_iso2d.c); component order (Sigma, x, y) ------------ */
+void mo_iso2d_to_conserved(const double P[3], double U[3]);                                   /* physics_iso2d.hpp:249-258 */
+int  mo_iso2d_recover_primitive(const double U[3], double P[3]);                              /* :351-362 */
+void mo_iso2d_to_conserved_angmom(const double P[3], const double x[2], double Q[3]);         /* :263-272 */
+int  mo_iso2d_recover_primitive_angmom(const double Q[3], const double x[2], double P[3]);    /* :376-390 */
+void mo_iso2d_flux(const double P[3], int axis, double cs2, double F[3]);                     /* :299-307 */
+void mo_iso2d_wavespeeds(const double P[3], int axis, double cs2, double lam[3]);             /* :320-337 */
+void mo_iso2d_riemann_hlle(const double Pl[3], const double Pr[3], double cs2l, double cs2r, int axis, double F[3]);   /* :488-506 */
+int  mo_iso2d_riemann_hllc(const double Pl[3], const double Pr[3], double cs2l, double cs2r, int axis, double F[3], double* contact); /* :556-583,:610-712 */
+void mo_iso2d_to_conserved_n(size_t n, const double* P, double* U);
+void mo_iso2d_recover_primitive_n(size_t n, const double* U, double* P, int* threw);
+void mo_iso2d_to_conserved_angmom_n(size_t n, const double* P, const double* x, double* Q);
+void mo_iso2d_recover_primitive_angmom_n(size_t n, const double* Q, const double* x, double* P, int* threw);
+void mo_iso2d_flux_n(size_t n, const double* P, const double* cs2, int axis, double* F);
+void mo_iso2d_wavespeeds_n(size_t n, const double* P, const double* cs2, int axis, double* lam);
+void mo_iso2d_riemann_n(size_t n, const double* Pl, const double* Pr, const double* cs2l, const double* cs2r, int axis,
+                        int solver, double* F, double* contact, int* threw);
+
 /* ---- integer / index work (bit-exact) ----------------------------------- */
 /* core_ndarray.hpp:820-836 : slab n of N over `count` rows -> [start, final) */
 void mo_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_);

@@ -66,6 +66,13 @@ def lib():
         _lib.mo_cloud_geometry.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, dp, dp]
         _lib.mo_cloud_advance.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
         _lib.mo_cloud_run.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, dp]
+        _lib.mo_iso2d_to_conserved_n.argtypes = [C.c_size_t, dp, dp]
+        _lib.mo_iso2d_recover_primitive_n.argtypes = [C.c_size_t, dp, dp, ip]
+        _lib.mo_iso2d_to_conserved_angmom_n.argtypes = [C.c_size_t, dp, dp, dp]
+        _lib.mo_iso2d_recover_primitive_angmom_n.argtypes = [C.c_size_t, dp, dp, dp, ip]
+        _lib.mo_iso2d_flux_n.argtypes = [C.c_size_t, dp, dp, C.c_int, dp]
+        _lib.mo_iso2d_wavespeeds_n.argtypes = [C.c_size_t, dp, dp, C.c_int, dp]
+        _lib.mo_iso2d_riemann_n.argtypes = [C.c_size_t, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, ip]
         sp = C.POINTER(C.c_size_t)
         _lib.mo_partition_rows.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
         _lib.mo_block_extent.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, sp, sp]
@@ -226,3 +233,63 @@ def cloud_run(u, rv, qv, inflow, dt, nsteps, rk=1, theta=1.2, tfloor=1e-8, gamma
     assert inflow.shape == (nsteps, nq, 5)
     st = lib().mo_cloud_run(nr, nq, _dp(rv), _dp(qv), _dp(inflow), gamma, theta, tfloor, rk, dt, nsteps, _dp(u))
     return u, st
+
+
+# ---- mara::iso2d ---------------------------------------------------------------------------------------------
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def iso2d_to_conserved(P):
+    P = _f64(P)
+    U = np.empty_like(P)
+    lib().mo_iso2d_to_conserved_n(P.size // 3, _dp(P), _dp(U))
+    return U
+
+
+def iso2d_recover_primitive(U):
+    U = _f64(U)
+    P = np.empty_like(U)
+    t = np.zeros(U.size // 3, dtype=np.int32)
+    lib().mo_iso2d_recover_primitive_n(U.size // 3, _dp(U), _dp(P), _ip(t))
+    return P, t
+
+
+def iso2d_to_conserved_angmom(P, x):
+    P, x = _f64(P), _f64(x)
+    Q = np.empty_like(P)
+    lib().mo_iso2d_to_conserved_angmom_n(P.size // 3, _dp(P), _dp(x), _dp(Q))
+    return Q
+
+
+def iso2d_recover_primitive_angmom(Q, x):
+    Q, x = _f64(Q), _f64(x)
+    P = np.empty_like(Q)
+    t = np.zeros(Q.size // 3, dtype=np.int32)
+    lib().mo_iso2d_recover_primitive_angmom_n(Q.size // 3, _dp(Q), _dp(x), _dp(P), _ip(t))
+    return P, t
+
+
+def iso2d_flux(P, cs2, axis):
+    P, cs2 = _f64(P), _f64(cs2)
+    F = np.empty_like(P)
+    lib().mo_iso2d_flux_n(P.size // 3, _dp(P), _dp(cs2), axis, _dp(F))
+    return F
+
+
+def iso2d_wavespeeds(P, cs2, axis):
+    P, cs2 = _f64(P), _f64(cs2)
+    lam = np.empty_like(P)
+    lib().mo_iso2d_wavespeeds_n(P.size // 3, _dp(P), _dp(cs2), axis, _dp(lam))
+    return lam
+
+
+def iso2d_riemann(Pl, Pr, cs2l, cs2r, axis, solver=RIEMANN_HLLE):
+    """Returns (F, contact_speed, threw)."""
+    Pl, Pr, cs2l, cs2r = _f64(Pl), _f64(Pr), _f64(cs2l), _f64(cs2r)
+    n = Pl.size // 3
+    F = np.empty_like(Pl)
+    contact = np.zeros(n)
+    t = np.zeros(n, dtype=np.int32)
+    lib().mo_iso2d_riemann_n(n, _dp(Pl), _dp(Pr), _dp(cs2l), _dp(cs2r), axis, solver, _dp(F), _dp(contact), _ip(t))
+    return F, contact, t
