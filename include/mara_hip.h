@@ -78,7 +78,7 @@ enum mh_status
 /* ------------------------------------------------------------------------ */
 typedef struct
 {
-    int    rank;            /* 2 or 3 (1-D: use rank 2 with n1 = 1 is NOT supported; see mh_sedov_*) */
+    int    rank;            /* 2 or 3 */
     int    n[3];            /* LOCAL cells per axis on this device (axis 0 = slab axis) */
     double dl[3];           /* cell sizes */
     double gamma;           /* gamma-law index */

@@ -37,8 +37,8 @@ int hip_fail(hipError_t e, const char* what)
 static int check_desc(const mh_euler_cart_desc* d)
 {
     if (! d) { set_error("null descriptor"); return MH_E_INVALID; }
-    if (d->rank != 2) { set_error("mh_euler_cart: rank %d not supported by this build (2 only)", d->rank); return MH_E_INVALID; }
-    if (d->n[0] < 2 || d->n[1] < 2) { set_error("mh_euler_cart: need at least 2 cells per axis"); return MH_E_INVALID; }
+    if (d->rank != 2 && d->rank != 3) { set_error("mh_euler_cart: rank %d not supported (2 or 3)", d->rank); return MH_E_INVALID; }
+    if (d->n[0] < 2 || d->n[1] < 2 || (d->rank == 3 && d->n[2] < 2)) { set_error("mh_euler_cart: need at least 2 cells per axis"); return MH_E_INVALID; }
     if (d->riemann != MH_RIEMANN_HLLE && d->riemann != MH_RIEMANN_HLLC) { set_error("unknown riemann solver %d", d->riemann); return MH_E_INVALID; }
     if (d->bc_transverse != MH_BC_OUTFLOW && d->bc_transverse != MH_BC_PERIODIC) { set_error("transverse bc must be outflow or periodic"); return MH_E_INVALID; }
     for (int bc : {d->bc_lo0, d->bc_hi0})
@@ -47,6 +47,13 @@ static int check_desc(const mh_euler_cart_desc* d)
     if (d->arith != MH_ARITH_STRICT && d->arith != MH_ARITH_FAST) { set_error("unknown arith mode %d", d->arith); return MH_E_INVALID; }
     if (!(d->gamma > 1.0)) { set_error("gamma must be > 1"); return MH_E_INVALID; }
     return MH_OK;
+}
+
+static hipError_t cart_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                    double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
+{
+    return d->rank == 3 ? euler3d_stage_launch(d, u_in, u_base, u_out, dt, weight, row_begin, row_end, status, stream)
+                        : euler2d_stage_launch(d, u_in, u_base, u_out, dt, weight, row_begin, row_end, status, stream);
 }
 
 static size_t row_pitch_of(const mh_euler_cart_desc* d) { return d->rank == 3 ? (size_t) d->n[1] * d->n[2] : (size_t) d->n[1]; }
@@ -210,7 +217,7 @@ int mh_euler_cart_stage(const mh_euler_cart_desc* d, const double* u_in, const d
     if (! u_in || ! u_out || u_in == u_out) { set_error("stage: u_in and u_out must be distinct device fields"); return MH_E_INVALID; }
     if (stage_weight != 1.0 && ! u_base) { set_error("stage: combine needs u_base"); return MH_E_INVALID; }
     if (row_begin < 0 || row_end > d->n[0] || row_begin > row_end) { set_error("stage: bad row range [%d,%d)", row_begin, row_end); return MH_E_INVALID; }
-    MH_HIP_TRY(euler2d_stage_launch(d, u_in, u_base, u_out, dt, stage_weight, row_begin, row_end, status, (hipStream_t) stream));
+    MH_HIP_TRY(cart_stage_launch(d, u_in, u_base, u_out, dt, stage_weight, row_begin, row_end, status, (hipStream_t) stream));
     return MH_OK;
 }
 
@@ -515,7 +522,7 @@ static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, d
         hipEventCreate(&ev.second);
         hipEventRecord(ev.first, c->stream);
     }
-    hipError_t e = euler2d_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
+    hipError_t e = cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
     if (c->profile)
     {
         hipEventRecord(ev.second, c->stream);

@@ -9,6 +9,9 @@ namespace mh {
 hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
 
+hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
+
 hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream);
 hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, size_t row_pitch, hipStream_t stream);
 hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStream_t stream);
