@@ -141,7 +141,7 @@ typedef struct
 {
     int    nz;              /* radial zones */
     double gamma;           /* 4/3 in the reference (#define at src/subprog_sedov.cpp:48) */
-    int    system;          /* MH_SYSTEM_EULER (newtonian=1); MH_SYSTEM_SRHD: not yet */
+    int    system;          /* MH_SYSTEM_SRHD (the sub-program's default) or MH_SYSTEM_EULER (newtonian=1) */
     int    arith;           /* MH_ARITH_STRICT */
 } mh_sedov_desc;
 int  mh_sedov_configure(mh_ctx* ctx, const mh_sedov_desc* d, const double* vertices_host);

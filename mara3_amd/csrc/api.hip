@@ -315,7 +315,7 @@ int mh_sedov_configure(mh_ctx* c, const mh_sedov_desc* d, const double* vertices
 {
     if (! c) return MH_E_INVALID;
     if (! d || ! vertices_host || d->nz < 2) { set_error("sedov: need a descriptor, vertices and nz >= 2"); return ctx_fail(c, MH_E_INVALID); }
-    if (d->system != MH_SYSTEM_EULER) { set_error("sedov: only the newtonian (mara::euler) system is built"); return ctx_fail(c, MH_E_INVALID); }
+    if (d->system != MH_SYSTEM_EULER && d->system != MH_SYSTEM_SRHD) { set_error("sedov: system must be MH_SYSTEM_EULER or MH_SYSTEM_SRHD"); return ctx_fail(c, MH_E_INVALID); }
     if (d->arith != MH_ARITH_STRICT) { set_error("sedov: only MH_ARITH_STRICT is built"); return ctx_fail(c, MH_E_INVALID); }
     MH_HIP_TRY(hipSetDevice(c->device));
     release_fields(c);
@@ -544,7 +544,7 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
         const double* rc = da + n + 1;
         for (int s = 0; s < nsteps; ++s)
         {
-            MH_HIP_TRY(sedov_stage_launch(c->field[0], c->field[1], dv, da, rc, n, c->sedov.gamma, dt, c->stream));
+            MH_HIP_TRY(sedov_stage_launch(c->sedov.system, c->field[0], c->field[1], dv, da, rc, n, c->sedov.gamma, dt, c->status, c->stream));
             std::swap(c->field[0], c->field[1]);
         }
         return MH_OK;

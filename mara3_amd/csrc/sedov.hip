@@ -1,4 +1,5 @@
-// 1-D spherical Euler stage for the `sedov` sub-program (BASELINE config 1):
+// 1-D spherical stage for the `sedov` sub-program (BASELINE config 1), for both of its hydro systems
+// (SedovProblem<HydroSystem>, src/subprog_sedov.cpp:652-659: mara::srhd by default, mara::euler with newtonian=1):
 // piecewise-constant reconstruction, HLLE, forward Euler, volume-integrated
 // conserved variables, reflecting inner / zero-gradient outer boundary.
 //
@@ -12,65 +13,91 @@
 // Config 1 is plumbing (512 zones): one thread per zone, neighbours'
 // primitives recomputed instead of exchanged. Not a performance kernel.
 #include <hip/hip_runtime.h>
-#include "euler_device.hpp"
 #include "launch.hpp"
+#include "euler_device.hpp"
+#include "srhd_device.hpp"
 
 namespace mh {
 
-__device__ inline State5 sedov_primitive(const double* u, const double* dv, int n, int i, const GammaLaw& g)
+// physics traits of the two systems the sub-program is instantiated for
+struct SedovEuler
+{
+    using Gamma = GammaLaw;
+    static __device__ Gamma gamma(double g) { return make_gamma_law(g); }
+    static __device__ int c2p(const State5& U, const Gamma& g, State5& P) { P = recover_primitive(U, g.gamma, 0.0); return 0; }
+    static __device__ State5 hlle(const State5& l, const State5& r, const Gamma& g) { return riemann_hlle<0>(l, r, g); }
+    // physics_euler.hpp:328-337
+    static __device__ double radial_source(const State5& P, double r, const Gamma&) { return (2.0 * P[4] + P[0] * P[2] * P[2]) / r; }
+};
+struct SedovSrhd
+{
+    using Gamma = srhd::Gamma;
+    static __device__ Gamma gamma(double g) { return srhd::make_gamma(g); }
+    static __device__ int c2p(const State5& U, const Gamma& g, State5& P) { return srhd::recover_primitive(U, g, 0.0, P); }
+    static __device__ State5 hlle(const State5& l, const State5& r, const Gamma& g) { return srhd::riemann_hlle<0>(l, r, g); }
+    // physics_srhd.hpp:339-348
+    static __device__ double radial_source(const State5& P, double r, const Gamma& g) { return (2.0 * P[4] + srhd::enthalpy_density(P, g) * P[2] * P[2]) / r; }
+};
+
+template<class S>
+__device__ inline State5 sedov_primitive(const double* u, const double* dv, int n, int i, const typename S::Gamma& g, int& status)
 {
     // u0 / dv | map(recover_primitive)  (:411)
     double x[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) x[q] = u[(size_t) q * n + i];
     divide_group<5>(x, make_recip(dv[i], 1.0));
-    State5 U;
+    State5 U, P;
 #pragma unroll
     for (int q = 0; q < 5; ++q) U[q] = x[q];
-    return recover_primitive(U, g.gamma, 0.0);
+    status |= S::c2p(U, g, P);
+    return P;
 }
 
+template<class S>
 __global__ __launch_bounds__(64)
 void sedov_stage_kernel(const double* __restrict__ u0, double* __restrict__ u1, const double* __restrict__ dv,
-                        const double* __restrict__ da, const double* __restrict__ rc, int n, double gamma, double dt)
+                        const double* __restrict__ da, const double* __restrict__ rc, int n, double gamma, double dt, int32_t* status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const GammaLaw g = make_gamma_law(gamma);
+    const typename S::Gamma g = S::gamma(gamma);
+    int bad = 0, ignore = 0;
 
-    const State5 P0 = sedov_primitive(u0, dv, n, i, g);
+    const State5 P0 = sedov_primitive<S>(u0, dv, n, i, g, bad);
     State5 Pl, Pr;
-    if (i > 0) Pl = sedov_primitive(u0, dv, n, i - 1, g);
+    if (i > 0) Pl = sedov_primitive<S>(u0, dv, n, i - 1, g, ignore);
     else { Pl = P0; Pl[1] = -P0[1]; }                       // reflecting inner: v_r -> -v_r
-    if (i < n - 1) Pr = sedov_primitive(u0, dv, n, i + 1, g);
+    if (i < n - 1) Pr = sedov_primitive<S>(u0, dv, n, i + 1, g, ignore);
     else Pr = P0;                                           // zero-gradient outer
 
-    const State5 Flo = riemann_hlle<0>(Pl, P0, g);
-    const State5 Fhi = riemann_hlle<0>(P0, Pr, g);
+    const State5 Flo = S::hlle(Pl, P0, g);
+    const State5 Fhi = S::hlle(P0, Pr, g);
 
     // spherical_geometry_source_terms_radial: only the radial-momentum row is non-zero
-    const double vq = P0[2], pg = P0[4], d = P0[0];
-    State5 S;
-    S[0] = 0.0;
-    S[1] = (2.0 * pg + d * vq * vq) / rc[i];
-    S[2] = 0.0;
-    S[3] = 0.0;
-    S[4] = 0.0;
+    State5 Src;
+    Src[0] = 0.0;
+    Src[1] = S::radial_source(P0, rc[i], g);
+    Src[2] = 0.0;
+    Src[3] = 0.0;
+    Src[4] = 0.0;
 
     const double na0 = -da[i], na1 = -da[i + 1];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
     {
         const double l0 = Fhi[q] * na1 - Flo[q] * na0;
-        const double s0 = S[q] * dv[i];
+        const double s0 = Src[q] * dv[i];
         u1[(size_t) q * n + i] = u0[(size_t) q * n + i] + (l0 + s0) * dt;
     }
+    if (bad && status) atomicOr(status, bad);
 }
 
-hipError_t sedov_stage_launch(const double* u0, double* u1, const double* dv, const double* da, const double* rc,
-                              int n, double gamma, double dt, hipStream_t stream)
+hipError_t sedov_stage_launch(int system, const double* u0, double* u1, const double* dv, const double* da, const double* rc,
+                              int n, double gamma, double dt, int32_t* status, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sedov_stage_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, u0, u1, dv, da, rc, n, gamma, dt);
+    if (system == MH_SYSTEM_SRHD) hipLaunchKernelGGL(sedov_stage_kernel<SedovSrhd>, dim3((n + 63) / 64), dim3(64), 0, stream, u0, u1, dv, da, rc, n, gamma, dt, status);
+    else                          hipLaunchKernelGGL(sedov_stage_kernel<SedovEuler>, dim3((n + 63) / 64), dim3(64), 0, stream, u0, u1, dv, da, rc, n, gamma, dt, status);
     return hipGetLastError();
 }
 

@@ -80,11 +80,11 @@ class EulerCartSolver:
 class SedovSolver:
     """Host mirror of SedovProblem<mara::euler> (src/subprog_sedov.cpp): vertices + volume-integrated conserved state."""
 
-    def __init__(self, vertices, gamma=4.0 / 3, device=0):
+    def __init__(self, vertices, gamma=4.0 / 3, device=0, system="euler"):
         self.lib = L.load_library()
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float64)
         self.nz = self.vertices.size - 1
-        d = L.SedovDesc(nz=self.nz, gamma=gamma, system=0, arith=L.ARITH_STRICT)
+        d = L.SedovDesc(nz=self.nz, gamma=gamma, system={"euler": 0, "srhd": 2}[system], arith=L.ARITH_STRICT)
         self.ctx = C.c_void_p()
         L.check(self.lib.mh_create(C.byref(self.ctx), device))
         L.check(self.lib.mh_sedov_configure(self.ctx, C.byref(d), self.vertices.ctypes.data_as(C.c_void_p)), self.ctx)
@@ -104,6 +104,11 @@ class SedovSolver:
 
     def step(self, dt, nsteps=1):
         L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
+
+    def status(self):
+        s = C.c_int32()
+        L.check(self.lib.mh_status_word(self.ctx, C.byref(s)), self.ctx)
+        return s.value
 
     def close(self):
         if self.ctx:

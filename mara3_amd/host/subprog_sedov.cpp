@@ -2,8 +2,8 @@
 // step, boundary conditions and run loop as the reference's subprog_sedov
 // (src/subprog_sedov.cpp; options :55-70, vertices :366-371, IC :353-363 and
 // :373-380, dt :404-405, loop :626-645, message :588-595), with the state resident
-// on the device and `next_solution` (:394-421) replaced by mh_step. Only the
-// newtonian (mara::euler) system is available this round.
+// on the device and `next_solution` (:394-421) replaced by mh_step. As upstream, the
+// default system is mara::srhd and newtonian=1 selects mara::euler (:652-659).
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -38,7 +38,7 @@ public:
     {
         auto cfg = config_template().update(argc, argv);
         if (! cfg.get_string("restart").empty()) throw std::invalid_argument("sedov: restart needs the HDF5 checkpoint reader (out of scope)");
-        if (cfg.get_int("newtonian") == 0) throw std::invalid_argument("sedov: run with newtonian=1 (the SRHD system is not built yet)");
+        const bool newtonian = cfg.get_int("newtonian") != 0;
         cfg.pretty_print(stdout, "config");
 
         // vertices: 10^linspace(-0.5, log10(R), int(decades*nr)+1)
@@ -57,13 +57,26 @@ public:
             const double d = r < 1.0 ? cfg.get_double("explosion_density") : std::pow(r, -dindex);
             const double p = r < 1.0 ? cfg.get_double("explosion_pressure") : std::pow(r, -dindex) * 1e-6;
             const double dv = (std::pow(v[i + 1], 3) - std::pow(v[i], 3)) / 3;
-            const double U[5] = {d, d * 0.0, d * 0.0, d * 0.0, 0.5 * d * (0.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0) + p / (gamma_law_index - 1)};
+            double U[5];
+            if (newtonian)      // mara::euler::primitive_t::to_conserved_density, physics_euler.hpp:209-220, with v = 0
+            {
+                const double Ue[5] = {d, d * 0.0, d * 0.0, d * 0.0, 0.5 * d * (0.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0) + p / (gamma_law_index - 1)};
+                for (int q = 0; q < 5; ++q) U[q] = Ue[q];
+            }
+            else                // mara::srhd::primitive_t::to_conserved_density, physics_srhd.hpp:213-227, with u = 0
+            {
+                const double W = std::sqrt(1.0 + (0.0 * 0.0 + 0.0 * 0.0 + 0.0 * 0.0));
+                const double h = (d + p * (1.0 + 1.0 / (gamma_law_index - 1.0))) / d;
+                const double D = d * W;
+                const double Us[5] = {D, D * 0.0 * h, D * 0.0 * h, D * 0.0 * h, D * h * W - p - D};
+                for (int q = 0; q < 5; ++q) U[q] = Us[q];
+            }
             for (int q = 0; q < 5; ++q) u[5 * i + q] = U[q] * dv;
         }
 
         mh_ctx* ctx = nullptr;
         host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
-        mh_sedov_desc d = {int(nz), gamma_law_index, MH_SYSTEM_EULER, MH_ARITH_STRICT};
+        mh_sedov_desc d = {int(nz), gamma_law_index, newtonian ? MH_SYSTEM_EULER : MH_SYSTEM_SRHD, MH_ARITH_STRICT};
         host::check(mh_sedov_configure(ctx, &d, v.data()), ctx, "mh_sedov_configure");
         host::check(mh_upload(ctx, u.data(), nz), ctx, "mh_upload");
 

@@ -208,6 +208,18 @@ def gen_iso2d(rng):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "sedov_srhd":
+        with tempfile.TemporaryDirectory() as d:
+            sed = {}
+            for ns in (1, 10, 100):
+                fv, f0, fn = (os.path.join(d, x) for x in ("v", "u0", "un"))
+                run_ref("sedov_ref", [256, hexf(100.0), ns, fv, f0, fn, "srhd"])
+                sed["vertices"] = np.fromfile(fv)
+                sed["u0"] = np.fromfile(f0).reshape(-1, 5)
+                sed["u_%d" % ns] = np.fromfile(fn).reshape(-1, 5)
+            np.savez_compressed(os.path.join(OUT, "sedov_srhd_nr256.npz"), **sed)
+            print("sedov srhd ok", sed["u0"].shape)
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == "iso2d":
         return gen_iso2d(np.random.default_rng(20260303))
     if len(sys.argv) > 1 and sys.argv[1] == "srhd":

@@ -404,6 +404,22 @@ static inline double shell_volume(double r0, double r1)
 }
 
 /* subprog_sedov.cpp:353-363,373-380 */
+void mo_sedov_initial_system(int srhd, size_t nz, const double* v, double gamma, double explosion_density,
+                             double explosion_pressure, double density_index, double* u)
+{
+    for (size_t i = 0; i < nz; ++i)
+    {
+        double r = (v[i] + v[i + 1]) * 0.5;
+        double P[5] = {0, 0, 0, 0, 0}, U[5];
+        P[0] = r < 1.0 ? explosion_density  : pow(r, -density_index);
+        P[4] = r < 1.0 ? explosion_pressure : pow(r, -density_index) * 1e-6;
+        if (srhd) mo_srhd_to_conserved_density(P, gamma, U);
+        else      mo_euler_to_conserved_density(P, gamma, U);
+        double dv = shell_volume(v[i], v[i + 1]);
+        for (int q = 0; q < 5; ++q) u[5 * i + q] = U[q] * dv;
+    }
+}
+
 void mo_sedov_initial(size_t nz, const double* v, double gamma, double explosion_density,
                       double explosion_pressure, double density_index, double* u)
 {
@@ -426,6 +442,45 @@ double mo_sedov_timestep(const double* v, double cfl)
 }
 
 /* subprog_sedov.cpp:394-421 (+ :217-250 BCs and flux) */
+/* the same with HydroSystem = mara::srhd (the sub-program's default, src/subprog_sedov.cpp:652-659);
+ * radial source term src/physics_srhd.hpp:339-348. Returns the OR of the c2p failure bits. */
+int mo_sedov_advance_srhd(size_t nz, const double* v, double gamma, double dt, const double* u0, double* u1)
+{
+    double* p = (double*) malloc(sizeof(double) * 5 * (nz + 2));
+    double* F = (double*) malloc(sizeof(double) * 5 * (nz + 1));
+    int status = 0;
+    for (size_t i = 0; i < nz; ++i)
+    {
+        double dv = shell_volume(v[i], v[i + 1]);
+        double U[5];
+        for (int q = 0; q < 5; ++q) U[q] = u0[5 * i + q] / dv;
+        status |= mo_srhd_recover_primitive(U, gamma, 0.0, p + 5 * (i + 1));
+    }
+    memcpy(p, p + 5, sizeof(double) * 5);
+    p[1] = -p[1];
+    memcpy(p + 5 * (nz + 1), p + 5 * nz, sizeof(double) * 5);
+    for (size_t f = 0; f <= nz; ++f)
+        mo_srhd_riemann_hlle(p + 5 * f, p + 5 * (f + 1), 0, gamma, F + 5 * f);
+    for (size_t i = 0; i < nz; ++i)
+    {
+        const double* P = p + 5 * (i + 1);
+        double dv = shell_volume(v[i], v[i + 1]);
+        double rc = (v[i] + v[i + 1]) * 0.5;
+        double H = P[0] + P[4] * (1.0 + 1.0 / (gamma - 1.0));
+        double S[5] = {0.0, (2.0 * P[4] + H * P[2] * P[2]) / rc, 0.0, 0.0, 0.0};
+        double da0 = v[i] * v[i], da1 = v[i + 1] * v[i + 1];
+        for (int q = 0; q < 5; ++q)
+        {
+            double l0 = F[5 * (i + 1) + q] * (-da1) - F[5 * i + q] * (-da0);
+            double s0 = S[q] * dv;
+            u1[5 * i + q] = u0[5 * i + q] + (l0 + s0) * dt;
+        }
+    }
+    free(p);
+    free(F);
+    return status;
+}
+
 void mo_sedov_advance(size_t nz, const double* v, double gamma, double dt, const double* u0, double* u1)
 {
     double* p = (double*) malloc(sizeof(double) * 5 * (nz + 2)); /* extended primitives */

@@ -81,6 +81,10 @@ void mo_sedov_initial(size_t nz, const double* vertices, double gamma, double ex
                       double explosion_pressure, double density_index, double* u);
 double mo_sedov_timestep(const double* vertices, double cfl);
 void mo_sedov_advance(size_t nz, const double* vertices, double gamma, double dt, const double* u0, double* u1);
+/* HydroSystem = mara::srhd (the sub-program's default system) */
+void mo_sedov_initial_system(int srhd, size_t nz, const double* vertices, double gamma, double explosion_density,
+                             double explosion_pressure, double density_index, double* u);
+int  mo_sedov_advance_srhd(size_t nz, const double* vertices, double gamma, double dt, const double* u0, double* u1);
 
 /* ---- mara::srhd and the `cloud` stage (mara_oracle_srhd.c) ------------------ */
 enum { MO_C2P_NOT_CONVERGED = 4, MO_C2P_NEG_DENSITY = 1, MO_C2P_NEG_PRESSURE = 2, MO_C2P_NAN = 8 };

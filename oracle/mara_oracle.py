@@ -58,6 +58,8 @@ def lib():
         _lib.mo_sedov_timestep.restype = C.c_double
         _lib.mo_sedov_timestep.argtypes = [dp, C.c_double]
         _lib.mo_sedov_advance.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, dp]
+        _lib.mo_sedov_advance_srhd.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, dp]
+        _lib.mo_sedov_initial_system.argtypes = [C.c_int, C.c_size_t, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp]
         ip = C.POINTER(C.c_int)
         _lib.mo_srhd_recover_primitive_n.argtypes = [C.c_size_t, dp, C.c_double, C.c_double, dp, ip]
         _lib.mo_srhd_to_conserved_density_n.argtypes = [C.c_size_t, dp, C.c_double, dp]
@@ -162,6 +164,20 @@ def sedov_initial(vertices, gamma=4.0 / 3, explosion_density=1.0, explosion_pres
     u = np.empty((v.size - 1, 5))
     lib().mo_sedov_initial(v.size - 1, _dp(v), gamma, explosion_density, explosion_pressure, density_index, _dp(u))
     return u
+
+
+def sedov_initial_srhd(vertices, gamma=4.0 / 3, explosion_density=1.0, explosion_pressure=1.0, density_index=0.0):
+    v = _f64(vertices)
+    u = np.empty((v.size - 1, 5))
+    lib().mo_sedov_initial_system(1, v.size - 1, _dp(v), gamma, explosion_density, explosion_pressure, density_index, _dp(u))
+    return u
+
+
+def sedov_advance_srhd(vertices, u0, dt, gamma=4.0 / 3):
+    v, u0 = _f64(vertices), _f64(u0)
+    u1 = np.empty_like(u0)
+    st = lib().mo_sedov_advance_srhd(u0.shape[0], _dp(v), gamma, dt, _dp(u0), _dp(u1))
+    return u1, st
 
 
 def sedov_timestep(vertices, cfl=0.4):

@@ -7,7 +7,8 @@
  * (subprog_sedov.cpp:353-421, BCs :217-250, geometry :166-181), with
  * gamma = 4/3 and CFL = 0.4 as #defined at :48-49.
  *
- * usage: sedov_ref <nr> <outer_radius> <nsteps> <out_vertices.f64> <out_u0.f64> <out_uN.f64>
+ * usage: sedov_ref <nr> <outer_radius> <nsteps> <out_vertices.f64> <out_u0.f64> <out_uN.f64> [srhd]
+ * (the optional last argument selects mara::srhd, the sub-program's default system, instead of mara::euler)
  */
 #include <cstdio>
 #include <cstdlib>
@@ -19,13 +20,16 @@
 #include "core_ndarray_ops.hpp"
 #include "core_dimensional.hpp"
 #include "core_sequence.hpp"
+#include "core_geometric.hpp"
+#include "core_rational.hpp"
 #include "physics_euler.hpp"
+#include "physics_srhd.hpp"
 
 static const double gamma_law = 4. / 3;
 static const double cfl = 0.4;
 
-using prim_t = mara::euler::primitive_t;
-using cons_t = mara::euler::conserved_t; // volume-integrated
+static auto negate_radial(const mara::euler::primitive_t& p) { return p.with_velocity_1(-p.velocity_1()); }
+static auto negate_radial(const mara::srhd::primitive_t& p) { return p.with_gamma_beta_1(-p.gamma_beta_1()); }
 
 template<typename V> static auto face_areas(V vertices)
 {
@@ -37,9 +41,11 @@ template<typename V> static auto cell_volumes(V vertices)
     return vertices | nd::zip_adjacent2_on_axis(0) | nd::apply(shell);
 }
 
-int main(int argc, char** argv)
+template<typename HydroSystem>
+static int run(int argc, char** argv)
 {
-    if (argc != 7) return 1;
+    using prim_t = typename HydroSystem::primitive_t;
+    using cons_t = typename HydroSystem::conserved_t; // volume-integrated
     int nr = std::atoi(argv[1]);
     double outer_radius = std::atof(argv[2]);
     int nsteps = std::atoi(argv[3]);
@@ -56,11 +62,11 @@ int main(int argc, char** argv)
         .with_gas_pressure(r < 1.0 ? 1.0 : std::pow(r, -0.0) * 1e-6);
     };
     auto to_cons = [] (prim_t p) { return p.to_conserved_density(gamma_law); };
-    auto c2p = [] (auto U) { return mara::euler::recover_primitive(U, gamma_law, 0.0); };
+    auto c2p = [] (auto U) { return HydroSystem::recover_primitive(U, gamma_law, 0.0); };
     auto nh = mara::unit_vector_t::on_axis_1();
-    auto riemann = [nh] (prim_t l, prim_t r) { return mara::euler::riemann_hlle(l, r, nh, gamma_law); };
+    auto riemann = [nh] (prim_t l, prim_t r) { return HydroSystem::riemann_hlle(l, r, nh, gamma_law); };
     auto source = [] (prim_t p, double r) { return p.spherical_geometry_source_terms_radial(r, gamma_law); };
-    auto reflect = [] (prim_t p) { return p.with_velocity_1(-p.velocity_1()); };
+    auto reflect = [] (prim_t p) { return negate_radial(p); };
 
     auto xc = vertices | nd::midpoint_on_axis(0);
     auto u = xc | nd::map(initial_p) | nd::map(to_cons) | nd::multiply(cell_volumes(vertices)) | nd::to_shared();
@@ -93,4 +99,10 @@ int main(int argc, char** argv)
     dump(argv[5], u_init.data(), u_init.size() * sizeof(cons_t));
     dump(argv[6], u.data(), u.size() * sizeof(cons_t));
     return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 7 && argc != 8) return 1;
+    return argc == 8 ? run<mara::srhd>(argc, argv) : run<mara::euler>(argc, argv);
 }

@@ -47,6 +47,15 @@ def test_sedov_subprogram_matches_reference(tmp_path):
             assert "[0100] t=" in stdout and "kzps=" in stdout
 
 
+def test_sedov_subprogram_default_system_is_srhd(tmp_path):
+    g = golden("sedov_srhd_nr256")
+    dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
+    run(["sedov", "nr=256", "tfinal=%r" % float(9.5 * dt)], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert d["iteration"] == 10
+    assert bits_equal(d["data"], g["u_10"])
+
+
 def test_sedov_subprogram_option_errors(tmp_path):
     out = subprocess.run([EXE, "sedov", "nosuchkey=1"], cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 1 and "unknown key" in out.stdout

@@ -70,3 +70,17 @@ def test_cloud_reports_c2p_failure_in_status_word(eng):
     s.set_inflow(g["inflow"][0])
     s.step(float(g["dt"]), 1)
     assert s.status() != 0
+
+
+def test_sedov_srhd_bit_exact_vs_reference(eng):
+    """`mara sedov` with its default system mara::srhd (512 zones, PCM + HLLE + forward Euler) after 1/10/100 steps."""
+    g = golden("sedov_srhd_nr256")
+    s = eng.SedovSolver(g["vertices"], system="srhd")
+    s.upload(g["u0"])
+    dt = s.timestep()
+    done = 0
+    for n in (1, 10, 100):
+        s.step(dt, n - done)
+        done = n
+        assert bits_equal(s.download(), g["u_%d" % n]), n
+    assert s.status() == 0

@@ -42,3 +42,18 @@ def test_cloud_steps_bit_exact(oracle, case):
     u, st = oracle.cloud_run(g["u0"], g["rv"], g["qv"], g["inflow"], float(g["dt"]), int(g["nsteps"]), int(g["rk"]), theta, float(g["tfloor"]))
     assert st == 0
     assert bits_equal(u, g["un"]), np.abs(u - g["un"]).max()
+
+
+def test_sedov_srhd_bit_exact(oracle):
+    """`mara sedov` with its default system (newtonian=0 -> mara::srhd), 512 zones, 100 steps."""
+    g = golden("sedov_srhd_nr256")
+    v = oracle.sedov_vertices(256, 100.0)
+    assert bits_equal(v, g["vertices"])
+    u = oracle.sedov_initial_srhd(v)
+    assert bits_equal(u, g["u0"])
+    dt = oracle.sedov_timestep(v)
+    for n in range(1, 101):
+        u, st = oracle.sedov_advance_srhd(v, u, dt)
+        assert st == 0
+        if "u_%d" % n in g.files:
+            assert bits_equal(u, g["u_%d" % n]), n
