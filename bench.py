@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--theta", type=float, default=1.5)
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--arith", default="fast", choices=["strict", "fast"], help="arithmetic contract of the headline value")
+    ap.add_argument("--stepper", default="native", choices=["native", "torch"],
+                    help="native: C++ slab stepper of libmara_hip.so (RCCL called from the library); torch: Python stepper over torch.distributed")
     ap.add_argument("--single-arith", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,43 +154,84 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.stepper == "native":
+        from mara3_amd.slab import NativeSlabStepper, native_comm_id
+
+    def make_stepper(arith):
+        if args.stepper == "native":
+            # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
+            comm_id = native_comm_id(rank, world, device="cuda") if world > 1 else None
+            return NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+                                     comm_id=comm_id, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+        return SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+                                device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=arith)
+
     def run_mode(arith):
         """W untimed + K timed steps of the whole (slab-decomposed) grid in one arithmetic mode."""
-        st = SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
-                              device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=arith)
+        st = make_stepper(arith)
         st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
+        native = args.stepper == "native"
         st.step(dt, args.warmup)
+        if native:
+            st.synchronize()
         fence()
-        st.timers = []
+        # HIP events around every bulk stage launch, on the stream it is launched on. At N = 1 they are recorded in
+        # the timed region itself; at N > 1 in a short extra pass, so that the timed region carries no event traffic.
+        live = world == 1
+        if live:
+            if native:
+                st.profile(True)
+            else:
+                st.timers = []
         t0 = time.perf_counter()
         st.step(dt, args.steps)
+        if native:
+            st.synchronize()
         fence()
         elapsed = time.perf_counter() - t0
-        timers, st.timers = st.timers, None
+        if not live:
+            if native:
+                st.profile(True)
+            else:
+                st.timers = []
+            st.step(dt, 3)
+            if native:
+                st.synchronize()
+            fence()
+        if native:
+            (avg1, avg2), (nl1, nl2), bulk_rows = st.profile_read()
+            st.profile(False)
+        else:
+            timers, st.timers = st.timers, None
+            dur = {1.0: [], 0.5: []}
+            for w, e0, e1 in timers:
+                dur[w].append(e0.elapsed_time(e1))
+            avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
+            avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
+            nl1, nl2, bulk_rows = len(dur[1.0]), len(dur[0.5]), st.n0 - 2 * st.edge_rows
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        dur = {1.0: [], 0.5: []}
-        for w, e0, e1 in timers:       # HIP events on the stream the bulk stage launches ran on
-            dur[w].append(e0.elapsed_time(e1))
-        cells_launch = (st.n0 - 2 * st.edge_rows) * n
-        avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
-        avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
+        cells_launch = bulk_rows * n
         value = n * n * args.steps / elapsed / 1e6
         res = {
             "value": value, "ms_per_step": elapsed / args.steps * 1e3, "status_word": st.status(),
             "roofline": {"bound": "hbm", "achieved": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, args.riemann),
-                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": len(dur[0.5])},
+                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": nl2,
+                         "timing": "HIP events on the launch stream, %s" % ("inside the timed region" if live else "3 extra steps after the timed region")},
             "roofline_stage1": {"achieved": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9,
                                 "frac": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1, "avg_launch_ms": avg1, "launches": len(dur[1.0])},
+                                "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1, "avg_launch_ms": avg1, "launches": nl1},
             "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
                               "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
         }
-        return res, st.u[2:2 + st.n0].clone()
+        final = torch.from_numpy(st.slab_host()) if native else st.u[2:2 + st.n0].permute(0, 2, 1).contiguous().cpu()
+        if native:
+            st.close()
+        return res, final
 
     primary = args.arith
     other = "strict" if primary == "fast" else "fast"
@@ -196,7 +239,7 @@ def main():
     res_other, u_other = (None, None) if args.single_arith else run_mode(other)
     l1 = None
     if u_other is not None:
-        s = (u_primary - u_other).abs().sum()
+        s = (u_primary - u_other).abs().sum().to("cuda")
         if world > 1:
             dist.all_reduce(s)
         l1 = float(s.item()) / (n * n * 5)
@@ -221,7 +264,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
-                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage" % world,
+                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, args.stepper),
                        "arith": arith_note[primary], "status_word": res["status_word"]},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }

@@ -195,6 +195,35 @@ int  mh_profile_enable(mh_ctx* ctx, int on);
 int  mh_profile_read(mh_ctx* ctx, double* avg_stage_ms, int* nlaunches);
 
 /* ------------------------------------------------------------------------ */
+/* Native slab stepper (one process per GPU): the 2-D Euler step with the     */
+/* axis-0 ghost exchange as RCCL send/recv over xGMI, overlapped with the     */
+/* interior update on a second stream and captured into one HIP graph.        */
+/* The cut is nd::partition_shape (src/core_ndarray.hpp:820-836), the         */
+/* execution policy it replaces is mara::evaluate_on<N> (src/app_parallel.hpp */
+/* :75-103) - thread slabs that share one address space upstream.             */
+/* ------------------------------------------------------------------------ */
+typedef struct mh_slab mh_slab;
+
+/* RCCL unique id (128 bytes) created on one rank; the host distributes it to the others (any transport). */
+int  mh_comm_unique_id(void* id128);
+/* `global`: the description of the WHOLE grid (n[0] = global rows; bc_lo0/bc_hi0 = the physical boundary
+ * condition). comm_id128 may be NULL when the rank has no neighbours. self_exchange != 0 with world == 1 and a
+ * periodic axis 0 makes the rank exchange with itself (exercises the whole path on one GPU). */
+int  mh_slab_create(mh_slab** slab, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
+                    const void* comm_id128, int self_exchange, int device_id);
+void mh_slab_destroy(mh_slab* slab);
+int  mh_slab_rows(const mh_slab* slab, int* row0, int* row1);                 /* this rank's rows [row0, row1) */
+int  mh_slab_upload(mh_slab* slab, const double* u_aos_slab_host);            /* host AoS [n0][n1][5] of this rank's rows */
+int  mh_slab_download(mh_slab* slab, double* u_aos_slab_host);
+int  mh_slab_step(mh_slab* slab, double dt, int nsteps, int use_graph);       /* use_graph: replay one captured step (RK2) */
+int  mh_slab_synchronize(mh_slab* slab);
+int  mh_slab_status_word(mh_slab* slab, int32_t* status);
+double* mh_slab_field_ptr(mh_slab* slab, int which);
+/* HIP-event timing of the bulk (interior) stage launches in eager mode: avg_ms[0|1] = first | second RK stage */
+int  mh_slab_profile_enable(mh_slab* slab, int on);
+int  mh_slab_profile_read(mh_slab* slab, double avg_ms[2], int nlaunches[2], int* bulk_rows);
+
+/* ------------------------------------------------------------------------ */
 /* Per-function device entry points (parity tests call these through the ABI) */
 /* inputs/outputs are DEVICE arrays of n items, AoS rows of 5 (or 3 / 1)      */
 /* ------------------------------------------------------------------------ */

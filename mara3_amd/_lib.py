@@ -71,6 +71,18 @@ SYMBOLS = [
     ("mh_field_ptr", _vp, [_vp, _i]),
     ("mh_profile_enable", _i, [_vp, _i]),
     ("mh_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
+    ("mh_comm_unique_id", _i, [_vp]),
+    ("mh_slab_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i, _i]),
+    ("mh_slab_destroy", None, [_vp]),
+    ("mh_slab_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("mh_slab_upload", _i, [_vp, _vp]),
+    ("mh_slab_download", _i, [_vp, _vp]),
+    ("mh_slab_step", _i, [_vp, _d, _i, _i]),
+    ("mh_slab_synchronize", _i, [_vp]),
+    ("mh_slab_status_word", _i, [_vp, C.POINTER(C.c_int32)]),
+    ("mh_slab_field_ptr", _vp, [_vp, _i]),
+    ("mh_slab_profile_enable", _i, [_vp, _i]),
+    ("mh_slab_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i), C.POINTER(_i)]),
     ("mh_plm_gradient_n", _i, [_sz, _dp, _dp, _dp, _d, _dp, _i, _vp]),
     ("mh_euler_recover_primitive_n", _i, [_sz, _dp, _d, _d, _dp, _i, _vp]),
     ("mh_euler_to_conserved_n", _i, [_sz, _dp, _d, _dp, _i, _vp]),

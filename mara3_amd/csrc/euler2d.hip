@@ -55,6 +55,7 @@ struct Stage2dParams
     long   row_stride;       // doubles between consecutive rows
     int    n0, n1;           // local rows, columns
     int    row_begin, row_end;
+    int    row_begin2, row_end2, nchunks_a;   // optional second row range: chunks >= nchunks_a march [row_begin2, row_end2)
     int    chunk_rows;
     int    nstrips, nchunks;
     int    bc_lo0, bc_hi0, bc1;
@@ -118,8 +119,13 @@ void euler2d_stage_kernel(Stage2dParams p)
     const int chunk = w / p.nstrips;
     const int strip = w - chunk * p.nstrips;
 
-    const int r0 = p.row_begin + chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, p.row_end);
+    int r0 = p.row_begin + chunk * p.chunk_rows;
+    int r1 = min(r0 + p.chunk_rows, p.row_end);
+    if (chunk >= p.nchunks_a)
+    {
+        r0 = p.row_begin2 + (chunk - p.nchunks_a) * p.chunk_rows;
+        r1 = min(r0 + p.chunk_rows, p.row_end2);
+    }
 
     // ---- column of this lane, with the axis-1 boundary condition folded into the index
     const int col = strip * STRIP - HALO + lane;
@@ -277,6 +283,13 @@ static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
 hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
 {
+    return euler2d_stage_launch2(d, u_in, u_base, u_out, dt, weight, row_begin, row_end, 0, 0, status, stream);
+}
+
+hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                 double dt, double weight, int row_begin, int row_end, int row_begin2, int row_end2,
+                                 int32_t* status, hipStream_t stream)
+{
     Stage2dParams p;
     p.u_in = u_in;
     p.u_base = u_base;
@@ -290,7 +303,10 @@ hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
     p.row_end = row_end;
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     p.nstrips = (p.n1 + STRIP - 1) / STRIP;
-    p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    p.nchunks_a = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    p.row_begin2 = row_begin2;
+    p.row_end2 = row_end2;
+    p.nchunks = p.nchunks_a + (row_end2 - row_begin2 + p.chunk_rows - 1) / p.chunk_rows;
     p.bc_lo0 = d->bc_lo0;
     p.bc_hi0 = d->bc_hi0;
     p.bc1 = d->bc_transverse;

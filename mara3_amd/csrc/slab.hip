@@ -1,0 +1,378 @@
+// Native slab stepper: one rank's share of a 2-D uniform-cartesian Euler run, with the ghost-row exchange as
+// RCCL point-to-point send/recv over xGMI, driven from C++ (HIP graph replay when the rank has no neighbours).
+//
+// Why native: at 8 GPUs a 4096^2 grid leaves ~60 us of device work per stage; issuing the launches and a P2P
+// group per stage from a host language costs several times that. Here the whole multi-step loop - edge launch,
+// the ncclSend/ncclRecv group and the interior launch on two streams - is issued from C++; without neighbours
+// the step is additionally captured into one HIP graph and replayed.
+//
+// The slab cut is nd::partition_shape (src/core_ndarray.hpp:820-836): rank n of N owns axis-0 rows
+// [n*Ni/N, (n+1)*Ni/N). The reference's slabs share an address space and exchange nothing; per stage each rank
+// sends its two edge row-blocks (contiguous 2*5*n1 doubles in the device layout) to the axis-0 neighbours and
+// receives their ghost row-blocks, all four operations in one RCCL group, overlapped with the interior update.
+//
+// RCCL is bound at run time (dlopen "librccl.so.1": inside a torch process that is the copy torch already
+// loaded), so the library has no link-time dependency on it and single-GPU hosts never touch it.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "launch.hpp"
+
+namespace mh {
+
+struct RcclApi
+{
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi* rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (! tried)
+    {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (api.handle)
+        {
+#define MH_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym))
+            MH_SYM(GetUniqueId, "ncclGetUniqueId");
+            MH_SYM(CommInitRank, "ncclCommInitRank");
+            MH_SYM(CommDestroy, "ncclCommDestroy");
+            MH_SYM(GroupStart, "ncclGroupStart");
+            MH_SYM(GroupEnd, "ncclGroupEnd");
+            MH_SYM(Send, "ncclSend");
+            MH_SYM(Recv, "ncclRecv");
+            MH_SYM(GetErrorString, "ncclGetErrorString");
+#undef MH_SYM
+            if (! (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv))
+            {
+                dlclose(api.handle);
+                api.handle = nullptr;
+            }
+        }
+    }
+    return api.handle ? &api : nullptr;
+}
+
+static int rccl_fail(ncclResult_t r, const char* what)
+{
+    RcclApi* a = rccl();
+    set_error("RCCL error %d (%s) in %s", (int) r, a && a->GetErrorString ? a->GetErrorString(r) : "?", what);
+    return MH_E_HIP;
+}
+#define MH_RCCL_TRY(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return rccl_fail(_r, #call); } while (0)
+
+} // namespace mh
+
+using namespace mh;
+
+struct mh_slab
+{
+    int device = 0, rank = 0, world = 1, rk_order = 2;
+    int lo = -1, hi = -1;                 // neighbour ranks on the low / high side of axis 0 (-1: physical boundary)
+    int row0 = 0, row1 = 0, n0 = 0, n1 = 0, edge_rows = 0;
+    mh_euler_cart_desc desc, edge_desc;
+    double* field[2] = {nullptr, nullptr};       // [0] solution, [1] stage scratch; layout of include/mara_hip.h
+    double* staging = nullptr;
+    int32_t* status = nullptr;
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    ncclComm_t comm = nullptr;
+    hipGraphExec_t exec = nullptr;
+    double graph_dt = 0.0;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];   // bulk launches of stage 1 / stage 2
+    std::string error;
+};
+
+static int slab_fail(mh_slab* s, int code) { if (s) s->error = mh_last_error(nullptr); return code; }
+
+static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
+{
+    if (s->lo < 0 && s->hi < 0) return MH_OK;
+    RcclApi* a = rccl();
+    const size_t blk = (size_t) 2 * 5 * s->n1;             // two rows, all variables: contiguous
+    MH_RCCL_TRY(a->GroupStart());
+    if (s->lo >= 0) MH_RCCL_TRY(a->Send(f + blk, blk, ncclDouble, s->lo, s->comm, stream));                             // rows 0,1
+    if (s->hi >= 0) MH_RCCL_TRY(a->Send(f + (size_t) s->n0 * 5 * s->n1, blk, ncclDouble, s->hi, s->comm, stream));      // rows n0-2,n0-1
+    // receive order mirrors the neighbours' send order (low rows first): matters when lo == hi
+    if (s->hi >= 0) MH_RCCL_TRY(a->Recv(f + (size_t) (s->n0 + 2) * 5 * s->n1, blk, ncclDouble, s->hi, s->comm, stream)); // ghosts n0,n0+1
+    if (s->lo >= 0) MH_RCCL_TRY(a->Recv(f, blk, ncclDouble, s->lo, s->comm, stream));                                   // ghosts -2,-1
+    MH_RCCL_TRY(a->GroupEnd());
+    return MH_OK;
+}
+
+static int slab_stage(mh_slab* s, const double* in, const double* base, double* out, double dt, double w, int which)
+{
+    const int n0 = s->n0, e = s->edge_rows;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    auto bulk = [&] (int a, int b) -> hipError_t
+    {
+        if (s->profile)
+        {
+            hipEventCreate(&ev.first);
+            hipEventCreate(&ev.second);
+            hipEventRecord(ev.first, s->main);
+        }
+        hipError_t r = euler2d_stage_launch(&s->desc, in, base, out, dt, w, a, b, s->status, s->main);
+        if (s->profile)
+        {
+            hipEventRecord(ev.second, s->main);
+            s->events[which].push_back(ev);
+        }
+        return r;
+    };
+    if (s->lo < 0 && s->hi < 0)
+    {
+        MH_HIP_TRY(bulk(0, n0));
+        return MH_OK;
+    }
+    // edge rows + exchange on the side stream, interior on the main stream
+    MH_HIP_TRY(hipEventRecord(s->fork, s->main));
+    MH_HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
+    MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
+    if (int rc = slab_exchange(s, out, s->side)) return rc;
+    MH_HIP_TRY(bulk(e, n0 - e));
+    MH_HIP_TRY(hipEventRecord(s->join, s->side));
+    MH_HIP_TRY(hipStreamWaitEvent(s->main, s->join, 0));
+    return MH_OK;
+}
+
+static int slab_one_step(mh_slab* s, double dt)
+{
+    if (s->rk_order == 1)
+    {
+        if (int rc = slab_stage(s, s->field[0], nullptr, s->field[1], dt, 1.0, 0)) return rc;
+        std::swap(s->field[0], s->field[1]);
+        return MH_OK;
+    }
+    if (int rc = slab_stage(s, s->field[0], nullptr, s->field[1], dt, 1.0, 0)) return rc;
+    return slab_stage(s, s->field[1], s->field[0], s->field[0], dt, 0.5, 1);
+}
+
+extern "C" {
+
+int mh_comm_unique_id(void* id128)
+{
+    RcclApi* a = rccl();
+    if (! a) { set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
+    ncclUniqueId id;
+    MH_RCCL_TRY(a->GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return MH_OK;
+}
+
+int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
+                   const void* comm_id128, int self_exchange, int device_id)
+{
+    if (! out || ! global) return MH_E_INVALID;
+    if (global->rank != 2) { set_error("mh_slab: 2-D only"); return MH_E_INVALID; }
+    if (rank < 0 || rank >= world) { set_error("mh_slab: rank %d of %d", rank, world); return MH_E_INVALID; }
+    if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return MH_E_INVALID; }
+    const bool periodic = global->bc_lo0 == MH_BC_PERIODIC;
+    if (periodic != (global->bc_hi0 == MH_BC_PERIODIC)) { set_error("periodic axis-0 bc must be set on both sides"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(device_id));
+    mh_slab* s = new mh_slab();
+    s->device = device_id; s->rank = rank; s->world = world; s->rk_order = rk_order;
+    size_t a, b;
+    mh_partition_rows((size_t) global->n[0], (size_t) world, (size_t) rank, &a, &b);
+    s->row0 = (int) a; s->row1 = (int) b; s->n0 = s->row1 - s->row0; s->n1 = global->n[1];
+    const bool wrap = periodic && (world > 1 || self_exchange);
+    s->lo = rank > 0 ? rank - 1 : (wrap ? world - 1 : -1);
+    s->hi = rank < world - 1 ? rank + 1 : (wrap ? 0 : -1);
+    s->desc = *global;
+    s->desc.n[0] = s->n0;
+    s->desc.bc_lo0 = s->lo >= 0 ? MH_BC_EXTERNAL : global->bc_lo0;
+    s->desc.bc_hi0 = s->hi >= 0 ? MH_BC_EXTERNAL : global->bc_hi0;
+    s->edge_desc = s->desc;
+    s->edge_desc.chunk_rows = 8;
+    s->edge_rows = (s->lo >= 0 || s->hi >= 0) ? 8 : 0;
+    if (2 * s->edge_rows > s->n0) s->edge_rows = s->n0 / 2;
+    if ((s->lo >= 0 || s->hi >= 0) && s->n0 < 4) { delete s; set_error("slab of %d rows is thinner than two ghost layers", s->n0); return MH_E_INVALID; }
+
+    auto cleanup = [&] () { mh_slab_destroy(s); };
+    if (hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, -1) != hipSuccess ||
+        hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
+    { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
+    const size_t doubles = mh_euler_cart_field_doubles(&s->desc);
+    for (auto& f : s->field)
+    {
+        if (hipMalloc((void**) &f, doubles * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab: hipMalloc failed"); return MH_E_NOMEM; }
+        hipMemsetAsync(f, 0, doubles * sizeof(double), s->main);
+    }
+    if (hipMalloc((void**) &s->status, 2 * sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
+    hipMemsetAsync(s->status, 0, 2 * sizeof(int32_t), s->main);
+    if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
+
+    if (s->lo >= 0 || s->hi >= 0)
+    {
+        RcclApi* api = rccl();
+        if (! api) { cleanup(); set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
+        if (! comm_id128) { cleanup(); set_error("mh_slab: neighbours exist but no RCCL unique id was given"); return MH_E_INVALID; }
+        ncclUniqueId id;
+        std::memcpy(&id, comm_id128, sizeof id);
+        ncclResult_t r = api->CommInitRank(&s->comm, world, id, rank);
+        if (r != ncclSuccess) { cleanup(); return rccl_fail(r, "ncclCommInitRank"); }
+    }
+    hipStreamSynchronize(s->main);
+    *out = s;
+    return MH_OK;
+}
+
+void mh_slab_destroy(mh_slab* s)
+{
+    if (! s) return;
+    hipSetDevice(s->device);
+    if (s->main) hipStreamSynchronize(s->main);
+    if (s->side) hipStreamSynchronize(s->side);
+    if (s->exec) hipGraphExecDestroy(s->exec);
+    if (s->comm && rccl()) rccl()->CommDestroy(s->comm);
+    for (auto& v : s->events) for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto& f : s->field) if (f) hipFree(f);
+    if (s->staging) hipFree(s->staging);
+    if (s->status) hipFree(s->status);
+    if (s->fork) hipEventDestroy(s->fork);
+    if (s->join) hipEventDestroy(s->join);
+    if (s->main) hipStreamDestroy(s->main);
+    if (s->side) hipStreamDestroy(s->side);
+    delete s;
+}
+
+int mh_slab_rows(const mh_slab* s, int* row0, int* row1)
+{
+    if (! s) return MH_E_INVALID;
+    if (row0) *row0 = s->row0;
+    if (row1) *row1 = s->row1;
+    return MH_OK;
+}
+
+int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
+{
+    if (! s || ! u_aos_slab_host) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    const size_t ncell = (size_t) s->n0 * s->n1;
+    MH_HIP_TRY(hipMemcpyAsync(s->staging, u_aos_slab_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, s->main));
+    MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
+    MH_HIP_TRY(fill_ghost_rows_launch(s->field[0], 5, s->n0, (size_t) s->n1, s->desc.bc_lo0, s->desc.bc_hi0, s->main));
+    if (int rc = slab_exchange(s, s->field[0], s->main)) return slab_fail(s, rc);
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    return MH_OK;
+}
+
+int mh_slab_download(mh_slab* s, double* u_aos_slab_host)
+{
+    if (! s || ! u_aos_slab_host) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    const size_t ncell = (size_t) s->n0 * s->n1;
+    MH_HIP_TRY(soa_to_aos_launch(s->field[0], s->staging, 5, s->n0, (size_t) s->n1, s->main));
+    MH_HIP_TRY(hipMemcpyAsync(u_aos_slab_host, s->staging, ncell * 5 * sizeof(double), hipMemcpyDeviceToHost, s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    return MH_OK;
+}
+
+int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
+{
+    if (! s) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    // RCCL point-to-point inside a stream capture crashes this stack (RCCL 2.26 / HIP 7.0: segfault in
+    // hipStreamEndCapture, also through torch), so only the neighbour-less step is replayed from a graph; with
+    // neighbours the step is issued eagerly from this loop (about ten HIP/RCCL calls per stage, no host language).
+    if (use_graph && s->rk_order == 2 && ! s->profile && s->lo < 0 && s->hi < 0)
+    {
+        if (! s->exec || s->graph_dt != dt)
+        {
+            if (s->exec) { hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            MH_HIP_TRY(hipStreamSynchronize(s->main));
+            MH_HIP_TRY(hipStreamBeginCapture(s->main, hipStreamCaptureModeRelaxed));
+            int rc = slab_one_step(s, dt);
+            hipError_t e = hipStreamEndCapture(s->main, &graph);
+            if (rc) return slab_fail(s, rc);
+            if (e != hipSuccess) return slab_fail(s, hip_fail(e, "hipStreamEndCapture"));
+            e = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) { s->exec = nullptr; return slab_fail(s, hip_fail(e, "hipGraphInstantiate")); }
+            s->graph_dt = dt;
+        }
+        for (int n = 0; n < nsteps; ++n) MH_HIP_TRY(hipGraphLaunch(s->exec, s->main));
+        return MH_OK;
+    }
+    for (int n = 0; n < nsteps; ++n)
+        if (int rc = slab_one_step(s, dt)) return slab_fail(s, rc);
+    return MH_OK;
+}
+
+int mh_slab_synchronize(mh_slab* s)
+{
+    if (! s) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    return MH_OK;
+}
+
+int mh_slab_status_word(mh_slab* s, int32_t* status)
+{
+    if (! s || ! status) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    int32_t h[2] = {0, 0};
+    MH_HIP_TRY(hipMemcpyAsync(h, s->status, sizeof h, hipMemcpyDeviceToHost, s->main));
+    MH_HIP_TRY(hipMemsetAsync(s->status, 0, sizeof h, s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    *status = h[0];
+    return MH_OK;
+}
+
+double* mh_slab_field_ptr(mh_slab* s, int which)
+{
+    return s && which >= 0 && which <= 1 ? s->field[which] : nullptr;
+}
+
+int mh_slab_profile_enable(mh_slab* s, int on)
+{
+    if (! s) return MH_E_INVALID;
+    for (auto& v : s->events) { for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } v.clear(); }
+    s->profile = on != 0;
+    return MH_OK;
+}
+
+int mh_slab_profile_read(mh_slab* s, double avg_ms[2], int nlaunches[2], int* bulk_rows)
+{
+    if (! s) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    for (int k = 0; k < 2; ++k)
+    {
+        double total = 0.0;
+        for (auto& ev : s->events[k])
+        {
+            float ms = 0.f;
+            MH_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+            total += ms;
+        }
+        if (avg_ms) avg_ms[k] = s->events[k].empty() ? 0.0 : total / s->events[k].size();
+        if (nlaunches) nlaunches[k] = (int) s->events[k].size();
+    }
+    if (bulk_rows) *bulk_rows = s->n0 - 2 * s->edge_rows;
+    return MH_OK;
+}
+
+} // extern "C"

@@ -133,6 +133,7 @@ class SlabEulerStepper:
         self.side = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap else None
 
         self.timers = None   # list of (stage_weight, start_event, end_event) when enabled
+        self.graph, self.graph_dt = None, None
         shape = (self.n0 + 2 * HALO, NQ, self.n1)
         self.u = torch.zeros(shape, dtype=torch.float64, device=self.device)
         self.scratch = torch.zeros(shape, dtype=torch.float64, device=self.device)
@@ -207,9 +208,33 @@ class SlabEulerStepper:
             self._launch_main(u_in, u_base, u_out, dt, weight, [(e, n0 - e)])
             self.exchange.finish(reqs)
 
+    def capture(self, dt):
+        """Capture one full time step (both RK stages, edge launches, the RCCL send/recv group and the
+        two-stream overlap) into a HIP graph; step() then replays it. Removes the per-step host cost
+        (8 launches + a P2P group issued from Python), which at 8 GPUs exceeds the ~60 us of device work per stage.
+        Call after at least one eager step (RCCL communicators must exist before capture). RK2 only
+        (RK1 swaps its two fields every step)."""
+        if self.rk_order != 2:
+            raise ValueError("graph capture is implemented for rk_order 2")
+        assert self.device.type == "cuda"
+        self.timers = None
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_eager(dt, 1)
+        self.graph, self.graph_dt = graph, dt
+        return graph
+
     def step(self, dt, nsteps=1):
         """nsteps full time steps. RK1: u <- advance(u). RK2: u <- u*0.5 + advance(advance(u))*0.5
         (src/subprog_cloud.cpp:682-695), the combine fused into the second stage and written in place."""
+        if self.graph is not None and dt == self.graph_dt and self.timers is None:
+            for _ in range(nsteps):
+                self.graph.replay()
+            return
+        self._step_eager(dt, nsteps)
+
+    def _step_eager(self, dt, nsteps=1):
         for _ in range(nsteps):
             if self.rk_order == 1:
                 self._stage(self.u, None, self.scratch, dt, 1.0)
@@ -225,3 +250,90 @@ class SlabEulerStepper:
         v = int(st[0].item())
         st.zero_()
         return v
+
+
+class NativeSlabStepper:
+    """The native (C++/HIP/RCCL) slab stepper of libmara_hip.so: same cut, ghost layout and message pattern as
+    SlabEulerStepper, but the exchange is RCCL called from the library and the whole step is one HIP graph.
+    `comm_id` is the 128-byte RCCL unique id every rank must share (see `native_comm_id`)."""
+
+    def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
+                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict"):
+        import numpy as np
+        self.np = np
+        self.lib = L.load_library()
+        d = L.EulerCartDesc()
+        d.rank = 2
+        d.n[0], d.n[1], d.n[2] = global_shape[0], global_shape[1], 1
+        d.dl[0], d.dl[1], d.dl[2] = dl[0], dl[1], 1.0
+        d.gamma, d.plm_theta = gamma, plm_theta
+        d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
+        phys = L.BC_PERIODIC if bc == "periodic" else L.BC_OUTFLOW
+        d.bc_lo0 = d.bc_hi0 = d.bc_transverse = phys
+        d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
+        d.chunk_rows = chunk_rows
+        self.handle = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
+        L.check(self.lib.mh_slab_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf,
+                                        1 if self_exchange else 0, device))
+        a, b = C.c_int(), C.c_int()
+        L.check(self.lib.mh_slab_rows(self.handle, C.byref(a), C.byref(b)))
+        self.row0, self.row1 = a.value, b.value
+        self.n0, self.n1 = self.row1 - self.row0, global_shape[1]
+
+    def load_slab(self, u_aos_slab):
+        u = self.np.ascontiguousarray(u_aos_slab, dtype=self.np.float64)
+        assert u.shape == (self.n0, self.n1, NQ)
+        L.check(self.lib.mh_slab_upload(self.handle, u.ctypes.data_as(C.c_void_p)))
+
+    def slab_host(self):
+        u = self.np.empty((self.n0, self.n1, NQ))
+        L.check(self.lib.mh_slab_download(self.handle, u.ctypes.data_as(C.c_void_p)))
+        return u
+
+    def step(self, dt, nsteps=1, graph=True):
+        L.check(self.lib.mh_slab_step(self.handle, dt, nsteps, 1 if graph else 0))
+
+    def synchronize(self):
+        L.check(self.lib.mh_slab_synchronize(self.handle))
+
+    def status(self):
+        s = C.c_int32()
+        L.check(self.lib.mh_slab_status_word(self.handle, C.byref(s)))
+        return s.value
+
+    def profile(self, on=True):
+        L.check(self.lib.mh_slab_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n, rows = (C.c_double * 2)(), (C.c_int * 2)(), C.c_int()
+        L.check(self.lib.mh_slab_profile_read(self.handle, ms, n, C.byref(rows)))
+        return (ms[0], ms[1]), (n[0], n[1]), rows.value
+
+    def field_tensor(self):
+        """The solution field as a torch tensor view is not needed by the product path; tests compare host copies."""
+        raise NotImplementedError
+
+    def close(self):
+        if self.handle:
+            self.lib.mh_slab_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def native_comm_id(rank, world, device=None):
+    """Create the RCCL unique id on rank 0 and broadcast it over the default torch.distributed group."""
+    lib = L.load_library()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        L.check(lib.mh_comm_unique_id(buf))
+    if world == 1:
+        return bytes(buf.raw)
+    t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device if device is not None else "cpu")
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
