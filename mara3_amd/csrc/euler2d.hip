@@ -301,8 +301,16 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     p.row_stride = 5L * p.n1;
     p.row_begin = row_begin;
     p.row_end = row_end;
-    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     p.nstrips = (p.n1 + STRIP - 1) / STRIP;
+    if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
+    else
+    {
+        // default: 32 rows per wave (7 % prologue overhead), shortened for thin slabs so that the launch still
+        // has ~4096 waves (2 per SIMD and two rounds); measured on 512/1024/2048-row slabs of 4096 columns
+        const long rows = (long) (row_end - row_begin) + (row_end2 - row_begin2);
+        long c = (rows * p.nstrips + 2048) / 4096;
+        p.chunk_rows = (int) (c < 8 ? 8 : (c > 32 ? 32 : c));
+    }
     p.nchunks_a = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
     p.row_begin2 = row_begin2;
     p.row_end2 = row_end2;

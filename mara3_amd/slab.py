@@ -216,6 +216,10 @@ class SlabEulerStepper:
         (RK1 swaps its two fields every step)."""
         if self.rk_order != 2:
             raise ValueError("graph capture is implemented for rk_order 2")
+        if self.has_neighbours:
+            # torch's process group cannot be captured on this stack (its watchdog polls events recorded in the
+            # capturing stream; RCCL P2P inside hipStreamEndCapture segfaults): use NativeSlabStepper instead
+            raise ValueError("graph capture with a ghost exchange is not supported by the torch stepper")
         assert self.device.type == "cuda"
         self.timers = None
         torch.cuda.synchronize()
