@@ -106,7 +106,7 @@ void cloud_stage_kernel(CloudParams p)
         const int per_xcd = gridDim.x >> 3;
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
     }
-    const int w = b * CWAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(b * CWAVES_PER_BLOCK + (int) (threadIdx.x >> 6));   // wave-uniform -> scalar registers
     if (w >= p.nstrips * p.nchunks) return;
     const int lane = threadIdx.x & 63;
     const int chunk = w / p.nstrips;

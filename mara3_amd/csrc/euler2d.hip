@@ -92,12 +92,21 @@ __device__ inline State5 from_right(const State5& s)
     return r;
 }
 
-__device__ inline State5 load_row(const double* base, long plane_stride, long offset)
+// row pointer is wave-uniform (scalar registers), lane_bytes is the lane's 32-bit byte offset inside the row:
+// lets the compiler use the scalar-base + vector-offset addressing mode (no 64-bit vector address arithmetic)
+__device__ inline State5 load_row(const double* row, long plane_stride, unsigned lane_bytes)
 {
     State5 U;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) U[q] = base[q * plane_stride + offset];
+    for (int q = 0; q < 5; ++q)
+        U[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row + q * plane_stride) + lane_bytes);
     return U;
+}
+__device__ inline void store_row(double* row, long plane_stride, unsigned lane_bytes, const State5& U)
+{
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(row + q * plane_stride) + lane_bytes) = U[q];
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
@@ -113,7 +122,9 @@ void euler2d_stage_kernel(Stage2dParams p)
         const int per_xcd = nblocks >> 3;
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
     }
-    const int w = b * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    // the wave index is uniform across the wave: tell the compiler, so that everything derived from it (chunk,
+    // strip, row loop, row addresses) lives in scalar registers and costs no vector instructions
+    const int w = __builtin_amdgcn_readfirstlane(b * WAVES_PER_BLOCK + (int) (threadIdx.x >> 6));
     if (w >= p.nstrips * p.nchunks) return;
     const int lane = threadIdx.x & 63;
     const int chunk = w / p.nstrips;
@@ -135,18 +146,19 @@ void euler2d_stage_kernel(Stage2dParams p)
     const bool writes = lane >= HALO && lane < WAVE - HALO && col < p.n1;
 
     const long row_stride = p.row_stride;
-    const double* in = p.u_in + jc;                  // row r, plane q lives at (r + 2) * row_stride + q * plane_stride
+    const double* in = p.u_in;                       // row r, plane q lives at (r + 2) * row_stride + q * plane_stride
     auto row_off = [row_stride] (int r) { return (long) (r + HALO) * row_stride; };
+    const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
 
     const double gamma = p.gamma, theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(gamma);
 
     // ---- prologue: rows r0-2 .. r0+1
-    State5 Ua = load_row(in, p.plane_stride, row_off(r0 - 2));
-    State5 Ub = load_row(in, p.plane_stride, row_off(r0 - 1));
-    State5 U0 = load_row(in, p.plane_stride, row_off(r0));
-    State5 U1 = load_row(in, p.plane_stride, row_off(r0 + 1));
-    State5 U2 = load_row(in, p.plane_stride, row_off(r0 + 2));   // first prefetch
+    State5 Ua = load_row(in + row_off(r0 - 2), p.plane_stride, jc8);
+    State5 Ub = load_row(in + row_off(r0 - 1), p.plane_stride, jc8);
+    State5 U0 = load_row(in + row_off(r0), p.plane_stride, jc8);
+    State5 U1 = load_row(in + row_off(r0 + 1), p.plane_stride, jc8);
+    State5 U2 = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
 
     State5 P0, P1, G0, Fx_lo;
     {
@@ -172,9 +184,9 @@ void euler2d_stage_kernel(Stage2dParams p)
     {
         // prefetch row r+3 (clamped to the stored ghost range; the value is unused past the chunk end)
         const int rp = min(r + 3, p.n0 + 1);
-        const State5 U3 = load_row(in, p.plane_stride, row_off(rp));
+        const State5 U3 = load_row(in + row_off(rp), p.plane_stride, jc8);
         State5 Ubase;
-        if constexpr (COMBINE) Ubase = load_row(p.u_base + jc, p.plane_stride, row_off(r));
+        if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);
 
         // ---- axis 0: flux through face r+1/2
         const State5 P2 = A::c2p(U2, gl);
@@ -216,43 +228,29 @@ void euler2d_stage_kernel(Stage2dParams p)
 
         if (writes)
         {
-            double* out = p.u_out + col;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(r)] = Un[q];
+            store_row(p.u_out + row_off(r), p.plane_stride, col8, Un);
 
             // keep the physical axis-0 ghost rows of the output current
             if (r < HALO)
             {
                 if (p.bc_lo0 == 0 && r == 0)
                 {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q)
-                    {
-                        out[q * p.plane_stride + row_off(-1)] = Un[q];
-                        out[q * p.plane_stride + row_off(-2)] = Un[q];
-                    }
+                    { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
                 }
                 if (p.bc_hi0 == 1)
                 {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(p.n0 + r)] = Un[q];
+                    store_row(p.u_out + row_off(p.n0 + r), p.plane_stride, col8, Un);
                 }
             }
             if (r >= p.n0 - HALO)
             {
                 if (p.bc_hi0 == 0 && r == p.n0 - 1)
                 {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q)
-                    {
-                        out[q * p.plane_stride + row_off(p.n0)] = Un[q];
-                        out[q * p.plane_stride + row_off(p.n0 + 1)] = Un[q];
-                    }
+                    { store_row(p.u_out + row_off(p.n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(p.n0 + 1), p.plane_stride, col8, Un); }
                 }
                 if (p.bc_lo0 == 1)
                 {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) out[q * p.plane_stride + row_off(r - p.n0)] = Un[q];
+                    store_row(p.u_out + row_off(r - p.n0), p.plane_stride, col8, Un);
                 }
             }
         }

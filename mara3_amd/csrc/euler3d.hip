@@ -107,7 +107,7 @@ void euler3d_stage_kernel(Stage3dParams p)
     const int t1 = (b / p.nstrips) % p.ntiles1;
     const int chunk = b / (p.nstrips * p.ntiles1);
     const int lane = threadIdx.x & 63;
-    const int row = threadIdx.x >> 6;                      // wave index = tile row
+    const int row = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // wave index = tile row (uniform -> scalar registers)
     const int r0 = p.row_begin + chunk * p.chunk_rows;
     const int r1 = min(r0 + p.chunk_rows, p.row_end);
 

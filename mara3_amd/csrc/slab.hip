@@ -103,6 +103,13 @@ struct mh_slab
 
 static int slab_fail(mh_slab* s, int code) { if (s) s->error = mh_last_error(nullptr); return code; }
 
+static hipError_t stage_launch(const mh_euler_cart_desc* d, const double* in, const double* base, double* out, double dt, double w,
+                               int a, int b, int32_t* status, hipStream_t stream)
+{
+    return d->rank == 3 ? euler3d_stage_launch(d, in, base, out, dt, w, a, b, status, stream)
+                        : euler2d_stage_launch(d, in, base, out, dt, w, a, b, status, stream);
+}
+
 static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
 {
     if (s->lo < 0 && s->hi < 0) return MH_OK;
@@ -130,7 +137,7 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
             hipEventCreate(&ev.second);
             hipEventRecord(ev.first, s->main);
         }
-        hipError_t r = euler2d_stage_launch(&s->desc, in, base, out, dt, w, a, b, s->status, s->main);
+        hipError_t r = stage_launch(&s->desc, in, base, out, dt, w, a, b, s->status, s->main);
         if (s->profile)
         {
             hipEventRecord(ev.second, s->main);
@@ -146,7 +153,15 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     // edge rows + exchange on the side stream, interior on the main stream
     MH_HIP_TRY(hipEventRecord(s->fork, s->main));
     MH_HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
-    MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
+    if (s->desc.rank == 2)
+    {
+        MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
+    }
+    else
+    {
+        MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, 0, e, s->status, s->side));
+        MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, n0 - e, n0, s->status, s->side));
+    }
     if (int rc = slab_exchange(s, out, s->side)) return rc;
     MH_HIP_TRY(bulk(e, n0 - e));
     MH_HIP_TRY(hipEventRecord(s->join, s->side));
@@ -182,7 +197,7 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
                    const void* comm_id128, int self_exchange, int device_id)
 {
     if (! out || ! global) return MH_E_INVALID;
-    if (global->rank != 2) { set_error("mh_slab: 2-D only"); return MH_E_INVALID; }
+    if (global->rank != 2 && global->rank != 3) { set_error("mh_slab: rank must be 2 or 3"); return MH_E_INVALID; }
     if (rank < 0 || rank >= world) { set_error("mh_slab: rank %d of %d", rank, world); return MH_E_INVALID; }
     if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return MH_E_INVALID; }
     const bool periodic = global->bc_lo0 == MH_BC_PERIODIC;
@@ -192,7 +207,8 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     s->device = device_id; s->rank = rank; s->world = world; s->rk_order = rk_order;
     size_t a, b;
     mh_partition_rows((size_t) global->n[0], (size_t) world, (size_t) rank, &a, &b);
-    s->row0 = (int) a; s->row1 = (int) b; s->n0 = s->row1 - s->row0; s->n1 = global->n[1];
+    s->row0 = (int) a; s->row1 = (int) b; s->n0 = s->row1 - s->row0;
+    s->n1 = global->rank == 3 ? global->n[1] * global->n[2] : global->n[1];      // row pitch: cells per axis-0 row (plane in 3-D)
     const bool wrap = periodic && (world > 1 || self_exchange);
     s->lo = rank > 0 ? rank - 1 : (wrap ? world - 1 : -1);
     s->hi = rank < world - 1 ? rank + 1 : (wrap ? 0 : -1);

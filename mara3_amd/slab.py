@@ -266,10 +266,12 @@ class NativeSlabStepper:
         import numpy as np
         self.np = np
         self.lib = L.load_library()
+        rank_ = len(global_shape)
         d = L.EulerCartDesc()
-        d.rank = 2
-        d.n[0], d.n[1], d.n[2] = global_shape[0], global_shape[1], 1
-        d.dl[0], d.dl[1], d.dl[2] = dl[0], dl[1], 1.0
+        d.rank = rank_
+        for a in range(3):
+            d.n[a] = global_shape[a] if a < rank_ else 1
+            d.dl[a] = dl[a] if a < rank_ else 1.0
         d.gamma, d.plm_theta = gamma, plm_theta
         d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
         phys = L.BC_PERIODIC if bc == "periodic" else L.BC_OUTFLOW
@@ -284,14 +286,15 @@ class NativeSlabStepper:
         L.check(self.lib.mh_slab_rows(self.handle, C.byref(a), C.byref(b)))
         self.row0, self.row1 = a.value, b.value
         self.n0, self.n1 = self.row1 - self.row0, global_shape[1]
+        self.slab_shape = (self.n0,) + tuple(global_shape[1:]) + (NQ,)
 
     def load_slab(self, u_aos_slab):
         u = self.np.ascontiguousarray(u_aos_slab, dtype=self.np.float64)
-        assert u.shape == (self.n0, self.n1, NQ)
+        assert u.shape == self.slab_shape, (u.shape, self.slab_shape)
         L.check(self.lib.mh_slab_upload(self.handle, u.ctypes.data_as(C.c_void_p)))
 
     def slab_host(self):
-        u = self.np.empty((self.n0, self.n1, NQ))
+        u = self.np.empty(self.slab_shape)
         L.check(self.lib.mh_slab_download(self.handle, u.ctypes.data_as(C.c_void_p)))
         return u
 

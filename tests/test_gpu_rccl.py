@@ -85,3 +85,19 @@ def test_native_slab_without_neighbours_matches_context_api():
     st = NativeSlabStepper(shape, dl, gamma, 1.5, "hllc", 2, "outflow")
     st.load_slab(u0); st.step(1e-3, 5, graph=True); st.synchronize()
     assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64))
+
+
+def test_native_slab_3d_self_exchange_equals_local_periodic():
+    """3-D (config-5 scheme) in the native slab stepper: axis-0 planes exchanged through RCCL to self."""
+    import numpy as np
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabStepper, native_comm_id
+    from mara3_amd.engine import EulerCartSolver
+    shape, gamma = (40, 20, 70), 1.4
+    dl = (1.0 / 40, 1.0 / 20, 1.0 / 70)
+    u0 = setups.wave_ic(shape, gamma, seed=6)
+    ref = EulerCartSolver(shape, dl, gamma, 1.5, "hlle", 2, "periodic")
+    ref.upload(u0); ref.step(2e-3, 4)
+    st = NativeSlabStepper(shape, dl, gamma, 1.5, "hlle", 2, "periodic", comm_id=native_comm_id(0, 1), self_exchange=True)
+    st.load_slab(u0); st.step(2e-3, 4); st.synchronize()
+    assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64))

@@ -84,3 +84,57 @@ def test_sedov_srhd_bit_exact_vs_reference(eng):
         done = n
         assert bits_equal(s.download(), g["u_%d" % n]), n
     assert s.status() == 0
+
+
+def test_cloud_slabs_on_one_gpu_bit_identical_to_single_domain(eng):
+    """BASELINE config 4 is a radial slab decomposition: run the `cloud` stage on two and three radial slabs in
+    one process (MH_BC_EXTERNAL sides, row_offset, ghost rows copied between the slabs as the RCCL exchange
+    would) and require the union to equal the single-domain reference-generated result bit for bit."""
+    import ctypes as C
+    from mara3_amd import _lib as L
+    from mara3_amd.engine import DeviceArray
+    lib = L.load_library()
+    g = golden("cloud_nr70_plm_rk2")
+    rv, qv, u0 = g["rv"], g["qv"], g["u0"]
+    nr, nq = u0.shape[0], u0.shape[1]
+    dt, nsteps = float(g["dt"]), int(g["nsteps"])
+    for nslabs in (2, 3):
+        cuts = [(k * nr) // nslabs for k in range(nslabs + 1)]
+        slabs = []
+        for k in range(nslabs):
+            a, b = cuts[k], cuts[k + 1]
+            d = L.CloudDesc(nr=b - a, nq=nq, nr_global=nr, row_offset=a, gamma=4.0 / 3, plm_theta=float(g["theta"]),
+                            temperature_floor=float(g["tfloor"]), bc_lo0=L.BC_INFLOW if k == 0 else L.BC_EXTERNAL,
+                            bc_hi0=L.BC_OUTFLOW if k == nslabs - 1 else L.BC_EXTERNAL, arith=L.ARITH_STRICT, chunk_rows=7)
+            geom = np.zeros(lib.mh_cloud_geometry_doubles(C.byref(d)))
+            L.check(lib.mh_cloud_pack_geometry(C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p), geom.ctypes.data_as(C.c_void_p)))
+            # host copies of the two fields in the device layout [n0+4][5][nq]
+            f = np.zeros((b - a + 4, 5, nq))
+            f[2:-2] = u0[a:b].transpose(0, 2, 1)
+            slabs.append(dict(d=d, n0=b - a, geom=DeviceArray(geom), u=DeviceArray(f), s=DeviceArray(np.zeros_like(f)),
+                              status=DeviceArray(np.zeros(1))))
+
+        def exchange(key):
+            host = [sl[key].get() for sl in slabs]
+            for k in range(nslabs - 1):
+                lo, hi = host[k], host[k + 1]
+                lo[slabs[k]["n0"] + 2:] = hi[2:4]
+                hi[0:2] = lo[slabs[k]["n0"]:slabs[k]["n0"] + 2]
+            for sl, h in zip(slabs, host):
+                sl[key] = DeviceArray(h)
+
+        def stage(src, dst, base, w, inflow):
+            for sl in slabs:
+                L.check(lib.mh_cloud_stage(C.byref(sl["d"]), sl["geom"].ptr, inflow.ptr, sl[src].ptr,
+                                           sl[base].ptr if base else None, sl[dst].ptr, dt, w, 0, sl["n0"], sl["status"].ptr, None))
+            L.check(lib.mh_device_synchronize())
+
+        exchange("u")
+        for n in range(nsteps):
+            inflow = DeviceArray(np.ascontiguousarray(g["inflow"][n].T))      # [5][nq]
+            stage("u", "s", None, 1.0, inflow)
+            exchange("s")
+            stage("s", "u", "u", 0.5, inflow)
+            exchange("u")
+        got = np.concatenate([sl["u"].get()[2:-2].transpose(0, 2, 1) for sl in slabs], axis=0)
+        assert bits_equal(got, g["un"]), (nslabs, np.abs(got - g["un"]).max())
