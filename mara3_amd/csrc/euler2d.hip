@@ -303,11 +303,15 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
     else
     {
-        // default: 32 rows per wave (7 % prologue overhead), shortened for thin slabs so that the launch still
-        // has ~4096 waves (2 per SIMD and two rounds); measured on 512/1024/2048-row slabs of 4096 columns
+        // default. These kernels hold 2 waves per SIMD (190-226 VGPRs), i.e. 2048 resident waves on the 256 CUs.
+        // A thin slab is fastest when the whole launch fits ONE residency round: chunk = rows / floor(2048 / strips)
+        // (measured on 512/1024/2048 x 4096 slabs: 0.135 / 0.269 / 0.522 ms per step against 0.158 / 0.297 / 0.534 with
+        // short chunks). Large grids need many rounds anyway: 32 rows per wave (7 % prologue overhead) is as fast
+        // there and keeps halo re-reads close together in time (L2 hits).
         const long rows = (long) (row_end - row_begin) + (row_end2 - row_begin2);
-        long c = (rows * p.nstrips + 2048) / 4096;
-        p.chunk_rows = (int) (c < 8 ? 8 : (c > 32 ? 32 : c));
+        const long chunks_max = 2048 / p.nstrips > 0 ? 2048 / p.nstrips : 1;
+        const long c = (rows + chunks_max - 1) / chunks_max;
+        p.chunk_rows = (int) (c > 96 ? 32 : (c < 4 ? 4 : c));
     }
     p.nchunks_a = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
     p.row_begin2 = row_begin2;

@@ -92,7 +92,7 @@ struct mh_slab
     double* staging = nullptr;
     int32_t* status = nullptr;
     hipStream_t main = nullptr, side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t ev_edge = nullptr, ev_interior = nullptr, join = nullptr;
     ncclComm_t comm = nullptr;
     hipGraphExec_t exec = nullptr;
     double graph_dt = 0.0;
@@ -150,9 +150,14 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
         MH_HIP_TRY(bulk(0, n0));
         return MH_OK;
     }
-    // edge rows + exchange on the side stream, interior on the main stream
-    MH_HIP_TRY(hipEventRecord(s->fork, s->main));
-    MH_HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
+    // Two dependency chains instead of a fork/join per stage:
+    //   side stream:  edge(k) -> exchange(k)          edge(k) needs interior(k-1) [event] and exchange(k-1) [stream order]
+    //   main stream:  interior(k)                      needs edge(k-1) [event] and interior(k-1) [stream order]
+    // The interior rows [8, n0-8) read rows 6..n0-7 of the previous stage: edge and interior output, never ghost rows,
+    // so the main stream does not wait for RCCL at all; the exchange latency only sits on the (short) edge chain.
+    // The waits are issued BEFORE the events are re-recorded, so they bind to the previous stage's records.
+    MH_HIP_TRY(hipStreamWaitEvent(s->main, s->ev_edge, 0));
+    MH_HIP_TRY(hipStreamWaitEvent(s->side, s->ev_interior, 0));
     if (s->desc.rank == 2)
     {
         MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
@@ -162,8 +167,17 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
         MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, 0, e, s->status, s->side));
         MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, n0 - e, n0, s->status, s->side));
     }
+    MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
     if (int rc = slab_exchange(s, out, s->side)) return rc;
     MH_HIP_TRY(bulk(e, n0 - e));
+    MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
+    return MH_OK;
+}
+
+// order the main stream after everything queued on the side stream (before a download / status read / return to the host)
+static int slab_join(mh_slab* s)
+{
+    if (s->lo < 0 && s->hi < 0) return MH_OK;
     MH_HIP_TRY(hipEventRecord(s->join, s->side));
     MH_HIP_TRY(hipStreamWaitEvent(s->main, s->join, 0));
     return MH_OK;
@@ -220,12 +234,26 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     s->edge_desc.chunk_rows = 8;
     s->edge_rows = (s->lo >= 0 || s->hi >= 0) ? 8 : 0;
     if (2 * s->edge_rows > s->n0) s->edge_rows = s->n0 / 2;
+    if (s->edge_rows > 0 && global->rank == 2 && global->chunk_rows == 0)
+    {
+        // The interior launch and the concurrent edge launch (2 chunks per strip) should together fit one residency
+        // round of 2048 waves, otherwise a handful of waves run alone in a second round (see euler2d.hip's default).
+        const long nstrips = (global->n[1] + 59) / 60;
+        const long chunks_max = 2048 / nstrips - 2;
+        const long rows = s->n0 - 2 * s->edge_rows;
+        if (chunks_max > 0)
+        {
+            const long c = (rows + chunks_max - 1) / chunks_max;
+            if (c <= 96) s->desc.chunk_rows = (int) (c < 4 ? 4 : c);
+        }
+    }
     if ((s->lo >= 0 || s->hi >= 0) && s->n0 < 4) { delete s; set_error("slab of %d rows is thinner than two ghost layers", s->n0); return MH_E_INVALID; }
 
     auto cleanup = [&] () { mh_slab_destroy(s); };
     if (hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
     { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
     const size_t doubles = mh_euler_cart_field_doubles(&s->desc);
@@ -265,7 +293,8 @@ void mh_slab_destroy(mh_slab* s)
     for (auto& f : s->field) if (f) hipFree(f);
     if (s->staging) hipFree(s->staging);
     if (s->status) hipFree(s->status);
-    if (s->fork) hipEventDestroy(s->fork);
+    if (s->ev_edge) hipEventDestroy(s->ev_edge);
+    if (s->ev_interior) hipEventDestroy(s->ev_interior);
     if (s->join) hipEventDestroy(s->join);
     if (s->main) hipStreamDestroy(s->main);
     if (s->side) hipStreamDestroy(s->side);
@@ -290,6 +319,9 @@ int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
     MH_HIP_TRY(fill_ghost_rows_launch(s->field[0], 5, s->n0, (size_t) s->n1, s->desc.bc_lo0, s->desc.bc_hi0, s->main));
     if (int rc = slab_exchange(s, s->field[0], s->main)) return slab_fail(s, rc);
     MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));      // both dependency chains start from "everything done"
+    MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
     return MH_OK;
 }
 
@@ -333,6 +365,7 @@ int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
     }
     for (int n = 0; n < nsteps; ++n)
         if (int rc = slab_one_step(s, dt)) return slab_fail(s, rc);
+    if (int rc = slab_join(s)) return slab_fail(s, rc);
     return MH_OK;
 }
 
