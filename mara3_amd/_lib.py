@@ -124,6 +124,12 @@ def load_library():
         raise MaraHipError(
             "libmara_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C mara3_amd/csrc`. mara3_amd has no CPU fallback." % _LIB_PATH)
+    # Inside a Python process that also uses torch, load torch FIRST: both link the HIP runtime by the same soname
+    # (libamdhip64.so.7) and whichever is loaded first serves the whole process; torch must get the copy it ships with.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(_LIB_PATH)
     except OSError as e:

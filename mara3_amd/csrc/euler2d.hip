@@ -31,6 +31,7 @@
 // stage of RK2) => 200 B per zone-update for RK2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
 #include "launch.hpp"
@@ -92,21 +93,27 @@ __device__ inline State5 from_right(const State5& s)
     return r;
 }
 
-// row pointer is wave-uniform (scalar registers), lane_bytes is the lane's 32-bit byte offset inside the row:
-// lets the compiler use the scalar-base + vector-offset addressing mode (no 64-bit vector address arithmetic)
+// One row of one field through a buffer resource: the row pointer is wave-uniform (scalar registers), the lane
+// contributes a 32-bit byte offset and the variable a scalar offset, so a row costs five buffer instructions and
+// no vector address arithmetic (cdna_hip_programming.md T8). The descriptor covers exactly the row block
+// (5 variables x n1 doubles): anything outside returns 0 / is dropped by the hardware range check.
+using b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
+
 __device__ inline State5 load_row(const double* row, long plane_stride, unsigned lane_bytes)
 {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, (int) (5 * plane_stride * 8), 0x00020000);
     State5 U;
 #pragma unroll
     for (int q = 0; q < 5; ++q)
-        U[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row + q * plane_stride) + lane_bytes);
+        U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * plane_stride * 8), 0));
     return U;
 }
 __device__ inline void store_row(double* row, long plane_stride, unsigned lane_bytes, const State5& U)
 {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int) (5 * plane_stride * 8), 0x00020000);
 #pragma unroll
     for (int q = 0; q < 5; ++q)
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(row + q * plane_stride) + lane_bytes) = U[q];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64_t, U[q]), rs, lane_bytes, (unsigned) (q * plane_stride * 8), 0);
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
@@ -153,65 +160,71 @@ void euler2d_stage_kernel(Stage2dParams p)
     const double gamma = p.gamma, theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(gamma);
 
-    // ---- prologue: rows r0-2 .. r0+1
-    State5 Ua = load_row(in + row_off(r0 - 2), p.plane_stride, jc8);
-    State5 Ub = load_row(in + row_off(r0 - 1), p.plane_stride, jc8);
-    State5 U0 = load_row(in + row_off(r0), p.plane_stride, jc8);
-    State5 U1 = load_row(in + row_off(r0 + 1), p.plane_stride, jc8);
-    State5 U2 = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
-
-    State5 P0, P1, G0, Fx_lo;
+    // ---- register window: three slots used as rings (index = row mod 3 relative to the chunk start), so that the
+    // row loop, unrolled by three, needs no register-to-register rotation at all.
+    //   U[k]: conserved of rows r, r+1, r+2        P[k]: primitives of rows r, r+1, r+2
+    //   G[k]: axis-0 slope of rows r, r+1          Fx[k]: axis-0 flux through faces r-1/2, r+1/2
+    State5 U[3], P[3], G[3], Fx[3];
     {
-        const State5 Pa = A::c2p(Ua, gl);
-        const State5 Pb = A::c2p(Ub, gl);
-        P0 = A::c2p(U0, gl);
-        P1 = A::c2p(U1, gl);
+        const State5 Pa = A::c2p(load_row(in + row_off(r0 - 2), p.plane_stride, jc8), gl);
+        const State5 Pb = A::c2p(load_row(in + row_off(r0 - 1), p.plane_stride, jc8), gl);
+        U[0] = load_row(in + row_off(r0), p.plane_stride, jc8);
+        U[1] = load_row(in + row_off(r0 + 1), p.plane_stride, jc8);
+        U[2] = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
+        P[0] = A::c2p(U[0], gl);
+        P[1] = A::c2p(U[1], gl);
         if constexpr (PLM)
         {
-            const State5 Gb = A::plm(Pa, Pb, P0, theta);
-            G0 = A::plm(Pb, P0, P1, theta);
-            Fx_lo = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P0, G0), gl);
+            const State5 Gb = A::plm(Pa, Pb, P[0], theta);
+            G[0] = A::plm(Pb, P[0], P[1], theta);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
         }
         else
         {
-            Fx_lo = A::template flux<RIEMANN, 0>(Pb, P0, gl);
+            Fx[0] = A::template flux<RIEMANN, 0>(Pb, P[0], gl);
         }
     }
 
     int32_t bad = 0;
+    // second prefetch stage: row r+3 is in flight in Upre while row r is processed, row r+4 is issued at its top.
+    // Two rows (10 loads of 512 B) in flight per wave keep ~40 KB outstanding per CU, enough to cover HBM latency
+    // at this kernel's bandwidth (one row in flight left the first RK stage latency-bound).
+    State5 Upre = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
 
-    for (int r = r0; r < r1; ++r)
+    // one row; K0 = ring slot of row r (compile-time), K1 / K2 = slots of rows r+1 / r+2
+    auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
     {
-        // prefetch row r+3 (clamped to the stored ghost range; the value is unused past the chunk end)
-        const int rp = min(r + 3, p.n0 + 1);
-        const State5 U3 = load_row(in + row_off(rp), p.plane_stride, jc8);
+        constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+
+        // issue the load of row r+4 (clamped to the stored ghost range; unused past the chunk end)
+        const int rp = min(r + 4, p.n0 + 1);
+        const State5 Unext = load_row(in + row_off(rp), p.plane_stride, jc8);
         State5 Ubase;
         if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);
 
         // ---- axis 0: flux through face r+1/2
-        const State5 P2 = A::c2p(U2, gl);
-        State5 G1, Fx_hi;
+        P[K2] = A::c2p(U[K2], gl);
         if constexpr (PLM)
         {
-            G1 = A::plm(P0, P1, P2, theta);
-            Fx_hi = A::template flux<RIEMANN, 0>(A::plus(P0, G0), A::minus(P1, G1), gl);
+            G[K1] = A::plm(P[K0], P[K1], P[K2], theta);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
         }
         else
         {
-            Fx_hi = A::template flux<RIEMANN, 0>(P0, P1, gl);
+            Fx[K1] = A::template flux<RIEMANN, 0>(P[K0], P[K1], gl);
         }
 
         // ---- axis 1: this lane computes the flux through its LEFT face (between lane-1 and lane)
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM)
         {
-            const State5 Gy = A::plm(from_left(P0), P0, from_right(P0), theta);
-            const State5 SL = from_left(A::plus(P0, Gy));       // left neighbour's right-going face state
-            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P0, Gy), gl);
+            const State5 Gy = A::plm(from_left(P[K0]), P[K0], from_right(P[K0]), theta);
+            const State5 SL = from_left(A::plus(P[K0], Gy));       // left neighbour's right-going face state
+            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy), gl);
         }
         else
         {
-            Fy_lo = A::template flux<RIEMANN, 1>(from_left(P0), P0, gl);
+            Fy_lo = A::template flux<RIEMANN, 1>(from_left(P[K0]), P[K0], gl);
         }
         Fy_hi = from_right(Fy_lo);
 
@@ -220,7 +233,7 @@ void euler2d_stage_kernel(Stage2dParams p)
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double u1 = A::update2(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+            const double u1 = A::update2(U[K0][q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
@@ -229,38 +242,28 @@ void euler2d_stage_kernel(Stage2dParams p)
         if (writes)
         {
             store_row(p.u_out + row_off(r), p.plane_stride, col8, Un);
-
-            // keep the physical axis-0 ghost rows of the output current
-            if (r < HALO)
+            // keep the physical axis-0 ghost rows of the output current (edge rows only: wave-uniform, cold)
+            if (r < HALO || r >= p.n0 - HALO)
             {
-                if (p.bc_lo0 == 0 && r == 0)
-                {
-                    { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
-                }
-                if (p.bc_hi0 == 1)
-                {
-                    store_row(p.u_out + row_off(p.n0 + r), p.plane_stride, col8, Un);
-                }
-            }
-            if (r >= p.n0 - HALO)
-            {
-                if (p.bc_hi0 == 0 && r == p.n0 - 1)
-                {
-                    { store_row(p.u_out + row_off(p.n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(p.n0 + 1), p.plane_stride, col8, Un); }
-                }
-                if (p.bc_lo0 == 1)
-                {
-                    store_row(p.u_out + row_off(r - p.n0), p.plane_stride, col8, Un);
-                }
+                if (p.bc_lo0 == 0 && r == 0) { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
+                if (p.bc_hi0 == 1 && r < HALO) store_row(p.u_out + row_off(p.n0 + r), p.plane_stride, col8, Un);
+                if (p.bc_hi0 == 0 && r == p.n0 - 1) { store_row(p.u_out + row_off(p.n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(p.n0 + 1), p.plane_stride, col8, Un); }
+                if (p.bc_lo0 == 1 && r >= p.n0 - HALO) store_row(p.u_out + row_off(r - p.n0), p.plane_stride, col8, Un);
             }
         }
+        U[K0] = Upre;       // slot of row r now holds row r+3 ...
+        Upre = Unext;       // ... and row r+4 stays in flight
+    };
 
-        // ---- rotate the register window
-        U0 = U1; U1 = U2; U2 = U3;
-        P0 = P1; P1 = P2;
-        if constexpr (PLM) G0 = G1;
-        Fx_lo = Fx_hi;
+    int r = r0;
+    for (; r + 3 <= r1; r += 3)
+    {
+        row_step(r, std::integral_constant<int, 0>());
+        row_step(r + 1, std::integral_constant<int, 1>());
+        row_step(r + 2, std::integral_constant<int, 2>());
     }
+    if (r < r1) row_step(r, std::integral_constant<int, 0>());
+    if (r + 1 < r1) row_step(r + 1, std::integral_constant<int, 1>());
 
     if (p.status)
     {

@@ -50,17 +50,17 @@ __device__ inline double sqrt_fast(double x)
     return g;
 }
 
+// minmod(a, b, c) = max(0, min(a, b, c)) + min(0, max(a, b, c)): the common-sign smallest magnitude, else 0.
+// Same value as 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min(|a|,|b|,|c|) for finite arguments (the sign of an exact
+// zero may differ); 7 fp64 instructions and no integer sign logic.
 __device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
 {
     const double a = (y0 - yl) * theta;
     const double b = (yr - yl) * 0.5;
     const double c = (yr - y0) * theta;
-    const double m = __builtin_fmin(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), __builtin_fabs(c));
-    const int ah = __double2hiint(a), bh = __double2hiint(b), ch = __double2hiint(c);
-    const int differ = (ah ^ bh) | (ah ^ ch);                       // sign bit set unless all three signs agree
-    const int hi = (__double2hiint(m) & 0x7fffffff) | (ah & 0x80000000);
-    const double s = __hiloint2double(hi, __double2loint(m));      // copysign(m, a)
-    return differ < 0 ? 0.0 : s;
+    const double lo = __builtin_fmin(__builtin_fmin(a, b), c);
+    const double hi = __builtin_fmax(__builtin_fmax(a, b), c);
+    return __builtin_fmax(0.0, lo) + __builtin_fmin(0.0, hi);
 }
 
 __device__ inline State5 plm_gradient(const State5& l, const State5& c, const State5& r, double theta)
