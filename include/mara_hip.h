@@ -262,6 +262,20 @@ void mh_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, 
 /* mara::propose_block_decomposition<Rank>, src/app_parallel.hpp:119-131 */
 int  mh_propose_block_decomposition(int rank, unsigned long nblocks, unsigned long* blocks_per_axis);
 
+/* Kepler two-body model, host side (src/model_two_body.hpp). Bodies are (mass, x, y, vx, vy).
+ * mh_two_body_state = mara::compute_two_body_state(full_orbital_elements_t, t) :209-268 (Newton solve for the
+ * eccentric anomaly :168-208); mh_orbital_elements_from_state = mara::compute_orbital_elements :295-381, which
+ * returns MH_E_PHYSICS where the reference throws (unbound orbit). */
+typedef struct { double separation, total_mass, mass_ratio, eccentricity; } mh_orbital_elements;
+typedef struct
+{
+    double pomega, tau, cm_position_x, cm_position_y, cm_velocity_x, cm_velocity_y;
+    mh_orbital_elements elements;
+} mh_full_orbital_elements;
+typedef struct { double body1[5], body2[5]; } mh_two_body_t;
+int  mh_two_body_state(const mh_full_orbital_elements* elements, double t, mh_two_body_t* out);
+int  mh_orbital_elements_from_state(const mh_two_body_t* state, double t, mh_full_orbital_elements* out);
+
 /* device utilities used by bench / tests without torch */
 int  mh_device_count(void);
 int  mh_malloc(void** ptr, size_t bytes);

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("mh_iso2d_riemann_n", _i, [_sz, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _vp, _vp]),
     ("mh_partition_rows", None, [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
+    ("mh_two_body_state", _i, [_vp, _d, _vp]),
+    ("mh_orbital_elements_from_state", _i, [_vp, _d, _vp]),
     ("mh_device_count", _i, []),
     ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
     ("mh_free", _i, [_vp]),

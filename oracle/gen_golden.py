@@ -220,6 +220,33 @@ def main():
             np.savez_compressed(os.path.join(OUT, "sedov_srhd_nr256.npz"), **sed)
             print("sedov srhd ok", sed["u0"].shape)
         return 0
+    if len(sys.argv) > 1 and sys.argv[1] == "two_body":
+        rng = np.random.default_rng(20260404)
+        n = 2048
+        P = np.empty((n, 11))
+        P[:, 0] = rng.uniform(-np.pi, np.pi, n)          # pomega
+        P[:, 1] = rng.uniform(-3, 3, n)                   # tau
+        P[:, 2:6] = rng.standard_normal((n, 4)) * 0.1      # centre-of-mass position / velocity
+        P[:, 6] = 10.0 ** rng.uniform(-0.5, 0.5, n)        # separation
+        P[:, 7] = 10.0 ** rng.uniform(-0.3, 0.3, n)        # total mass
+        P[:, 8] = rng.uniform(0.05, 1.0, n)                # mass ratio
+        P[:, 9] = rng.uniform(0.0, 0.9, n)                 # eccentricity
+        P[:256, 9] = 0.0                                   # circular orbits take the other branch
+        P[:, 10] = rng.uniform(-5, 20, n)                  # time
+        P[0] = (0, 0, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0.0, 0.0)   # the sub-program's default binary at t = 0
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+            P.tofile(fin)
+            run_ref("two_body_ref", ["state", n, fin, fout])
+            S = np.fromfile(fout).reshape(n, 10)
+            X = np.hstack([S, P[:, 10:11]])
+            X[-64:, 3:5] *= 3.0                             # unbound: the reference throws
+            X.tofile(fin)
+            run_ref("two_body_ref", ["elements", n, fin, fout])
+            E = np.fromfile(fout).reshape(n, 11)
+        np.savez_compressed(os.path.join(OUT, "two_body.npz"), elements_in=P, state=S, state_in=X, elements=E[:, :10], threw=E[:, 10])
+        print("two_body ok; throws:", int(E[:, 10].sum()))
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == "iso2d":
         return gen_iso2d(np.random.default_rng(20260303))
     if len(sys.argv) > 1 and sys.argv[1] == "srhd":
