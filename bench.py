@@ -154,15 +154,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.stepper == "native":
-        from mara3_amd.slab import NativeSlabStepper, native_comm_id
+    from mara3_amd.slab import NativeSlabStepper, native_comm_id
+
+    state = {"stepper": args.stepper}
 
     def make_stepper(arith):
-        if args.stepper == "native":
-            # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
-            comm_id = native_comm_id(rank, world, device="cuda") if world > 1 else None
-            return NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
-                                     comm_id=comm_id, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+        if state["stepper"] == "native":
+            st, err = None, None
+            try:
+                # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
+                comm_id = native_comm_id(rank, world, device="cuda") if world > 1 else None
+                st = NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+                                       comm_id=comm_id, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+            except mara3_amd.MaraHipError as e:
+                err = e
+            ok = torch.tensor([0 if st is None else 1], device="cuda")
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must take the same path
+            if int(ok.item()) == 1:
+                return st
+            if world == 1:
+                raise err
+            if rank == 0:
+                print("bench.py: native slab stepper unavailable (%s); using the torch.distributed stepper" % err, file=sys.stderr)
+            if st is not None:
+                st.close()
+            state["stepper"] = "torch"
         return SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
                                 device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=arith)
 
@@ -170,7 +187,7 @@ def main():
         """W untimed + K timed steps of the whole (slab-decomposed) grid in one arithmetic mode."""
         st = make_stepper(arith)
         st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
-        native = args.stepper == "native"
+        native = isinstance(st, NativeSlabStepper)
         st.step(dt, args.warmup)
         if native:
             st.synchronize()
@@ -264,7 +281,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
-                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, args.stepper),
+                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, state["stepper"]),
                        "arith": arith_note[primary], "status_word": res["status_word"]},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
