@@ -206,6 +206,34 @@ def gen_iso2d(rng):
     print("iso2d ok; c2p_neg throws", int(out["c2p_neg_threw"].sum()), "hllc throws", int(out["hllc_threw_0"].sum()))
 
 
+BINARY_CASES = {
+    # name: overrides of the sub-program's configuration (src/subprog_binary.cpp:55-99) + nsteps / safe_mode
+    "binary_d2_b16": dict(depth=2, block_size=16, domain_radius=4.0, nsteps=3),
+    "binary_d1_b24_nu": dict(depth=1, block_size=24, domain_radius=3.0, fixed_dt=1, nu=1e-3, alpha_cutoff_radius=1.5, mass_ratio=0.5,
+                             eccentricity=0.3, density_floor=0.05, rk_order=1, nsteps=4, sink_radius=0.2, softening_radius=0.1),
+    "binary_d3_b8_axisym": dict(depth=3, block_size=8, domain_radius=6.0, axisymmetric_cs2=1, counter_rotate=1, mdot=1e-5, nsteps=2,
+                                no_accretion_force=1, plm_theta=1.2),
+    "binary_d2_b16_safe": dict(depth=2, block_size=16, domain_radius=4.0, nsteps=1, safe_mode=1),
+    "binary_d2_b32": dict(depth=2, block_size=32, nsteps=2),
+}
+
+
+def gen_binary():
+    import json
+    for name, cfg in BINARY_CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            prefix = os.path.join(d, "b")
+            run_ref("binary_ref", [prefix] + ["%s=%s" % (k, repr(float(v))) for k, v in cfg.items()])
+            n = int(cfg["block_size"]) << int(cfg["depth"])
+            out = {"config": np.array(json.dumps(cfg))}
+            for key, shape in (("xv", (n + 1,)), ("yv", (n + 1,)), ("u_init", (n, n, 3)), ("br", (n, n)), ("u_stage", (n, n, 3)),
+                               ("stage_scalars", (-1,)), ("u_final", (n, n, 3)), ("scalars", (-1,))):
+                out[key] = np.fromfile(prefix + "." + key + ".f64").reshape(shape)
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+            print(name, "ok", n, "dt", out["stage_scalars"][0])
+    return 0
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "sedov_srhd":
@@ -247,6 +275,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "two_body.npz"), elements_in=P, state=S, state_in=X, elements=E[:, :10], threw=E[:, 10])
         print("two_body ok; throws:", int(E[:, 10].sum()))
         return 0
+    if len(sys.argv) > 1 and sys.argv[1] == "binary":
+        return gen_binary()
     if len(sys.argv) > 1 and sys.argv[1] == "iso2d":
         return gen_iso2d(np.random.default_rng(20260303))
     if len(sys.argv) > 1 and sys.argv[1] == "srhd":

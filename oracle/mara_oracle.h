@@ -141,6 +141,35 @@ void mo_propose_block_decomposition(int rank, unsigned long nblocks, unsigned lo
 /* app_parallel.hpp:148-179 : block b of B along an axis with n cells -> [start, final) */
 void mo_block_extent(size_t n, size_t nblocks, size_t b, size_t* start, size_t* final_);
 
+/* ---- circumbinary disk scheme (mara_oracle_binary.c; BASELINE config 3) ---- */
+enum { MO_T_MASS_ACC = 0, MO_T_L_ACC = 2, MO_T_TORQUE = 4, MO_T_PX_ACC = 6, MO_T_PY_ACC = 8, MO_T_FX = 10, MO_T_FY = 12,
+       MO_T_WORK = 14, MO_T_MASS_EJ = 16, MO_T_L_EJ = 17, MO_BINARY_NTOTALS = 18 };   /* source_term_total_t scheme.cpp:17-32; [2] = per body */
+typedef struct
+{
+    int    n;                   /* cells per side = block_size << depth */
+    int    block_size;
+    double domain_radius, mach_number, alpha, nu, alpha_cutoff_radius;
+    double sink_rate, sink_radius, softening_radius;
+    double density_floor;       /* absolute surface density (config density_floor * disk_mass, solver_data.cpp:100) */
+    double plm_theta;           /* 0 in safe mode (scheme.cpp:792) */
+    int    axisymmetric_cs2;
+} mo_binary_params;
+typedef struct
+{
+    double softening_radius, disk_radius, mach_number, disk_mass, ambient_density, mdot;
+    int    counter_rotate;
+    double buffer_damping_rate, domain_radius, cfl_number;
+} mo_binary_model;
+/* bodies = (mass, x, y, vx, vy) of body 1 then body 2; fields are [n][n][3] row-major in (Sigma, px, py); returns 1 where validate_u throws */
+int    mo_binary_advance_u(const mo_binary_params* P, const double* xv, const double* yv, const double* u0, const double* u_init,
+                           const double* br, const double bodies[10], double dt, double* u1, double totals[MO_BINARY_NTOTALS]);
+double mo_binary_maximum_timestep(const mo_binary_params* P, const double* xv, const double* yv, const double* u, const double bodies[10]);
+double mo_binary_cs2(const mo_binary_params* P, double x, double y, const double bodies[10]);
+double mo_binary_nu(const mo_binary_params* P, double x, double y, double cs2);
+void   mo_binary_vertices(int block_size, int depth, double domain_radius, double* v);   /* v[(block_size << depth) + 1] */
+void   mo_binary_disk_profile(const mo_binary_model* m, double x, double y, double prim[3]);
+double mo_binary_solver_data(const mo_binary_model* m, int n, const double* xv, const double* yv, double* u_init, double* br);  /* returns recommended_time_step */
+
 #ifdef __cplusplus
 }
 #endif

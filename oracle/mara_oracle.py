@@ -309,3 +309,105 @@ def iso2d_riemann(Pl, Pr, cs2l, cs2r, axis, solver=RIEMANN_HLLE):
     t = np.zeros(n, dtype=np.int32)
     lib().mo_iso2d_riemann_n(n, _dp(Pl), _dp(Pr), _dp(cs2l), _dp(cs2r), axis, solver, _dp(F), _dp(contact), _ip(t))
     return F, contact, t
+
+
+# ---- circumbinary disk scheme (mara_oracle_binary.c) -----------------------------------------------------------
+T_MASS_ACC, T_L_ACC, T_TORQUE, T_PX_ACC, T_PY_ACC, T_FX, T_FY, T_WORK, T_MASS_EJ, T_L_EJ, BINARY_NTOTALS = 0, 2, 4, 6, 8, 10, 12, 14, 16, 17, 18
+
+# the sub-program's run configuration, src/subprog_binary.cpp:55-99 (numeric items only)
+BINARY_DEFAULTS = dict(
+    cfl_number=0.4, fixed_dt=0, depth=4, begin_live_binary=1e6, block_size=24, rk_order=2, plm_theta=1.8,
+    source_term_softening=1.0, softening_radius=0.05, sink_radius=0.05, sink_rate=1.0, buffer_damping_rate=10.0,
+    domain_radius=12.0, disk_radius=2.0, disk_mass=1e-3, ambient_density=1e-4, density_floor=0.0, separation=1.0,
+    mass_ratio=1.0, eccentricity=0.0, counter_rotate=0, mach_number=10.0, axisymmetric_cs2=0, no_accretion_force=0,
+    alpha_cutoff_radius=0.0, alpha=0.1, nu=0.0, mdot=0.0)
+
+
+class _BinaryParams(C.Structure):
+    _fields_ = [("n", C.c_int), ("block_size", C.c_int), ("domain_radius", C.c_double), ("mach_number", C.c_double),
+                ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
+                ("sink_radius", C.c_double), ("softening_radius", C.c_double), ("density_floor", C.c_double),
+                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int)]
+
+
+class _BinaryModel(C.Structure):
+    _fields_ = [("softening_radius", C.c_double), ("disk_radius", C.c_double), ("mach_number", C.c_double),
+                ("disk_mass", C.c_double), ("ambient_density", C.c_double), ("mdot", C.c_double), ("counter_rotate", C.c_int),
+                ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
+
+
+def binary_config(**overrides):
+    cfg = dict(BINARY_DEFAULTS)
+    for k, v in overrides.items():
+        if k not in cfg:
+            raise KeyError(k)
+        cfg[k] = v
+    return cfg
+
+
+def _binary_params(cfg, safe_mode=False):
+    P = _BinaryParams()
+    P.n = int(cfg["block_size"]) << int(cfg["depth"])
+    P.block_size = int(cfg["block_size"])
+    for k in ("domain_radius", "mach_number", "alpha", "nu", "alpha_cutoff_radius", "sink_rate", "sink_radius", "softening_radius"):
+        setattr(P, k, float(cfg[k]))
+    P.density_floor = float(cfg["density_floor"]) * float(cfg["disk_mass"])
+    P.plm_theta = 0.0 if safe_mode else float(cfg["plm_theta"])
+    P.axisymmetric_cs2 = int(cfg["axisymmetric_cs2"])
+    return P
+
+
+def _binary_model(cfg):
+    m = _BinaryModel()
+    for k in ("softening_radius", "disk_radius", "mach_number", "disk_mass", "ambient_density", "mdot", "buffer_damping_rate", "domain_radius", "cfl_number"):
+        setattr(m, k, float(cfg[k]))
+    m.counter_rotate = int(cfg["counter_rotate"])
+    return m
+
+
+def _binary_lib():
+    L = lib()
+    if not getattr(L, "_binary_ready", False):
+        dp = C.POINTER(C.c_double)
+        L.mo_binary_advance_u.argtypes = [C.POINTER(_BinaryParams), dp, dp, dp, dp, dp, dp, C.c_double, dp, dp]
+        L.mo_binary_advance_u.restype = C.c_int
+        L.mo_binary_maximum_timestep.argtypes = [C.POINTER(_BinaryParams), dp, dp, dp, dp]
+        L.mo_binary_maximum_timestep.restype = C.c_double
+        L.mo_binary_vertices.argtypes = [C.c_int, C.c_int, C.c_double, dp]
+        L.mo_binary_solver_data.argtypes = [C.POINTER(_BinaryModel), C.c_int, dp, dp, dp, dp]
+        L.mo_binary_solver_data.restype = C.c_double
+        L._binary_ready = True
+    return L
+
+
+def binary_vertices(cfg):
+    n = int(cfg["block_size"]) << int(cfg["depth"])
+    v = np.zeros(n + 1)
+    _binary_lib().mo_binary_vertices(int(cfg["block_size"]), int(cfg["depth"]), float(cfg["domain_radius"]), _dp(v))
+    return v
+
+
+def binary_solver_data(cfg, xv, yv):
+    """-> (u_init [n][n][3], buffer_rate [n][n], recommended_time_step)"""
+    n = len(xv) - 1
+    u = np.zeros((n, n, 3))
+    br = np.zeros((n, n))
+    m = _binary_model(cfg)
+    dt = _binary_lib().mo_binary_solver_data(C.byref(m), n, _dp(_f64(xv)), _dp(_f64(yv)), _dp(u), _dp(br))
+    return u, br, dt
+
+
+def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False):
+    """-> (u1, totals[18], negative_density)"""
+    P = _binary_params(cfg, safe_mode)
+    u0 = _f64(u0)
+    u1 = np.zeros_like(u0)
+    tot = np.zeros(BINARY_NTOTALS)
+    neg = _binary_lib().mo_binary_advance_u(C.byref(P), _dp(_f64(xv)), _dp(_f64(yv)), _dp(u0), _dp(_f64(u_init)), _dp(_f64(br)),
+                                           _dp(_f64(bodies)), float(dt), _dp(u1), _dp(tot))
+    return u1, tot, bool(neg)
+
+
+def binary_maximum_timestep(cfg, xv, yv, u, bodies):
+    P = _binary_params(cfg)
+    return _binary_lib().mo_binary_maximum_timestep(C.byref(P), _dp(_f64(xv)), _dp(_f64(yv)), _dp(_f64(u)), _dp(_f64(bodies)))
