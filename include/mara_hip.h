@@ -276,6 +276,96 @@ typedef struct { double body1[5], body2[5]; } mh_two_body_t;
 int  mh_two_body_state(const mh_full_orbital_elements* elements, double t, mh_two_body_t* out);
 int  mh_orbital_elements_from_state(const mh_two_body_t* state, double t, mh_full_orbital_elements* out);
 
+/* Difference of two sets of orbital elements, mara::diff(a, b) src/model_two_body.hpp:492-518 (b - a, with pomega wrapped
+ * to the nearest image mod 2 pi and tau mod the orbital period of b). */
+void mh_orbital_elements_diff(const mh_full_orbital_elements* a, const mh_full_orbital_elements* b, mh_full_orbital_elements* out);
+
+/* ---- `binary` sub-program: isothermal circumbinary disk on a uniform-depth block tree (BASELINE config 3) --------------
+ * Replaces binary::advance_u / next_solution / maximum_timestep (src/subprog_binary_scheme.cpp:790-904, :1107-1126;
+ * src/subprog_binary.cpp:258-293) for a tree whose every node is refined (focus_factor large): the blocks tile a periodic
+ * n x n tensor-product mesh, n = block_size << depth. Fields are iso2d conserved_per_area (Sigma, px, py) in the LOGICAL
+ * order (never the std::tuple storage order): host AoS [n][n][3], axis 0 = x; device SoA as above with nq = 3.
+ * Arithmetic: reference operation order, IEEE division / sqrt, no FMA contraction; the reference's pow(x, 1/2), pow(x, 3/2),
+ * exp and tanh are evaluated by sqrt / x sqrt(x) / the device math library, so parity is to L1 <= 1e-12, not bit-exact. */
+typedef struct mh_binary_desc
+{
+    int32_t n;                      /* cells per side */
+    int32_t block_size;             /* cells per side of one tree block: grouping of the source-term totals (work_done_on) */
+    double  domain_radius, mach_number, alpha, nu, alpha_cutoff_radius;
+    double  sink_rate, sink_radius, softening_radius;
+    double  density_floor;          /* absolute: run_config density_floor * disk_mass (solver_data.cpp:100) */
+    double  plm_theta;
+    int32_t axisymmetric_cs2;
+    int32_t chunk_rows;             /* rows marched per wavefront; 0 = default */
+} mh_binary_desc;
+
+/* source_term_total_t (scheme.cpp:17-32), [2] = per body */
+enum mh_binary_total { MH_T_MASS_ACC = 0, MH_T_L_ACC = 2, MH_T_TORQUE = 4, MH_T_PX_ACC = 6, MH_T_PY_ACC = 8, MH_T_FX = 10, MH_T_FY = 12,
+                       MH_T_WORK = 14, MH_T_MASS_EJ = 16, MH_T_L_EJ = 17, MH_BINARY_NTOTALS = 18 };
+
+size_t mh_binary_field_doubles(const mh_binary_desc* d);      /* 3 * (n + 4) * n */
+size_t mh_binary_scratch_doubles(const mh_binary_desc* d);    /* reduction scratch of one stage */
+/* One stage (stateless launcher; all pointers DEVICE except bodies = host (mass, x, y, vx, vy) x 2):
+ *   u_out = advance_u(u_in)                      (stage_weight == 1)
+ *   u_out = u_base (1 - w) + advance_u(u_in) w   (otherwise; w = 0.5 is the RK2 combine)
+ * u_init is a field like u; buffer_rate is [n][n]; xv, yv are the n + 1 vertex coordinates; totals_dev receives the
+ * MH_BINARY_NTOTALS source-term totals of this stage; status |= MH_STATUS_NEG_DENSITY where validate_u would throw. */
+int  mh_binary_stage(const mh_binary_desc* d, const double* xv_dev, const double* yv_dev, const double* u_in, const double* u_base,
+                     double* u_out, const double* u_init, const double* buffer_rate, const double* bodies_host, double dt,
+                     double stage_weight, double* totals_dev, double* scratch_dev, int32_t* status, void* stream);
+/* max over cells of primitive_t::max_wavespeed(cs2(x_c)) -> one double on the device (maximum_timestep = spacing / that) */
+int  mh_binary_max_wavespeed(const mh_binary_desc* d, const double* xv_dev, const double* yv_dev, const double* u,
+                             const double* bodies_host, double* result_dev, void* stream);
+
+/* The scalar part of binary::solution_t (src/subprog_binary.hpp:130-150) */
+typedef struct mh_binary_state
+{
+    double  time;
+    int64_t iteration;
+    double  mass_accreted_on[2], angular_momentum_accreted_on[2], integrated_torque_on[2], work_done_on[2];
+    double  mass_ejected, angular_momentum_ejected;
+    mh_full_orbital_elements orbital_elements_acc, orbital_elements_grav, orbital_elements;
+} mh_binary_state;
+typedef struct mh_binary_run
+{
+    int32_t rk_order;               /* 1 or 2 */
+    int32_t fixed_dt;               /* use recommended_time_step instead of cfl * maximum_timestep */
+    int32_t no_accretion_force;
+    int32_t reserved;
+    double  cfl_number, recommended_time_step, begin_live_binary;
+} mh_binary_run;
+/* Host-side set-up of the `binary` problem, evaluated with the host libm exactly as upstream (no device work):
+ * mh_binary_vertices = the vertex coordinates of mara::create_vertex_quadtree for an always-true predicate
+ * (mesh_tree_operators.hpp:158-190: linspace(-1, 1, block_size + 1), `depth` rounds of prolong_verts) times domain_radius
+ * (subprog_binary.cpp:165-185); out[(block_size << depth) + 1], the same for both axes.
+ * mh_binary_solver_data = create_disk_profile (subprog_binary.cpp:105-153) sampled at the cell centres as conserved_per_area,
+ * the buffer-rate field and recommended_time_step of create_solver_data (subprog_binary_solver_data.cpp:20-102). */
+typedef struct mh_binary_model
+{
+    double  softening_radius, disk_radius, mach_number, disk_mass, ambient_density, mdot;
+    int32_t counter_rotate, reserved;
+    double  buffer_damping_rate, domain_radius, cfl_number;
+} mh_binary_model;
+int  mh_binary_vertices(int block_size, int depth, double domain_radius, double* out_host);
+int  mh_binary_solver_data(const mh_binary_model* m, int n, const double* xv_host, const double* yv_host, double* u_init_aos_host,
+                           double* buffer_rate_host, double* recommended_time_step);
+typedef struct mh_binary mh_binary;
+/* Solver object: owns the device fields (solution, stage buffers, static solver data). Host arrays are copied. */
+int  mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
+                      const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host);
+void mh_binary_destroy(mh_binary* b);
+/* u_aos_host = NULL: start from the initial field */
+int  mh_binary_set_solution(mh_binary* b, const double* u_aos_host, const mh_binary_state* state);
+int  mh_binary_get_solution(mh_binary* b, double* u_aos_host /* may be NULL */, mh_binary_state* state /* may be NULL */);
+/* nsteps x binary::next_solution: dt choice, RK stages, accumulators and orbital-element perturbations, and the safe-mode
+ * retry (dt * 0.1, theta = 0) when a stage reports a negative density (the reference catches the exception and retries
+ * from the old solution, subprog_binary.cpp:285-292). safe_mode_steps (may be NULL) counts the steps that needed it.
+ * Returns MH_E_PHYSICS if the safe-mode retry fails too (the reference's exception then escapes). */
+int  mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps);
+double mh_binary_last_dt(const mh_binary* b);
+const double* mh_binary_field_ptr(mh_binary* b);
+int  mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaunches);
+
 /* device utilities used by bench / tests without torch */
 int  mh_device_count(void);
 int  mh_malloc(void** ptr, size_t bytes);

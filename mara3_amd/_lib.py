@@ -43,6 +43,49 @@ class CloudDesc(C.Structure):
                 ("arith", C.c_int), ("chunk_rows", C.c_int)]
 
 
+class BinaryDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("block_size", C.c_int32), ("domain_radius", C.c_double), ("mach_number", C.c_double),
+                ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
+                ("sink_radius", C.c_double), ("softening_radius", C.c_double), ("density_floor", C.c_double),
+                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int32), ("chunk_rows", C.c_int32)]
+
+
+class OrbitalElements(C.Structure):
+    _fields_ = [("separation", C.c_double), ("total_mass", C.c_double), ("mass_ratio", C.c_double), ("eccentricity", C.c_double)]
+
+
+class FullOrbitalElements(C.Structure):
+    _fields_ = [("pomega", C.c_double), ("tau", C.c_double), ("cm_position_x", C.c_double), ("cm_position_y", C.c_double),
+                ("cm_velocity_x", C.c_double), ("cm_velocity_y", C.c_double), ("elements", OrbitalElements)]
+
+    def as_array(self):
+        e = self.elements
+        return [self.pomega, self.tau, self.cm_position_x, self.cm_position_y, self.cm_velocity_x, self.cm_velocity_y,
+                e.separation, e.total_mass, e.mass_ratio, e.eccentricity]
+
+
+class BinaryState(C.Structure):
+    _fields_ = [("time", C.c_double), ("iteration", C.c_int64), ("mass_accreted_on", C.c_double * 2),
+                ("angular_momentum_accreted_on", C.c_double * 2), ("integrated_torque_on", C.c_double * 2),
+                ("work_done_on", C.c_double * 2), ("mass_ejected", C.c_double), ("angular_momentum_ejected", C.c_double),
+                ("orbital_elements_acc", FullOrbitalElements), ("orbital_elements_grav", FullOrbitalElements),
+                ("orbital_elements", FullOrbitalElements)]
+
+
+class BinaryModel(C.Structure):
+    _fields_ = [("softening_radius", C.c_double), ("disk_radius", C.c_double), ("mach_number", C.c_double),
+                ("disk_mass", C.c_double), ("ambient_density", C.c_double), ("mdot", C.c_double), ("counter_rotate", C.c_int32),
+                ("reserved", C.c_int32), ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
+
+
+class BinaryRun(C.Structure):
+    _fields_ = [("rk_order", C.c_int32), ("fixed_dt", C.c_int32), ("no_accretion_force", C.c_int32), ("reserved", C.c_int32),
+                ("cfl_number", C.c_double), ("recommended_time_step", C.c_double), ("begin_live_binary", C.c_double)]
+
+
+BINARY_NTOTALS = 18
+T_MASS_ACC, T_L_ACC, T_TORQUE, T_PX_ACC, T_PY_ACC, T_FX, T_FY, T_WORK, T_MASS_EJ, T_L_EJ = 0, 2, 4, 6, 8, 10, 12, 14, 16, 17
+
 # every symbol include/mara_hip.h declares: (name, restype, argtypes)
 _vp, _dp, _sz, _i, _d = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
 _descp = C.POINTER(EulerCartDesc)
@@ -102,6 +145,21 @@ SYMBOLS = [
     ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
     ("mh_two_body_state", _i, [_vp, _d, _vp]),
     ("mh_orbital_elements_from_state", _i, [_vp, _d, _vp]),
+    ("mh_orbital_elements_diff", None, [_vp, _vp, _vp]),
+    ("mh_binary_field_doubles", _sz, [C.POINTER(BinaryDesc)]),
+    ("mh_binary_scratch_doubles", _sz, [C.POINTER(BinaryDesc)]),
+    ("mh_binary_stage", _i, [C.POINTER(BinaryDesc), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _vp, _d, _d, _dp, _dp, _vp, _vp]),
+    ("mh_binary_max_wavespeed", _i, [C.POINTER(BinaryDesc), _dp, _dp, _dp, _vp, _dp, _vp]),
+    ("mh_binary_vertices", _i, [_i, _i, _d, _vp]),
+    ("mh_binary_solver_data", _i, [C.POINTER(BinaryModel), _i, _vp, _vp, _vp, _vp, C.POINTER(_d)]),
+    ("mh_binary_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
+    ("mh_binary_destroy", None, [_vp]),
+    ("mh_binary_set_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
+    ("mh_binary_get_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
+    ("mh_binary_next", _i, [_vp, _i, C.POINTER(_i)]),
+    ("mh_binary_last_dt", _d, [_vp]),
+    ("mh_binary_field_ptr", _vp, [_vp]),
+    ("mh_binary_profile", _i, [_vp, _i, C.POINTER(_d), C.POINTER(_i)]),
     ("mh_device_count", _i, []),
     ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
     ("mh_free", _i, [_vp]),

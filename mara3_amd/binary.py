@@ -1,0 +1,180 @@
+"""Host-side mirror of the `binary` sub-program's interface (src/subprog_binary.cpp) over the C ABI.
+
+The run configuration uses the reference's item names and defaults (create_config_template, :55-99). All arithmetic -
+set-up with the host libm, time stepping on the device - happens in libmara_hip.so; this module owns none and there is
+no CPU fallback.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib as L
+
+# numeric items of binary::create_config_template (src/subprog_binary.cpp:55-99)
+DEFAULTS = dict(
+    cfl_number=0.4, fixed_dt=0, depth=4, begin_live_binary=1e6, block_size=24, rk_order=2, plm_theta=1.8,
+    source_term_softening=1.0, softening_radius=0.05, sink_radius=0.05, sink_rate=1.0, buffer_damping_rate=10.0,
+    domain_radius=12.0, disk_radius=2.0, disk_mass=1e-3, ambient_density=1e-4, density_floor=0.0, separation=1.0,
+    mass_ratio=1.0, eccentricity=0.0, counter_rotate=0, mach_number=10.0, axisymmetric_cs2=0, no_accretion_force=0,
+    alpha_cutoff_radius=0.0, alpha=0.1, nu=0.0, mdot=0.0, conserve_linear_p=1)
+
+ELEMENT_NAMES = ("pomega", "tau", "cm_position_x", "cm_position_y", "cm_velocity_x", "cm_velocity_y",
+                 "separation", "total_mass", "mass_ratio", "eccentricity")
+
+
+def config(**overrides):
+    cfg = dict(DEFAULTS)
+    for k, v in overrides.items():
+        if k not in cfg:
+            raise KeyError("binary: no run_config item '%s'" % k)
+        cfg[k] = v
+    if not int(cfg["conserve_linear_p"]):
+        raise NotImplementedError("binary: only the linear-momentum conserving scheme (advance_u) is built; conserve_linear_p=0 is not")
+    return cfg
+
+
+def grid_size(cfg):
+    return int(cfg["block_size"]) << int(cfg["depth"])
+
+
+def vertices(cfg):
+    """Vertex coordinates of the uniform-depth block tree (the same array for both axes)."""
+    lib = L.load_library()
+    v = np.zeros(grid_size(cfg) + 1)
+    L.check(lib.mh_binary_vertices(int(cfg["block_size"]), int(cfg["depth"]), float(cfg["domain_radius"]), v.ctypes.data_as(C.c_void_p)))
+    return v
+
+
+def _model(cfg):
+    m = L.BinaryModel()
+    for k in ("softening_radius", "disk_radius", "mach_number", "disk_mass", "ambient_density", "mdot", "buffer_damping_rate", "domain_radius", "cfl_number"):
+        setattr(m, k, float(cfg[k]))
+    m.counter_rotate = int(cfg["counter_rotate"])
+    return m
+
+
+def solver_data(cfg, xv=None, yv=None):
+    """(u_init [n][n][3], buffer_rate [n][n], recommended_time_step) - binary::create_solver_data."""
+    lib = L.load_library()
+    xv = vertices(cfg) if xv is None else np.ascontiguousarray(xv, dtype=np.float64)
+    yv = xv if yv is None else np.ascontiguousarray(yv, dtype=np.float64)
+    n = len(xv) - 1
+    u = np.zeros((n, n, 3))
+    br = np.zeros((n, n))
+    dt = C.c_double()
+    m = _model(cfg)
+    L.check(lib.mh_binary_solver_data(C.byref(m), n, xv.ctypes.data_as(C.c_void_p), yv.ctypes.data_as(C.c_void_p),
+                                      u.ctypes.data_as(C.c_void_p), br.ctypes.data_as(C.c_void_p), C.byref(dt)))
+    return u, br, dt.value
+
+
+def make_desc(cfg, safe_mode=False, chunk_rows=0):
+    d = L.BinaryDesc()
+    d.n = grid_size(cfg)
+    d.block_size = int(cfg["block_size"])
+    for k in ("domain_radius", "mach_number", "alpha", "nu", "alpha_cutoff_radius", "sink_rate", "sink_radius", "softening_radius"):
+        setattr(d, k, float(cfg[k]))
+    d.density_floor = float(cfg["density_floor"]) * float(cfg["disk_mass"])
+    d.plm_theta = 0.0 if safe_mode else float(cfg["plm_theta"])
+    d.axisymmetric_cs2 = int(cfg["axisymmetric_cs2"])
+    d.chunk_rows = int(chunk_rows)
+    return d
+
+
+def initial_elements(cfg):
+    """make_full_orbital_elements(create_binary_params(run_config)) - src/subprog_binary.cpp:187-195."""
+    E = L.FullOrbitalElements()
+    E.elements.total_mass = 1.0
+    E.elements.separation = float(cfg["separation"])
+    E.elements.mass_ratio = float(cfg["mass_ratio"])
+    E.elements.eccentricity = float(cfg["eccentricity"])
+    return E
+
+
+def two_body_state(elements, t):
+    """bodies = (mass, x, y, vx, vy) x 2 of mara::compute_two_body_state."""
+    lib = L.load_library()
+    out = (C.c_double * 10)()
+    L.check(lib.mh_two_body_state(C.byref(elements), float(t), out))
+    return np.array(out[:])
+
+
+def state_as_dict(s):
+    return dict(
+        time=s.time, iteration=s.iteration,
+        mass_accreted_on=list(s.mass_accreted_on), angular_momentum_accreted_on=list(s.angular_momentum_accreted_on),
+        integrated_torque_on=list(s.integrated_torque_on), work_done_on=list(s.work_done_on),
+        mass_ejected=s.mass_ejected, angular_momentum_ejected=s.angular_momentum_ejected,
+        orbital_elements_acc=s.orbital_elements_acc.as_array(), orbital_elements_grav=s.orbital_elements_grav.as_array(),
+        orbital_elements=s.orbital_elements.as_array())
+
+
+class BinarySolver:
+    """binary::state_t's solution + next_solution on one MI355X (uniform-depth tree)."""
+
+    def __init__(self, cfg, device=0, xv=None, yv=None, u_init=None, buffer_rate=None, recommended_time_step=None, chunk_rows=0):
+        self.lib = L.load_library()
+        self.cfg = cfg
+        self.n = grid_size(cfg)
+        self.xv = vertices(cfg) if xv is None else np.ascontiguousarray(xv, dtype=np.float64)
+        self.yv = self.xv if yv is None else np.ascontiguousarray(yv, dtype=np.float64)
+        if u_init is None or buffer_rate is None or recommended_time_step is None:
+            u_init, buffer_rate, recommended_time_step = solver_data(cfg, self.xv, self.yv)
+        self.u_init = np.ascontiguousarray(u_init, dtype=np.float64)
+        self.buffer_rate = np.ascontiguousarray(buffer_rate, dtype=np.float64)
+        assert self.u_init.shape == (self.n, self.n, 3) and self.buffer_rate.shape == (self.n, self.n)
+        self.desc = make_desc(cfg, chunk_rows=chunk_rows)
+        run = L.BinaryRun()
+        run.rk_order = int(cfg["rk_order"])
+        run.fixed_dt = int(cfg["fixed_dt"])
+        run.no_accretion_force = int(cfg["no_accretion_force"])
+        run.cfl_number = float(cfg["cfl_number"])
+        run.recommended_time_step = float(recommended_time_step)
+        run.begin_live_binary = float(cfg["begin_live_binary"])
+        self.run = run
+        self.handle = C.c_void_p()
+        L.check(self.lib.mh_binary_create(C.byref(self.handle), device, C.byref(self.desc), C.byref(run),
+                                          self.xv.ctypes.data_as(C.c_void_p), self.yv.ctypes.data_as(C.c_void_p),
+                                          self.u_init.ctypes.data_as(C.c_void_p), self.buffer_rate.ctypes.data_as(C.c_void_p)))
+        # binary::create_solution (src/subprog_binary.cpp:197-229)
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
+
+    def set_solution(self, u, state):
+        up = None if u is None else np.ascontiguousarray(u, dtype=np.float64).ctypes.data_as(C.c_void_p)
+        L.check(self.lib.mh_binary_set_solution(self.handle, up, C.byref(state)))
+
+    def state(self):
+        s = L.BinaryState()
+        L.check(self.lib.mh_binary_get_solution(self.handle, None, C.byref(s)))
+        return s
+
+    def solution(self):
+        u = np.empty((self.n, self.n, 3))
+        L.check(self.lib.mh_binary_get_solution(self.handle, u.ctypes.data_as(C.c_void_p), None))
+        return u
+
+    def next(self, nsteps=1):
+        """nsteps x binary::next_solution; returns how many of them fell back to safe mode."""
+        safe = C.c_int(0)
+        L.check(self.lib.mh_binary_next(self.handle, int(nsteps), C.byref(safe)))
+        return safe.value
+
+    @property
+    def last_dt(self):
+        return self.lib.mh_binary_last_dt(self.handle)
+
+    def profile(self, enable=True):
+        ms, nl = C.c_double(), C.c_int()
+        L.check(self.lib.mh_binary_profile(self.handle, int(enable), C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mh_binary_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,626 @@
+// `binary` sub-program stage on gfx950: 2-D locally isothermal circumbinary disk on a uniform-depth
+// block tree (BASELINE config 3). Replaces one evaluation of
+// binary::advance_u (src/subprog_binary_scheme.cpp:790-904) and, with stage_weight != 1, the conserved
+// part of the RK combine s0 * 1/2 + s2 * 1/2 (:1033-1069, src/subprog_binary.cpp:264-277):
+//     p0      = iso2d::recover_primitive(u0)                                          :802, physics_iso2d.hpp:351
+//     gx, gy  = plm_gradient(p0 on axis 0 / 1, theta) / spacing                        :794-800
+//     fhat_x  = (hlle(pl + gl h/2, pr - gr h/2, cs2(xf)) + viscous_flux) * dy          :472-516, :268-293, :220-262
+//     fhat_y  = likewise * dx
+//     u1      = u0 - (diff_x fhat_x + diff_y fhat_y) * dt / dA + s                     :568-587
+//     s       = gravity(2) + sink(2) + buffer + floor                                   :345-411
+// and the ten source-term totals of :390-408. On a tree whose every node is refined, the blocks tile a
+// periodic n x n tensor-product mesh (block neighbours wrap, core_tree.hpp:203-204), no flux correction
+// applies (:614-720 only acts at refinement jumps), and the only trace of the blocks in the arithmetic is
+// (i) the position of a block's OUTER faces, which are its own vertices - so the two sides of the periodic
+// seam are evaluated separately, at x = -R and x = +R - and (ii) the grouping of the totals: work_done_on
+// is a nonlinear function of each block's sink sums (:356-365, :409-410).
+//
+// Kernels:
+//  * binary_stage_kernel  - the wave-marching stencil of euler2d.hip (one wavefront = 60 columns + 2 halo
+//    lanes per side, marching along axis 0; axis-0 face fluxes reused between iterations, axis-1 neighbours
+//    through DPP wave shifts), extended by the transverse slopes the viscous flux needs, the position-
+//    dependent sound speed / viscosity, the source terms, and per-wave partial sums of the 8 totals that
+//    are linear in the cells (torque, force, ejected mass / angular momentum).
+//  * binary_sink_kernel   - one workgroup per tree block: the sink sums of that block and, from them, the
+//    block's work_done_on. Blocks further than the range of exp(-a2) from both bodies (a2 > 750: the rate
+//    underflows to exactly 0 there, in glibc and here) contribute exact zeros and return at once.
+//  * binary_reduce_kernel - fixed-order reduction of both partial sets into the 18 totals (deterministic).
+//  * binary_maxw_kernel   - max over cells of primitive_t::max_wavespeed(cs2(x_c)) for maximum_timestep (:1107-1126).
+//
+// Arithmetic: reference operation order with IEEE division and sqrt and no FMA contraction (as STRICT in
+// euler2d.hip), EXCEPT the three libm calls the reference makes per cell/face: pow(x, 1/2) is evaluated as
+// sqrt(x), pow(x, 3/2) as x * sqrt(x), exp / tanh by the device math library. These differ from glibc in the
+// last bit or two, so parity with the reference is to the north-star tolerance (L1 <= 1e-12), not bit-exact.
+//
+// Algorithmic HBM bytes per cell per stage: read u0 (24) + u_init (24) + buffer rate (8) + write u1 (24) = 80;
+// the second RK stage also reads the step-start field (+24) = 104. RK2: 184 B per zone-update.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "launch.hpp"
+#include "euler_device.hpp"
+#include "iso2d_device.hpp"
+
+namespace mh {
+
+using iso2d::State3;
+
+static constexpr int BWAVE = 64;
+static constexpr int BHALO = 2;
+static constexpr int BSTRIP = BWAVE - 2 * BHALO;
+static constexpr int BWAVES_PER_BLOCK = 4;
+static constexpr int NPART = 8;    // per-wave partial sums: torque[2], fx[2], fy[2], mass_ejected, L_ejected
+static constexpr int NBLK = 10;    // per-block results: mass_acc[2], L_acc[2], px_acc[2], py_acc[2], work[2]
+
+struct BinaryConsts
+{
+    double h;                 // grid spacing 2 R / block_size / 2^depth
+    double mach, alpha, nu, rc_cut;
+    double sink_rate, s2, rs2, floor_sigma;
+    int    axisym;
+    double body[10];          // (mass, x, y, vx, vy) x 2
+};
+
+struct BinaryStageParams
+{
+    const double* u_in;
+    const double* u_base;
+    double*       u_out;
+    const double* u_init;
+    const double* br;
+    const double* xv;
+    const double* yv;
+    double*       partials;   // [nwaves][NPART]
+    int32_t*      status;
+    int    n, chunk_rows, nstrips, nchunks;
+    double theta, dt, weight;
+    BinaryConsts c;
+};
+
+__device__ inline double bdpp_left(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double bdpp_right(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline State3 bdpp_left(const State3& s) { State3 r; for (int q = 0; q < 3; ++q) r[q] = bdpp_left(s[q]); return r; }
+__device__ inline State3 bdpp_right(const State3& s) { State3 r; for (int q = 0; q < 3; ++q) r[q] = bdpp_right(s[q]); return r; }
+
+using bb64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
+
+// one row of a 3-plane field: wave-uniform row pointer (scalar), per-lane byte offset
+__device__ inline State3 load_row3(const double* row, int n, unsigned lane_bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, 3 * n * 8, 0x00020000);
+    State3 U;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * n * 8), 0));
+    return U;
+}
+__device__ inline void store_row3(double* row, int n, unsigned lane_bytes, const State3& U)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, 3 * n * 8, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bb64_t, U[q]), rs, lane_bytes, (unsigned) (q * n * 8), 0);
+}
+__device__ inline double load_row1(const double* row, int n, unsigned lane_bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, n * 8, 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, 0, 0));
+}
+
+// ---- position-dependent closures of the scheme ------------------------------------------------------------------
+// cs2_at_position :160-175 with grav_phi_field :101-111
+__device__ inline double binary_cs2(const BinaryConsts& c, const Recip& rmach, double x, double y)
+{
+    if (c.axisym)
+    {
+        const double a = 1.0 / sqrt(x * x + y * y);
+        return divide(divide(a, rmach), rmach);
+    }
+    const double d0 = x - c.body[1], d1 = y - c.body[2];
+    const double e0 = x - c.body[6], e1 = y - c.body[7];
+    const double phi1 = (-1.0 * c.body[0]) / sqrt(d0 * d0 + d1 * d1 + c.rs2);
+    const double phi2 = (-1.0 * c.body[5]) / sqrt(e0 * e0 + e1 * e1 + c.rs2);
+    return divide(divide(-(phi1 + phi2), rmach), rmach);
+}
+
+// nu_at_position :177-193
+__device__ inline double binary_nu(const BinaryConsts& c, const Recip& rmach, double x, double y, double cs2)
+{
+    const double radius = sqrt(x * x + y * y);
+    const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
+    if (c.nu > 0.0)
+        return profile * c.nu;
+    return profile * c.alpha * sqrt(cs2) * divide(radius, rmach);
+}
+
+// intercell_flux_u :268-293 + viscous_flux :220-262 ; g = slopes along AXIS, t = transverse slopes (both per length)
+template<int AXIS>
+__device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rmach, double xf, double yf,
+    const State3& pl, const State3& pr, const State3& gl, const State3& gr, const State3& tl, const State3& tr)
+{
+    State3 pl_hat, pr_hat;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+    {
+        pl_hat[q] = pl[q] + gl[q] * 0.5 * c.h;
+        pr_hat[q] = pr[q] - gr[q] * 0.5 * c.h;
+    }
+    const double cs2 = binary_cs2(c, rmach, xf, yf);
+    const double nu = binary_nu(c, rmach, xf, yf, cs2);
+    const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
+    State3 F = iso2d::riemann_hlle<AXIS>(pl_hat, pr_hat, cs2, cs2);
+    if constexpr (AXIS == 0)
+    {
+        const double dx_ux = 0.5 * (gl[1] + gr[1]);
+        const double dx_uy = 0.5 * (gl[2] + gr[2]);
+        const double dy_ux = 0.5 * (tl[1] + tr[1]);
+        const double dy_uy = 0.5 * (tl[2] + tr[2]);
+        const double tauxx = mu * (dx_ux - dy_uy);
+        const double tauxy = mu * (dx_uy + dy_ux);
+        F[0] = F[0] + 0.0;
+        F[1] = F[1] + -tauxx;
+        F[2] = F[2] + -tauxy;
+    }
+    else
+    {
+        const double dx_ux = 0.5 * (tl[1] + tr[1]);
+        const double dx_uy = 0.5 * (tl[2] + tr[2]);
+        const double dy_ux = 0.5 * (gl[1] + gr[1]);
+        const double dy_uy = 0.5 * (gl[2] + gr[2]);
+        const double tauyx =  mu * (dx_uy + dy_ux);
+        const double tauyy = -mu * (dx_ux - dy_uy);
+        F[0] = F[0] + 0.0;
+        F[1] = F[1] + -tauyx;
+        F[2] = F[2] + -tauyy;
+    }
+    return F;
+}
+
+// the sink rate of one body at a cell, sink_rate_field :117-126. exp(-a2) == 0 exactly for a2 > 750 (glibc and ocml
+// both underflow to zero below exp(-745.2)), so the call is skipped when no lane of the wave is in range.
+__device__ inline double binary_sink_rate(const BinaryConsts& c, double d0, double d1)
+{
+    const double a2 = (d0 * d0 + d1 * d1) / c.s2 / 2.0;
+    double e = 0.0;
+    if (__any(a2 < 750.0)) e = exp(-a2);
+    return c.sink_rate * e;
+}
+
+__device__ inline State3 plm3_per_length(const State3& l, const State3& m, const State3& r, double theta, const Recip& rh)
+{
+    State3 g;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) g[q] = plm_gradient(l[q], m[q], r[q], theta);
+    divide_group<3>(g.v, rh);
+    return g;
+}
+
+__device__ inline State3 c2p3(const State3& U)
+{
+    State3 P;
+    iso2d::recover_primitive(U, P);
+    return P;
+}
+
+__device__ inline double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+template<bool COMBINE>
+__global__ __launch_bounds__(BWAVE * BWAVES_PER_BLOCK, 2)
+void binary_stage_kernel(BinaryStageParams p)
+{
+    const int nblocks = gridDim.x;
+    int b = blockIdx.x;
+    {
+        const int per_xcd = nblocks >> 3;
+        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
+    }
+    const int w = __builtin_amdgcn_readfirstlane(b * BWAVES_PER_BLOCK + (int) (threadIdx.x >> 6));
+    if (w >= p.nstrips * p.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const int chunk = w / p.nstrips;
+    const int strip = w - chunk * p.nstrips;
+    const int n = p.n;
+    const int r0 = chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, n);
+
+    // column of this lane: `col` is the un-wrapped index (positions), `jc` the periodic image (data)
+    const int col = strip * BSTRIP - BHALO + lane;
+    int jc = col < 0 ? col + n : (col >= n ? col - n : col);
+    jc = min(max(jc, 0), n - 1);
+    const bool writes = lane >= BHALO && lane < BWAVE - BHALO && col < n;
+    const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
+
+    const int cv = min(max(col, 0), n - 1);
+    const double yv_lo = p.yv[min(max(col, 0), n)];        // position of this lane's LEFT face
+    const double yc = (p.yv[cv] + p.yv[cv + 1]) * 0.5;
+    const double dy = p.yv[cv + 1] - p.yv[cv];
+
+    const BinaryConsts& c = p.c;
+    const Recip rmach = make_recip(c.mach, 1.0);
+    const Recip rh = make_recip(c.h, 1.0);
+    const double theta = p.theta, dt = p.dt;
+    const long row_stride = 3L * n;
+    auto row_off = [row_stride] (int r) { return (long) (r + BHALO) * row_stride; };
+    const double* in = p.u_in;
+
+    // ring slots (index = row mod 3 relative to the chunk start), as in euler2d.hip:
+    //   U[k], P[k]: rows r, r+1, r+2     Gx[k], Gy[k]: slopes of rows r, r+1     Fx[k]: faces r, r+1 (times dy)
+    State3 U[3], P[3], Gx[3], Gy[3], Fx[3];
+    {
+        const State3 Pa = c2p3(load_row3(in + row_off(r0 - 2), n, jc8));
+        const State3 Pb = c2p3(load_row3(in + row_off(r0 - 1), n, jc8));
+        U[0] = load_row3(in + row_off(r0), n, jc8);
+        U[1] = load_row3(in + row_off(r0 + 1), n, jc8);
+        U[2] = load_row3(in + row_off(r0 + 2), n, jc8);
+        P[0] = c2p3(U[0]);
+        P[1] = c2p3(U[1]);
+        const State3 Gxb = plm3_per_length(Pa, Pb, P[0], theta, rh);
+        const State3 Gyb = plm3_per_length(bdpp_left(Pb), Pb, bdpp_right(Pb), theta, rh);
+        Gx[0] = plm3_per_length(Pb, P[0], P[1], theta, rh);
+        Gy[0] = plm3_per_length(bdpp_left(P[0]), P[0], bdpp_right(P[0]), theta, rh);
+        Fx[0] = binary_face_flux<0>(c, rmach, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Fx[0][q] = Fx[0][q] * dy;
+    }
+    State3 Upre = load_row3(in + row_off(min(r0 + 3, n + 1)), n, jc8);
+
+    double part[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) part[k] = 0.0;
+    int32_t bad = 0;
+
+    auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
+    {
+        constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+        const State3 Unext = load_row3(in + row_off(min(r + 4, n + 1)), n, jc8);
+        const State3 Uinit = load_row3(p.u_init + row_off(r), n, jc8);
+        const double brate = load_row1(p.br + (long) r * n, n, jc8);
+        State3 Ubase;
+        if constexpr (COMBINE) Ubase = load_row3(p.u_base + row_off(r), n, jc8);
+
+        const double xlo = p.xv[r], xhi = p.xv[r + 1];
+        const double xc = (xlo + xhi) * 0.5;
+        const double dx = xhi - xlo;
+
+        // ---- axis 0: slopes of row r+1, flux through face r+1 (at x = xv[r+1])
+        P[K2] = c2p3(U[K2]);
+        Gx[K1] = plm3_per_length(P[K0], P[K1], P[K2], theta, rh);
+        Gy[K1] = plm3_per_length(bdpp_left(P[K1]), P[K1], bdpp_right(P[K1]), theta, rh);
+        Fx[K1] = binary_face_flux<0>(c, rmach, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Fx[K1][q] = Fx[K1][q] * dy;
+
+        // ---- axis 1: this lane's LEFT face (at y = yv[col]), handed to the left neighbour as its right face
+        State3 Fy_lo = binary_face_flux<1>(c, rmach, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Fy_lo[q] = Fy_lo[q] * dx;
+        const State3 Fy_hi = bdpp_right(Fy_lo);
+
+        // ---- source terms :345-411
+        const State3& u0 = U[K0];
+        const double dA = dx * dy;
+        double fg[2][2], s_grav[2][3], s_sink[2][3], s_buffer[3], s_floor[3];
+#pragma unroll
+        for (int bdy = 0; bdy < 2; ++bdy)
+        {
+            const double d0 = xc - c.body[5 * bdy + 1], d1 = yc - c.body[5 * bdy + 2];
+            const double r2s = d0 * d0 + d1 * d1 + c.rs2;
+            const double den = r2s * sqrt(r2s);                     // pow<3, 2>
+            double a[2] = {-d0, -d1};
+            divide_group<2>(a, make_recip(den, 1.0));
+            fg[bdy][0] = (a[0] * 1.0 * c.body[5 * bdy]) * u0[0];
+            fg[bdy][1] = (a[1] * 1.0 * c.body[5 * bdy]) * u0[0];
+            s_grav[bdy][0] = 0.0 * dt;
+            s_grav[bdy][1] = fg[bdy][0] * dt;
+            s_grav[bdy][2] = fg[bdy][1] * dt;
+            const double rate = binary_sink_rate(c, d0, d1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) s_sink[bdy][q] = -u0[q] * rate * dt;
+        }
+        const double fl = u0[0] < c.floor_sigma ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            s_buffer[q] = (Uinit[q] - u0[q]) * brate * dt;
+            s_floor[q] = u0[q] * 1e-2 * fl;
+        }
+        if (writes)
+        {
+#pragma unroll
+            for (int bdy = 0; bdy < 2; ++bdy)
+            {
+                part[0 + bdy] = part[0 + bdy] + (xc * s_grav[bdy][2] - yc * s_grav[bdy][1]) * dA;
+                part[2 + bdy] = part[2 + bdy] + fg[bdy][0] * dt * dA;
+                part[4 + bdy] = part[4 + bdy] + fg[bdy][1] * dt * dA;
+            }
+            part[6] = part[6] + s_buffer[0] * dA;
+            part[7] = part[7] + (xc * s_buffer[2] - yc * s_buffer[1]) * dA;
+        }
+
+        // ---- update :568-587 (+ RK combine)
+        State3 Un;
+        {
+            double l[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) l[q] = ((Fx[K1][q] - Fx[K0][q]) + (Fy_hi[q] - Fy_lo[q])) * dt;
+            divide_group<3>(l, make_recip(dA, 1.0));
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+            {
+                const double s = s_grav[0][q] + s_grav[1][q] + s_sink[0][q] + s_sink[1][q] + s_buffer[q] + s_floor[q];
+                const double u1 = u0[q] - l[q] + s;
+                if constexpr (COMBINE) Un[q] = Ubase[q] * (1.0 - p.weight) + u1 * p.weight;
+                else                   Un[q] = u1;
+                if (q == 0 && !(u1 >= 0.0)) bad |= 1;          // validate_u :726-752 (and NaN)
+            }
+        }
+        if (writes)
+        {
+            store_row3(p.u_out + row_off(r), n, col8, Un);
+            if (r < BHALO) store_row3(p.u_out + row_off(n + r), n, col8, Un);          // periodic ghost rows of the output
+            if (r >= n - BHALO) store_row3(p.u_out + row_off(r - n), n, col8, Un);
+        }
+        U[K0] = Upre;
+        Upre = Unext;
+    };
+
+    int r = r0;
+    for (; r + 3 <= r1; r += 3)
+    {
+        row_step(r, std::integral_constant<int, 0>());
+        row_step(r + 1, std::integral_constant<int, 1>());
+        row_step(r + 2, std::integral_constant<int, 2>());
+    }
+    if (r < r1) row_step(r, std::integral_constant<int, 0>());
+    if (r + 1 < r1) row_step(r + 1, std::integral_constant<int, 1>());
+
+#pragma unroll
+    for (int k = 0; k < NPART; ++k)
+    {
+        const double s = wave_sum(part[k]);
+        if (lane == 0) p.partials[(long) w * NPART + k] = s;
+    }
+    if (p.status)
+    {
+        const bool any_bad = __any(writes && bad);
+        if (any_bad && lane == 0) atomicOr(p.status, MH_STATUS_NEG_DENSITY);
+    }
+}
+
+// ---- per-block sink sums and work --------------------------------------------------------------------------------
+struct BinarySinkParams
+{
+    const double* u_in;
+    const double* xv;
+    const double* yv;
+    double*       block_out;   // [nb * nb][NBLK]
+    int    n, bs, nb;
+    double dt;
+    BinaryConsts c;
+};
+
+__global__ __launch_bounds__(256)
+void binary_sink_kernel(BinarySinkParams p)
+{
+    const int blk = blockIdx.x;
+    const int bi = blk / p.nb, bj = blk - bi * p.nb;
+    const int n = p.n, bs = p.bs;
+    const BinaryConsts& c = p.c;
+    double* out = p.block_out + (long) blk * NBLK;
+
+    // out of range of both sinks? (distance from the body to the block's rectangle)
+    const double x0 = p.xv[bi * bs], x1 = p.xv[(bi + 1) * bs], y0 = p.yv[bj * bs], y1 = p.yv[(bj + 1) * bs];
+    bool near = false;
+    for (int b = 0; b < 2; ++b)
+    {
+        const double bx = c.body[5 * b + 1], by = c.body[5 * b + 2];
+        const double ex = fmax(fmax(x0 - bx, bx - x1), 0.0), ey = fmax(fmax(y0 - by, by - y1), 0.0);
+        if ((ex * ex + ey * ey) / c.s2 / 2.0 < 760.0) near = true;
+    }
+    if (!near)
+    {
+        if (threadIdx.x < NBLK) out[threadIdx.x] = 0.0;
+        return;
+    }
+
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // per body: mass, Lz, px, py of s_sink * dA
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    {
+        const int i = bi * bs + idx / bs, j = bj * bs + idx % bs;
+        const double xc = (p.xv[i] + p.xv[i + 1]) * 0.5, yc = (p.yv[j] + p.yv[j + 1]) * 0.5;
+        const double dA = (p.xv[i + 1] - p.xv[i]) * (p.yv[j + 1] - p.yv[j]);
+        const double* u = p.u_in + (long) (i + BHALO) * 3 * n + j;
+        const double u0[3] = {u[0], u[n], u[2 * n]};
+        for (int b = 0; b < 2; ++b)
+        {
+            const double d0 = xc - c.body[5 * b + 1], d1 = yc - c.body[5 * b + 2];
+            const double a2 = (d0 * d0 + d1 * d1) / c.s2 / 2.0;
+            const double rate = c.sink_rate * (a2 < 750.0 ? exp(-a2) : 0.0);
+            double s[3];
+            for (int q = 0; q < 3; ++q) s[q] = -u0[q] * rate * p.dt;
+            acc[4 * b + 0] = acc[4 * b + 0] + s[0] * dA;
+            acc[4 * b + 1] = acc[4 * b + 1] + (xc * s[2] - yc * s[1]) * dA;
+            acc[4 * b + 2] = acc[4 * b + 2] + s[1] * dA;
+            acc[4 * b + 3] = acc[4 * b + 3] + s[2] * dA;
+        }
+    }
+    __shared__ double red[8][256];
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+        if ((int) threadIdx.x < off)
+            for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = red[k][threadIdx.x] + red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        for (int b = 0; b < 2; ++b)
+        {
+            const double dm = -red[4 * b + 0][0], dl = -red[4 * b + 1][0], dpx = -red[4 * b + 2][0], dpy = -red[4 * b + 3][0];
+            out[0 + b] = dm;
+            out[2 + b] = dl;
+            out[4 + b] = dpx;
+            out[6 + b] = dpy;
+            // work :356-365
+            const double M0 = c.body[5 * b], px0 = c.body[5 * b + 3] * M0, py0 = c.body[5 * b + 4] * M0;
+            const double M1 = M0 + dm, px1 = px0 + dpx, py1 = py0 + dpy;
+            out[8 + b] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+        }
+    }
+}
+
+// ---- totals: fixed-order reduction ----------------------------------------------------------------------------------
+// totals[] in the order of mh_binary_total (include/mara_hip.h): mass_acc[2], L_acc[2], torque[2], px_acc[2], py_acc[2],
+// fx[2], fy[2], work[2], mass_ejected, L_ejected
+__global__ __launch_bounds__(1024)
+void binary_reduce_kernel(const double* partials, int nwaves, const double* block_out, int nblocks, double* totals)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < MH_BINARY_NTOTALS; t += 16)
+    {
+        // which source does total t come from?
+        //   blocks: 0,1 mass  2,3 L  6,7 px  8,9 py  14,15 work         waves (negated): 4,5 torque 10,11 fx 12,13 fy 16 mass_ej 17 L_ej
+        int from_block = -1, from_wave = -1;
+        if (t < 4) from_block = t;
+        else if (t < 6) from_wave = t - 4;
+        else if (t < 10) from_block = t - 2;
+        else if (t < 14) from_wave = t - 8;
+        else if (t < 16) from_block = t - 6;
+        else from_wave = t - 10;
+        double s = 0.0;
+        if (from_block >= 0)
+            for (int k = lane; k < nblocks; k += 64) s = s + block_out[(long) k * NBLK + from_block];
+        else
+            for (int k = lane; k < nwaves; k += 64) s = s + partials[(long) k * NPART + from_wave];
+        s = wave_sum(s);
+        if (lane == 0) totals[t] = from_block >= 0 ? s : -s;
+    }
+}
+
+// ---- maximum wavespeed ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int n, BinaryConsts c, unsigned long long* result)
+{
+    const Recip rmach = make_recip(c.mach, 1.0);
+    double m = 0.0;
+    const long total = (long) n * n;
+    for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
+    {
+        const int i = (int) (idx / n), j = (int) (idx - (long) i * n);
+        const double* q = u + (long) (i + BHALO) * 3 * n + j;
+        State3 U, P;
+        U[0] = q[0]; U[1] = q[n]; U[2] = q[2 * n];
+        iso2d::recover_primitive(U, P);
+        const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
+        const double wsp = iso2d::max_wavespeed(P, binary_cs2(c, rmach, xc, yc));
+        m = (m < wsp) ? wsp : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (m < o) ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(result, (unsigned long long) __double_as_longlong(m));   // non-negative doubles order as integers
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------
+static BinaryConsts make_consts(const mh_binary_desc* d, const double bodies[10])
+{
+    BinaryConsts c;
+    int depth = 0;
+    while ((d->block_size << depth) < d->n) ++depth;
+    c.h = 2.0 * d->domain_radius / d->block_size / (1 << depth);     // scheme.cpp:274, :793
+    c.mach = d->mach_number;
+    c.alpha = d->alpha;
+    c.nu = d->nu;
+    c.rc_cut = d->alpha_cutoff_radius;
+    c.sink_rate = d->sink_rate;
+    c.s2 = d->sink_radius * d->sink_radius;
+    c.rs2 = d->softening_radius * d->softening_radius;
+    c.floor_sigma = d->density_floor;
+    c.axisym = d->axisymmetric_cs2;
+    for (int k = 0; k < 10; ++k) c.body[k] = bodies[k];
+    return c;
+}
+
+static int binary_chunk_rows(const mh_binary_desc* d, int nstrips)
+{
+    if (d->chunk_rows > 0) return d->chunk_rows;
+    const long chunks_max = 2048 / nstrips > 0 ? 2048 / nstrips : 1;     // one residency round at 2 waves / SIMD
+    const long c = (d->n + chunks_max - 1) / chunks_max;
+    return (int) (c > 96 ? 32 : (c < 4 ? 4 : c));
+}
+
+size_t binary_scratch_doubles(const mh_binary_desc* d)
+{
+    const int nstrips = (d->n + BSTRIP - 1) / BSTRIP;
+    const int chunk = binary_chunk_rows(d, nstrips);
+    const long nwaves = (long) nstrips * ((d->n + chunk - 1) / chunk);
+    const long nb = d->n / d->block_size;
+    return (size_t) (nwaves * NPART + nb * nb * NBLK);
+}
+
+hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
+                               double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream)
+{
+    BinaryStageParams p;
+    p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.u_init = u_init; p.br = br; p.xv = xv; p.yv = yv;
+    p.status = status;
+    p.n = d->n;
+    p.nstrips = (d->n + BSTRIP - 1) / BSTRIP;
+    p.chunk_rows = binary_chunk_rows(d, p.nstrips);
+    p.nchunks = (d->n + p.chunk_rows - 1) / p.chunk_rows;
+    p.theta = theta;
+    p.dt = dt;
+    p.weight = weight;
+    p.c = make_consts(d, bodies);
+    const int nwaves = p.nstrips * p.nchunks;
+    p.partials = scratch;
+    const int nblocks = (nwaves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
+    if (weight != 1.0) hipLaunchKernelGGL((binary_stage_kernel<true>), dim3(nblocks), dim3(BWAVE * BWAVES_PER_BLOCK), 0, stream, p);
+    else               hipLaunchKernelGGL((binary_stage_kernel<false>), dim3(nblocks), dim3(BWAVE * BWAVES_PER_BLOCK), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    BinarySinkParams s;
+    s.u_in = u_in; s.xv = xv; s.yv = yv;
+    s.block_out = scratch + (long) nwaves * NPART;
+    s.n = d->n; s.bs = d->block_size; s.nb = d->n / d->block_size;
+    s.dt = dt;
+    s.c = p.c;
+    hipLaunchKernelGGL(binary_sink_kernel, dim3(s.nb * s.nb), dim3(256), 0, stream, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.partials, nwaves, s.block_out, s.nb * s.nb, totals);
+    return hipGetLastError();
+}
+
+hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
+                              double* result, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(result, 0, sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    const BinaryConsts c = make_consts(d, bodies);
+    const long total = (long) d->n * d->n;
+    const int nblocks = (int) ((total + 256 * 4 - 1) / (256 * 4) < 4096 ? (total + 256 * 4 - 1) / (256 * 4) : 4096);
+    hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv, yv, d->n, c, reinterpret_cast<unsigned long long*>(result));
+    return hipGetLastError();
+}
+
+} // namespace mh

@@ -1,0 +1,388 @@
+// C ABI of the `binary` sub-program path (include/mara_hip.h, "binary" section): the stateless stage launchers and the
+// solver object that replaces binary::next_solution (src/subprog_binary.cpp:258-293) around them.
+//
+// One time step = [maximum wavespeed reduction ->] stage 1 -> stage 2 (fused with the RK combine) -> ONE host
+// synchronisation that brings back 2 x 18 totals, the status word and (when the binary is not live, i.e. always before
+// begin_live_binary) the maximum wavespeed of the NEW state for the next step's dt. The reference synchronises
+// implicitly after every array expression; here the field never leaves the device and the host only sees ~300 bytes
+// per step. The step is transactional: stage outputs go to alternate buffers and the solution pointer is swapped
+// only after the status word came back clean, because the reference's safe-mode retry restarts from the OLD solution.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "launch.hpp"
+#include "binary_host.hpp"
+
+namespace mh {
+
+size_t binary_scratch_doubles(const mh_binary_desc* d);
+hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
+                               double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream);
+hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
+                              double* result, hipStream_t stream);
+
+static int check_binary_desc(const mh_binary_desc* d)
+{
+    if (! d) { set_error("binary: null descriptor"); return MH_E_INVALID; }
+    if (d->n < 8 || d->block_size < 1 || d->n % d->block_size != 0) { set_error("binary: n = %d must be a multiple of block_size = %d (and >= 8)", d->n, d->block_size); return MH_E_INVALID; }
+    int depth = 0;
+    while ((d->block_size << depth) < d->n) ++depth;
+    if ((d->block_size << depth) != d->n) { set_error("binary: n / block_size = %d is not a power of two (uniform-depth tree)", d->n / d->block_size); return MH_E_INVALID; }
+    if (! (d->mach_number > 0.0) || ! (d->sink_radius > 0.0) || ! (d->domain_radius > 0.0)) { set_error("binary: mach_number, sink_radius and domain_radius must be positive"); return MH_E_INVALID; }
+    return MH_OK;
+}
+
+struct HostMirror        // pinned: what one step brings back
+{
+    double  totals[2][MH_BINARY_NTOTALS];
+    double  maxw;
+    int32_t status[2];
+};
+
+} // namespace mh
+
+using namespace mh;
+
+struct mh_binary
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mh_binary_desc desc;
+    mh_binary_run run;
+    double h = 0.0;
+    size_t field_doubles = 0;
+    double* u[3] = {nullptr, nullptr, nullptr};     // [0] solution, [1] first-stage result, [2] step result
+    double* u_init = nullptr;
+    double* br = nullptr;
+    double* xv = nullptr;
+    double* yv = nullptr;
+    double* scratch = nullptr;
+    double* dev_small = nullptr;                     // totals[2][18], maxw
+    int32_t* status = nullptr;
+    double* staging = nullptr;
+    HostMirror* mirror = nullptr;
+    mh_binary_state state;
+    double last_dt = 0.0;
+    // maximum wavespeed of the current solution, computed ahead by the previous step
+    bool   maxw_ready = false;
+    double maxw_value = 0.0;
+    mh_binary_state maxw_for;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+static double* totals_dev(mh_binary* b, int stage) { return b->dev_small + stage * MH_BINARY_NTOTALS; }
+static double* maxw_dev(mh_binary* b) { return b->dev_small + 2 * MH_BINARY_NTOTALS; }
+
+static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_body_t* B)
+{
+    return mh_two_body_state(&E, t, B);
+}
+
+static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, double* u_out, const mh_two_body_t& B, double dt,
+                        double weight, double theta, int slot)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->profile)
+    {
+        MH_HIP_TRY(hipEventCreate(&e0));
+        MH_HIP_TRY(hipEventCreate(&e1));
+        MH_HIP_TRY(hipEventRecord(e0, b->stream));
+    }
+    MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
+                                   totals_dev(b, slot), b->scratch, b->status, b->stream));
+    if (b->profile)
+    {
+        MH_HIP_TRY(hipEventRecord(e1, b->stream));
+        b->events.emplace_back(e0, e1);
+    }
+    return MH_OK;
+}
+
+static bool same_point(const mh_binary_state& a, const mh_binary_state& c)
+{
+    return a.time == c.time && memcmp(&a.orbital_elements, &c.orbital_elements, sizeof(mh_full_orbital_elements)) == 0;
+}
+
+// one attempt at a full step from (u[0], state); on success the new solution is in u[0] and *out
+static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch_maxw, mh_binary_state* out, bool* failed)
+{
+    static_assert(sizeof(mh_two_body_t) == 10 * sizeof(double), "bodies are passed as double[10]");
+    const mh_binary_state S0 = b->state;
+    const double theta = safe_mode ? 0.0 : b->desc.plm_theta;
+    const bool naf = b->run.no_accretion_force != 0;
+    *failed = false;
+    mh_two_body_t B1, B2;
+    if (int rc = binary_bodies(S0.orbital_elements, S0.time, &B1)) return rc;
+    MH_HIP_TRY(hipMemsetAsync(b->status, 0, 2 * sizeof(int32_t), b->stream));
+
+    auto fetch = [b] () -> int
+    {
+        MH_HIP_TRY(hipMemcpyAsync(b->mirror->totals, b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        MH_HIP_TRY(hipMemcpyAsync(b->mirror->status, b->status, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+        MH_HIP_TRY(hipStreamSynchronize(b->stream));
+        return MH_OK;
+    };
+
+    if (b->run.rk_order == 1)
+    {
+        if (int rc = launch_stage(b, b->u[0], nullptr, b->u[2], B1, dt, 1.0, theta, 0)) return rc;
+        if (int rc = fetch()) return rc;
+        if (b->mirror->status[0]) { *failed = true; return MH_OK; }
+        if (binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, out) != MH_OK) { *failed = true; return MH_OK; }
+        return MH_OK;
+    }
+
+    if (int rc = launch_stage(b, b->u[0], nullptr, b->u[1], B1, dt, 1.0, theta, 0)) return rc;
+    mh_binary_state S1;
+    const bool live = S0.time > b->run.begin_live_binary;
+    if (live)
+    {
+        // the elements the second stage is evaluated with depend on the first stage's totals
+        if (int rc = fetch()) return rc;
+        if (b->mirror->status[0]) { *failed = true; return MH_OK; }
+        if (binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
+        if (int rc = binary_bodies(S1.orbital_elements, S1.time, &B2)) return rc;
+    }
+    else
+    {
+        if (int rc = binary_bodies(S0.orbital_elements, S0.time + dt, &B2)) return rc;   // elements + (...) * 0 = elements
+    }
+    if (int rc = launch_stage(b, b->u[1], b->u[0], b->u[2], B2, dt, 0.5, theta, 1)) return rc;
+
+    // look ahead: the next step's maximum wavespeed, evaluated on the step result while the totals travel
+    mh_binary_state ahead = S0;
+    bool launched_ahead = false;
+    if (prefetch_maxw && ! live && ! b->run.fixed_dt)
+    {
+        ahead.time = S0.time * 0.5 + ((S0.time + dt) + dt) * 0.5;
+        mh_two_body_t Bn;
+        if (binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK)
+        {
+            MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[2], Bn.body1, maxw_dev(b), b->stream));
+            launched_ahead = true;
+        }
+    }
+    if (int rc = fetch()) return rc;
+    if (b->mirror->status[0]) { *failed = true; return MH_OK; }
+    if (! live && binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
+    mh_two_body_t B2s;
+    if (int rc = binary_bodies(S1.orbital_elements, S1.time, &B2s)) return rc;
+    if (memcmp(&B2s, &B2, sizeof(B2)) != 0)
+    {
+        // cannot happen unless an orbital-element perturbation was non-finite; the stage ran with other bodies than the
+        // bookkeeping assumes: treat like a failed stage
+        *failed = true;
+        return MH_OK;
+    }
+    mh_binary_state S2;
+    if (binary_apply_totals(S1, B2, b->mirror->totals[1], dt, naf, b->run.begin_live_binary, &S2) != MH_OK) { *failed = true; return MH_OK; }
+    binary_combine_scalars(S0, S2, out);
+    if (launched_ahead)
+    {
+        b->maxw_ready = true;
+        b->maxw_value = b->mirror->maxw;
+        b->maxw_for = ahead;
+    }
+    return MH_OK;
+}
+
+extern "C" {
+
+size_t mh_binary_field_doubles(const mh_binary_desc* d)
+{
+    return d ? (size_t) 3 * (d->n + 4) * d->n : 0;
+}
+
+size_t mh_binary_scratch_doubles(const mh_binary_desc* d)
+{
+    if (check_binary_desc(d) != MH_OK) return 0;
+    return binary_scratch_doubles(d);
+}
+
+int mh_binary_stage(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base, double* u_out,
+                    const double* u_init, const double* br, const double* bodies, double dt, double w, double* totals, double* scratch,
+                    int32_t* status, void* stream)
+{
+    if (int rc = check_binary_desc(d)) return rc;
+    if (! xv || ! yv || ! u_in || ! u_out || ! u_init || ! br || ! bodies || ! totals || ! scratch || u_in == u_out) { set_error("binary stage: null or aliased argument"); return MH_E_INVALID; }
+    if (w != 1.0 && ! u_base) { set_error("binary stage: combine needs u_base"); return MH_E_INVALID; }
+    MH_HIP_TRY(binary_stage_launch(d, xv, yv, u_in, u_base, u_out, u_init, br, bodies, dt, w, d->plm_theta, totals, scratch, status, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_binary_max_wavespeed(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double* bodies,
+                            double* result, void* stream)
+{
+    if (int rc = check_binary_desc(d)) return rc;
+    if (! xv || ! yv || ! u || ! bodies || ! result) { set_error("binary max_wavespeed: null argument"); return MH_E_INVALID; }
+    MH_HIP_TRY(binary_maxw_launch(d, xv, yv, u, bodies, result, (hipStream_t) stream));
+    return MH_OK;
+}
+
+int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
+                     const double* u_init_aos, const double* br)
+{
+    if (! out || ! run || ! xv || ! yv || ! u_init_aos || ! br) { set_error("binary create: null argument"); return MH_E_INVALID; }
+    if (int rc = check_binary_desc(d)) return rc;
+    if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(device));
+    mh_binary* b = new mh_binary();
+    b->device = device;
+    b->desc = *d;
+    b->run = *run;
+    const size_t n = d->n;
+    int depth = 0;
+    while ((d->block_size << depth) < d->n) ++depth;
+    b->h = 2.0 * d->domain_radius / d->block_size / (1 << depth);
+    b->field_doubles = mh_binary_field_doubles(d);
+    auto fail = [&] (hipError_t e, const char* what) { mh_binary_destroy(b); return hip_fail(e, what); };
+#define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
+    B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->br, n * n * sizeof(double)));
+    B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->scratch, binary_scratch_doubles(d) * sizeof(double)));
+    B_TRY(hipMalloc(&b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->status, 2 * sizeof(int32_t)));
+    B_TRY(hipMalloc(&b->staging, n * n * 3 * sizeof(double)));
+    B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
+    B_TRY(hipMemcpyAsync(b->xv, xv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->yv, yv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->br, br, n * n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->staging, u_init_aos, n * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(aos_to_soa_launch(b->staging, b->u_init, 3, d->n, n, b->stream));
+    B_TRY(fill_ghost_rows_launch(b->u_init, 3, d->n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+    B_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    B_TRY(hipStreamSynchronize(b->stream));
+#undef B_TRY
+    memset(&b->state, 0, sizeof(b->state));
+    *out = b;
+    return MH_OK;
+}
+
+void mh_binary_destroy(mh_binary* b)
+{
+    if (! b) return;
+    (void) hipSetDevice(b->device);
+    if (b->stream) (void) hipStreamSynchronize(b->stream);
+    for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
+    (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
+    (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->status); (void) hipFree(b->staging);
+    if (b->mirror) (void) hipHostFree(b->mirror);
+    if (b->stream) (void) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int mh_binary_set_solution(mh_binary* b, const double* u_aos, const mh_binary_state* state)
+{
+    if (! b || ! state) { set_error("binary set_solution: null argument"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(b->device));
+    const size_t n = b->desc.n;
+    if (u_aos)
+    {
+        MH_HIP_TRY(hipMemcpyAsync(b->staging, u_aos, n * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        MH_HIP_TRY(aos_to_soa_launch(b->staging, b->u[0], 3, b->desc.n, n, b->stream));
+        MH_HIP_TRY(fill_ghost_rows_launch(b->u[0], 3, b->desc.n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+    }
+    else
+    {
+        MH_HIP_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    }
+    MH_HIP_TRY(hipStreamSynchronize(b->stream));
+    b->state = *state;
+    b->maxw_ready = false;
+    return MH_OK;
+}
+
+int mh_binary_get_solution(mh_binary* b, double* u_aos, mh_binary_state* state)
+{
+    if (! b) { set_error("binary get_solution: null solver"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(b->device));
+    if (u_aos)
+    {
+        const size_t n = b->desc.n;
+        MH_HIP_TRY(soa_to_aos_launch(b->u[0], b->staging, 3, b->desc.n, n, b->stream));
+        MH_HIP_TRY(hipMemcpyAsync(u_aos, b->staging, n * n * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        MH_HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    if (state) *state = b->state;
+    return MH_OK;
+}
+
+int mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps)
+{
+    if (! b || nsteps < 0) { set_error("binary next: bad argument"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(b->device));
+    if (safe_mode_steps) *safe_mode_steps = 0;
+    for (int s = 0; s < nsteps; ++s)
+    {
+        // dt: subprog_binary.cpp:281-283
+        double dt = b->run.recommended_time_step;
+        if (! b->run.fixed_dt)
+        {
+            double maxw;
+            if (b->maxw_ready && same_point(b->maxw_for, b->state)) maxw = b->maxw_value;
+            else
+            {
+                mh_two_body_t B;
+                if (int rc = binary_bodies(b->state.orbital_elements, b->state.time, &B)) return rc;
+                MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[0], B.body1, maxw_dev(b), b->stream));
+                MH_HIP_TRY(hipMemcpyAsync(&b->mirror->maxw, maxw_dev(b), sizeof(double), hipMemcpyDeviceToHost, b->stream));
+                MH_HIP_TRY(hipStreamSynchronize(b->stream));
+                maxw = b->mirror->maxw;
+            }
+            dt = b->run.cfl_number * (b->h / maxw);
+        }
+        b->maxw_ready = false;
+        mh_binary_state next;
+        bool failed = false;
+        if (int rc = binary_attempt(b, dt, false, s + 1 < nsteps, &next, &failed)) return rc;
+        if (failed)
+        {
+            if (safe_mode_steps) ++*safe_mode_steps;
+            dt = dt * 0.1;
+            b->maxw_ready = false;
+            if (int rc = binary_attempt(b, dt, true, false, &next, &failed)) return rc;
+            if (failed) { set_error("negative density in updated state"); return MH_E_PHYSICS; }
+        }
+        double* t = b->u[0]; b->u[0] = b->u[2]; b->u[2] = t;      // commit
+        b->state = next;
+        b->last_dt = dt;
+    }
+    return MH_OK;
+}
+
+double mh_binary_last_dt(const mh_binary* b) { return b ? b->last_dt : 0.0; }
+
+const double* mh_binary_field_ptr(mh_binary* b) { return b ? b->u[0] : nullptr; }
+
+int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaunches)
+{
+    if (! b) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(b->device));
+    if (avg_stage_ms || nlaunches)
+    {
+        MH_HIP_TRY(hipStreamSynchronize(b->stream));
+        double total = 0.0;
+        for (auto& e : b->events)
+        {
+            float ms = 0.f;
+            MH_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+            total += ms;
+        }
+        if (avg_stage_ms) *avg_stage_ms = b->events.empty() ? 0.0 : total / b->events.size();
+        if (nlaunches) *nlaunches = (int) b->events.size();
+    }
+    for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    b->events.clear();
+    b->profile = enable != 0;
+    return MH_OK;
+}
+
+} // extern "C"

@@ -5,6 +5,7 @@
 //   mara::compute_two_body_state(full_orbital_elements_t, t)  src/model_two_body.hpp:209-268
 //   mara::compute_orbital_elements(two_body_state_t, t)       src/model_two_body.hpp:295-381
 //   mara::orbital_period                                      src/model_two_body.hpp:391-396
+//   mara::diff(full_orbital_elements_t, full_orbital_elements_t) src/model_two_body.hpp:492-518
 // so that results are bit-identical to the reference (same libm: sin/cos/atan2/sqrt; no FMA contraction).
 // No device code in this file: it is compiled with g++ like the reference (a host compiler may pair sin/cos calls
 // or schedule libm differently; two of 2048 fixture rows differed by one ulp when clang compiled it).
@@ -139,6 +140,30 @@ int mh_orbital_elements_from_state(const mh_two_body_t* st, double t, mh_full_or
     P->elements.mass_ratio = q;
     P->elements.eccentricity = e;
     return MH_OK;
+}
+
+void mh_orbital_elements_diff(const mh_full_orbital_elements* a, const mh_full_orbital_elements* b, mh_full_orbital_elements* out)
+{
+    // mara::diff :492-518
+    auto wrap = [] (double delta, double per)
+    {
+        const double x = delta, y = delta + per, z = delta - per;
+        if (std::abs(x) < std::min(std::abs(y), std::abs(z))) return x;
+        if (std::abs(y) < std::abs(z)) return y;
+        return z;
+    };
+    mh_full_orbital_elements r;
+    r.pomega = wrap(b->pomega - a->pomega, 2 * M_PI);
+    r.tau = wrap(b->tau - a->tau, period(b->elements));
+    r.cm_position_x = b->cm_position_x - a->cm_position_x;
+    r.cm_position_y = b->cm_position_y - a->cm_position_y;
+    r.cm_velocity_x = b->cm_velocity_x - a->cm_velocity_x;
+    r.cm_velocity_y = b->cm_velocity_y - a->cm_velocity_y;
+    r.elements.separation = b->elements.separation - a->elements.separation;
+    r.elements.total_mass = b->elements.total_mass - a->elements.total_mass;
+    r.elements.mass_ratio = b->elements.mass_ratio - a->elements.mass_ratio;
+    r.elements.eccentricity = b->elements.eccentricity - a->elements.eccentricity;
+    *out = r;
 }
 
 } // extern "C"
