@@ -535,7 +535,14 @@ void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (m < o) ? o : m; }
-    if ((threadIdx.x & 63) == 0) atomicMax(result, (unsigned long long) __double_as_longlong(m));   // non-negative doubles order as integers
+    __shared__ double wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int k = 1; k < 4; ++k) m = (m < wmax[k]) ? wmax[k] : m;
+        atomicMax(result, (unsigned long long) __double_as_longlong(m));   // non-negative doubles order as integers; one atomic per workgroup
+    }
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------
@@ -618,7 +625,7 @@ hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const d
     if (e != hipSuccess) return e;
     const BinaryConsts c = make_consts(d, bodies);
     const long total = (long) d->n * d->n;
-    const int nblocks = (int) ((total + 256 * 4 - 1) / (256 * 4) < 4096 ? (total + 256 * 4 - 1) / (256 * 4) : 4096);
+    const int nblocks = (int) ((total + 256 * 4 - 1) / (256 * 4) < 2048 ? (total + 256 * 4 - 1) / (256 * 4) : 2048);
     hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv, yv, d->n, c, reinterpret_cast<unsigned long long*>(result));
     return hipGetLastError();
 }

@@ -22,3 +22,4 @@ public:
 std::unique_ptr<mara::sub_program_t> make_subprog_sedov();
 std::unique_ptr<mara::sub_program_t> make_subprog_euler2d();
 std::unique_ptr<mara::sub_program_t> make_subprog_cloud();
+std::unique_ptr<mara::sub_program_t> make_subprog_binary();

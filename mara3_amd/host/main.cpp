@@ -11,6 +11,7 @@ int main(int argc, const char* argv[])
     programs["sedov"] = make_subprog_sedov();
     programs["euler2d"] = make_subprog_euler2d();
     programs["cloud"] = make_subprog_cloud();
+    programs["binary"] = make_subprog_binary();
 
     if (argc == 1)
     {

@@ -1,0 +1,172 @@
+// `binary` sub-program: isothermal circumbinary disk (BASELINE config 3), the compiled host of the reference's
+// src/subprog_binary.cpp over the C ABI. Same run_config items and defaults (create_config_template :55-99), same run
+// loop (`while simulation_should_continue: next_state`, :414-438, with time measured per iteration and the
+// `[iter] orbits=... kzps=...` message of :394-404), same set-up (vertices :165-185, disk model :105-153, solver data
+// subprog_binary_solver_data.cpp:20-102) - evaluated by the library's host functions with the host libm - and the same
+// step semantics including the safe-mode retry (:258-293), which the library performs on the device-resident state.
+//
+// Restrictions, stated rather than silently ignored: the tree must be of uniform depth (every node refined; upstream that
+// is `focus_factor` large, here it is the only mode: focus_factor / focus_index are accepted and must describe such a
+// tree), conserve_linear_p must be 1 (advance_u), and the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
+// tsi) are out of scope; a raw dump of the final state replaces them.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "app_config.hpp"
+#include "app_subprogram.hpp"
+#include "host_common.hpp"
+
+namespace {
+
+mara::config_t config_template()
+{
+    return mara::config_t()
+    .item("restart",             "")
+    .item("outdir",              "data")
+    .item("cpi",                 10.0)
+    .item("dfi",                  1.0)
+    .item("tsi",                 2e-3)
+    .item("tfinal",               1.0)
+    .item("cfl_number",           0.4)
+    .item("fixed_dt",               0)
+    .item("depth",                  4)
+    .item("begin_live_binary",    1e6)
+    .item("conserve_linear_p",      1)
+    .item("block_size",            24)
+    .item("focus_factor",         1e9)          // upstream default 2.0 builds a graded tree; only uniform depth is built here
+    .item("focus_index",         2.00)
+    .item("threaded",               1)          // accepted for command-line compatibility; the device replaces the thread pool
+    .item("rk_order",               2)
+    .item("reconstruct_method", "plm")
+    .item("plm_theta",            1.8)
+    .item("source_term_softening", 1.)
+    .item("softening_radius",    0.05)
+    .item("sink_radius",         0.05)
+    .item("sink_rate",            1.0)
+    .item("buffer_damping_rate", 10.0)
+    .item("domain_radius",       12.0)
+    .item("disk_radius",          2.0)
+    .item("disk_mass",           1e-3)
+    .item("ambient_density",     1e-4)
+    .item("density_floor",        0.0)
+    .item("separation",           1.0)
+    .item("mass_ratio",           1.0)
+    .item("eccentricity",         0.0)
+    .item("counter_rotate",         0)
+    .item("mach_number",         10.0)
+    .item("axisymmetric_cs2",       0)
+    .item("no_accretion_force",     0)
+    .item("alpha_cutoff_radius",  0.0)
+    .item("alpha",                0.1)
+    .item("nu",                   0.0)
+    .item("mdot",                 0.0)
+    // not upstream:
+    .item("max_iterations",         0)          // stop after this many iterations (0 = run to tfinal)
+    .item("steps_per_call",         1)          // iterations per mh_binary_next call (the state stays on the device either way)
+    .item("write_final",            1)
+    .item("device",                 0);
+}
+
+void check(int rc, const char* what)
+{
+    if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(nullptr));
+}
+
+class subprog_binary : public mara::sub_program_t
+{
+public:
+    int main(int argc, const char* argv[]) override
+    {
+        auto cfg = config_template().update(argc, argv);
+        cfg.pretty_print(stdout, "config");
+        if (! cfg.get_string("restart").empty()) throw std::invalid_argument("binary: restart from an HDF5 checkpoint is out of scope in this build");
+        if (! cfg.get_int("conserve_linear_p")) throw std::invalid_argument("binary: conserve_linear_p=0 (advance_q) is not built");
+        if (cfg.get_string("reconstruct_method") != "plm" && cfg.get_string("reconstruct_method") != "pcm")
+            throw std::invalid_argument("invalid reconstruct_method '" + cfg.get_string("reconstruct_method") + "', must be plm or pcm");
+        const int depth = cfg.get_int("depth"), bs = cfg.get_int("block_size");
+        // refinement predicate subprog_binary.cpp:174-177: a node at `level` with centroid radius rc refines if
+        // rc < focus_factor / level^focus_index. Uniform depth needs it true up to the corner blocks of the deepest level.
+        for (int level = 1; level < depth; ++level)
+            if (! (std::sqrt(2.0) < cfg.get_double("focus_factor") / std::pow(double(level), cfg.get_double("focus_index"))))
+                throw std::invalid_argument("binary: this build needs a uniform-depth tree (use a large focus_factor, e.g. 1e9)");
+        const int n = bs << depth;
+
+        std::vector<double> xv(n + 1), u(std::size_t(3) * n * n), br(std::size_t(n) * n);
+        check(mh_binary_vertices(bs, depth, cfg.get_double("domain_radius"), xv.data()), "mh_binary_vertices");
+        mh_binary_model model = {};
+        model.softening_radius = cfg.get_double("softening_radius");
+        model.disk_radius = cfg.get_double("disk_radius");
+        model.mach_number = cfg.get_double("mach_number");
+        model.disk_mass = cfg.get_double("disk_mass");
+        model.ambient_density = cfg.get_double("ambient_density");
+        model.mdot = cfg.get_double("mdot");
+        model.counter_rotate = cfg.get_int("counter_rotate");
+        model.buffer_damping_rate = cfg.get_double("buffer_damping_rate");
+        model.domain_radius = cfg.get_double("domain_radius");
+        model.cfl_number = cfg.get_double("cfl_number");
+        mh_binary_run run = {};
+        check(mh_binary_solver_data(&model, n, xv.data(), xv.data(), u.data(), br.data(), &run.recommended_time_step), "mh_binary_solver_data");
+        run.rk_order = cfg.get_int("rk_order");
+        run.fixed_dt = cfg.get_int("fixed_dt");
+        run.no_accretion_force = cfg.get_int("no_accretion_force");
+        run.cfl_number = cfg.get_double("cfl_number");
+        run.begin_live_binary = cfg.get_double("begin_live_binary");
+
+        mh_binary_desc d = {};
+        d.n = n;
+        d.block_size = bs;
+        d.domain_radius = cfg.get_double("domain_radius");
+        d.mach_number = cfg.get_double("mach_number");
+        d.alpha = cfg.get_double("alpha");
+        d.nu = cfg.get_double("nu");
+        d.alpha_cutoff_radius = cfg.get_double("alpha_cutoff_radius");
+        d.sink_rate = cfg.get_double("sink_rate");
+        d.sink_radius = cfg.get_double("sink_radius");
+        d.softening_radius = cfg.get_double("softening_radius");
+        d.density_floor = cfg.get_double("density_floor") * cfg.get_double("disk_mass");
+        d.axisymmetric_cs2 = cfg.get_int("axisymmetric_cs2");
+        d.plm_theta = cfg.get_double("plm_theta");       // upstream validates reconstruct_method (solver_data.cpp:110-112) but the scheme never reads it
+
+        mh_binary* solver = nullptr;
+        check(mh_binary_create(&solver, cfg.get_int("device"), &d, &run, xv.data(), xv.data(), u.data(), br.data()), "mh_binary_create");
+        mh_binary_state state = {};      // binary::create_solution :197-229
+        state.orbital_elements.elements.total_mass = 1.0;
+        state.orbital_elements.elements.separation = cfg.get_double("separation");
+        state.orbital_elements.elements.mass_ratio = cfg.get_double("mass_ratio");
+        state.orbital_elements.elements.eccentricity = cfg.get_double("eccentricity");
+        check(mh_binary_set_solution(solver, nullptr, &state), "mh_binary_set_solution");
+
+        const double tfinal = cfg.get_double("tfinal");
+        const int batch = std::max(1, cfg.get_int("steps_per_call"));
+        const int max_iter = cfg.get_int("max_iterations");
+        while (state.time / (2 * M_PI) < tfinal && (max_iter == 0 || state.iteration < max_iter))
+        {
+            const int todo = max_iter ? int(std::min<long>(batch, max_iter - state.iteration)) : batch;
+            int safe = 0;
+            const double ms = host::time_ms([&] { check(mh_binary_next(solver, todo, &safe), "mh_binary_next"); });
+            check(mh_binary_get_solution(solver, nullptr, &state), "mh_binary_get_solution");
+            if (safe) std::printf("negative density in updated state\n");        // what the reference prints before its safe-mode retry
+            std::printf("[%04ld] orbits=%3.7lf kzps=%3.2lf\n", long(state.iteration), state.time / (2 * M_PI), double(n) * n * todo / ms);
+            std::fflush(stdout);
+        }
+        if (cfg.get_int("write_final"))
+        {
+            check(mh_binary_get_solution(solver, u.data(), &state), "mh_binary_get_solution");
+            const std::vector<double> scalars = {
+                state.mass_accreted_on[0], state.mass_accreted_on[1], state.angular_momentum_accreted_on[0], state.angular_momentum_accreted_on[1],
+                state.integrated_torque_on[0], state.integrated_torque_on[1], state.work_done_on[0], state.work_done_on[1],
+                state.mass_ejected, state.angular_momentum_ejected};
+            std::vector<double> extra = xv;
+            extra.insert(extra.end(), scalars.begin(), scalars.end());
+            host::dump_state(cfg.get_string("outdir"), "final.bin", {long(n), long(n)}, 3, state.time, state.iteration, extra, u);
+        }
+        mh_binary_destroy(solver);
+        return 0;
+    }
+
+    std::string name() const override { return "binary"; }
+};
+
+} // namespace
+
+std::unique_ptr<mara::sub_program_t> make_subprog_binary() { return std::make_unique<subprog_binary>(); }

@@ -98,7 +98,7 @@ def test_stage_is_independent_of_the_chunking(mods):
     for chunk in (5, 32, 128):
         b, tb, _, _ = run_stage(mods, cfg, g, g["u_init"], ss[61:71], ss[0], chunk_rows=chunk)
         assert np.array_equal(a, b)
-        assert np.allclose(ta, tb, rtol=1e-12, atol=1e-30)
+        assert np.allclose(ta, tb, rtol=1e-12, atol=1e-12 * np.abs(ta).max())     # partial sums are grouped by chunk
 
 
 def test_rk_combine_is_fused_exactly(mods):

@@ -89,3 +89,36 @@ def test_cloud_subprogram_matches_reference(tmp_path, case, args):
     assert bits_equal(inflow, g["inflow"][0])
     assert bits_equal(d["data"], g["un"]), np.abs(d["data"] - g["un"]).max()
     assert "kzps=" in stdout
+
+
+@pytest.mark.parametrize("case", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym"])
+def test_binary_subprogram_matches_reference(tmp_path, case):
+    """The whole host path of `mara_hip binary`: set-up with the host libm (bit-exact vertices), dt choice, RK steps,
+    totals and the run-loop message. Field tolerance as in tests/test_gpu_binary.py (device libm: 1e-12 of the field scale)."""
+    import json
+    g = golden(case)
+    over = json.loads(str(g["config"]))
+    nsteps = int(over.pop("nsteps"))
+    args = ["%s=%r" % (k, int(v) if float(v).is_integer() and k in ("depth", "block_size", "fixed_dt", "rk_order", "axisymmetric_cs2", "counter_rotate", "no_accretion_force") else float(v)) for k, v in over.items()]
+    stdout = run(["binary"] + args + ["max_iterations=%d" % nsteps, "tfinal=100.0"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    n = g["u_final"].shape[0]
+    assert d["iteration"] == nsteps
+    assert bits_equal(d["vertices"][:n + 1], g["xv"])
+    sc = g["scalars"]
+    assert abs(d["time"] - sc[0]) <= 1e-13 * sc[0]
+    scale = np.abs(g["u_final"]).reshape(-1, 3).max(axis=0)
+    err = np.abs(d["data"] - g["u_final"]).reshape(-1, 3).max(axis=0)
+    assert np.all(err <= 1e-12 * scale), err / scale
+    acc = d["vertices"][n + 1:]
+    assert np.allclose(acc, sc[2:12], rtol=1e-9, atol=1e-11 * np.abs(sc[2:12]).max())
+    assert "[%04d] orbits=" % nsteps in stdout and "kzps=" in stdout
+
+
+def test_binary_subprogram_rejects_what_is_not_built(tmp_path):
+    out = subprocess.run([EXE, "binary", "conserve_linear_p=0"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 1 and "advance_q" in out.stdout
+    out = subprocess.run([EXE, "binary", "focus_factor=2.0", "depth=4"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 1 and "uniform-depth" in out.stdout
+    out = subprocess.run([EXE, "binary", "reconstruct_method=weno"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 1 and "must be plm or pcm" in out.stdout
