@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Measurements of the BASELINE configs OTHER than the headline one, on one MI355X. `bench.py` keeps
+the driver's contract (config C2); this script prints one JSON line per requested config in the same schema:
+
+    python bench_configs.py --config c3        # `binary`  depth=5 block_size=64 fixed_dt=1 rk_order=2  (2048^2)
+    python bench_configs.py --config c4        # `cloud`   nr=4096 num_decades=1 rk_order=2 PLM theta=1.2 (compiled host)
+    python bench_configs.py --config c5        # 3-D Euler blast, PLM+HLLE RK2, --grid^3 on one GPU (512^3 = one rank's share of 1024^3 / 8)
+
+value = zone-updates/s with the state resident in HBM; roofline = algorithmic bytes of the stage kernel / its average
+duration from HIP events on the launch stream; cpu_baseline = the oracle (test infrastructure) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mara_oracle
+    mara_oracle.lib()
+    return mara_oracle
+
+
+def run_c3(args):
+    import numpy as np
+    from mara3_amd import binary
+    cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
+    n = binary.grid_size(cfg)
+    s = binary.BinarySolver(cfg)
+    s.next(args.warmup)
+    t0 = time.perf_counter()
+    safe = s.next(args.steps)
+    elapsed = time.perf_counter() - t0
+    s.profile(True)
+    s.next(5)
+    avg_ms, nl = s.profile(False)
+    u = s.solution()
+    ok = bool(np.isfinite(u).all() and (u[..., 0] > 0).all())
+    st = binary.state_as_dict(s.state())
+    s.close()
+    bytes_stage = n * n * (80 + 104) / 2          # mean of the two stage kinds of RK2
+    out = {
+        "metric": "zone-updates/sec (Mcells/s), subprog_binary 2048^2 (depth=5 block_size=64), PLM+HLLE+viscosity RK2, 1 GPU",
+        "value": n * n * args.steps / elapsed / 1e6, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "binary depth=5 block_size=64 focus_factor=1e9 fixed_dt=1 rk_order=2 plm_theta=1.8, other run_config defaults",
+                   "safe_mode_steps": safe, "finite_and_positive": ok, "iteration": st["iteration"],
+                   "note": "one host synchronisation per step (2 x 18 totals + status word)"},
+        "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "binary_stage_kernel + binary_sink_kernel + binary_reduce_kernel (one stage)",
+                     "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
+                     "timing": "HIP events on the launch stream, 5 extra steps after the timed region"},
+    }
+    if not args.no_cpu_baseline:
+        mo = oracle()
+        ocfg = mo.binary_config(depth=4, block_size=64, fixed_dt=1)
+        xv = mo.binary_vertices(ocfg)
+        u0, br, dt = mo.binary_solver_data(ocfg, xv, xv)
+        bodies = binary.two_body_state(binary.initial_elements(cfg), 0.0)
+        t0 = time.perf_counter()
+        u1, _, _ = mo.binary_advance_u(ocfg, xv, xv, u0, u0, br, bodies, dt)
+        mo.binary_advance_u(ocfg, xv, xv, u1, u0, br, bodies, dt)
+        t = time.perf_counter() - t0
+        m = len(xv) - 1
+        out["cpu_baseline"] = {"value": m * m / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+                               "sample": "one RK2 step (two advance_u stages) at %dx%d (depth=4 block_size=64), oracle/mara_oracle_binary.c, 1 thread" % (m, m)}
+    return out
+
+
+def run_c4(args):
+    exe = os.path.join(ROOT, "mara3_amd", "host", "mara_hip")
+    nr = args.grid or 4096
+    total = args.warmup + args.steps
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        cmd = [exe, "cloud", "nr=%d" % nr, "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=%d" % total, "profile=1", "outdir=out"]
+        p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=1200)
+        if p.returncode != 0:
+            raise SystemExit(p.stdout[-2000:] + p.stderr[-2000:])
+    kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
+    shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches", p.stdout)
+    avg_ms, nl = float(shape.group(1)), int(shape.group(2))
+    m = re.search(r"write out/final.bin", p.stdout)
+    nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
+    vertices = (nr + 1) * (nq + 1)
+    ms = [vertices / k for k in kz[args.warmup:]]   # the host prints vertices per ms, like the reference (:858)
+    per_step = sum(ms) / len(ms)
+    cells = nr * nq
+    bytes_stage = cells * (80 + 120) / 2
+    return {
+        "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, 1 GPU" % (nr, nq),
+        "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % nr,
+                   "final_state_written": bool(m)},
+        "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "cloud_stage_kernel<PLM> (mean of both RK2 stages)",
+                     "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
+                     "timing": "HIP events on the launch stream, inside the timed region"},
+        "cpu_baseline": None if args.no_cpu_baseline else cloud_cpu_baseline(),
+    }
+
+
+def cloud_cpu_baseline():
+    import numpy as np
+    mo = oracle()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cloud_nr32_plm_rk2.npz"))
+    rv, qv, u0 = g["rv"], g["qv"], g["u0"]
+    dt = float(g["dt"])
+    reps = 200
+    inflow = np.repeat(g["inflow"][:1], reps, axis=0)      # the nozzle row of the first step, held fixed
+    t0 = time.perf_counter()
+    mo.cloud_run(u0.copy(), rv, qv, inflow, dt, reps, rk=2, theta=1.2)
+    t = time.perf_counter() - t0
+    cells = (len(rv) - 1) * (len(qv) - 1)
+    return {"value": cells * reps / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": "%d RK2 steps of the %dx%d golden case (tests/golden/cloud_nr32_plm_rk2.npz), oracle/mara_oracle_srhd.c, 1 thread" % (reps, len(rv) - 1, len(qv) - 1)}
+
+
+def run_c5(args):
+    import numpy as np
+    import mara3_amd
+    from mara3_amd import setups
+    from mara3_amd.engine import EulerCartSolver
+    n = args.grid or 512
+    gamma = 5.0 / 3
+    res = {}
+    for arith in ("fast", "strict"):
+        s = EulerCartSolver((n, n, n), (1.0 / n,) * 3, gamma, 1.5, args.riemann, 2, "outflow", arith=arith)
+        s.upload(setups.blast_ic((n, n, n), gamma))
+        dt = setups.baseline_dt(n)
+        s.step(dt, args.warmup)
+        s.synchronize()
+        s.profile(True)
+        t0 = time.perf_counter()
+        s.step(dt, args.steps)
+        s.synchronize()
+        elapsed = time.perf_counter() - t0
+        avg_ms, nl = s.profile_read()
+        s.profile(False)
+        status = s.status()
+        s.close()
+        bytes_stage = n ** 3 * (80 + 120) / 2
+        res[arith] = {"value": n ** 3 * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "status_word": status,
+                      "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel": "euler3d_stage_kernel<%s,%s,PLM> (mean of both RK2 stages)" % (arith, args.riemann),
+                                   "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
+                                   "timing": "HIP events on the launch stream, inside the timed region"}}
+    out = {
+        "metric": "zone-updates/sec (Mcells/s), 3D Euler blast %d^3 PLM+%s RK2, 1 GPU" % (n, args.riemann.upper()),
+        "value": res["fast"]["value"], "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["fast"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3D Euler blast (radius 0.1), %d^3 uniform grid = one rank's share of the 1024^3 / 8-GPU case when 512, PLM(theta=1.5)+%s, RK2, fixed dt=0.3*dx/6" % (n, args.riemann.upper()),
+                   "arith": "fast (headline of this line); strict beside it", "status_word": res["fast"]["status_word"]},
+        "roofline": res["fast"]["roofline"], "arith_strict": res["strict"],
+    }
+    if not args.no_cpu_baseline:
+        mo = oracle()
+        m, cores = 96, min(16, os.cpu_count() or 1)
+        u = setups.blast_ic((m, m, m), gamma)
+        kind = mo.RIEMANN_HLLC if args.riemann == "hllc" else mo.RIEMANN_HLLE
+        t0 = time.perf_counter()
+        mo.euler_cart_run(u, (1.0 / m,) * 3, setups.baseline_dt(m), 4, gamma, 1.5, 2, kind, mo.BC_OUTFLOW, nthreads=cores)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": m ** 3 * 4 / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+                               "sample": "4 RK2 steps at %d^3, oracle/mara_oracle.c with %d slab threads" % (m, cores)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True, choices=["c3", "c4", "c5"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--riemann", default="hlle", choices=["hlle", "hllc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    import mara3_amd
+    lib = mara3_amd.load_library()
+    if lib.mh_device_count() < 1:
+        raise SystemExit("bench_configs.py needs an MI355X; there is no CPU path")
+    out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -522,7 +522,9 @@ static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, d
         hipEventCreate(&ev.second);
         hipEventRecord(ev.first, c->stream);
     }
-    hipError_t e = cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
+    hipError_t e = c->kind == mh_ctx::KIND_CLOUD
+        ? cloud_stage_launch(&c->cloud, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream)
+        : cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
     if (c->profile)
     {
         hipEventRecord(ev.second, c->stream);
@@ -551,18 +553,17 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
     }
     if (c->kind == mh_ctx::KIND_CLOUD)
     {
-        const mh_cloud_desc* d = &c->cloud;
         for (int s = 0; s < nsteps; ++s)
         {
             if (c->rk_order == 1)
             {
-                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[0], nullptr, c->field[1], dt, 1.0, 0, d->nr, c->status, c->stream));
+                MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
                 std::swap(c->field[0], c->field[1]);
             }
             else
             {
-                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[0], nullptr, c->field[1], dt, 1.0, 0, d->nr, c->status, c->stream));
-                MH_HIP_TRY(cloud_stage_launch(d, c->geom, c->inflow, c->field[1], c->field[0], c->field[0], dt, 0.5, 0, d->nr, c->status, c->stream));
+                MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+                MH_HIP_TRY(timed_stage(c, c->field[1], c->field[0], c->field[0], dt, 0.5));
             }
         }
         return MH_OK;

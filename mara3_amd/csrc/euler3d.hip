@@ -8,18 +8,24 @@
 // 2.5-D plane marching. A workgroup of 8 wavefronts owns a tile of 8 axis-1
 // rows x 60 axis-2 columns and marches along axis 0:
 //   * axis 0 (march): primitives of planes i..i+2, the slope of plane i and the
-//     flux through face i-1/2 live in registers; each flux is computed once;
+//     flux through face i-1/2 live in registers (three-slot rings, loop unrolled
+//     x3); each flux is computed once;
 //   * axis 2 (lanes): DPP wave shifts, exactly as in the 2-D kernel;
-//   * axis 1 (across waves): three small LDS exchanges per plane - primitives,
-//     right-going face states, face fluxes - separated by workgroup barriers.
-//     All 8 waves own interior rows; the first wave also builds the face state
-//     below the tile, the last wave the flux through the tile's top face, so no
-//     wave slots are spent on halo rows.
+//   * axis 1 (across waves): ONE LDS exchange per plane - the primitives of the
+//     tile's rows and of two rows on either side (fetched by four helper waves),
+//     double-buffered by plane parity - and one workgroup barrier. Each wave then
+//     computes both of its axis-1 face fluxes itself (a fourth Riemann problem per
+//     cell; identical code on identical inputs on both sides of a face). An earlier
+//     version exchanged face states and fluxes as well: three barriers per plane
+//     and an edge wave with a ninth face left the VALU 57 % busy (rocprofv3 SQ
+//     counters, profiles/r01); trading redundant arithmetic for two barriers and a
+//     balanced workgroup is faster on this part.
 // Conserved planes are read once (+ halo re-reads that hit in L2) and written
 // once; nothing else touches HBM. Algorithmic bytes: 80 / 120 B per cell per
 // stage as in 2-D. Device layout: include/mara_hip.h with row_pitch = n1*n2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
 #include "launch.hpp"
@@ -69,12 +75,12 @@ __device__ inline int fold_index(int j, int n, int bc)
     return min(max(j, 0), n - 1);
 }
 
-// LDS exchange buffers: [slot][variable][lane]
+// LDS exchange buffer: primitives of one axis-0 plane for the tile's rows and two rows on either side, double-buffered by
+// the parity of the plane index: [parity][slot = tile row + 2][variable][lane]
 struct Tile3d
 {
-    double P[ROWS3 + 2][5][W3];      // slot r+1 = primitives of tile row r (slots 0 and ROWS3+1: rows below / above)
-    double S[ROWS3 + 1][5][W3];      // slot r+1 = P + G/2 of tile row r    (slot 0: row below the tile)
-    double F[ROWS3 + 1][5][W3];      // slot f   = axis-1 flux through the face below tile row f (slot ROWS3: top face)
+    double P[2][ROWS3 + 2 * H3][5][W3];
+    double U[ROWS3][3][5][W3];             // per-wave private ring: conserved state of planes r, r+1, r+2 (no barrier needed)
 };
 
 __device__ inline void lds_put(double (*dst)[W3], int lane, const State5& s)
@@ -88,6 +94,27 @@ __device__ inline State5 lds_get(double (*src)[W3], int lane)
 #pragma unroll
     for (int q = 0; q < 5; ++q) s[q] = src[q][lane];
     return s;
+}
+
+using b64x_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
+
+// the 5 variables of one cell per lane out of one axis-0 plane: wave-uniform plane pointer (scalar), per-lane byte offset of
+// the cell, scalar offset of the variable (cdna_hip_programming.md T8). The descriptor spans exactly the plane's 5 variables.
+__device__ inline State5 load_plane(const double* plane_ptr, long plane_doubles, unsigned cell_bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(plane_ptr), 0, (int) (5 * plane_doubles * 8), 0x00020000);
+    State5 U;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, cell_bytes, (unsigned) (q * plane_doubles * 8), 0));
+    return U;
+}
+__device__ inline void store_plane(double* plane_ptr, long plane_doubles, unsigned cell_bytes, const State5& U)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(plane_ptr, 0, (int) (5 * plane_doubles * 8), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64x_t, U[q]), rs, cell_bytes, (unsigned) (q * plane_doubles * 8), 0);
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
@@ -116,139 +143,133 @@ void euler3d_stage_kernel(Stage3dParams p)
     const int col = strip * STRIP3 - H3 + lane;
     const int kc = fold_index(col, p.n2, p.bc_t);
     const bool writes = lane >= H3 && lane < W3 - H3 && col < p.n2 && j < p.n1;
-    const bool first = row == 0, last = row == ROWS3 - 1;
 
     const long row_stride = p.row_stride, plane = p.plane_stride;
-    auto cell = [&] (int jj) { return (long) fold_index(jj, p.n1, p.bc_t) * p.n2 + kc; };
     auto row_off = [row_stride] (int r) { return (long) (r + H3) * row_stride; };
-    auto load = [&] (const double* base, long c, int r) -> State5
-    {
-        State5 U;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) U[q] = base[q * plane + c + row_off(r)];
-        return U;
-    };
-    const long c0 = (long) jc * p.n2 + kc;
-    // extra rows handled by the edge waves: two below the tile (first wave) / two above it (last wave)
-    const int je1 = first ? t1 * ROWS3 - 1 : t1 * ROWS3 + ROWS3;
-    const int je2 = first ? t1 * ROWS3 - 2 : t1 * ROWS3 + ROWS3 + 1;
-    const long ce1 = cell(je1), ce2 = cell(je2);
-    const bool edge = first || last;
+    const unsigned c0 = (unsigned) (((long) jc * p.n2 + kc) * 8);
+    const unsigned cw = (unsigned) (writes ? ((long) j * p.n2 + col) * 8 : 0);
+
+    // Rows just outside the tile (two on either side with PLM, one without): the first four waves each fetch one of them
+    // per plane and publish its primitives, so that this duty is spread instead of loading the tile's edge waves.
+    //   wave 0: row -2   wave 1: row -1   wave 2: row ROWS3   wave 3: row ROWS3 + 1
+    const int eoff = row == 0 ? -2 : (row == 1 ? -1 : (row == 2 ? ROWS3 : ROWS3 + 1));
+    const bool helper = row < 4 && (PLM || row == 1 || row == 2);
+    const unsigned ce = (unsigned) (((long) fold_index(t1 * ROWS3 + eoff, p.n1, p.bc_t) * p.n2 + kc) * 8);
+    const int eslot = eoff + H3;
 
     const double theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(p.gamma);
+    const double* in = p.u_in;
 
-    // ---- prologue along axis 0
-    State5 U0 = load(p.u_in, c0, r0), U1 = load(p.u_in, c0, r0 + 1), U2 = load(p.u_in, c0, r0 + 2);
-    State5 P0, P1, G0, Fx_lo;
+    // ---- register window along axis 0: three slots used as rings (index = plane mod 3 relative to the chunk start)
+    // The conserved state of a plane is needed twice, three planes apart (primitives, then the update). Between the two uses
+    // it waits in a private LDS ring instead of 20 VGPRs: this kernel sits at the 256-register limit, and reading the plane
+    // again from memory missed in L2 (FETCH_SIZE doubled).
+    State5 P[3], G[3], Fx[3];
     {
-        const State5 Pa = A::c2p(load(p.u_in, c0, r0 - 2), gl);
-        const State5 Pb = A::c2p(load(p.u_in, c0, r0 - 1), gl);
-        P0 = A::c2p(U0, gl);
-        P1 = A::c2p(U1, gl);
+        const State5 Pa = A::c2p(load_plane(in + row_off(r0 - 2), plane, c0), gl);
+        const State5 Pb = A::c2p(load_plane(in + row_off(r0 - 1), plane, c0), gl);
+        const State5 Ua = load_plane(in + row_off(r0), plane, c0), Ub = load_plane(in + row_off(r0 + 1), plane, c0);
+        lds_put(tile.U[row][0], lane, Ua);
+        lds_put(tile.U[row][1], lane, Ub);
+        P[0] = A::c2p(Ua, gl);
+        P[1] = A::c2p(Ub, gl);
         if constexpr (PLM)
         {
-            const State5 Gb = A::plm(Pa, Pb, P0, theta);
-            G0 = A::plm(Pb, P0, P1, theta);
-            Fx_lo = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P0, G0), gl);
+            const State5 Gb = A::plm(Pa, Pb, P[0], theta);
+            G[0] = A::plm(Pb, P[0], P[1], theta);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
         }
         else
         {
-            Fx_lo = A::template flux<RIEMANN, 0>(Pb, P0, gl);
+            Fx[0] = A::template flux<RIEMANN, 0>(Pb, P[0], gl);
         }
     }
+    State5 Uin = load_plane(in + row_off(r0 + 2), plane, c0);      // plane r+2, in flight for one iteration
     int32_t bad = 0;
 
-    for (int r = r0; r < r1; ++r)
+    // One plane. ONE workgroup barrier: before it every wave publishes the primitives of its row of plane r (and the helper
+    // waves those of the outside rows) and does the axis-0 and axis-2 work, which needs no other wave; after it every wave
+    // reads its four axis-1 neighbours and computes BOTH of its axis-1 face fluxes itself. The face between two tile rows
+    // is thereby evaluated twice (by identical code on identical inputs, so conservation holds bit for bit): that costs a
+    // fourth Riemann problem per cell, but removes the two further exchanges (face states, fluxes) with their barriers and
+    // the imbalance of an edge wave computing the tile's ninth face.
+    auto plane_step = [&] (int r, auto k0) __attribute__((always_inline))
     {
-        const int rp = min(r + 3, p.n0 + 1);
-        const State5 U3 = load(p.u_in, c0, rp);
-        State5 Ubase;
-        if constexpr (COMBINE) Ubase = load(p.u_base, c0, r);
+        constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+        const int pb = r & 1;
 
-        // ---- phase 1: publish this plane's primitives (tile rows, plus the row just outside for the edge waves)
-        State5 Pe1, Pe2;
-        lds_put(tile.P[row + 1], lane, P0);
-        if (edge)
-        {
-            Pe1 = A::c2p(load(p.u_in, ce1, r), gl);
-            if constexpr (PLM) Pe2 = A::c2p(load(p.u_in, ce2, r), gl);
-            lds_put(tile.P[first ? 0 : ROWS3 + 1], lane, Pe1);
-        }
-        // with 8 rows the first and last wave are distinct, so each edge wave has exactly one outside row
+        const State5 Unext = load_plane(in + row_off(min(r + 3, p.n0 + 1)), plane, c0);
+        State5 Ue;
+        if (helper) Ue = load_plane(in + row_off(r), plane, ce);
 
-        // ---- axis 0 while the others arrive
-        const State5 P2 = A::c2p(U2, gl);
-        State5 G1, Fx_hi;
+        lds_put(tile.P[pb][row + H3], lane, P[K0]);
+
+        // ---- axis 0: flux through face r+1/2
+        P[K2] = A::c2p(Uin, gl);
+        lds_put(tile.U[row][K2], lane, Uin);
+        Uin = Unext;
         if constexpr (PLM)
         {
-            G1 = A::plm(P0, P1, P2, theta);
-            Fx_hi = A::template flux<RIEMANN, 0>(A::plus(P0, G0), A::minus(P1, G1), gl);
+            G[K1] = A::plm(P[K0], P[K1], P[K2], theta);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
         }
         else
         {
-            Fx_hi = A::template flux<RIEMANN, 0>(P0, P1, gl);
+            Fx[K1] = A::template flux<RIEMANN, 0>(P[K0], P[K1], gl);
         }
 
-        // ---- axis 2 (lanes)
+        // ---- axis 2 (lanes): this lane computes the flux through its LEFT face
         State5 Fz_lo, Fz_hi;
         if constexpr (PLM)
         {
-            const State5 Gz = A::plm(dpp3_left(P0), P0, dpp3_right(P0), theta);
-            const State5 SL = dpp3_left(A::plus(P0, Gz));
-            Fz_lo = A::template flux<RIEMANN, 2>(SL, A::minus(P0, Gz), gl);
+            const State5 Gz = A::plm(dpp3_left(P[K0]), P[K0], dpp3_right(P[K0]), theta);
+            const State5 SL = dpp3_left(A::plus(P[K0], Gz));
+            Fz_lo = A::template flux<RIEMANN, 2>(SL, A::minus(P[K0], Gz), gl);
         }
         else
         {
-            Fz_lo = A::template flux<RIEMANN, 2>(dpp3_left(P0), P0, gl);
+            Fz_lo = A::template flux<RIEMANN, 2>(dpp3_left(P[K0]), P[K0], gl);
         }
         Fz_hi = dpp3_right(Fz_lo);
 
+        if (helper) lds_put(tile.P[pb][eslot], lane, A::c2p(Ue, gl));
+#ifndef MH_E3D_NOBARRIER      // diagnostic builds only: wrong results, shows what the barrier costs
         __syncthreads();
+#endif
+        State5 Ubase;
+        if constexpr (COMBINE) Ubase = load_plane(p.u_base + row_off(r), plane, c0);
 
-        // ---- phase 2 (axis 1): slopes and right-going face states
-        const State5 Pdn = lds_get(tile.P[row], lane), Pup = lds_get(tile.P[row + 2], lane);
-        State5 Gy, SRy;
-        if constexpr (PLM)
+        // ---- axis 1 (across waves): both faces of this row
+        State5 Fy_lo, Fy_hi;
         {
-            Gy = A::plm(Pdn, P0, Pup, theta);
-            lds_put(tile.S[row + 1], lane, A::plus(P0, Gy));
-            SRy = A::minus(P0, Gy);
-            if (first)
+            const State5 Pm1 = lds_get(tile.P[pb][row + H3 - 1], lane), Pp1 = lds_get(tile.P[pb][row + H3 + 1], lane);
+            if constexpr (PLM)
             {
-                const State5 Ge = A::plm(Pe2, Pe1, P0, theta);          // slope of the row below the tile
-                lds_put(tile.S[0], lane, A::plus(Pe1, Ge));
+                const State5 Gy = A::plm(Pm1, P[K0], Pp1, theta);
+                {
+                    const State5 Pm2 = lds_get(tile.P[pb][row + H3 - 2], lane);
+                    Fy_lo = A::template flux<RIEMANN, 1>(A::plus(Pm1, A::plm(Pm2, Pm1, P[K0], theta)), A::minus(P[K0], Gy), gl);
+                }
+                {
+                    const State5 Pp2 = lds_get(tile.P[pb][row + H3 + 2], lane);
+                    Fy_hi = A::template flux<RIEMANN, 1>(A::plus(P[K0], Gy), A::minus(Pp1, A::plm(P[K0], Pp1, Pp2, theta)), gl);
+                }
+            }
+            else
+            {
+                Fy_lo = A::template flux<RIEMANN, 1>(Pm1, P[K0], gl);
+                Fy_hi = A::template flux<RIEMANN, 1>(P[K0], Pp1, gl);
             }
         }
-        else
-        {
-            lds_put(tile.S[row + 1], lane, P0);
-            SRy = P0;
-            if (first) lds_put(tile.S[0], lane, Pe1);
-        }
-        __syncthreads();
 
-        // ---- phase 3: flux through the face below this row (and, for the last wave, the tile's top face)
-        const State5 Fy_lo = A::template flux<RIEMANN, 1>(lds_get(tile.S[row], lane), SRy, gl);
-        lds_put(tile.F[row], lane, Fy_lo);
-        if (last)
-        {
-            State5 SRe;
-            if constexpr (PLM) SRe = A::minus(Pe1, A::plm(P0, Pe1, Pe2, theta));
-            else               SRe = Pe1;
-            State5 SLown;
-            if constexpr (PLM) SLown = A::plus(P0, Gy); else SLown = P0;
-            lds_put(tile.F[ROWS3], lane, A::template flux<RIEMANN, 1>(SLown, SRe, gl));
-        }
-        __syncthreads();
-        const State5 Fy_hi = lds_get(tile.F[row + 1], lane);
-
-        // ---- update
+        // ---- update (+ RK combine)
+        const State5 Ucur = lds_get(tile.U[row][K0], lane);
         State5 Un;
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double u1 = A::update3(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], Fz_lo[q], Fz_hi[q], p.cx, p.cy, p.cz);
+            const double u1 = A::update3(Ucur[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], Fz_lo[q], Fz_hi[q], p.cx, p.cy, p.cz);
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
@@ -256,42 +277,26 @@ void euler3d_stage_kernel(Stage3dParams p)
 
         if (writes)
         {
-            double* out = p.u_out + (long) j * p.n2 + col;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) out[q * plane + row_off(r)] = Un[q];
-            if (r < H3)
+            store_plane(p.u_out + row_off(r), plane, cw, Un);
+            if (r < H3 || r >= p.n0 - H3)          // keep the physical axis-0 ghost planes of the output current (wave-uniform, cold)
             {
-                if (p.bc_lo0 == 0 && r == 0)
-                {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) { out[q * plane + row_off(-1)] = Un[q]; out[q * plane + row_off(-2)] = Un[q]; }
-                }
-                if (p.bc_hi0 == 1)
-                {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) out[q * plane + row_off(p.n0 + r)] = Un[q];
-                }
-            }
-            if (r >= p.n0 - H3)
-            {
-                if (p.bc_hi0 == 0 && r == p.n0 - 1)
-                {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) { out[q * plane + row_off(p.n0)] = Un[q]; out[q * plane + row_off(p.n0 + 1)] = Un[q]; }
-                }
-                if (p.bc_lo0 == 1)
-                {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) out[q * plane + row_off(r - p.n0)] = Un[q];
-                }
+                if (p.bc_lo0 == 0 && r == 0) { store_plane(p.u_out + row_off(-1), plane, cw, Un); store_plane(p.u_out + row_off(-2), plane, cw, Un); }
+                if (p.bc_hi0 == 1 && r < H3) store_plane(p.u_out + row_off(p.n0 + r), plane, cw, Un);
+                if (p.bc_hi0 == 0 && r == p.n0 - 1) { store_plane(p.u_out + row_off(p.n0), plane, cw, Un); store_plane(p.u_out + row_off(p.n0 + 1), plane, cw, Un); }
+                if (p.bc_lo0 == 1 && r >= p.n0 - H3) store_plane(p.u_out + row_off(r - p.n0), plane, cw, Un);
             }
         }
+    };
 
-        U0 = U1; U1 = U2; U2 = U3;
-        P0 = P1; P1 = P2;
-        if constexpr (PLM) G0 = G1;
-        Fx_lo = Fx_hi;
+    int r = r0;
+    for (; r + 3 <= r1; r += 3)
+    {
+        plane_step(r, std::integral_constant<int, 0>());
+        plane_step(r + 1, std::integral_constant<int, 1>());
+        plane_step(r + 2, std::integral_constant<int, 2>());
     }
+    if (r < r1) plane_step(r, std::integral_constant<int, 0>());
+    if (r + 1 < r1) plane_step(r + 1, std::integral_constant<int, 1>());
 
     if (p.status)
     {
@@ -304,7 +309,7 @@ static hipError_t launch3(const Stage3dParams& p, hipStream_t stream)
 {
     const int nblocks = p.nstrips * p.ntiles1 * p.nchunks;
     auto kernel = euler3d_stage_kernel<A, RIEMANN, PLM, COMBINE>;
-    static bool attr_set = false;           // 70 KB of LDS per workgroup: above the 64 KB static limit, so dynamic + opt-in
+    static bool attr_set = false;           // 120 KB of LDS per workgroup: dynamic + opt-in
     if (! attr_set)
     {
         hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Tile3d));

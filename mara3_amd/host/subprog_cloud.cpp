@@ -43,6 +43,7 @@ mara::config_t config_template()
     .item("reconstruct_method", 2)
     .item("plm_theta", 1.2)
     .item("temperature_floor", 1e-8)
+    .item("profile", 0)              // print the average stage-kernel time from HIP events at the end; not a reference option
     .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
     .item("write_inflow", 0)         // also dump the nozzle row of the first step (tests)
     .item("device", 0);
@@ -141,6 +142,7 @@ public:
         const double dt = (rv[1] - rv[0]) / 1.0 * cfg.get_double("cfl_number");
         const double tfinal = cfg.get_double("tfinal");
         const long max_steps = cfg.get_int("max_steps");
+        if (cfg.get_int("profile")) host::check(mh_profile_enable(ctx, 1), ctx, "mh_profile_enable");
         double time = 0.0;
         long iteration = 0;
         std::vector<double> inflow(std::size_t(5) * nq, 0.0), inflow_first;
@@ -167,6 +169,13 @@ public:
             host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
             if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");
             std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
+        }
+        if (cfg.get_int("profile"))
+        {
+            double avg_ms = 0.0;
+            int launches = 0;
+            host::check(mh_profile_read(ctx, &avg_ms, &launches), ctx, "mh_profile_read");
+            std::printf("profile: stage kernel avg %.6f ms over %d launches\n", avg_ms, launches);
         }
         host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
         std::vector<double> vertices(rv);
