@@ -215,6 +215,13 @@ BINARY_CASES = {
                                 no_accretion_force=1, plm_theta=1.2),
     "binary_d2_b16_safe": dict(depth=2, block_size=16, domain_radius=4.0, nsteps=1, safe_mode=1),
     "binary_d2_b32": dict(depth=2, block_size=32, nsteps=2),
+    # the binary is live from the second stage on: orbital elements evolve and feed back into the next stage's body positions
+    # the angular-momentum conserving scheme, advance_q (conserve_linear_p = 0)
+    "binary_d2_b16_q": dict(depth=2, block_size=16, domain_radius=4.0, conserve_linear_p=0, nsteps=3),
+    "binary_d1_b24_q_nu": dict(depth=1, block_size=24, domain_radius=3.0, conserve_linear_p=0, fixed_dt=1, nu=1e-3, mass_ratio=0.5, eccentricity=0.3,
+                               rk_order=1, nsteps=4, sink_radius=0.2, softening_radius=0.1, source_term_softening=4.0, axisymmetric_cs2=1),
+    "binary_d2_b16_live": dict(depth=2, block_size=16, domain_radius=4.0, begin_live_binary=0.0, mass_ratio=0.7, eccentricity=0.2,
+                               disk_mass=1e-2, nsteps=3),
 }
 
 

@@ -153,12 +153,15 @@ typedef struct
     double density_floor;       /* absolute surface density (config density_floor * disk_mass, solver_data.cpp:100) */
     double plm_theta;           /* 0 in safe mode (scheme.cpp:792) */
     int    axisymmetric_cs2;
+    int    angmom_form;         /* conserve_linear_p == 0: fields are (Sigma, Sigma s_r, Sigma l_z) and the stage is advance_q */
+    double gst_suppr_radius;    /* source_term_softening * min(dx, dy) (solver_data.cpp:91); used by advance_q only */
 } mo_binary_params;
 typedef struct
 {
     double softening_radius, disk_radius, mach_number, disk_mass, ambient_density, mdot;
     int    counter_rotate;
     double buffer_damping_rate, domain_radius, cfl_number;
+    int    angmom_form;
 } mo_binary_model;
 /* bodies = (mass, x, y, vx, vy) of body 1 then body 2; fields are [n][n][3] row-major in (Sigma, px, py); returns 1 where validate_u throws */
 int    mo_binary_advance_u(const mo_binary_params* P, const double* xv, const double* yv, const double* u0, const double* u_init,

@@ -320,20 +320,20 @@ BINARY_DEFAULTS = dict(
     source_term_softening=1.0, softening_radius=0.05, sink_radius=0.05, sink_rate=1.0, buffer_damping_rate=10.0,
     domain_radius=12.0, disk_radius=2.0, disk_mass=1e-3, ambient_density=1e-4, density_floor=0.0, separation=1.0,
     mass_ratio=1.0, eccentricity=0.0, counter_rotate=0, mach_number=10.0, axisymmetric_cs2=0, no_accretion_force=0,
-    alpha_cutoff_radius=0.0, alpha=0.1, nu=0.0, mdot=0.0)
+    alpha_cutoff_radius=0.0, alpha=0.1, nu=0.0, mdot=0.0, conserve_linear_p=1)
 
 
 class _BinaryParams(C.Structure):
     _fields_ = [("n", C.c_int), ("block_size", C.c_int), ("domain_radius", C.c_double), ("mach_number", C.c_double),
                 ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
                 ("sink_radius", C.c_double), ("softening_radius", C.c_double), ("density_floor", C.c_double),
-                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int)]
+                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int), ("angmom_form", C.c_int), ("gst_suppr_radius", C.c_double)]
 
 
 class _BinaryModel(C.Structure):
     _fields_ = [("softening_radius", C.c_double), ("disk_radius", C.c_double), ("mach_number", C.c_double),
                 ("disk_mass", C.c_double), ("ambient_density", C.c_double), ("mdot", C.c_double), ("counter_rotate", C.c_int),
-                ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
+                ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double), ("angmom_form", C.c_int)]
 
 
 def binary_config(**overrides):
@@ -345,7 +345,7 @@ def binary_config(**overrides):
     return cfg
 
 
-def _binary_params(cfg, safe_mode=False):
+def _binary_params(cfg, safe_mode=False, xv=None, yv=None):
     P = _BinaryParams()
     P.n = int(cfg["block_size"]) << int(cfg["depth"])
     P.block_size = int(cfg["block_size"])
@@ -354,6 +354,9 @@ def _binary_params(cfg, safe_mode=False):
     P.density_floor = float(cfg["density_floor"]) * float(cfg["disk_mass"])
     P.plm_theta = 0.0 if safe_mode else float(cfg["plm_theta"])
     P.axisymmetric_cs2 = int(cfg["axisymmetric_cs2"])
+    P.angmom_form = 0 if int(cfg["conserve_linear_p"]) else 1
+    if xv is not None:      # source_term_softening * min(min_dx, min_dy), solver_data.cpp:91
+        P.gst_suppr_radius = float(cfg["source_term_softening"]) * min(float(np.diff(_f64(xv)).min()), float(np.diff(_f64(yv)).min()))
     return P
 
 
@@ -362,6 +365,7 @@ def _binary_model(cfg):
     for k in ("softening_radius", "disk_radius", "mach_number", "disk_mass", "ambient_density", "mdot", "buffer_damping_rate", "domain_radius", "cfl_number"):
         setattr(m, k, float(cfg[k]))
     m.counter_rotate = int(cfg["counter_rotate"])
+    m.angmom_form = 0 if int(cfg["conserve_linear_p"]) else 1
     return m
 
 
@@ -399,7 +403,7 @@ def binary_solver_data(cfg, xv, yv):
 
 def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False):
     """-> (u1, totals[18], negative_density)"""
-    P = _binary_params(cfg, safe_mode)
+    P = _binary_params(cfg, safe_mode, xv, yv)
     u0 = _f64(u0)
     u1 = np.zeros_like(u0)
     tot = np.zeros(BINARY_NTOTALS)
@@ -409,5 +413,5 @@ def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False):
 
 
 def binary_maximum_timestep(cfg, xv, yv, u, bodies):
-    P = _binary_params(cfg)
+    P = _binary_params(cfg, False, xv, yv)
     return _binary_lib().mo_binary_maximum_timestep(C.byref(P), _dp(_f64(xv)), _dp(_f64(yv)), _dp(_f64(u)), _dp(_f64(bodies)))

@@ -2,7 +2,7 @@
  * mara_oracle_binary.c — TEST INFRASTRUCTURE (see mara_oracle.h).
  *
  * Plain-C restatement of one stage of the circumbinary-disk scheme, binary::advance_u
- * (src/subprog_binary_scheme.cpp:790-904) on a uniform-depth block tree (every node
+ * (src/subprog_binary_scheme.cpp:790-904) and, with angmom_form set, binary::advance_q (:906-1020) on a uniform-depth block tree (every node
  * refined, so the grid is a periodic n x n tensor-product mesh of blocks of
  * block_size^2 cells), with the static solver data of
  * src/subprog_binary_solver_data.cpp:20-102, the initial model of
@@ -91,6 +91,17 @@ static void face_flux(const mo_binary_params* P, int axis, double spacing, doubl
         F[1] = F[1] + -tauyx;
         F[2] = F[2] + -tauyy;
     }
+    if (P->angmom_form)
+    {
+        /* to_angmom_fluxes scheme.cpp:199-214 */
+        double rd = P->domain_radius;
+        double flux_sr = xf * F[1] + yf * F[2];
+        double flux_lz = xf * F[2] - yf * F[1];
+        if (axis == 0 && (xf == -rd || xf == rd)) flux_lz = 0.0;
+        if (axis == 1 && (yf == -rd || yf == rd)) flux_lz = 0.0;
+        F[1] = flux_sr;
+        F[2] = flux_lz;
+    }
 }
 
 /* arithmetic_binary_tree_t::sum core_tree.hpp:502 over sequence_t::sum core_sequence.hpp:216 */
@@ -125,8 +136,14 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
     double* fy = malloc((size_t) N * (N + 1) * 3 * sizeof(double));
     double* blk = calloc((size_t) MO_BINARY_NTOTALS * nb * nb, sizeof(double));
 
-    for (size_t n = 0; n < ncell; ++n)
-        mo_iso2d_recover_primitive(u0 + 3 * n, p + 3 * n);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j)
+        {
+            size_t n = AT(i, j);
+            double x[2] = {(xv[i] + xv[i + 1]) * 0.5, (yv[j] + yv[j + 1]) * 0.5};
+            if (P->angmom_form) mo_iso2d_recover_primitive_angmom(u0 + 3 * n, x, p + 3 * n);
+            else                mo_iso2d_recover_primitive(u0 + 3 * n, p + 3 * n);
+        }
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
             for (int q = 0; q < 3; ++q)
@@ -188,7 +205,29 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
                         s_buffer[q] = (u_init[3 * AT(i, j) + q] - u[q]) * br[AT(i, j)] * dt;
                         s_floor[q] = u[q] * 1e-2 * fl;
                     }
-#define LZ(s) (xc * (s)[2] - yc * (s)[1])   /* iso2d::angular_momentum physics_iso2d.hpp:444-447 */
+                    double dps[2][3];
+                    for (int b = 0; b < 2; ++b) for (int q = 0; q < 3; ++q) dps[b][q] = s_sink[b][q];
+                    if (P->angmom_form)
+                    {
+                        /* source_terms_q :417-466 */
+                        double sr2 = pow(P->gst_suppr_radius, 2.0);
+                        double ramp = 1.0 - exp(-(xc * xc + yc * yc) / sr2);
+                        const double* pc = p + 3 * AT(i, j);
+                        double cs2 = mo_binary_cs2(P, xc, yc, bodies);
+                        double Ek = 0.5 * pc[0] * (pc[1] * pc[1] + pc[2] * pc[2]);      /* source_terms_conserved_angmom physics_iso2d.hpp:277-285 */
+                        double pg = pc[0] * cs2;
+                        double sg[3] = {0.0, (Ek + pg) * 2.0, 0.0};
+                        for (int b = 0; b < 2; ++b)
+                        {
+                            s_grav[b][1] = (xc * fg[b][0] + yc * fg[b][1]) * dt;
+                            s_grav[b][2] = (xc * fg[b][1] - yc * fg[b][0]) * dt;
+                            double r2 = 0.0 + xc * xc + yc * yc;                       /* to_conserved_per_area(Q, x) physics_iso2d.hpp:404-414 */
+                            dps[b][1] = (s_sink[b][1] * xc - s_sink[b][2] * yc) / r2;
+                            dps[b][2] = (s_sink[b][1] * yc + s_sink[b][2] * xc) / r2;
+                        }
+                        for (int q = 0; q < 3; ++q) s_floor[q] = sg[q] * ramp * dt;    /* s_geom takes the floor term's place in the sum */
+                    }
+#define LZ(s) (P->angmom_form ? (s)[2] : (xc * (s)[2] - yc * (s)[1]))   /* iso2d::angular_momentum physics_iso2d.hpp:444-447, or component 2 */
                     for (int b = 0; b < 2; ++b)
                     {
                         t[MO_T_MASS_ACC + b] = t[MO_T_MASS_ACC + b] + s_sink[b][0] * dA;
@@ -196,8 +235,8 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
                         t[MO_T_TORQUE + b]   = t[MO_T_TORQUE + b] + LZ(s_grav[b]) * dA;
                         t[MO_T_FX + b]       = t[MO_T_FX + b] + fg[b][0] * dt * dA;
                         t[MO_T_FY + b]       = t[MO_T_FY + b] + fg[b][1] * dt * dA;
-                        t[MO_T_PX_ACC + b]   = t[MO_T_PX_ACC + b] + s_sink[b][1] * dA;
-                        t[MO_T_PY_ACC + b]   = t[MO_T_PY_ACC + b] + s_sink[b][2] * dA;
+                        t[MO_T_PX_ACC + b]   = t[MO_T_PX_ACC + b] + dps[b][1] * dA;
+                        t[MO_T_PY_ACC + b]   = t[MO_T_PY_ACC + b] + dps[b][2] * dA;
                         for (int q = 0; q < 3; ++q) sink_sum[b][q] = sink_sum[b][q] + s_sink[b][q] * dA;
                     }
                     t[MO_T_L_EJ]    = t[MO_T_L_EJ] + LZ(s_buffer) * dA;
@@ -221,6 +260,7 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
                 double M0 = body[0], px0 = body[3] * M0, py0 = body[4] * M0;
                 double M1 = M0 + -sink_sum[b][0], px1 = px0 + -sink_sum[b][1], py1 = py0 + -sink_sum[b][2];
                 t[MO_T_WORK + b] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+                if (P->angmom_form) t[MO_T_WORK + b] = 0.0;    /* source_terms_q never sets work_done_on */
             }
             for (int k = 0; k < MO_BINARY_NTOTALS; ++k) blk[(size_t) k * nb * nb + bi * nb + bj] = t[k];
         }
@@ -245,7 +285,9 @@ double mo_binary_maximum_timestep(const mo_binary_params* P, const double* xv, c
                 for (int j = bj * bs; j < (bj + 1) * bs; ++j)
                 {
                     double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5, prim[3], lx[3], ly[3];
-                    mo_iso2d_recover_primitive(u + 3 * ((size_t) i * N + j), prim);
+                    double xx[2] = {xc, yc};
+                    if (P->angmom_form) mo_iso2d_recover_primitive_angmom(u + 3 * ((size_t) i * N + j), xx, prim);
+                    else                mo_iso2d_recover_primitive(u + 3 * ((size_t) i * N + j), prim);
                     double cs2 = mo_binary_cs2(P, xc, yc, bodies);
                     mo_iso2d_wavespeeds(prim, 0, cs2, lx);
                     mo_iso2d_wavespeeds(prim, 1, cs2, ly);
@@ -312,7 +354,9 @@ double mo_binary_solver_data(const mo_binary_model* m, int n, const double* xv, 
         {
             double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5, prim[3];
             mo_binary_disk_profile(m, xc, yc, prim);
-            mo_iso2d_to_conserved(prim, u_init + 3 * ((size_t) i * n + j));
+            double xx[2] = {xc, yc};
+            if (m->angmom_form) mo_iso2d_to_conserved_angmom(prim, xx, u_init + 3 * ((size_t) i * n + j));
+            else                mo_iso2d_to_conserved(prim, u_init + 3 * ((size_t) i * n + j));
             double v = sqrt(prim[1] * prim[1] + prim[2] * prim[2]);
             if (max_v < v) max_v = v;
             double rc = pow(xc * xc + yc * yc, 0.5);

@@ -67,6 +67,12 @@ static cons_t to_ref(cons3 u)
 }
 static cons3 from_ref(const cons_t& U) { return {mara::get<0>(U).value, mara::get<1>(U).value, mara::get<2>(U).value}; }
 static loc_t make_loc(double x, double y) { return {{mara::make_length(x), mara::make_length(y)}}; }
+using consq_t = mara::iso2d::conserved_angmom_per_area_t;
+static consq_t to_ref_q(cons3 q)
+{
+    return consq_t().set<0>(mara::make_dimensional<-2, 1, 0>(q.s)).set<1>(mara::make_dimensional<0, 1, -1>(q.px)).set<2>(mara::make_dimensional<0, 1, -1>(q.py));
+}
+static cons3 from_ref_q(const consq_t& Q) { return {mara::get<0>(Q).value, mara::get<1>(Q).value, mara::get<2>(Q).value}; }
 
 enum { T_MASS_ACC = 0, T_L_ACC = 2, T_TORQUE = 4, T_PX_ACC = 6, T_PY_ACC = 8, T_FX = 10, T_FY = 12, T_WORK = 14, T_MASS_EJ = 16, T_L_EJ = 17, NTOT = 18 };
 
@@ -78,6 +84,7 @@ struct params_t
     std::vector<double> xv, yv, br;
     std::vector<cons3> u_init;
     double h = 0, gst = 0, recommended_dt = 0;
+    bool qform = false;      // conserve_linear_p == 0: the cons3 fields hold (Sigma, Sigma s_r, Sigma l_z), scheme.cpp:906-1020
 };
 
 struct solution_t
@@ -164,7 +171,18 @@ static cons3 face_flux(const params_t& P, int axis, double xf, double yf, const 
         v1 = -(mu * (dx_uy + dy_ux));
         v2 = -(-mu * (dx_ux - dy_uy));
     }
-    return {f0 + 0.0, f1 + v1, f2 + v2};
+    cons3 f = {f0 + 0.0, f1 + v1, f2 + v2};
+    if (P.qform)
+    {
+        // to_angmom_fluxes scheme.cpp:199-214
+        double rd = P.get("domain_radius");
+        double flux_sr = xf * f.px + yf * f.py;
+        double flux_lz = xf * f.py - yf * f.px;
+        if (axis == 0 && (xf == -rd || xf == rd)) flux_lz = 0.0;
+        if (axis == 1 && (yf == -rd || yf == rd)) flux_lz = 0.0;
+        f = {f.s, flux_sr, flux_lz};
+    }
+    return f;
 }
 
 static double fold_tree(const std::vector<double>& block_vals, int nb, int level, int depth, int bi, int bj)
@@ -184,8 +202,14 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
     const double th = safe_mode ? 0.0 : P.get("plm_theta");
     auto at = [N] (int i, int j) { return std::size_t(((i + N) % N)) * N + ((j + N) % N); };
     std::vector<prim_t> p(std::size_t(N) * N), gx(p.size()), gy(p.size());
-    for (std::size_t n = 0; n < p.size(); ++n)
-        p[n] = mara::iso2d::recover_primitive(to_ref(S.u[n]));
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j)
+        {
+            std::size_t n = at(i, j);
+            p[n] = P.qform
+            ? mara::iso2d::recover_primitive(to_ref_q(S.u[n]), make_loc((P.xv[i] + P.xv[i + 1]) * 0.5, (P.yv[j] + P.yv[j + 1]) * 0.5))
+            : mara::iso2d::recover_primitive(to_ref(S.u[n]));
+        }
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
         {
@@ -256,21 +280,35 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
                     cons3 s_buffer = {(ui.s - u0.s) * br * dt, (ui.px - u0.px) * br * dt, (ui.py - u0.py) * br * dt};
                     double fl = double(u0.s < floor_sigma);
                     cons3 s_floor = {u0.s * 1e-2 * fl, u0.px * 1e-2 * fl, u0.py * 1e-2 * fl};
+                    cons3 dps[2] = {s_sink[0], s_sink[1]};
+                    if (P.qform)
+                    {
+                        // source_terms_q :417-466: gravity in (s_r, l_z) form, a geometrical source instead of the floor term
+                        for (int b = 0; b < 2; ++b)
+                        {
+                            s_grav[b] = {0.0 * dt, (xc * fg[b][0] + yc * fg[b][1]) * dt, (xc * fg[b][1] - yc * fg[b][0]) * dt};
+                            dps[b] = from_ref(mara::iso2d::to_conserved_per_area(to_ref_q(s_sink[b]), make_loc(xc, yc)));
+                        }
+                        double sr2 = std::pow(P.gst, 2.0);           // gst_suppr_radius.pow<2>() :421
+                        double ramp = 1.0 - std::exp(-(xc * xc + yc * yc) / sr2);
+                        auto sg = p[at(i, j)].source_terms_conserved_angmom(cs2_at(P, xc, yc, B));
+                        s_floor = {mara::get<0>(sg).value * ramp * dt, mara::get<1>(sg).value * ramp * dt, mara::get<2>(sg).value * ramp * dt};
+                    }
 
                     for (int b = 0; b < 2; ++b)
                     {
                         t[T_MASS_ACC + b] = t[T_MASS_ACC + b] + s_sink[b].s * dA;
-                        t[T_L_ACC + b]    = t[T_L_ACC + b] + lz(s_sink[b]) * dA;
-                        t[T_TORQUE + b]   = t[T_TORQUE + b] + lz(s_grav[b]) * dA;
+                        t[T_L_ACC + b]    = t[T_L_ACC + b] + (P.qform ? s_sink[b].py : lz(s_sink[b])) * dA;
+                        t[T_TORQUE + b]   = t[T_TORQUE + b] + (P.qform ? s_grav[b].py : lz(s_grav[b])) * dA;
                         t[T_FX + b]       = t[T_FX + b] + fg[b][0] * dt * dA;
                         t[T_FY + b]       = t[T_FY + b] + fg[b][1] * dt * dA;
-                        t[T_PX_ACC + b]   = t[T_PX_ACC + b] + s_sink[b].px * dA;
-                        t[T_PY_ACC + b]   = t[T_PY_ACC + b] + s_sink[b].py * dA;
+                        t[T_PX_ACC + b]   = t[T_PX_ACC + b] + dps[b].px * dA;
+                        t[T_PY_ACC + b]   = t[T_PY_ACC + b] + dps[b].py * dA;
                         sink_sum[b][0] = sink_sum[b][0] + s_sink[b].s * dA;
                         sink_sum[b][1] = sink_sum[b][1] + s_sink[b].px * dA;
                         sink_sum[b][2] = sink_sum[b][2] + s_sink[b].py * dA;
                     }
-                    t[T_L_EJ]    = t[T_L_EJ] + lz(s_buffer) * dA;
+                    t[T_L_EJ]    = t[T_L_EJ] + (P.qform ? s_buffer.py : lz(s_buffer)) * dA;
                     t[T_MASS_EJ] = t[T_MASS_EJ] + s_buffer.s * dA;
 
                     // block_update_u :568-587
@@ -296,6 +334,7 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
                 double M0 = bodies[b].mass, px0 = bodies[b].velocity_x * M0, py0 = bodies[b].velocity_y * M0;
                 double M1 = M0 + -sink_sum[b][0], px1 = px0 + -sink_sum[b][1], py1 = py0 + -sink_sum[b][2];
                 t[T_WORK + b] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+                if (P.qform) t[T_WORK + b] = 0.0;      // source_terms_q leaves work_done_on at its initial zero
             }
             for (int k = 0; k < NTOT; ++k) blk[k][bi * nb + bj] = t[k];
         }
@@ -362,7 +401,8 @@ static double maximum_timestep(const params_t& P, const solution_t& S)
                 for (int j = bj * bs; j < (bj + 1) * bs; ++j)
                 {
                     double xc = (P.xv[i] + P.xv[i + 1]) * 0.5, yc = (P.yv[j] + P.yv[j + 1]) * 0.5;
-                    auto p = mara::iso2d::recover_primitive(to_ref(S.u[std::size_t(i) * N + j]));
+                    auto p = P.qform ? mara::iso2d::recover_primitive(to_ref_q(S.u[std::size_t(i) * N + j]), make_loc(xc, yc))
+                                     : mara::iso2d::recover_primitive(to_ref(S.u[std::size_t(i) * N + j]));
                     double w = p.max_wavespeed(cs2_at(P, xc, yc, B));
                     a = f0 ? w : std::max(a, w); f0 = false;
                 }
@@ -395,7 +435,7 @@ int main(int argc, char** argv)
         {"buffer_damping_rate", 10.0}, {"domain_radius", 12.0}, {"disk_radius", 2.0}, {"disk_mass", 1e-3}, {"ambient_density", 1e-4},
         {"density_floor", 0.0}, {"separation", 1.0}, {"mass_ratio", 1.0}, {"eccentricity", 0.0}, {"counter_rotate", 0},
         {"mach_number", 10.0}, {"axisymmetric_cs2", 0}, {"no_accretion_force", 0}, {"alpha_cutoff_radius", 0.0}, {"alpha", 0.1},
-        {"nu", 0.0}, {"mdot", 0.0}, {"nsteps", 1}, {"safe_mode", 0}};
+        {"nu", 0.0}, {"mdot", 0.0}, {"nsteps", 1}, {"safe_mode", 0}, {"conserve_linear_p", 1}};
     for (int a = 2; a < argc; ++a)
     {
         std::string kv = argv[a];
@@ -403,6 +443,7 @@ int main(int argc, char** argv)
         if (eq == std::string::npos || ! P.cfg.count(kv.substr(0, eq))) { std::fprintf(stderr, "bad argument %s\n", argv[a]); return 1; }
         P.cfg[kv.substr(0, eq)] = std::atof(kv.substr(eq + 1).data());
     }
+    P.qform = int(P.get("conserve_linear_p")) == 0;
     P.depth = int(P.get("depth"));
     P.bs = int(P.get("block_size"));
     P.N = P.bs << P.depth;
@@ -446,7 +487,7 @@ int main(int argc, char** argv)
         {
             double xc = (P.xv[i] + P.xv[i + 1]) * 0.5, yc = (P.yv[j] + P.yv[j + 1]) * 0.5;
             auto p = disk_profile(P, xc, yc);
-            P.u_init[std::size_t(i) * N + j] = from_ref(p.to_conserved_per_area());
+            P.u_init[std::size_t(i) * N + j] = P.qform ? from_ref_q(p.to_conserved_angmom_per_area(make_loc(xc, yc))) : from_ref(p.to_conserved_per_area());
             max_v = std::max(max_v, p.velocity_magnitude().value);
             double rc = std::pow(xc * xc + yc * yc, 0.5);
             P.br[std::size_t(i) * N + j] = P.get("buffer_damping_rate") * (1.0 + std::tanh(3.0 * (rc - R)));

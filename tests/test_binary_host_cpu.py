@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from conftest import golden, bits_equal
 
-CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b32"]
+CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b32", "binary_d2_b16_live"]
 
 
 def cfg_of(g):
