@@ -297,6 +297,10 @@ typedef struct mh_binary_desc
     double  plm_theta;
     int32_t axisymmetric_cs2;
     int32_t chunk_rows;             /* rows marched per wavefront; 0 = default */
+    int32_t angmom_form;            /* 0: conserve_linear_p = 1, fields (Sigma, px, py), advance_u;
+                                       1: conserve_linear_p = 0, fields (Sigma, Sigma s_r, Sigma l_z), advance_q (scheme.cpp:906-1020) */
+    int32_t reserved;
+    double  gst_suppr_radius;       /* source_term_softening * min(dx, dy) (solver_data.cpp:91); advance_q only */
 } mh_binary_desc;
 
 /* source_term_total_t (scheme.cpp:17-32), [2] = per body */
@@ -343,7 +347,8 @@ typedef struct mh_binary_run
 typedef struct mh_binary_model
 {
     double  softening_radius, disk_radius, mach_number, disk_mass, ambient_density, mdot;
-    int32_t counter_rotate, reserved;
+    int32_t counter_rotate;
+    int32_t angmom_form;            /* initial field as to_conserved_angmom_per_area(x) (subprog_binary.cpp:208-216) */
     double  buffer_damping_rate, domain_radius, cfl_number;
 } mh_binary_model;
 int  mh_binary_vertices(int block_size, int depth, double domain_radius, double* out_host);

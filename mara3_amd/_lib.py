@@ -47,7 +47,8 @@ class BinaryDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("block_size", C.c_int32), ("domain_radius", C.c_double), ("mach_number", C.c_double),
                 ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
                 ("sink_radius", C.c_double), ("softening_radius", C.c_double), ("density_floor", C.c_double),
-                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int32), ("chunk_rows", C.c_int32)]
+                ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int32), ("chunk_rows", C.c_int32), ("angmom_form", C.c_int32),
+                ("reserved", C.c_int32), ("gst_suppr_radius", C.c_double)]
 
 
 class OrbitalElements(C.Structure):
@@ -75,7 +76,7 @@ class BinaryState(C.Structure):
 class BinaryModel(C.Structure):
     _fields_ = [("softening_radius", C.c_double), ("disk_radius", C.c_double), ("mach_number", C.c_double),
                 ("disk_mass", C.c_double), ("ambient_density", C.c_double), ("mdot", C.c_double), ("counter_rotate", C.c_int32),
-                ("reserved", C.c_int32), ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
+                ("angmom_form", C.c_int32), ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
 
 
 class BinaryRun(C.Structure):

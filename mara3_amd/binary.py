@@ -26,8 +26,6 @@ def config(**overrides):
         if k not in cfg:
             raise KeyError("binary: no run_config item '%s'" % k)
         cfg[k] = v
-    if not int(cfg["conserve_linear_p"]):
-        raise NotImplementedError("binary: only the linear-momentum conserving scheme (advance_u) is built; conserve_linear_p=0 is not")
     return cfg
 
 
@@ -48,6 +46,7 @@ def _model(cfg):
     for k in ("softening_radius", "disk_radius", "mach_number", "disk_mass", "ambient_density", "mdot", "buffer_damping_rate", "domain_radius", "cfl_number"):
         setattr(m, k, float(cfg[k]))
     m.counter_rotate = int(cfg["counter_rotate"])
+    m.angmom_form = 0 if int(cfg["conserve_linear_p"]) else 1
     return m
 
 
@@ -66,7 +65,13 @@ def solver_data(cfg, xv=None, yv=None):
     return u, br, dt.value
 
 
-def make_desc(cfg, safe_mode=False, chunk_rows=0):
+def gst_suppr_radius(cfg, xv, yv):
+    """source_term_softening * min(min_dx, min_dy) - src/subprog_binary_solver_data.cpp:91."""
+    return float(cfg["source_term_softening"]) * min(float(np.diff(xv).min()), float(np.diff(yv).min()))
+
+
+def make_desc(cfg, safe_mode=False, chunk_rows=0, xv=None, yv=None):
+    """conserve_linear_p = 0 selects the angular-momentum form (advance_q) and needs the vertices for gst_suppr_radius."""
     d = L.BinaryDesc()
     d.n = grid_size(cfg)
     d.block_size = int(cfg["block_size"])
@@ -76,6 +81,11 @@ def make_desc(cfg, safe_mode=False, chunk_rows=0):
     d.plm_theta = 0.0 if safe_mode else float(cfg["plm_theta"])
     d.axisymmetric_cs2 = int(cfg["axisymmetric_cs2"])
     d.chunk_rows = int(chunk_rows)
+    d.angmom_form = 0 if int(cfg["conserve_linear_p"]) else 1
+    if d.angmom_form:
+        xv = vertices(cfg) if xv is None else np.ascontiguousarray(xv, dtype=np.float64)
+        yv = xv if yv is None else np.ascontiguousarray(yv, dtype=np.float64)
+        d.gst_suppr_radius = gst_suppr_radius(cfg, xv, yv)
     return d
 
 
@@ -121,7 +131,7 @@ class BinarySolver:
         self.u_init = np.ascontiguousarray(u_init, dtype=np.float64)
         self.buffer_rate = np.ascontiguousarray(buffer_rate, dtype=np.float64)
         assert self.u_init.shape == (self.n, self.n, 3) and self.buffer_rate.shape == (self.n, self.n)
-        self.desc = make_desc(cfg, chunk_rows=chunk_rows)
+        self.desc = make_desc(cfg, chunk_rows=chunk_rows, xv=self.xv, yv=self.yv)
         run = L.BinaryRun()
         run.rk_order = int(cfg["rk_order"])
         run.fixed_dt = int(cfg["fixed_dt"])

@@ -1,6 +1,6 @@
 // `binary` sub-program stage on gfx950: 2-D locally isothermal circumbinary disk on a uniform-depth
 // block tree (BASELINE config 3). Replaces one evaluation of
-// binary::advance_u (src/subprog_binary_scheme.cpp:790-904) and, with stage_weight != 1, the conserved
+// binary::advance_u (src/subprog_binary_scheme.cpp:790-904) - or, with angmom_form set, binary::advance_q (:906-1020) - and, with stage_weight != 1, the conserved
 // part of the RK combine s0 * 1/2 + s2 * 1/2 (:1033-1069, src/subprog_binary.cpp:264-277):
 //     p0      = iso2d::recover_primitive(u0)                                          :802, physics_iso2d.hpp:351
 //     gx, gy  = plm_gradient(p0 on axis 0 / 1, theta) / spacing                        :794-800
@@ -58,6 +58,8 @@ struct BinaryConsts
     double mach, alpha, nu, rc_cut;
     double sink_rate, s2, rs2, floor_sigma;
     int    axisym;
+    double rd;                // domain radius (the angular-momentum flux through x, y = +-rd is set to zero, scheme.cpp:208-209)
+    double sr2;               // gst_suppr_radius^2: range of the ramp on advance_q's geometrical source term (:421, :440)
     double body[10];          // (mass, x, y, vx, vy) x 2
 };
 
@@ -146,7 +148,7 @@ __device__ inline double binary_nu(const BinaryConsts& c, const Recip& rmach, do
 }
 
 // intercell_flux_u :268-293 + viscous_flux :220-262 ; g = slopes along AXIS, t = transverse slopes (both per length)
-template<int AXIS>
+template<int AXIS, bool QFORM>
 __device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rmach, double xf, double yf,
     const State3& pl, const State3& pr, const State3& gl, const State3& gr, const State3& tl, const State3& tr)
 {
@@ -185,6 +187,16 @@ __device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rm
         F[1] = F[1] + -tauyx;
         F[2] = F[2] + -tauyy;
     }
+    if constexpr (QFORM)
+    {
+        // to_angmom_fluxes scheme.cpp:199-214
+        const double flux_sr = xf * F[1] + yf * F[2];
+        double flux_lz = xf * F[2] - yf * F[1];
+        if (AXIS == 0 && (xf == -c.rd || xf == c.rd)) flux_lz = 0.0;
+        if (AXIS == 1 && (yf == -c.rd || yf == c.rd)) flux_lz = 0.0;
+        F[1] = flux_sr;
+        F[2] = flux_lz;
+    }
     return F;
 }
 
@@ -207,10 +219,13 @@ __device__ inline State3 plm3_per_length(const State3& l, const State3& m, const
     return g;
 }
 
-__device__ inline State3 c2p3(const State3& U)
+// iso2d::recover_primitive(U) physics_iso2d.hpp:351-362, or (Q, x) :376-390 at the centre of the cell the data belongs to
+template<bool QFORM>
+__device__ inline State3 c2p3(const State3& U, double xc, double yc)
 {
     State3 P;
-    iso2d::recover_primitive(U, P);
+    if constexpr (QFORM) iso2d::recover_primitive_angmom(U, xc, yc, P);
+    else                 iso2d::recover_primitive(U, P);
     return P;
 }
 
@@ -221,7 +236,7 @@ __device__ inline double wave_sum(double x)
     return x;
 }
 
-template<bool COMBINE>
+template<bool COMBINE, bool QFORM>
 __global__ __launch_bounds__(BWAVE * BWAVES_PER_BLOCK, 2)
 void binary_stage_kernel(BinaryStageParams p)
 {
@@ -247,10 +262,12 @@ void binary_stage_kernel(BinaryStageParams p)
     const bool writes = lane >= BHALO && lane < BWAVE - BHALO && col < n;
     const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
 
-    const int cv = min(max(col, 0), n - 1);
-    const double yv_lo = p.yv[min(max(col, 0), n)];        // position of this lane's LEFT face
-    const double yc = (p.yv[cv] + p.yv[cv + 1]) * 0.5;
-    const double dy = p.yv[cv + 1] - p.yv[cv];
+    // positions: the LEFT face of this lane sits at the un-wrapped vertex (so the two sides of the periodic seam differ);
+    // everything cell-centred belongs to the cell whose data the lane holds, i.e. the wrapped column jc
+    const double yv_lo = p.yv[min(max(col, 0), n)];
+    const double yc = (p.yv[jc] + p.yv[jc + 1]) * 0.5;
+    const double dy = p.yv[jc + 1] - p.yv[jc];
+    auto xc_of = [&p, n] (int r) { const int rw = r < 0 ? r + n : (r >= n ? r - n : r); return (p.xv[rw] + p.xv[rw + 1]) * 0.5; };
 
     const BinaryConsts& c = p.c;
     const Recip rmach = make_recip(c.mach, 1.0);
@@ -264,18 +281,18 @@ void binary_stage_kernel(BinaryStageParams p)
     //   U[k], P[k]: rows r, r+1, r+2     Gx[k], Gy[k]: slopes of rows r, r+1     Fx[k]: faces r, r+1 (times dy)
     State3 U[3], P[3], Gx[3], Gy[3], Fx[3];
     {
-        const State3 Pa = c2p3(load_row3(in + row_off(r0 - 2), n, jc8));
-        const State3 Pb = c2p3(load_row3(in + row_off(r0 - 1), n, jc8));
+        const State3 Pa = c2p3<QFORM>(load_row3(in + row_off(r0 - 2), n, jc8), xc_of(r0 - 2), yc);
+        const State3 Pb = c2p3<QFORM>(load_row3(in + row_off(r0 - 1), n, jc8), xc_of(r0 - 1), yc);
         U[0] = load_row3(in + row_off(r0), n, jc8);
         U[1] = load_row3(in + row_off(r0 + 1), n, jc8);
         U[2] = load_row3(in + row_off(r0 + 2), n, jc8);
-        P[0] = c2p3(U[0]);
-        P[1] = c2p3(U[1]);
+        P[0] = c2p3<QFORM>(U[0], xc_of(r0), yc);
+        P[1] = c2p3<QFORM>(U[1], xc_of(r0 + 1), yc);
         const State3 Gxb = plm3_per_length(Pa, Pb, P[0], theta, rh);
         const State3 Gyb = plm3_per_length(bdpp_left(Pb), Pb, bdpp_right(Pb), theta, rh);
         Gx[0] = plm3_per_length(Pb, P[0], P[1], theta, rh);
         Gy[0] = plm3_per_length(bdpp_left(P[0]), P[0], bdpp_right(P[0]), theta, rh);
-        Fx[0] = binary_face_flux<0>(c, rmach, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
+        Fx[0] = binary_face_flux<0, QFORM>(c, rmach, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fx[0][q] = Fx[0][q] * dy;
     }
@@ -300,15 +317,15 @@ void binary_stage_kernel(BinaryStageParams p)
         const double dx = xhi - xlo;
 
         // ---- axis 0: slopes of row r+1, flux through face r+1 (at x = xv[r+1])
-        P[K2] = c2p3(U[K2]);
+        P[K2] = c2p3<QFORM>(U[K2], xc_of(r + 2), yc);
         Gx[K1] = plm3_per_length(P[K0], P[K1], P[K2], theta, rh);
         Gy[K1] = plm3_per_length(bdpp_left(P[K1]), P[K1], bdpp_right(P[K1]), theta, rh);
-        Fx[K1] = binary_face_flux<0>(c, rmach, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
+        Fx[K1] = binary_face_flux<0, QFORM>(c, rmach, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fx[K1][q] = Fx[K1][q] * dy;
 
         // ---- axis 1: this lane's LEFT face (at y = yv[col]), handed to the left neighbour as its right face
-        State3 Fy_lo = binary_face_flux<1>(c, rmach, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
+        State3 Fy_lo = binary_face_flux<1, QFORM>(c, rmach, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fy_lo[q] = Fy_lo[q] * dx;
         const State3 Fy_hi = bdpp_right(Fy_lo);
@@ -341,17 +358,39 @@ void binary_stage_kernel(BinaryStageParams p)
             s_buffer[q] = (Uinit[q] - u0[q]) * brate * dt;
             s_floor[q] = u0[q] * 1e-2 * fl;
         }
+        if constexpr (QFORM)
+        {
+            // source_terms_q :417-466: gravity as (s_r, l_z) sources, and the geometrical source of the s_r equation
+            // (source_terms_conserved_angmom physics_iso2d.hpp:277-285, ramped down within gst_suppr_radius of the origin)
+            // in the place of the density-floor term
+#pragma unroll
+            for (int bdy = 0; bdy < 2; ++bdy)
+            {
+                s_grav[bdy][1] = (xc * fg[bdy][0] + yc * fg[bdy][1]) * dt;
+                s_grav[bdy][2] = (xc * fg[bdy][1] - yc * fg[bdy][0]) * dt;
+            }
+            const double a = -(xc * xc + yc * yc) / c.sr2;
+            double e = 0.0;
+            if (__any(a > -750.0)) e = exp(a);            // exp underflows to exactly 0 below -745.2
+            const double ramp = 1.0 - e;
+            const State3& pc = P[K0];
+            const double Ek = 0.5 * pc[0] * (pc[1] * pc[1] + pc[2] * pc[2]);
+            const double pg = pc[0] * binary_cs2(c, rmach, xc, yc);
+            s_floor[0] = 0.0 * ramp * dt;
+            s_floor[1] = (Ek + pg) * 2.0 * ramp * dt;
+            s_floor[2] = 0.0 * ramp * dt;
+        }
         if (writes)
         {
 #pragma unroll
             for (int bdy = 0; bdy < 2; ++bdy)
             {
-                part[0 + bdy] = part[0 + bdy] + (xc * s_grav[bdy][2] - yc * s_grav[bdy][1]) * dA;
+                part[0 + bdy] = part[0 + bdy] + (QFORM ? s_grav[bdy][2] : (xc * s_grav[bdy][2] - yc * s_grav[bdy][1])) * dA;
                 part[2 + bdy] = part[2 + bdy] + fg[bdy][0] * dt * dA;
                 part[4 + bdy] = part[4 + bdy] + fg[bdy][1] * dt * dA;
             }
             part[6] = part[6] + s_buffer[0] * dA;
-            part[7] = part[7] + (xc * s_buffer[2] - yc * s_buffer[1]) * dA;
+            part[7] = part[7] + (QFORM ? s_buffer[2] : (xc * s_buffer[2] - yc * s_buffer[1])) * dA;
         }
 
         // ---- update :568-587 (+ RK combine)
@@ -411,7 +450,7 @@ struct BinarySinkParams
     const double* xv;
     const double* yv;
     double*       block_out;   // [nb * nb][NBLK]
-    int    n, bs, nb;
+    int    n, bs, nb, qform;
     double dt;
     BinaryConsts c;
 };
@@ -456,9 +495,21 @@ void binary_sink_kernel(BinarySinkParams p)
             double s[3];
             for (int q = 0; q < 3; ++q) s[q] = -u0[q] * rate * p.dt;
             acc[4 * b + 0] = acc[4 * b + 0] + s[0] * dA;
-            acc[4 * b + 1] = acc[4 * b + 1] + (xc * s[2] - yc * s[1]) * dA;
-            acc[4 * b + 2] = acc[4 * b + 2] + s[1] * dA;
-            acc[4 * b + 3] = acc[4 * b + 3] + s[2] * dA;
+            if (p.qform)
+            {
+                // totals of source_terms_q :447-462: l_z is component 2; the accreted linear momentum goes through
+                // iso2d::to_conserved_per_area(Q, x) physics_iso2d.hpp:404-414
+                const double r2 = 0.0 + xc * xc + yc * yc;
+                acc[4 * b + 1] = acc[4 * b + 1] + s[2] * dA;
+                acc[4 * b + 2] = acc[4 * b + 2] + (s[1] * xc - s[2] * yc) / r2 * dA;
+                acc[4 * b + 3] = acc[4 * b + 3] + (s[1] * yc + s[2] * xc) / r2 * dA;
+            }
+            else
+            {
+                acc[4 * b + 1] = acc[4 * b + 1] + (xc * s[2] - yc * s[1]) * dA;
+                acc[4 * b + 2] = acc[4 * b + 2] + s[1] * dA;
+                acc[4 * b + 3] = acc[4 * b + 3] + s[2] * dA;
+            }
         }
     }
     __shared__ double red[8][256];
@@ -482,7 +533,7 @@ void binary_sink_kernel(BinarySinkParams p)
             // work :356-365
             const double M0 = c.body[5 * b], px0 = c.body[5 * b + 3] * M0, py0 = c.body[5 * b + 4] * M0;
             const double M1 = M0 + dm, px1 = px0 + dpx, py1 = py0 + dpy;
-            out[8 + b] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+            out[8 + b] = p.qform ? 0.0 : ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;   // source_terms_q never sets it
         }
     }
 }
@@ -517,7 +568,7 @@ void binary_reduce_kernel(const double* partials, int nwaves, const double* bloc
 
 // ---- maximum wavespeed ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int n, BinaryConsts c, unsigned long long* result)
+void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int n, int qform, BinaryConsts c, unsigned long long* result)
 {
     const Recip rmach = make_recip(c.mach, 1.0);
     double m = 0.0;
@@ -528,8 +579,9 @@ void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int
         const double* q = u + (long) (i + BHALO) * 3 * n + j;
         State3 U, P;
         U[0] = q[0]; U[1] = q[n]; U[2] = q[2 * n];
-        iso2d::recover_primitive(U, P);
         const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
+        if (qform) iso2d::recover_primitive_angmom(U, xc, yc, P);
+        else       iso2d::recover_primitive(U, P);
         const double wsp = iso2d::max_wavespeed(P, binary_cs2(c, rmach, xc, yc));
         m = (m < wsp) ? wsp : m;
     }
@@ -561,6 +613,8 @@ static BinaryConsts make_consts(const mh_binary_desc* d, const double bodies[10]
     c.rs2 = d->softening_radius * d->softening_radius;
     c.floor_sigma = d->density_floor;
     c.axisym = d->axisymmetric_cs2;
+    c.rd = d->domain_radius;
+    c.sr2 = d->gst_suppr_radius * d->gst_suppr_radius;
     for (int k = 0; k < 10; ++k) c.body[k] = bodies[k];
     return c;
 }
@@ -600,15 +654,25 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     const int nwaves = p.nstrips * p.nchunks;
     p.partials = scratch;
     const int nblocks = (nwaves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
-    if (weight != 1.0) hipLaunchKernelGGL((binary_stage_kernel<true>), dim3(nblocks), dim3(BWAVE * BWAVES_PER_BLOCK), 0, stream, p);
-    else               hipLaunchKernelGGL((binary_stage_kernel<false>), dim3(nblocks), dim3(BWAVE * BWAVES_PER_BLOCK), 0, stream, p);
+    const dim3 grid(nblocks), block(BWAVE * BWAVES_PER_BLOCK);
+    const bool combine = weight != 1.0;
+    if (d->angmom_form)
+    {
+        if (combine) hipLaunchKernelGGL((binary_stage_kernel<true, true>), grid, block, 0, stream, p);
+        else         hipLaunchKernelGGL((binary_stage_kernel<false, true>), grid, block, 0, stream, p);
+    }
+    else
+    {
+        if (combine) hipLaunchKernelGGL((binary_stage_kernel<true, false>), grid, block, 0, stream, p);
+        else         hipLaunchKernelGGL((binary_stage_kernel<false, false>), grid, block, 0, stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 
     BinarySinkParams s;
     s.u_in = u_in; s.xv = xv; s.yv = yv;
     s.block_out = scratch + (long) nwaves * NPART;
-    s.n = d->n; s.bs = d->block_size; s.nb = d->n / d->block_size;
+    s.n = d->n; s.bs = d->block_size; s.nb = d->n / d->block_size; s.qform = d->angmom_form;
     s.dt = dt;
     s.c = p.c;
     hipLaunchKernelGGL(binary_sink_kernel, dim3(s.nb * s.nb), dim3(256), 0, stream, s);
@@ -626,7 +690,7 @@ hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const d
     const BinaryConsts c = make_consts(d, bodies);
     const long total = (long) d->n * d->n;
     const int nblocks = (int) ((total + 256 * 4 - 1) / (256 * 4) < 2048 ? (total + 256 * 4 - 1) / (256 * 4) : 2048);
-    hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv, yv, d->n, c, reinterpret_cast<unsigned long long*>(result));
+    hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv, yv, d->n, (int) d->angmom_form, c, reinterpret_cast<unsigned long long*>(result));
     return hipGetLastError();
 }
 

@@ -163,9 +163,17 @@ int mh_binary_solver_data(const mh_binary_model* m, int n, const double* xv, con
             const double vy = vr * (y / r) + vp * ( x / r);
             const double sg = sigma(r);
             double* u = u_init + 3 * ((size_t) i * n + j);
-            u[0] = sg;                                                    // to_conserved_per_area physics_iso2d.hpp:249-258
-            u[1] = sg * vx;
-            u[2] = sg * vy;
+            u[0] = sg;
+            if (m->angmom_form)
+            {
+                u[1] = sg * (x * vx + y * vy);                            // to_conserved_angmom_per_area physics_iso2d.hpp:263-272
+                u[2] = sg * (x * vy - y * vx);
+            }
+            else
+            {
+                u[1] = sg * vx;                                           // to_conserved_per_area physics_iso2d.hpp:249-258
+                u[2] = sg * vy;
+            }
             const double v = std::sqrt(vx * vx + vy * vy);
             if (max_v < v) max_v = v;
             const double rcen = std::pow(x * x + y * y, 0.5);

@@ -7,7 +7,7 @@
 //
 // Restrictions, stated rather than silently ignored: the tree must be of uniform depth (every node refined; upstream that
 // is `focus_factor` large, here it is the only mode: focus_factor / focus_index are accepted and must describe such a
-// tree), conserve_linear_p must be 1 (advance_u), and the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
+// tree), and the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
 // tsi) are out of scope; a raw dump of the final state replaces them.
 #include <cmath>
 #include <cstdio>
@@ -80,7 +80,6 @@ public:
         auto cfg = config_template().update(argc, argv);
         cfg.pretty_print(stdout, "config");
         if (! cfg.get_string("restart").empty()) throw std::invalid_argument("binary: restart from an HDF5 checkpoint is out of scope in this build");
-        if (! cfg.get_int("conserve_linear_p")) throw std::invalid_argument("binary: conserve_linear_p=0 (advance_q) is not built");
         if (cfg.get_string("reconstruct_method") != "plm" && cfg.get_string("reconstruct_method") != "pcm")
             throw std::invalid_argument("invalid reconstruct_method '" + cfg.get_string("reconstruct_method") + "', must be plm or pcm");
         const int depth = cfg.get_int("depth"), bs = cfg.get_int("block_size");
@@ -101,6 +100,7 @@ public:
         model.ambient_density = cfg.get_double("ambient_density");
         model.mdot = cfg.get_double("mdot");
         model.counter_rotate = cfg.get_int("counter_rotate");
+        model.angmom_form = cfg.get_int("conserve_linear_p") ? 0 : 1;
         model.buffer_damping_rate = cfg.get_double("buffer_damping_rate");
         model.domain_radius = cfg.get_double("domain_radius");
         model.cfl_number = cfg.get_double("cfl_number");
@@ -125,6 +125,12 @@ public:
         d.softening_radius = cfg.get_double("softening_radius");
         d.density_floor = cfg.get_double("density_floor") * cfg.get_double("disk_mass");
         d.axisymmetric_cs2 = cfg.get_int("axisymmetric_cs2");
+        d.angmom_form = model.angmom_form;
+        {
+            double min_d = xv[1] - xv[0];                                  // solver_data.cpp:37-52, :91 (both axes share the vertex array)
+            for (int i = 0; i < n; ++i) min_d = std::min(min_d, xv[i + 1] - xv[i]);
+            d.gst_suppr_radius = cfg.get_double("source_term_softening") * min_d;
+        }
         d.plm_theta = cfg.get_double("plm_theta");       // upstream validates reconstruct_method (solver_data.cpp:110-112) but the scheme never reads it
 
         mh_binary* solver = nullptr;

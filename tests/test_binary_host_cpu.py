@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 from conftest import golden, bits_equal
 
-CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b32", "binary_d2_b16_live"]
+CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b32", "binary_d2_b16_live", "binary_d2_b16_q", "binary_d1_b24_q_nu"]
 
 
 def cfg_of(g):
@@ -63,5 +63,5 @@ def test_bad_descriptors_are_rejected():
     assert lib.mh_binary_scratch_doubles(C.byref(d)) == 0
     d.n = 48        # 48 / 16 = 3 blocks per side: not a uniform-depth tree
     assert lib.mh_binary_scratch_doubles(C.byref(d)) == 0
-    with pytest.raises(NotImplementedError):
-        binary.config(conserve_linear_p=0)
+    with pytest.raises(KeyError):
+        binary.config(no_such_item=1)

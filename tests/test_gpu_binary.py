@@ -15,7 +15,7 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 REL = 1e-12
-CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b16_safe", "binary_d2_b32", "binary_d2_b16_live"]
+CASES = ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b16_safe", "binary_d2_b32", "binary_d2_b16_live", "binary_d2_b16_q", "binary_d1_b24_q_nu"]
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +51,7 @@ def field_close(a, b, rel=REL):
 def run_stage(mods, cfg, g, u0, bodies, dt, safe=False, base=None, weight=1.0, chunk_rows=0):
     lib, binary, engine, L = mods
     n = binary.grid_size(cfg)
-    d = binary.make_desc(cfg, safe_mode=safe, chunk_rows=chunk_rows)
+    d = binary.make_desc(cfg, safe_mode=safe, chunk_rows=chunk_rows, xv=g["xv"], yv=g["yv"])
     D = engine.DeviceArray
     xv, yv = D(g["xv"]), D(g["yv"])
     u_in, u_init, br = D(to_field(u0)), D(to_field(g["u_init"])), D(g["br"])
@@ -117,7 +117,7 @@ def test_maximum_wavespeed(mods):
         g = golden(name)
         cfg, _ = cfg_of(binary, g)
         ss = g["stage_scalars"]
-        d = binary.make_desc(cfg)
+        d = binary.make_desc(cfg, xv=g["xv"], yv=g["yv"])
         D = engine.DeviceArray
         xv, yv, u = D(g["xv"]), D(g["yv"]), D(to_field(g["u_init"]))
         out = D.empty((1,))

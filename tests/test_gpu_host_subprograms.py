@@ -91,7 +91,7 @@ def test_cloud_subprogram_matches_reference(tmp_path, case, args):
     assert "kzps=" in stdout
 
 
-@pytest.mark.parametrize("case", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym"])
+@pytest.mark.parametrize("case", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b16_q", "binary_d2_b16_live"])
 def test_binary_subprogram_matches_reference(tmp_path, case):
     """The whole host path of `mara_hip binary`: set-up with the host libm (bit-exact vertices), dt choice, RK steps,
     totals and the run-loop message. Field tolerance as in tests/test_gpu_binary.py (device libm: 1e-12 of the field scale)."""
@@ -99,7 +99,7 @@ def test_binary_subprogram_matches_reference(tmp_path, case):
     g = golden(case)
     over = json.loads(str(g["config"]))
     nsteps = int(over.pop("nsteps"))
-    args = ["%s=%r" % (k, int(v) if float(v).is_integer() and k in ("depth", "block_size", "fixed_dt", "rk_order", "axisymmetric_cs2", "counter_rotate", "no_accretion_force") else float(v)) for k, v in over.items()]
+    args = ["%s=%r" % (k, int(v) if float(v).is_integer() and k in ("depth", "block_size", "fixed_dt", "rk_order", "axisymmetric_cs2", "counter_rotate", "no_accretion_force", "conserve_linear_p") else float(v)) for k, v in over.items()]
     stdout = run(["binary"] + args + ["max_iterations=%d" % nsteps, "tfinal=100.0"], str(tmp_path))
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     n = g["u_final"].shape[0]
@@ -116,8 +116,6 @@ def test_binary_subprogram_matches_reference(tmp_path, case):
 
 
 def test_binary_subprogram_rejects_what_is_not_built(tmp_path):
-    out = subprocess.run([EXE, "binary", "conserve_linear_p=0"], cwd=str(tmp_path), capture_output=True, text=True)
-    assert out.returncode == 1 and "advance_q" in out.stdout
     out = subprocess.run([EXE, "binary", "focus_factor=2.0", "depth=4"], cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 1 and "uniform-depth" in out.stdout
     out = subprocess.run([EXE, "binary", "reconstruct_method=weno"], cwd=str(tmp_path), capture_output=True, text=True)
