@@ -256,6 +256,93 @@ class SlabEulerStepper:
         return v
 
 
+
+class CloudHipStage:
+    """Stage function of the `cloud` path: mh_cloud_stage (C ABI) on the current torch stream."""
+
+    def __init__(self, desc, geom, inflow):
+        self.lib = L.load_library()
+        self.desc, self.geom, self.inflow = desc, geom, inflow
+        self.status = torch.zeros(2, dtype=torch.int32, device=geom.device)
+
+    def __call__(self, u_in, u_base, u_out, dt, weight, row_ranges):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        base = C.c_void_p(u_base.data_ptr()) if u_base is not None else None
+        for (a, b) in row_ranges:
+            if b > a:
+                L.check(self.lib.mh_cloud_stage(C.byref(self.desc), C.c_void_p(self.geom.data_ptr()), C.c_void_p(self.inflow.data_ptr()),
+                                                C.c_void_p(u_in.data_ptr()), base, C.c_void_p(u_out.data_ptr()), dt, weight, a, b,
+                                                C.c_void_p(self.status.data_ptr()), stream))
+
+
+class SlabCloudStepper(SlabEulerStepper):
+    """One rank's RADIAL slab of the `cloud` sub-program's grid (BASELINE config 4: slab decomposition + RCCL halo).
+
+    Same cut, layout, exchange and stream overlap as SlabEulerStepper; the stage is CloudProblem::advance
+    (src/subprog_cloud.cpp:511-584) on rows [row0, row1) of the global radial grid: rank 0 keeps the nozzle-inflow inner
+    boundary, the last rank the zero-gradient outer one, cut sides are MH_BC_EXTERNAL (ghost rows from the neighbour).
+    The kernel takes the GLOBAL radial vertices plus row_offset, so geometry factors are bit-identical to the single-domain
+    run; physical boundaries are applied inside the kernel (no stored ghost rows to fill)."""
+
+    def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3,
+                 rank=0, world=1, device="cuda", stage_fn=None, exchange=None, overlap=True, chunk_rows=0, edge_chunk_rows=8):
+        import numpy as np
+        rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
+        qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
+        nr, nq = len(rv) - 1, len(qv) - 1
+        self.global_shape = (nr, nq)
+        self.rank, self.world = rank, world
+        self.row0, self.row1 = partition_rows(nr, world, rank)
+        self.n0, self.n1 = self.row1 - self.row0, nq
+        if self.n0 < 2 * HALO and world > 1:
+            raise ValueError("slab of %d rows is thinner than two ghost layers" % self.n0)
+        self.rk_order = rk_order
+        self.device = torch.device(device)
+        self.exchange = exchange if exchange is not None else TorchDistExchange(rank, world, False)
+        has_lo = getattr(self.exchange, "lo", None) is not None
+        has_hi = getattr(self.exchange, "hi", None) is not None
+        d = L.CloudDesc(nr=self.n0, nq=nq, nr_global=nr, row_offset=self.row0, gamma=gamma, plm_theta=plm_theta,
+                        temperature_floor=temperature_floor, bc_lo0=L.BC_EXTERNAL if has_lo else L.BC_INFLOW,
+                        bc_hi0=L.BC_EXTERNAL if has_hi else L.BC_OUTFLOW, arith=L.ARITH_STRICT, chunk_rows=chunk_rows)
+        self.desc = d
+        self.edge_desc = L.CloudDesc.from_buffer_copy(d)
+        self.edge_desc.chunk_rows = edge_chunk_rows
+        self.has_neighbours = has_lo or has_hi
+        self.edge_rows = edge_chunk_rows if self.has_neighbours else 0
+        if 2 * self.edge_rows > self.n0:
+            self.edge_rows = max(HALO, self.n0 // 2) if self.has_neighbours else 0
+        self.r_vertices, self.q_vertices = rv, qv
+        self.inflow = torch.zeros((NQ, nq), dtype=torch.float64, device=self.device)       # [5][nq] primitives of the inner ghost row
+        if stage_fn is None:
+            if self.device.type != "cuda":
+                raise L.MaraHipError("SlabCloudStepper has no CPU path: pass device='cuda' (tests inject stage_fn)")
+            lib = L.load_library()
+            geom = np.zeros(lib.mh_cloud_geometry_doubles(C.byref(d)))
+            L.check(lib.mh_cloud_pack_geometry(C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p), geom.ctypes.data_as(C.c_void_p)))
+            self.geom = torch.from_numpy(geom).to(self.device)
+            self.stage = CloudHipStage(self.desc, self.geom, self.inflow)
+            self.edge_stage = CloudHipStage(self.edge_desc, self.geom, self.inflow)
+            self.edge_stage.status = self.stage.status
+        else:
+            self.stage = self.edge_stage = stage_fn
+        self.overlap = overlap and self.has_neighbours and self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device, priority=-1) if self.overlap else None
+        self.timers = None
+        self.graph, self.graph_dt = None, None
+        shape = (self.n0 + 2 * HALO, NQ, self.n1)
+        self.u = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        self.scratch = torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def set_inflow(self, inflow_prims):
+        """Nozzle primitives [nq][5] of the inner ghost row at the step-start time (src/subprog_cloud.cpp:466-493); every rank
+        may call it, only rank 0's kernel reads it."""
+        t = torch.as_tensor(inflow_prims, dtype=torch.float64)
+        assert tuple(t.shape) == (self.n1, NQ)
+        self.inflow.copy_(t.t().contiguous())
+
+    def fill_ghosts_physical_only(self, f):
+        pass        # inflow / zero-gradient rows are formed inside the kernel from the nozzle row / the last real row
+
 class NativeSlabStepper:
     """The native (C++/HIP/RCCL) slab stepper of libmara_hip.so: same cut, ghost layout and message pattern as
     SlabEulerStepper, but the exchange is RCCL called from the library and the whole step is one HIP graph.

@@ -32,3 +32,33 @@ class OracleStage:
         for a, b in row_ranges:
             out[2 + a:2 + b] = new[a:b].transpose(0, 2, 1)
         st.fill_ghosts_physical_only(u_out)
+
+
+class OracleCloudStage:
+    """`cloud` stage of one radial slab with the oracle: the slab plus its two ghost rows per cut side is advanced as a small
+    domain of its own (global vertices of those rows); rows within two of a cut are discarded - they are exactly the ghost
+    rows - so the oracle's physical boundary treatment at the artificial ends never reaches a kept row."""
+
+    def __init__(self, rv, qv, theta, tfloor, stepper_ref):
+        import mara_oracle
+        self.o = mara_oracle
+        self.rv, self.qv, self.theta, self.tfloor = rv, qv, theta, tfloor
+        self.stepper_ref = stepper_ref
+
+    def __call__(self, u_in, u_base, u_out, dt, weight, row_ranges):
+        st = self.stepper_ref[0]
+        n0 = st.n0
+        lo = 2 if st.desc.bc_lo0 == 2 else 0          # MH_BC_EXTERNAL
+        hi = 2 if st.desc.bc_hi0 == 2 else 0
+        ext = u_in.numpy()[2 - lo:n0 + 2 + hi].transpose(0, 2, 1).copy()
+        rv = self.rv[st.row0 - lo:st.row1 + hi + 1]
+        inflow = st.inflow.numpy().T.copy()[None]
+        adv, status = self.o.cloud_run(ext, rv, self.qv, inflow, dt, 1, rk=1, theta=self.theta, tfloor=self.tfloor)
+        assert status == 0
+        new = adv[lo:lo + n0]
+        if weight != 1.0:
+            base = u_base.numpy()[2:n0 + 2].transpose(0, 2, 1)
+            new = base * (1.0 - weight) + new * weight
+        out = u_out.numpy()
+        for a, b in row_ranges:
+            out[2 + a:2 + b] = new[a:b].transpose(0, 2, 1)

@@ -64,3 +64,45 @@ def test_slabs_over_gloo_match_single_domain(tmp_path, oracle, world, shape, bc,
         covered += b - a
     assert covered == shape[0]
     assert bits_equal(got, want), np.abs(got - want).max()
+
+
+def _cloud_worker(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import golden
+        from slab_helpers import OracleCloudStage
+        from mara3_amd.slab import SlabCloudStepper
+        g = golden(case)
+        ref = []
+        stage = OracleCloudStage(g["rv"], g["qv"], float(g["theta"]), float(g["tfloor"]), ref)
+        st = SlabCloudStepper(g["rv"], g["qv"], rk_order=int(g["rk"]), plm_theta=float(g["theta"]), temperature_floor=float(g["tfloor"]),
+                              rank=rank, world=world, device="cpu", stage_fn=stage, edge_chunk_rows=3)
+        ref.append(st)
+        st.load_slab(g["u0"][st.row0:st.row1])
+        for n in range(int(g["nsteps"])):
+            st.set_inflow(g["inflow"][n])
+            st.step(float(g["dt"]), 1)
+        np.save(os.path.join(out_dir, "slab_%d.npy" % rank), st.slab().numpy())
+        np.save(os.path.join(out_dir, "rows_%d.npy" % rank), np.array([st.row0, st.row1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "cloud_nr32_plm_rk2"), (3, "cloud_nr70_plm_rk2")])
+def test_cloud_radial_slabs_over_gloo_match_the_reference(tmp_path, oracle, world, case):
+    """BASELINE config 4's decomposition: radial slabs of the `cloud` grid, two ghost rows exchanged per stage. The gathered
+    result must equal the single-domain REFERENCE-generated vector bit for bit."""
+    from conftest import golden
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_cloud_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    g = golden(case)
+    got = np.empty_like(g["un"])
+    covered = 0
+    for r in range(world):
+        a, b = np.load(os.path.join(tmp_path, "rows_%d.npy" % r))
+        got[a:b] = np.load(os.path.join(tmp_path, "slab_%d.npy" % r))
+        covered += b - a
+    assert covered == g["un"].shape[0]
+    assert bits_equal(got, g["un"]), np.abs(got - g["un"]).max()
