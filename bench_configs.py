@@ -83,14 +83,30 @@ def run_c4(args):
     total = args.warmup + args.steps
     import tempfile
     with tempfile.TemporaryDirectory() as d:
-        cmd = [exe, "cloud", "nr=%d" % nr, "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=%d" % total, "profile=1", "outdir=out"]
-        p = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=1200)
-        if p.returncode != 0:
-            raise SystemExit(p.stdout[-2000:] + p.stderr[-2000:])
+        runs = {}
+        for arith in ("fast", "strict"):
+            cmd = [exe, "cloud", "nr=%d" % nr, "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=%d" % total, "profile=1",
+                   "outdir=out_" + arith, "arith=" + arith]
+            runs[arith] = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=1200)
+            if runs[arith].returncode != 0:
+                raise SystemExit(runs[arith].stdout[-2000:] + runs[arith].stderr[-2000:])
+    res = {}
+    for arith, p in runs.items():
+        res[arith] = c4_parse(args, p.stdout, nr, arith)
+    out = res["fast"]
+    out["arith_strict"] = {k: res["strict"][k] for k in ("value", "ms_per_step", "roofline")}
+    out["cpu_baseline"] = None if args.no_cpu_baseline else cloud_cpu_baseline()
+    return out
+
+
+def c4_parse(args, stdout, nr, arith):
+    class p:
+        pass
+    p.stdout = stdout
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
     shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches", p.stdout)
     avg_ms, nl = float(shape.group(1)), int(shape.group(2))
-    m = re.search(r"write out/final.bin", p.stdout)
+    m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
     vertices = (nr + 1) * (nq + 1)
     ms = [vertices / k for k in kz[args.warmup:]]   # the host prints vertices per ms, like the reference (:858)
@@ -101,13 +117,12 @@ def run_c4(args):
         "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, 1 GPU" % (nr, nq),
         "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % nr,
+        "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 arith=%s (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % (nr, arith),
                    "final_state_written": bool(m)},
         "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "cloud_stage_kernel<PLM> (mean of both RK2 stages)",
+                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith,
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
                      "timing": "HIP events on the launch stream, inside the timed region"},
-        "cpu_baseline": None if args.no_cpu_baseline else cloud_cpu_baseline(),
     }
 
 

@@ -349,7 +349,7 @@ static int check_cloud(const mh_cloud_desc* d)
     if (! d) { set_error("null descriptor"); return MH_E_INVALID; }
     if (d->nr < 2 || d->nq < 3) { set_error("cloud: need nr >= 2 and nq >= 3"); return MH_E_INVALID; }
     if (d->row_offset < 0 || d->row_offset + d->nr > d->nr_global) { set_error("cloud: slab [%d,%d) outside the global grid of %d rows", d->row_offset, d->row_offset + d->nr, d->nr_global); return MH_E_INVALID; }
-    if (d->arith != MH_ARITH_STRICT) { set_error("cloud: only MH_ARITH_STRICT is built"); return MH_E_INVALID; }
+    if (d->arith != MH_ARITH_STRICT && d->arith != MH_ARITH_FAST) { set_error("cloud: unknown arith mode %d", d->arith); return MH_E_INVALID; }
     if (d->bc_lo0 != MH_BC_INFLOW && d->bc_lo0 != MH_BC_EXTERNAL) { set_error("cloud: bc_lo0 must be inflow or external"); return MH_E_INVALID; }
     if (d->bc_hi0 != MH_BC_OUTFLOW && d->bc_hi0 != MH_BC_EXTERNAL) { set_error("cloud: bc_hi0 must be outflow or external"); return MH_E_INVALID; }
     if ((d->bc_lo0 == MH_BC_INFLOW) != (d->row_offset == 0) || (d->bc_hi0 == MH_BC_OUTFLOW) != (d->row_offset + d->nr == d->nr_global)) { set_error("cloud: physical boundary flags do not match the slab position"); return MH_E_INVALID; }

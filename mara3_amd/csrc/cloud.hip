@@ -25,6 +25,7 @@
 #include "launch.hpp"
 #include "euler_device.hpp"
 #include "srhd_device.hpp"
+#include "srhd_device_fast.hpp"
 
 namespace mh {
 
@@ -97,8 +98,8 @@ __device__ inline double cell_volume(const RowGeom& rg, const ColGeom& cg, const
     return divide(rg.d3 * cg.dmu * 2 * M_PI, three);
 }
 
-template<bool PLM, bool COMBINE>
-__global__ __launch_bounds__(CWAVE * CWAVES_PER_BLOCK, 2)
+template<class S, bool PLM, bool COMBINE>
+__global__ __launch_bounds__(CWAVE * CWAVES_PER_BLOCK, S::min_waves_per_simd)
 void cloud_stage_kernel(CloudParams p)
 {
     int b = blockIdx.x;
@@ -129,22 +130,44 @@ void cloud_stage_kernel(CloudParams p)
     auto row_off = [row_stride] (int r) { return (long) (r + CHALO) * row_stride; };
     int bad = 0;
 
-    // primitive of a stored row (real row, or a ghost row received from the neighbouring slab)
-    auto prim_of_row = [&] (int r) -> State5
+    // the five conserved variables of a stored row (clamped to the stored range: rows -2 .. n0+1)
+    auto load_raw = [&] (int r) -> State5
+    {
+        const int rr = min(max(r, -CHALO), p.n0 + CHALO - 1);
+        State5 U;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) U[q] = in[q * plane + row_off(rr)];
+        return U;
+    };
+    // primitive of a stored row (real row, or a ghost row received from the neighbouring slab) from its loaded variables
+    auto prim_of_raw = [&] (int r, const State5& raw) -> State5
     {
         const RowGeom rg = row_geometry(p.rv, p.row_offset + r);
         double x[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) x[q] = in[q * plane + row_off(r)];
-        divide_group<5>(x, make_recip(cell_volume(rg, cg, three), 1.0));
+        for (int q = 0; q < 5; ++q) x[q] = raw[q];
+        S::to_density(x, cell_volume(rg, cg, three));
         State5 U, P;
 #pragma unroll
         for (int q = 0; q < 5; ++q) U[q] = x[q];
-        const int st = srhd::recover_primitive(U, g, tfloor, P);
+        const int st = S::c2p(U, g, tfloor, P);
         if (r >= 0 && r < p.n0) bad |= st;
         return P;
     };
-    // primitive of row r with the physical boundary conditions applied
+    auto prim_of_row = [&] (int r) -> State5 { return prim_of_raw(r, load_raw(r)); };
+    // primitive of row r with the physical boundary conditions applied; `raw` = its variables if already loaded
+    auto prim_bc_raw = [&] (int r, const State5& last, const State5& raw) -> State5
+    {
+        if (r < 0 && p.bc_lo0 != MH_BC_EXTERNAL)
+        {
+            State5 P;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) P[q] = p.inflow[(long) q * p.n1 + jc];
+            return P;
+        }
+        if (r >= p.n0 && p.bc_hi0 != MH_BC_EXTERNAL) return last;
+        return prim_of_raw(r, raw);
+    };
     auto prim_bc = [&] (int r, const State5& last) -> State5
     {
         if (r < 0 && p.bc_lo0 != MH_BC_EXTERNAL)
@@ -168,49 +191,55 @@ void cloud_stage_kernel(CloudParams p)
         P1 = prim_bc(r0 + 1, P0);
         if constexpr (PLM)
         {
-            G0 = plm_gradient(Pb, P0, P1, theta);
+            G0 = S::plm(Pb, P0, P1, theta);
             State5 Gb;
             if (r0 == 0 && phys_lo) Gb = times_zero(G0);                       // extend_zeros on G
-            else                    Gb = plm_gradient(prim_bc(r0 - 2, dummy), Pb, P0, theta);
-            Fx_lo = srhd::riemann_hlle<0>(face_plus(Pb, Gb), face_minus(P0, G0), g);
+            else                    Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, theta);
+            Fx_lo = S::template hlle<0>(face_plus(Pb, Gb), face_minus(P0, G0), g);
         }
         else
         {
-            Fx_lo = srhd::riemann_hlle<0>(Pb, P0, g);
+            Fx_lo = S::template hlle<0>(Pb, P0, g);
         }
     }
 
+    // software pipeline: row r+2 (needed now, for the primitives of the face after next) was requested one iteration ago;
+    // row r+3 is requested at the top of the iteration
+    State5 Uahead = load_raw(r0 + 2);
     for (int r = r0; r < r1; ++r)
     {
+        const State5 Unext = load_raw(r + 3);
+
         // ---- radial face r+1/2
-        const State5 P2 = prim_bc(r + 2, P1);
+        const State5 P2 = prim_bc_raw(r + 2, P1, Uahead);
+        Uahead = Unext;
         State5 G1, Fx_hi;
         if constexpr (PLM)
         {
             if (r + 1 == p.n0 && phys_hi) G1 = times_zero(G0);
-            else                          G1 = plm_gradient(P0, P1, P2, theta);
-            Fx_hi = srhd::riemann_hlle<0>(face_plus(P0, G0), face_minus(P1, G1), g);
+            else                          G1 = S::plm(P0, P1, P2, theta);
+            Fx_hi = S::template hlle<0>(face_plus(P0, G0), face_minus(P1, G1), g);
         }
         else
         {
-            Fx_hi = srhd::riemann_hlle<0>(P0, P1, g);
+            Fx_hi = S::template hlle<0>(P0, P1, g);
         }
 
         // ---- polar faces: this lane computes its LEFT face; pole faces carry the neighbouring flux times zero
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM)
         {
-            const State5 Graw = plm_gradient(dpp_left(P0), P0, dpp_right(P0), theta);
+            const State5 Graw = S::plm(dpp_left(P0), P0, dpp_right(P0), theta);
             const State5 Gl = dpp_left(Graw), Gr = dpp_right(Graw);
             State5 Gy;
 #pragma unroll
             for (int q = 0; q < 5; ++q) Gy[q] = pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]);
             const State5 SL = dpp_left(face_plus(P0, Gy));
-            Fy_lo = srhd::riemann_hlle<1>(SL, face_minus(P0, Gy), g);
+            Fy_lo = S::template hlle<1>(SL, face_minus(P0, Gy), g);
         }
         else
         {
-            Fy_lo = srhd::riemann_hlle<1>(dpp_left(P0), P0, g);
+            Fy_lo = S::template hlle<1>(dpp_left(P0), P0, g);
         }
         Fy_hi = dpp_right(Fy_lo);
         if (pole_lo) Fy_lo = times_zero(Fy_hi);
@@ -223,18 +252,15 @@ void cloud_stage_kernel(CloudParams p)
         const double nAr_hi = -(rg.rr_hi * cg.dmu * 2 * M_PI);
         const double nAq_lo = -(rg.rcdr * cg.sin_lo * 2 * M_PI);
         const double nAq_hi = -(rg.rcdr * cg.sin_hi * 2 * M_PI);
-        const State5 S = srhd::source_terms(P0, rg.rc, cg.cot, g);
+        const State5 Src = S::source(P0, rg.rc, cg.cot, g);
 
         State5 Un;
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double lr = Fx_hi[q] * nAr_hi - Fx_lo[q] * nAr_lo;
-            const double lq = Fy_hi[q] * nAq_hi - Fy_lo[q] * nAq_lo;
-            const double s0 = S[q] * dv;
             const double u0 = in[q * plane + row_off(r)];
-            const double u1 = u0 + (lr + lq + s0) * p.dt;
-            if constexpr (COMBINE) Un[q] = p.u_base[jc + q * plane + row_off(r)] * (1.0 - p.weight) + u1 * p.weight;
+            const double u1 = S::update(u0, Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], nAr_lo, nAr_hi, nAq_lo, nAq_hi, Src[q], dv, p.dt);
+            if constexpr (COMBINE) Un[q] = S::combine(p.u_base[jc + q * plane + row_off(r)], u1, p.weight);
             else                   Un[q] = u1;
         }
         if (writes)
@@ -284,10 +310,20 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     const int nwaves = p.nstrips * p.nchunks;
     const dim3 grid((nwaves + CWAVES_PER_BLOCK - 1) / CWAVES_PER_BLOCK), block(CWAVE * CWAVES_PER_BLOCK);
     const bool plm = d->plm_theta >= 0.0, combine = weight != 1.0;
-    if (plm && combine)       hipLaunchKernelGGL((cloud_stage_kernel<true, true>), grid, block, 0, stream, p);
-    else if (plm)             hipLaunchKernelGGL((cloud_stage_kernel<true, false>), grid, block, 0, stream, p);
-    else if (combine)         hipLaunchKernelGGL((cloud_stage_kernel<false, true>), grid, block, 0, stream, p);
-    else                      hipLaunchKernelGGL((cloud_stage_kernel<false, false>), grid, block, 0, stream, p);
+    if (d->arith == MH_ARITH_FAST)
+    {
+        if (plm && combine)       hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, true, true>), grid, block, 0, stream, p);
+        else if (plm)             hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, true, false>), grid, block, 0, stream, p);
+        else if (combine)         hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, false, true>), grid, block, 0, stream, p);
+        else                      hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, false, false>), grid, block, 0, stream, p);
+    }
+    else
+    {
+        if (plm && combine)       hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrict, true, true>), grid, block, 0, stream, p);
+        else if (plm)             hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrict, true, false>), grid, block, 0, stream, p);
+        else if (combine)         hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrict, false, true>), grid, block, 0, stream, p);
+        else                      hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrict, false, false>), grid, block, 0, stream, p);
+    }
     return hipGetLastError();
 }
 

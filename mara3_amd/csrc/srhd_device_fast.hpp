@@ -1,0 +1,170 @@
+// MH_ARITH_FAST device physics for mara::srhd on gfx950: the formulas of srhd_device.hpp (same reference lines) with the
+// arithmetic freedoms of euler_device_fast.hpp - x / d as x * (v_rcp_f64 + two Newton steps), sqrt via v_rsq_f64 +
+// Goldschmidt, explicit FMAs, no literal 0/1 normal-vector products. NOT bit-exact: bound by the north star's tolerance
+// (conserved-variable L1 <= 1e-12 relative to the field scale, asserted in tests/test_gpu_srhd_cloud.py::test_fast_*).
+// The Newton iteration of recover_primitive keeps the reference's start value, update and stopping rule, so it walks the
+// same sequence of iterates up to rounding; where |f| lands within rounding of the 1e-10 threshold one more or one fewer
+// step is taken, which moves p by O(f / f') ~ 1e-10 p in that cell - rare, and far inside the L1 bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "euler_device_fast.hpp"
+#include "srhd_device.hpp"
+
+namespace mh {
+namespace srhd_fast {
+
+using srhd::Gamma;
+
+__device__ inline int recover_primitive(const State5& U, const Gamma& g, double temperature_floor, State5& P)
+{
+    const double gm = g.gamma;
+    const double D = U[0], tau = U[4];
+    const double SS = __builtin_fma(U[3], U[3], __builtin_fma(U[2], U[2], U[1] * U[1]));
+    const double rD = fast::rcp_nr(D);
+    bool solution_found = false;
+    int iteration = 0;
+    double W0 = 1.0, rW0 = 1.0;
+    double p = 0.0;
+
+    while (iteration < 50)
+    {
+        const double x = tau + D + p;
+        const double rx = fast::rcp_nr(x);
+        const double v2 = __builtin_fmin(SS * rx * rx, 1.0 - 1e-10);
+        const double W2 = fast::rcp_nr(1.0 - v2);
+        double W, rW;
+        fast::sqrt_rsqrt(W2, W, rW);
+        const double e = __builtin_fma(p, 1.0 - W2, __builtin_fma(D, 1.0 - W, tau)) * rD * rW;
+        const double d = D * rW;
+        const double h = 1.0 + e + p * W * rD;
+        const double cs2 = gm * p * fast::rcp_nr(d * h);
+        const double f = __builtin_fma(d * e, gm - 1.0, -p);
+        const double gg = __builtin_fma(v2, cs2, -1.0);
+        p = __builtin_fma(-f, fast::rcp_nr(gg), p);
+        if (fabs(f) < 1e-10)
+        {
+            W0 = W;
+            rW0 = rW;
+            solution_found = true;
+            break;
+        }
+        ++iteration;
+    }
+    if (temperature_floor > 0.0) p = __builtin_fmax(p, temperature_floor * D * rW0);
+    const double s = W0 * fast::rcp_nr(tau + D + p);
+    P[0] = D * rW0;
+    P[1] = s * U[1];
+    P[2] = s * U[2];
+    P[3] = s * U[3];
+    P[4] = p;
+    int status = 0;
+    if (! solution_found) status |= MH_STATUS_C2P_FAILED;
+    if (P[0] <= 0.0) status |= MH_STATUS_NEG_DENSITY;
+    if (P[4] <= 0.0) status |= MH_STATUS_NEG_PRESSURE;
+    if (W0 != W0) status |= MH_STATUS_NAN;
+    return status;
+}
+
+template<int AXIS>
+__device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, State5& F, double& lam_m, double& lam_p)
+{
+    const double uu = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    double W, rW;
+    fast::sqrt_rsqrt(1.0 + uu, W, rW);
+    const double H = __builtin_fma(P[4], g.hfac, P[0]);
+    const double rH = fast::rcp_nr(H);
+    const double D = P[0] * W;
+    const double p = P[4];
+    const double Dh = H * W;                       // D h = rho W (H / rho)
+    U[0] = D;
+    U[1] = Dh * P[1];
+    U[2] = Dh * P[2];
+    U[3] = Dh * P[3];
+    U[4] = __builtin_fma(Dh, W, -p) - D;
+    const double v = P[1 + AXIS] * rW;
+    F[0] = v * U[0];
+    F[1] = AXIS == 0 ? __builtin_fma(v, U[1], p) : v * U[1];
+    F[2] = AXIS == 1 ? __builtin_fma(v, U[2], p) : v * U[2];
+    F[3] = AXIS == 2 ? __builtin_fma(v, U[3], p) : v * U[3];
+    F[4] = v * (U[4] + p);
+    const double c2 = g.gamma * p * rH;
+    const double vv = uu * rW * rW;                // uu / (1 + uu)
+    const double v2 = v * v;
+    const double k0 = fast::sqrt_fast(c2 * (1 - vv) * (1 - vv * c2 - v2 * (1 - c2)));
+    const double rden = fast::rcp_nr(1 - vv * c2);
+    const double a = v * (1 - c2);
+    lam_m = (a - k0) * rden;
+    lam_p = (a + k0) * rden;
+}
+
+template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const Gamma& g)
+{
+    State5 Ul, Ur, Fl, Fr;
+    double alm, alp, arm, arp;
+    side_fast<AXIS>(Pl, g, Ul, Fl, alm, alp);
+    side_fast<AXIS>(Pr, g, Ur, Fr, arm, arp);
+    const double ap = __builtin_fmax(0.0, __builtin_fmax(alp, arp));
+    const double am = __builtin_fmin(0.0, __builtin_fmin(alm, arm));
+    const double rden = fast::rcp_nr(ap - am);
+    const double apam = ap * am;
+    State5 F;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        F[q] = __builtin_fma(-(Ul[q] - Ur[q]), apam, __builtin_fma(-Fr[q], am, Fl[q] * ap)) * rden;
+    return F;
+}
+
+__device__ inline State5 source_terms(const State5& P, double r, double cotq, const Gamma& g)
+{
+    const double ur = P[1], uq = P[2], up = P[3], pg = P[4];
+    const double H = __builtin_fma(P[4], g.hfac, P[0]);
+    const double rr = fast::rcp_nr(r);
+    State5 S;
+    S[0] = 0.0;
+    S[1] = __builtin_fma(H, __builtin_fma(uq, uq, up * up), 2.0 * pg) * rr;
+    S[2] = __builtin_fma(H, __builtin_fma(up * up, cotq, -ur * uq), cotq * pg) * rr;
+    S[3] = -up * H * __builtin_fma(uq, cotq, ur) * rr;
+    S[4] = 0.0;
+    return S;
+}
+
+} // namespace srhd_fast
+
+// ---- arithmetic policies of the cloud kernel ---------------------------------------------------------------------
+struct SrhdStrict
+{
+    static constexpr int min_waves_per_simd = 2;      // 163-167 VGPRs: three waves fit anyway
+    static __device__ inline void to_density(double (&x)[5], double dv) { divide_group<5>(x, make_recip(dv, 1.0)); }
+    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return plm_gradient(l, c, r, th); }
+    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd::riemann_hlle<AXIS>(Pl, Pr, g); }
+    static __device__ inline State5 source(const State5& P, double r, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
+    // u0 + ((Fr_hi (-dAr_hi) - Fr_lo (-dAr_lo)) + (Fq_hi (-dAq_hi) - Fq_lo (-dAq_lo)) + S dv) dt     src/subprog_cloud.cpp:572-574
+    static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
+    {
+        const double lr = fxh * nArh - fxl * nArl;
+        const double lq = fyh * nAqh - fyl * nAql;
+        const double s0 = s * dv;
+        return u0 + (lr + lq + s0) * dt;
+    }
+    static __device__ inline double combine(double base, double u1, double w) { return base * (1.0 - w) + u1 * w; }
+};
+
+struct SrhdFast
+{
+    static constexpr int min_waves_per_simd = 3;      // hold the allocation at 168 VGPRs
+    static __device__ inline void to_density(double (&x)[5], double dv) { const double r = fast::rcp_nr(dv); for (int q = 0; q < 5; ++q) x[q] *= r; }
+    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive(U, g, tf, P); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return fast::plm_gradient(l, c, r, th); }
+    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd_fast::riemann_hlle<AXIS>(Pl, Pr, g); }
+    static __device__ inline State5 source(const State5& P, double r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms(P, r, cot, g); }
+    static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
+    {
+        const double lr = __builtin_fma(fxh, nArh, -fxl * nArl);
+        const double lq = __builtin_fma(fyh, nAqh, -fyl * nAql);
+        return __builtin_fma(__builtin_fma(s, dv, lr + lq), dt, u0);
+    }
+    static __device__ inline double combine(double base, double u1, double w) { return __builtin_fma(u1, w, base * (1.0 - w)); }
+};
+
+} // namespace mh

@@ -126,14 +126,15 @@ class CloudSolver:
     """Host mirror of CloudProblem's (solution_t, advance, next_solution) (src/subprog_cloud.cpp): vertices,
     cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
 
-    def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0):
+    def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0,
+                 arith="strict"):
         self.lib = L.load_library()
         self.rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
         self.qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
         self.nr, self.nq = self.rv.size - 1, self.qv.size - 1
         d = L.CloudDesc(nr=self.nr, nq=self.nq, nr_global=self.nr, row_offset=0, gamma=gamma, plm_theta=plm_theta,
-                        temperature_floor=temperature_floor, bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith=L.ARITH_STRICT,
-                        chunk_rows=chunk_rows)
+                        temperature_floor=temperature_floor, bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW,
+                        arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith], chunk_rows=chunk_rows)
         self.ctx = C.c_void_p()
         L.check(self.lib.mh_create(C.byref(self.ctx), device))
         L.check(self.lib.mh_cloud_configure(self.ctx, C.byref(d), self.rv.ctypes.data_as(C.c_void_p),

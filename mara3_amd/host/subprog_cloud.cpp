@@ -43,6 +43,7 @@ mara::config_t config_template()
     .item("reconstruct_method", 2)
     .item("plm_theta", 1.2)
     .item("temperature_floor", 1e-8)
+    .item("arith", "strict")         // strict (bit-identical to the reference) | fast (L1 <= 1e-12); not a reference option
     .item("profile", 0)              // print the average stage-kernel time from HIP events at the end; not a reference option
     .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
     .item("write_inflow", 0)         // also dump the nozzle row of the first step (tests)
@@ -132,7 +133,7 @@ public:
         if (cfg.get_int("reconstruct_method") != 1 && cfg.get_int("reconstruct_method") != 2) throw std::invalid_argument("reconstruct_method must be 1 or 2");
         d.temperature_floor = cfg.get_double("temperature_floor");
         d.bc_lo0 = MH_BC_INFLOW; d.bc_hi0 = MH_BC_OUTFLOW;
-        d.arith = MH_ARITH_STRICT;
+        d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
 
         mh_ctx* ctx = nullptr;
         host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");

@@ -285,7 +285,8 @@ class SlabCloudStepper(SlabEulerStepper):
     run; physical boundaries are applied inside the kernel (no stored ghost rows to fill)."""
 
     def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3,
-                 rank=0, world=1, device="cuda", stage_fn=None, exchange=None, overlap=True, chunk_rows=0, edge_chunk_rows=8):
+                 rank=0, world=1, device="cuda", stage_fn=None, exchange=None, overlap=True, chunk_rows=0, edge_chunk_rows=8,
+                 arith="strict"):
         import numpy as np
         rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
         qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
@@ -303,7 +304,8 @@ class SlabCloudStepper(SlabEulerStepper):
         has_hi = getattr(self.exchange, "hi", None) is not None
         d = L.CloudDesc(nr=self.n0, nq=nq, nr_global=nr, row_offset=self.row0, gamma=gamma, plm_theta=plm_theta,
                         temperature_floor=temperature_floor, bc_lo0=L.BC_EXTERNAL if has_lo else L.BC_INFLOW,
-                        bc_hi0=L.BC_EXTERNAL if has_hi else L.BC_OUTFLOW, arith=L.ARITH_STRICT, chunk_rows=chunk_rows)
+                        bc_hi0=L.BC_EXTERNAL if has_hi else L.BC_OUTFLOW,
+                        arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith], chunk_rows=chunk_rows)
         self.desc = d
         self.edge_desc = L.CloudDesc.from_buffer_copy(d)
         self.edge_desc.chunk_rows = edge_chunk_rows
