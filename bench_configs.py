@@ -34,7 +34,16 @@ def run_c3(args):
     from mara3_amd import binary
     cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
     n = binary.grid_size(cfg)
-    s = binary.BinarySolver(cfg)
+    fast = c3_run(args, binary, cfg, n, "fast")
+    fast["arith_strict"] = {k: v for k, v in c3_run(args, binary, cfg, n, "strict").items() if k in ("value", "ms_per_step", "roofline")}
+    if not args.no_cpu_baseline:
+        fast["cpu_baseline"] = c3_cpu_baseline(binary, cfg)
+    return fast
+
+
+def c3_run(args, binary, cfg, n, arith):
+    import numpy as np
+    s = binary.BinarySolver(cfg, arith=arith)
     s.next(args.warmup)
     t0 = time.perf_counter()
     safe = s.next(args.steps)
@@ -52,7 +61,7 @@ def run_c3(args):
         "value": n * n * args.steps / elapsed / 1e6, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "binary depth=5 block_size=64 focus_factor=1e9 fixed_dt=1 rk_order=2 plm_theta=1.8, other run_config defaults",
+        "config": {"workload": "binary depth=5 block_size=64 focus_factor=1e9 fixed_dt=1 rk_order=2 plm_theta=1.8, other run_config defaults; arith=" + arith,
                    "safe_mode_steps": safe, "finite_and_positive": ok, "iteration": st["iteration"],
                    "note": "one host synchronisation per step (2 x 18 totals + status word)"},
         "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -61,7 +70,11 @@ def run_c3(args):
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
                      "timing": "HIP events on the launch stream, 5 extra steps after the timed region"},
     }
-    if not args.no_cpu_baseline:
+    return out
+
+
+def c3_cpu_baseline(binary, cfg):
+    if True:
         mo = oracle()
         ocfg = mo.binary_config(depth=4, block_size=64, fixed_dt=1)
         xv = mo.binary_vertices(ocfg)
@@ -72,9 +85,8 @@ def run_c3(args):
         mo.binary_advance_u(ocfg, xv, xv, u1, u0, br, bodies, dt)
         t = time.perf_counter() - t0
         m = len(xv) - 1
-        out["cpu_baseline"] = {"value": m * m / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
-                               "sample": "one RK2 step (two advance_u stages) at %dx%d (depth=4 block_size=64), oracle/mara_oracle_binary.c, 1 thread" % (m, m)}
-    return out
+        return {"value": m * m / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+                "sample": "one RK2 step (two advance_u stages) at %dx%d (depth=4 block_size=64), oracle/mara_oracle_binary.c, 1 thread" % (m, m)}
 
 
 def run_c4(args):

@@ -299,7 +299,7 @@ typedef struct mh_binary_desc
     int32_t chunk_rows;             /* rows marched per wavefront; 0 = default */
     int32_t angmom_form;            /* 0: conserve_linear_p = 1, fields (Sigma, px, py), advance_u;
                                        1: conserve_linear_p = 0, fields (Sigma, Sigma s_r, Sigma l_z), advance_q (scheme.cpp:906-1020) */
-    int32_t reserved;
+    int32_t arith;                  /* MH_ARITH_STRICT (reference operation order, IEEE division / sqrt) or MH_ARITH_FAST */
     double  gst_suppr_radius;       /* source_term_softening * min(dx, dy) (solver_data.cpp:91); advance_q only */
 } mh_binary_desc;
 

@@ -48,7 +48,7 @@ class BinaryDesc(C.Structure):
                 ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
                 ("sink_radius", C.c_double), ("softening_radius", C.c_double), ("density_floor", C.c_double),
                 ("plm_theta", C.c_double), ("axisymmetric_cs2", C.c_int32), ("chunk_rows", C.c_int32), ("angmom_form", C.c_int32),
-                ("reserved", C.c_int32), ("gst_suppr_radius", C.c_double)]
+                ("arith", C.c_int32), ("gst_suppr_radius", C.c_double)]
 
 
 class OrbitalElements(C.Structure):

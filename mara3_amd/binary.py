@@ -70,7 +70,7 @@ def gst_suppr_radius(cfg, xv, yv):
     return float(cfg["source_term_softening"]) * min(float(np.diff(xv).min()), float(np.diff(yv).min()))
 
 
-def make_desc(cfg, safe_mode=False, chunk_rows=0, xv=None, yv=None):
+def make_desc(cfg, safe_mode=False, chunk_rows=0, xv=None, yv=None, arith="strict"):
     """conserve_linear_p = 0 selects the angular-momentum form (advance_q) and needs the vertices for gst_suppr_radius."""
     d = L.BinaryDesc()
     d.n = grid_size(cfg)
@@ -81,6 +81,7 @@ def make_desc(cfg, safe_mode=False, chunk_rows=0, xv=None, yv=None):
     d.plm_theta = 0.0 if safe_mode else float(cfg["plm_theta"])
     d.axisymmetric_cs2 = int(cfg["axisymmetric_cs2"])
     d.chunk_rows = int(chunk_rows)
+    d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
     d.angmom_form = 0 if int(cfg["conserve_linear_p"]) else 1
     if d.angmom_form:
         xv = vertices(cfg) if xv is None else np.ascontiguousarray(xv, dtype=np.float64)
@@ -120,7 +121,8 @@ def state_as_dict(s):
 class BinarySolver:
     """binary::state_t's solution + next_solution on one MI355X (uniform-depth tree)."""
 
-    def __init__(self, cfg, device=0, xv=None, yv=None, u_init=None, buffer_rate=None, recommended_time_step=None, chunk_rows=0):
+    def __init__(self, cfg, device=0, xv=None, yv=None, u_init=None, buffer_rate=None, recommended_time_step=None, chunk_rows=0,
+                 arith="strict"):
         self.lib = L.load_library()
         self.cfg = cfg
         self.n = grid_size(cfg)
@@ -131,7 +133,7 @@ class BinarySolver:
         self.u_init = np.ascontiguousarray(u_init, dtype=np.float64)
         self.buffer_rate = np.ascontiguousarray(buffer_rate, dtype=np.float64)
         assert self.u_init.shape == (self.n, self.n, 3) and self.buffer_rate.shape == (self.n, self.n)
-        self.desc = make_desc(cfg, chunk_rows=chunk_rows, xv=self.xv, yv=self.yv)
+        self.desc = make_desc(cfg, chunk_rows=chunk_rows, xv=self.xv, yv=self.yv, arith=arith)
         run = L.BinaryRun()
         run.rk_order = int(cfg["rk_order"])
         run.fixed_dt = int(cfg["fixed_dt"])

@@ -39,6 +39,7 @@
 #include <type_traits>
 #include "launch.hpp"
 #include "euler_device.hpp"
+#include "euler_device_fast.hpp"
 #include "iso2d_device.hpp"
 
 namespace mh {
@@ -121,35 +122,173 @@ __device__ inline double load_row1(const double* row, int n, unsigned lane_bytes
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, 0, 0));
 }
 
-// ---- position-dependent closures of the scheme ------------------------------------------------------------------
-// cs2_at_position :160-175 with grav_phi_field :101-111
+// ---- arithmetic policies ----------------------------------------------------------------------------------------------
+// BinStrict: reference operation order, IEEE division / sqrt (shared-denominator form), no contraction.
+// BinFast:   MH_ARITH_FAST as in euler_device_fast.hpp: reciprocal + two Newton steps per denominator, rsq-Goldschmidt square
+//            roots (1 / sqrt directly where the reference divides by a root), FMAs, min/max limiter. Tolerance as STRICT's
+//            (which already differs from the reference through libm): 1e-12 of the field scale, tests/test_gpu_binary.py.
+struct BinStrict
+{
+    static constexpr int arith = MH_ARITH_STRICT;
+    struct Ctx { Recip rmach, rh; };
+    static __device__ inline Ctx make(const BinaryConsts& c) { return {make_recip(c.mach, 1.0), make_recip(c.h, 1.0)}; }
+
+    // cs2_at_position :160-175 with grav_phi_field :101-111
+    static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
+    {
+        if (c.axisym)
+        {
+            const double a = 1.0 / sqrt(x * x + y * y);
+            return divide(divide(a, k.rmach), k.rmach);
+        }
+        const double d0 = x - c.body[1], d1 = y - c.body[2];
+        const double e0 = x - c.body[6], e1 = y - c.body[7];
+        const double phi1 = (-1.0 * c.body[0]) / sqrt(d0 * d0 + d1 * d1 + c.rs2);
+        const double phi2 = (-1.0 * c.body[5]) / sqrt(e0 * e0 + e1 * e1 + c.rs2);
+        return divide(divide(-(phi1 + phi2), k.rmach), k.rmach);
+    }
+    // nu_at_position :177-193
+    static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
+    {
+        const double radius = sqrt(x * x + y * y);
+        const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
+        if (c.nu > 0.0)
+            return profile * c.nu;
+        return profile * c.alpha * sqrt(cs2v) * divide(radius, k.rmach);
+    }
+    template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v) { return iso2d::riemann_hlle<AXIS>(pl, pr, cs2v, cs2v); }
+    static __device__ inline State3 plm_per_length(const State3& l, const State3& m, const State3& r, double theta, const Ctx& k)
+    {
+        State3 g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = plm_gradient(l[q], m[q], r[q], theta);
+        divide_group<3>(g.v, k.rh);
+        return g;
+    }
+    // iso2d::recover_primitive(U) physics_iso2d.hpp:351-362, or (Q, x) :376-390 at the centre of the cell the data belongs to
+    template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
+    {
+        State3 P;
+        if constexpr (QFORM) iso2d::recover_primitive_angmom(U, xc, yc, P);
+        else                 iso2d::recover_primitive(U, P);
+        return P;
+    }
+    // grav_vdot_field :85-95 times sigma (:369-370)
+    static __device__ inline void gravity(const BinaryConsts& c, int b, double d0, double d1, double sigma, double (&fg)[2])
+    {
+        const double r2s = d0 * d0 + d1 * d1 + c.rs2;
+        const double den = r2s * sqrt(r2s);                     // pow<3, 2>
+        double a[2] = {-d0, -d1};
+        divide_group<2>(a, make_recip(den, 1.0));
+        fg[0] = (a[0] * 1.0 * c.body[5 * b]) * sigma;
+        fg[1] = (a[1] * 1.0 * c.body[5 * b]) * sigma;
+    }
+    static __device__ inline double sink_a2(const BinaryConsts& c, double d0, double d1) { return (d0 * d0 + d1 * d1) / c.s2 / 2.0; }
+    static __device__ inline void over_area(double (&l)[3], double dA) { divide_group<3>(l, make_recip(dA, 1.0)); }
+};
+
+struct BinFast
+{
+    static constexpr int arith = MH_ARITH_FAST;
+    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2; };
+    static __device__ inline Ctx make(const BinaryConsts& c)
+    {
+        const double im = fast::rcp_nr(c.mach);
+        return {im, im * im, fast::rcp_nr(c.h), fast::rcp_nr(2.0 * c.s2)};
+    }
+    static __device__ inline double rsqrt(double x) { double g, h2; fast::sqrt_rsqrt(x, g, h2); return h2; }
+    static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
+    {
+        if (c.axisym) return rsqrt(__builtin_fma(x, x, y * y)) * k.inv_mach2;
+        const double d0 = x - c.body[1], d1 = y - c.body[2];
+        const double e0 = x - c.body[6], e1 = y - c.body[7];
+        const double r1 = rsqrt(__builtin_fma(d0, d0, __builtin_fma(d1, d1, c.rs2)));
+        const double r2 = rsqrt(__builtin_fma(e0, e0, __builtin_fma(e1, e1, c.rs2)));
+        return __builtin_fma(c.body[0], r1, c.body[5] * r2) * k.inv_mach2;
+    }
+    static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
+    {
+        const double radius = fast::sqrt_fast(__builtin_fma(x, x, y * y));
+        const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
+        if (c.nu > 0.0)
+            return profile * c.nu;
+        return profile * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);
+    }
+    // iso2d::riemann_hlle physics_iso2d.hpp:488-506 with one sound speed for both sides (the scheme passes cs2 twice, :288)
+    template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v)
+    {
+        const double cs = fast::sqrt_fast(cs2v);
+        const double vl = pl[1 + AXIS], vr = pr[1 + AXIS];
+        const double ap = __builtin_fmax(0.0, __builtin_fmax(vl + cs, vr + cs));
+        const double am = __builtin_fmin(0.0, __builtin_fmin(vl - cs, vr - cs));
+        const double rden = fast::rcp_nr(ap - am), apam = ap * am;
+        State3 F;
+        const State3* side[2] = {&pl, &pr};
+        double Ul[3], Ur[3], Fl[3], Fr[3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+        {
+            const State3& P = *side[s];
+            double* U = s == 0 ? Ul : Ur;
+            double* Fx = s == 0 ? Fl : Fr;
+            const double v = P[1 + AXIS], p = P[0] * cs2v;
+            U[0] = P[0]; U[1] = P[0] * P[1]; U[2] = P[0] * P[2];
+            Fx[0] = v * U[0];
+            Fx[1] = AXIS == 0 ? __builtin_fma(v, U[1], p) : v * U[1];
+            Fx[2] = AXIS == 1 ? __builtin_fma(v, U[2], p) : v * U[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            F[q] = __builtin_fma(-(Ul[q] - Ur[q]), apam, __builtin_fma(-Fr[q], am, Fl[q] * ap)) * rden;
+        return F;
+    }
+    static __device__ inline State3 plm_per_length(const State3& l, const State3& m, const State3& r, double theta, const Ctx& k)
+    {
+        State3 g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = fast::plm_gradient(l[q], m[q], r[q], theta) * k.inv_h;
+        return g;
+    }
+    template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
+    {
+        State3 P;
+        const double rs = fast::rcp_nr(U[0]);
+        P[0] = U[0];
+        if constexpr (QFORM)
+        {
+            const double sr = U[1] * rs, lz = U[2] * rs;
+            const double rr2 = fast::rcp_nr(__builtin_fma(xc, xc, yc * yc));
+            P[1] = __builtin_fma(sr, xc, -lz * yc) * rr2;
+            P[2] = __builtin_fma(sr, yc, lz * xc) * rr2;
+        }
+        else
+        {
+            P[1] = U[1] * rs;
+            P[2] = U[2] * rs;
+        }
+        return P;
+    }
+    static __device__ inline void gravity(const BinaryConsts& c, int b, double d0, double d1, double sigma, double (&fg)[2])
+    {
+        const double rs = rsqrt(__builtin_fma(d0, d0, __builtin_fma(d1, d1, c.rs2)));
+        const double w = -(rs * rs * rs) * c.body[5 * b] * sigma;
+        fg[0] = d0 * w;
+        fg[1] = d1 * w;
+    }
+    static __device__ inline double sink_a2(const BinaryConsts& c, double d0, double d1) { return __builtin_fma(d0, d0, d1 * d1) * fast::rcp_nr(2.0 * c.s2); }
+    static __device__ inline void over_area(double (&l)[3], double dA) { const double r = fast::rcp_nr(dA); for (int q = 0; q < 3; ++q) l[q] *= r; }
+};
+
+// strict helpers used by the small kernels (sink sums, maximum wavespeed)
 __device__ inline double binary_cs2(const BinaryConsts& c, const Recip& rmach, double x, double y)
 {
-    if (c.axisym)
-    {
-        const double a = 1.0 / sqrt(x * x + y * y);
-        return divide(divide(a, rmach), rmach);
-    }
-    const double d0 = x - c.body[1], d1 = y - c.body[2];
-    const double e0 = x - c.body[6], e1 = y - c.body[7];
-    const double phi1 = (-1.0 * c.body[0]) / sqrt(d0 * d0 + d1 * d1 + c.rs2);
-    const double phi2 = (-1.0 * c.body[5]) / sqrt(e0 * e0 + e1 * e1 + c.rs2);
-    return divide(divide(-(phi1 + phi2), rmach), rmach);
-}
-
-// nu_at_position :177-193
-__device__ inline double binary_nu(const BinaryConsts& c, const Recip& rmach, double x, double y, double cs2)
-{
-    const double radius = sqrt(x * x + y * y);
-    const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
-    if (c.nu > 0.0)
-        return profile * c.nu;
-    return profile * c.alpha * sqrt(cs2) * divide(radius, rmach);
+    BinStrict::Ctx k = {rmach, rmach};
+    return BinStrict::cs2(c, k, x, y);
 }
 
 // intercell_flux_u :268-293 + viscous_flux :220-262 ; g = slopes along AXIS, t = transverse slopes (both per length)
-template<int AXIS, bool QFORM>
-__device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rmach, double xf, double yf,
+template<class A, int AXIS, bool QFORM>
+__device__ inline State3 binary_face_flux(const BinaryConsts& c, const typename A::Ctx& k, double xf, double yf,
     const State3& pl, const State3& pr, const State3& gl, const State3& gr, const State3& tl, const State3& tr)
 {
     State3 pl_hat, pr_hat;
@@ -159,10 +298,10 @@ __device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rm
         pl_hat[q] = pl[q] + gl[q] * 0.5 * c.h;
         pr_hat[q] = pr[q] - gr[q] * 0.5 * c.h;
     }
-    const double cs2 = binary_cs2(c, rmach, xf, yf);
-    const double nu = binary_nu(c, rmach, xf, yf, cs2);
+    const double cs2 = A::cs2(c, k, xf, yf);
+    const double nu = A::nu(c, k, xf, yf, cs2);
     const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
-    State3 F = iso2d::riemann_hlle<AXIS>(pl_hat, pr_hat, cs2, cs2);
+    State3 F = A::template hlle<AXIS>(pl_hat, pr_hat, cs2);
     if constexpr (AXIS == 0)
     {
         const double dx_ux = 0.5 * (gl[1] + gr[1]);
@@ -202,31 +341,13 @@ __device__ inline State3 binary_face_flux(const BinaryConsts& c, const Recip& rm
 
 // the sink rate of one body at a cell, sink_rate_field :117-126. exp(-a2) == 0 exactly for a2 > 750 (glibc and ocml
 // both underflow to zero below exp(-745.2)), so the call is skipped when no lane of the wave is in range.
+template<class A>
 __device__ inline double binary_sink_rate(const BinaryConsts& c, double d0, double d1)
 {
-    const double a2 = (d0 * d0 + d1 * d1) / c.s2 / 2.0;
+    const double a2 = A::sink_a2(c, d0, d1);
     double e = 0.0;
     if (__any(a2 < 750.0)) e = exp(-a2);
     return c.sink_rate * e;
-}
-
-__device__ inline State3 plm3_per_length(const State3& l, const State3& m, const State3& r, double theta, const Recip& rh)
-{
-    State3 g;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) g[q] = plm_gradient(l[q], m[q], r[q], theta);
-    divide_group<3>(g.v, rh);
-    return g;
-}
-
-// iso2d::recover_primitive(U) physics_iso2d.hpp:351-362, or (Q, x) :376-390 at the centre of the cell the data belongs to
-template<bool QFORM>
-__device__ inline State3 c2p3(const State3& U, double xc, double yc)
-{
-    State3 P;
-    if constexpr (QFORM) iso2d::recover_primitive_angmom(U, xc, yc, P);
-    else                 iso2d::recover_primitive(U, P);
-    return P;
 }
 
 __device__ inline double wave_sum(double x)
@@ -236,7 +357,7 @@ __device__ inline double wave_sum(double x)
     return x;
 }
 
-template<bool COMBINE, bool QFORM>
+template<class A, bool COMBINE, bool QFORM>
 __global__ __launch_bounds__(BWAVE * BWAVES_PER_BLOCK, 2)
 void binary_stage_kernel(BinaryStageParams p)
 {
@@ -270,8 +391,7 @@ void binary_stage_kernel(BinaryStageParams p)
     auto xc_of = [&p, n] (int r) { const int rw = r < 0 ? r + n : (r >= n ? r - n : r); return (p.xv[rw] + p.xv[rw + 1]) * 0.5; };
 
     const BinaryConsts& c = p.c;
-    const Recip rmach = make_recip(c.mach, 1.0);
-    const Recip rh = make_recip(c.h, 1.0);
+    const typename A::Ctx k = A::make(c);
     const double theta = p.theta, dt = p.dt;
     const long row_stride = 3L * n;
     auto row_off = [row_stride] (int r) { return (long) (r + BHALO) * row_stride; };
@@ -281,18 +401,18 @@ void binary_stage_kernel(BinaryStageParams p)
     //   U[k], P[k]: rows r, r+1, r+2     Gx[k], Gy[k]: slopes of rows r, r+1     Fx[k]: faces r, r+1 (times dy)
     State3 U[3], P[3], Gx[3], Gy[3], Fx[3];
     {
-        const State3 Pa = c2p3<QFORM>(load_row3(in + row_off(r0 - 2), n, jc8), xc_of(r0 - 2), yc);
-        const State3 Pb = c2p3<QFORM>(load_row3(in + row_off(r0 - 1), n, jc8), xc_of(r0 - 1), yc);
+        const State3 Pa = A::template c2p<QFORM>(load_row3(in + row_off(r0 - 2), n, jc8), xc_of(r0 - 2), yc);
+        const State3 Pb = A::template c2p<QFORM>(load_row3(in + row_off(r0 - 1), n, jc8), xc_of(r0 - 1), yc);
         U[0] = load_row3(in + row_off(r0), n, jc8);
         U[1] = load_row3(in + row_off(r0 + 1), n, jc8);
         U[2] = load_row3(in + row_off(r0 + 2), n, jc8);
-        P[0] = c2p3<QFORM>(U[0], xc_of(r0), yc);
-        P[1] = c2p3<QFORM>(U[1], xc_of(r0 + 1), yc);
-        const State3 Gxb = plm3_per_length(Pa, Pb, P[0], theta, rh);
-        const State3 Gyb = plm3_per_length(bdpp_left(Pb), Pb, bdpp_right(Pb), theta, rh);
-        Gx[0] = plm3_per_length(Pb, P[0], P[1], theta, rh);
-        Gy[0] = plm3_per_length(bdpp_left(P[0]), P[0], bdpp_right(P[0]), theta, rh);
-        Fx[0] = binary_face_flux<0, QFORM>(c, rmach, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
+        P[0] = A::template c2p<QFORM>(U[0], xc_of(r0), yc);
+        P[1] = A::template c2p<QFORM>(U[1], xc_of(r0 + 1), yc);
+        const State3 Gxb = A::plm_per_length(Pa, Pb, P[0], theta, k);
+        const State3 Gyb = A::plm_per_length(bdpp_left(Pb), Pb, bdpp_right(Pb), theta, k);
+        Gx[0] = A::plm_per_length(Pb, P[0], P[1], theta, k);
+        Gy[0] = A::plm_per_length(bdpp_left(P[0]), P[0], bdpp_right(P[0]), theta, k);
+        Fx[0] = binary_face_flux<A, 0, QFORM>(c, k, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fx[0][q] = Fx[0][q] * dy;
     }
@@ -317,15 +437,15 @@ void binary_stage_kernel(BinaryStageParams p)
         const double dx = xhi - xlo;
 
         // ---- axis 0: slopes of row r+1, flux through face r+1 (at x = xv[r+1])
-        P[K2] = c2p3<QFORM>(U[K2], xc_of(r + 2), yc);
-        Gx[K1] = plm3_per_length(P[K0], P[K1], P[K2], theta, rh);
-        Gy[K1] = plm3_per_length(bdpp_left(P[K1]), P[K1], bdpp_right(P[K1]), theta, rh);
-        Fx[K1] = binary_face_flux<0, QFORM>(c, rmach, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
+        P[K2] = A::template c2p<QFORM>(U[K2], xc_of(r + 2), yc);
+        Gx[K1] = A::plm_per_length(P[K0], P[K1], P[K2], theta, k);
+        Gy[K1] = A::plm_per_length(bdpp_left(P[K1]), P[K1], bdpp_right(P[K1]), theta, k);
+        Fx[K1] = binary_face_flux<A, 0, QFORM>(c, k, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fx[K1][q] = Fx[K1][q] * dy;
 
         // ---- axis 1: this lane's LEFT face (at y = yv[col]), handed to the left neighbour as its right face
-        State3 Fy_lo = binary_face_flux<1, QFORM>(c, rmach, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
+        State3 Fy_lo = binary_face_flux<A, 1, QFORM>(c, k, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fy_lo[q] = Fy_lo[q] * dx;
         const State3 Fy_hi = bdpp_right(Fy_lo);
@@ -338,16 +458,11 @@ void binary_stage_kernel(BinaryStageParams p)
         for (int bdy = 0; bdy < 2; ++bdy)
         {
             const double d0 = xc - c.body[5 * bdy + 1], d1 = yc - c.body[5 * bdy + 2];
-            const double r2s = d0 * d0 + d1 * d1 + c.rs2;
-            const double den = r2s * sqrt(r2s);                     // pow<3, 2>
-            double a[2] = {-d0, -d1};
-            divide_group<2>(a, make_recip(den, 1.0));
-            fg[bdy][0] = (a[0] * 1.0 * c.body[5 * bdy]) * u0[0];
-            fg[bdy][1] = (a[1] * 1.0 * c.body[5 * bdy]) * u0[0];
+            A::gravity(c, bdy, d0, d1, u0[0], fg[bdy]);
             s_grav[bdy][0] = 0.0 * dt;
             s_grav[bdy][1] = fg[bdy][0] * dt;
             s_grav[bdy][2] = fg[bdy][1] * dt;
-            const double rate = binary_sink_rate(c, d0, d1);
+            const double rate = binary_sink_rate<A>(c, d0, d1);
 #pragma unroll
             for (int q = 0; q < 3; ++q) s_sink[bdy][q] = -u0[q] * rate * dt;
         }
@@ -375,7 +490,7 @@ void binary_stage_kernel(BinaryStageParams p)
             const double ramp = 1.0 - e;
             const State3& pc = P[K0];
             const double Ek = 0.5 * pc[0] * (pc[1] * pc[1] + pc[2] * pc[2]);
-            const double pg = pc[0] * binary_cs2(c, rmach, xc, yc);
+            const double pg = pc[0] * A::cs2(c, k, xc, yc);
             s_floor[0] = 0.0 * ramp * dt;
             s_floor[1] = (Ek + pg) * 2.0 * ramp * dt;
             s_floor[2] = 0.0 * ramp * dt;
@@ -399,7 +514,7 @@ void binary_stage_kernel(BinaryStageParams p)
             double l[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) l[q] = ((Fx[K1][q] - Fx[K0][q]) + (Fy_hi[q] - Fy_lo[q])) * dt;
-            divide_group<3>(l, make_recip(dA, 1.0));
+            A::over_area(l, dA);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
             {
@@ -656,15 +771,17 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     const int nblocks = (nwaves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
     const dim3 grid(nblocks), block(BWAVE * BWAVES_PER_BLOCK);
     const bool combine = weight != 1.0;
-    if (d->angmom_form)
+    const int key = (d->arith == MH_ARITH_FAST ? 4 : 0) | (d->angmom_form ? 2 : 0) | (combine ? 1 : 0);
+    switch (key)
     {
-        if (combine) hipLaunchKernelGGL((binary_stage_kernel<true, true>), grid, block, 0, stream, p);
-        else         hipLaunchKernelGGL((binary_stage_kernel<false, true>), grid, block, 0, stream, p);
-    }
-    else
-    {
-        if (combine) hipLaunchKernelGGL((binary_stage_kernel<true, false>), grid, block, 0, stream, p);
-        else         hipLaunchKernelGGL((binary_stage_kernel<false, false>), grid, block, 0, stream, p);
+        case 0: hipLaunchKernelGGL((binary_stage_kernel<BinStrict, false, false>), grid, block, 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((binary_stage_kernel<BinStrict, true,  false>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((binary_stage_kernel<BinStrict, false, true >), grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((binary_stage_kernel<BinStrict, true,  true >), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((binary_stage_kernel<BinFast, false, false>), grid, block, 0, stream, p); break;
+        case 5: hipLaunchKernelGGL((binary_stage_kernel<BinFast, true,  false>), grid, block, 0, stream, p); break;
+        case 6: hipLaunchKernelGGL((binary_stage_kernel<BinFast, false, true >), grid, block, 0, stream, p); break;
+        case 7: hipLaunchKernelGGL((binary_stage_kernel<BinFast, true,  true >), grid, block, 0, stream, p); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -61,6 +61,7 @@ mara::config_t config_template()
     .item("nu",                   0.0)
     .item("mdot",                 0.0)
     // not upstream:
+    .item("arith",           "strict")          // strict | fast (see include/mara_hip.h)
     .item("max_iterations",         0)          // stop after this many iterations (0 = run to tfinal)
     .item("steps_per_call",         1)          // iterations per mh_binary_next call (the state stays on the device either way)
     .item("write_final",            1)
@@ -126,6 +127,7 @@ public:
         d.density_floor = cfg.get_double("density_floor") * cfg.get_double("disk_mass");
         d.axisymmetric_cs2 = cfg.get_int("axisymmetric_cs2");
         d.angmom_form = model.angmom_form;
+        d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
         {
             double min_d = xv[1] - xv[0];                                  // solver_data.cpp:37-52, :91 (both axes share the vertex array)
             for (int i = 0; i < n; ++i) min_d = std::min(min_d, xv[i + 1] - xv[i]);

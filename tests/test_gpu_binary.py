@@ -164,6 +164,22 @@ def test_next_solution_against_reference_vectors(mods, name):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b32", "binary_d2_b16_q", "binary_d1_b24_q_nu"])
+def test_fast_arithmetic_within_tolerance_of_reference(mods, name):
+    """MH_ARITH_FAST (reciprocal / rsq arithmetic, FMAs) for the binary stage: same tolerance as the strict kernel."""
+    lib, binary, engine, L = mods
+    g = golden(name)
+    cfg, over = cfg_of(binary, g)
+    s = binary.BinarySolver(cfg, xv=g["xv"], yv=g["yv"], u_init=g["u_init"], buffer_rate=g["br"], recommended_time_step=g["stage_scalars"][1], arith="fast")
+    nsteps = int(over["nsteps"])
+    assert s.next(nsteps) == 0
+    ok, rel = field_close(s.solution(), g["u_final"])
+    assert ok, rel
+    sc = g["scalars"]
+    assert abs(s.state().time - sc[0]) <= 1e-12 * abs(sc[0])
+    s.close()
+
+
 def test_next_in_one_call_equals_step_by_step(mods):
     """The look-ahead wavespeed reduction must not change a single bit."""
     lib, binary, engine, L = mods
