@@ -25,6 +25,9 @@ public:
     int get_int(const std::string& key) const { return std::get<int>(at(key)); }
     double get_double(const std::string& key) const { return std::get<double>(at(key)); }
     std::string get_string(const std::string& key) const { return std::get<std::string>(at(key)); }
+    bool has(const std::string& key) const { return values.count(key) != 0; }
+    int type_of(const std::string& key) const { return (int) at(key).index(); }         // 0 int, 1 double, 2 string
+    const std::map<std::string, value_t>& items() const { return values; }
 
     // argv[1..] = key=value
     config_t& update(int argc, const char* argv[])

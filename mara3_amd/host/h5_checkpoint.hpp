@@ -1,0 +1,324 @@
+// HDF5 checkpoint / restart files of the compiled hosts, in the reference's layout:
+//
+//   chkpt.NNNN.h5
+//     /solution/time                  f64 scalar
+//     /solution/iteration             int[2] scalar        mara::rational_number_t   (app_serialize.hpp:274-284)
+//     /solution/vertices | radial_vertices, polar_vertices   f64 [n]
+//     /solution/conserved             [nz] or [nr][nq] of H5T_ARRAY{5 x f64}          (arithmetic_sequence_t, app_serialize.hpp:240-252)
+//     /schedule/<task>/{name (C string), num_times_performed (int), last_performed (f64)}   (write_schedule :61-70)
+//     /config/<item>                  int | f64 | fixed-length C string (size max(1, len)), scalar   (write_config :90-96, core_hdf5.hpp:474-477)
+//
+// written by subprog_sedov.cpp:329-335,486-495 and subprog_cloud.cpp:590-597,758-767 upstream. The reference wraps the HDF5 C
+// API in core_hdf5.hpp; here the C API is called directly. libhdf5 is bound at run time (dlopen), like RCCL in slab.hip: the
+// host executable has no link-time dependency on it and runs without it as long as no checkpoint is requested.
+//
+// Parity status of this file format: UNPINNED. The reference executable cannot be built in this environment (generated header),
+// so no reference-written file exists to compare with; the layout above is taken from the reference's writer code, checked
+// with h5dump, and the round trip (write, restart, continue) is tested to reproduce an uninterrupted run bit for bit.
+#pragma once
+#include <dlfcn.h>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <hdf5.h>
+#include "app_config.hpp"
+
+namespace h5io {
+
+// ---- run-time binding of the HDF5 C library ----------------------------------------------------------------------------
+struct Lib
+{
+    void* handle = nullptr;
+#define H5IO_FN(name) decltype(&::name) name = nullptr
+    H5IO_FN(H5open); H5IO_FN(H5Fcreate); H5IO_FN(H5Fopen); H5IO_FN(H5Fclose); H5IO_FN(H5Gcreate2); H5IO_FN(H5Gopen2); H5IO_FN(H5Gclose);
+    H5IO_FN(H5Lexists); H5IO_FN(H5Screate); H5IO_FN(H5Screate_simple); H5IO_FN(H5Sclose); H5IO_FN(H5Sget_simple_extent_ndims);
+    H5IO_FN(H5Sget_simple_extent_dims); H5IO_FN(H5Tcopy); H5IO_FN(H5Tset_size); H5IO_FN(H5Tarray_create2); H5IO_FN(H5Tclose);
+    H5IO_FN(H5Tget_size); H5IO_FN(H5Tget_class); H5IO_FN(H5Dcreate2); H5IO_FN(H5Dopen2); H5IO_FN(H5Dwrite); H5IO_FN(H5Dread);
+    H5IO_FN(H5Dget_space); H5IO_FN(H5Dget_type); H5IO_FN(H5Dclose); H5IO_FN(H5Literate);
+#undef H5IO_FN
+    hid_t native_double = -1, native_int = -1, c_s1 = -1;
+
+    static Lib& get()
+    {
+        static Lib lib;
+        if (! lib.handle)
+        {
+            for (const char* name : {"libhdf5.so.103", "libhdf5.so", "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so"})
+                if ((lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (! lib.handle) throw std::runtime_error("HDF5 is not available: libhdf5.so could not be loaded (checkpoint / restart need it)");
+#define H5IO_SYM(name) if (! (lib.name = reinterpret_cast<decltype(lib.name)>(dlsym(lib.handle, #name)))) throw std::runtime_error("libhdf5 lacks " #name)
+            H5IO_SYM(H5open); H5IO_SYM(H5Fcreate); H5IO_SYM(H5Fopen); H5IO_SYM(H5Fclose); H5IO_SYM(H5Gcreate2); H5IO_SYM(H5Gopen2); H5IO_SYM(H5Gclose);
+            H5IO_SYM(H5Lexists); H5IO_SYM(H5Screate); H5IO_SYM(H5Screate_simple); H5IO_SYM(H5Sclose); H5IO_SYM(H5Sget_simple_extent_ndims);
+            H5IO_SYM(H5Sget_simple_extent_dims); H5IO_SYM(H5Tcopy); H5IO_SYM(H5Tset_size); H5IO_SYM(H5Tarray_create2); H5IO_SYM(H5Tclose);
+            H5IO_SYM(H5Tget_size); H5IO_SYM(H5Tget_class); H5IO_SYM(H5Dcreate2); H5IO_SYM(H5Dopen2); H5IO_SYM(H5Dwrite); H5IO_SYM(H5Dread);
+            H5IO_SYM(H5Dget_space); H5IO_SYM(H5Dget_type); H5IO_SYM(H5Dclose); H5IO_SYM(H5Literate);
+#undef H5IO_SYM
+            lib.H5open();
+            auto global = [&] (const char* sym) { auto p = static_cast<hid_t*>(dlsym(lib.handle, sym)); if (! p) throw std::runtime_error(std::string("libhdf5 lacks ") + sym); return *p; };
+            lib.native_double = global("H5T_NATIVE_DOUBLE_g");
+            lib.native_int = global("H5T_NATIVE_INT_g");
+            lib.c_s1 = global("H5T_C_S1_g");
+        }
+        return lib;
+    }
+};
+
+// false (with one note on stdout) where libhdf5 cannot be loaded: the hosts then run without writing checkpoints
+inline bool available()
+{
+    try { Lib::get(); return true; }
+    catch (const std::exception& e) { std::printf("%s; no checkpoints will be written\n", e.what()); return false; }
+}
+
+inline void check(hid_t id, const std::string& what) { if (id < 0) throw std::runtime_error("HDF5: " + what + " failed"); }
+
+// a file or group handle
+struct Node
+{
+    hid_t id = -1;
+    bool is_file = false;
+    Node() {}
+    Node(hid_t i, bool f) : id(i), is_file(f) {}
+    Node(const Node&) = delete;
+    Node(Node&& o) : id(o.id), is_file(o.is_file) { o.id = -1; }
+    ~Node() { if (id >= 0) { if (is_file) Lib::get().H5Fclose(id); else Lib::get().H5Gclose(id); } }
+
+    static Node create_file(const std::string& path)
+    {
+        hid_t f = Lib::get().H5Fcreate(path.c_str(), 0x0002u /* H5F_ACC_TRUNC without the macro's H5open() */, H5P_DEFAULT, H5P_DEFAULT);
+        check(f, "create " + path);
+        return Node(f, true);
+    }
+    static Node open_file(const std::string& path)
+    {
+        hid_t f = Lib::get().H5Fopen(path.c_str(), 0x0000u /* H5F_ACC_RDONLY */, H5P_DEFAULT);
+        check(f, "open " + path);
+        return Node(f, true);
+    }
+    bool has(const std::string& name) const { return Lib::get().H5Lexists(id, name.c_str(), H5P_DEFAULT) > 0; }
+    Node require_group(const std::string& name) const
+    {
+        auto& L = Lib::get();
+        hid_t g = has(name) ? L.H5Gopen2(id, name.c_str(), H5P_DEFAULT) : L.H5Gcreate2(id, name.c_str(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        check(g, "group " + name);
+        return Node(g, false);
+    }
+    Node open_group(const std::string& name) const
+    {
+        hid_t g = Lib::get().H5Gopen2(id, name.c_str(), H5P_DEFAULT);
+        check(g, "open group " + name);
+        return Node(g, false);
+    }
+    std::vector<std::string> names() const
+    {
+        std::vector<std::string> out;
+        auto op = [] (hid_t, const char* name, const H5L_info_t*, void* data) -> herr_t { static_cast<std::vector<std::string>*>(data)->push_back(name); return 0; };
+        Lib::get().H5Literate(id, H5_INDEX_NAME, H5_ITER_INC, nullptr, op, &out);
+        return out;
+    }
+
+    // ---- writers
+    void write_raw(const std::string& name, hid_t type, int rank, const hsize_t* dims, const void* data) const
+    {
+        auto& L = Lib::get();
+        hid_t space = rank == 0 ? L.H5Screate(H5S_SCALAR) : L.H5Screate_simple(rank, dims, nullptr);
+        hid_t ds = L.H5Dcreate2(id, name.c_str(), type, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        check(ds, "create dataset " + name);
+        if (L.H5Dwrite(ds, type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) throw std::runtime_error("HDF5: write " + name + " failed");
+        L.H5Dclose(ds);
+        L.H5Sclose(space);
+    }
+    void write(const std::string& name, double v) const { write_raw(name, Lib::get().native_double, 0, nullptr, &v); }
+    void write(const std::string& name, int v) const { write_raw(name, Lib::get().native_int, 0, nullptr, &v); }
+    void write(const std::string& name, const std::string& v) const
+    {
+        auto& L = Lib::get();
+        hid_t t = L.H5Tcopy(L.c_s1);
+        L.H5Tset_size(t, std::max<std::size_t>(1, v.size()));          // core_hdf5.hpp:477
+        std::string buf = v.empty() ? std::string(1, '\0') : v;
+        write_raw(name, t, 0, nullptr, buf.data());
+        L.H5Tclose(t);
+    }
+    void write_rational(const std::string& name, int num, int den) const
+    {
+        auto& L = Lib::get();
+        const hsize_t two = 2;
+        hid_t t = L.H5Tarray_create2(L.native_int, 1, &two);
+        const int v[2] = {num, den};
+        write_raw(name, t, 0, nullptr, v);
+        L.H5Tclose(t);
+    }
+    void write(const std::string& name, const std::vector<double>& v) const
+    {
+        const hsize_t n = v.size();
+        write_raw(name, Lib::get().native_double, 1, &n, v.data());
+    }
+    // cells[shape...][nq] as a dataset of shape `shape` whose element is an array of nq doubles
+    void write_cells(const std::string& name, const std::vector<hsize_t>& shape, int nq, const double* data) const
+    {
+        auto& L = Lib::get();
+        const hsize_t q = nq;
+        hid_t t = L.H5Tarray_create2(L.native_double, 1, &q);
+        write_raw(name, t, (int) shape.size(), shape.data(), data);
+        L.H5Tclose(t);
+    }
+
+    // ---- readers
+    struct Dataset
+    {
+        hid_t ds = -1, space = -1, type = -1;
+        ~Dataset() { auto& L = Lib::get(); if (type >= 0) L.H5Tclose(type); if (space >= 0) L.H5Sclose(space); if (ds >= 0) L.H5Dclose(ds); }
+    };
+    void open(const std::string& name, Dataset& d) const
+    {
+        auto& L = Lib::get();
+        d.ds = L.H5Dopen2(id, name.c_str(), H5P_DEFAULT);
+        check(d.ds, "open dataset " + name);
+        d.space = L.H5Dget_space(d.ds);
+        d.type = L.H5Dget_type(d.ds);
+    }
+    double read_double(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        double v = 0;
+        if (Lib::get().H5Dread(d.ds, Lib::get().native_double, H5S_ALL, H5S_ALL, H5P_DEFAULT, &v) < 0) throw std::runtime_error("HDF5: read " + name);
+        return v;
+    }
+    int read_int(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        int v = 0;
+        if (Lib::get().H5Dread(d.ds, Lib::get().native_int, H5S_ALL, H5S_ALL, H5P_DEFAULT, &v) < 0) throw std::runtime_error("HDF5: read " + name);
+        return v;
+    }
+    std::string read_string(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        std::string s(Lib::get().H5Tget_size(d.type), '\0');
+        if (Lib::get().H5Dread(d.ds, d.type, H5S_ALL, H5S_ALL, H5P_DEFAULT, s.data()) < 0) throw std::runtime_error("HDF5: read " + name);
+        while (! s.empty() && s.back() == '\0') s.pop_back();
+        return s;
+    }
+    void read_rational(const std::string& name, int& num, int& den) const
+    {
+        Dataset d; open(name, d);
+        int v[2] = {0, 1};
+        if (Lib::get().H5Dread(d.ds, d.type, H5S_ALL, H5S_ALL, H5P_DEFAULT, v) < 0) throw std::runtime_error("HDF5: read " + name);
+        num = v[0]; den = v[1];
+    }
+    std::vector<hsize_t> shape_of(const Dataset& d) const
+    {
+        auto& L = Lib::get();
+        const int rank = L.H5Sget_simple_extent_ndims(d.space);
+        std::vector<hsize_t> dims(rank > 0 ? rank : 0);
+        if (rank > 0) L.H5Sget_simple_extent_dims(d.space, dims.data(), nullptr);
+        return dims;
+    }
+    std::vector<double> read_vector(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        const auto dims = shape_of(d);
+        hsize_t n = 1;
+        for (auto x : dims) n *= x;
+        std::vector<double> v(n);
+        if (Lib::get().H5Dread(d.ds, Lib::get().native_double, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data()) < 0) throw std::runtime_error("HDF5: read " + name);
+        return v;
+    }
+    std::vector<double> read_cells(const std::string& name, int nq, std::vector<hsize_t>& shape) const
+    {
+        Dataset d; open(name, d);
+        shape = shape_of(d);
+        if (Lib::get().H5Tget_size(d.type) != std::size_t(nq) * sizeof(double)) throw std::runtime_error("HDF5: " + name + " does not hold arrays of " + std::to_string(nq) + " doubles");
+        hsize_t n = nq;
+        for (auto x : shape) n *= x;
+        std::vector<double> v(n);
+        if (Lib::get().H5Dread(d.ds, d.type, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data()) < 0) throw std::runtime_error("HDF5: read " + name);
+        return v;
+    }
+    H5T_class_t class_of(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        return Lib::get().H5Tget_class(d.type);
+    }
+};
+
+// ---- mara::schedule_t (src/app_schedule.hpp:55-160) -----------------------------------------------------------------------
+struct schedule_t
+{
+    struct task_t { std::string name; int num_times_performed = 0; double last_performed = 0.0; bool is_due = false; };
+    std::map<std::string, task_t> tasks;
+
+    task_t& at(const std::string& n) { auto it = tasks.find(n); if (it == tasks.end()) throw std::out_of_range("no task scheduled with the name " + n); return it->second; }
+    const task_t& at(const std::string& n) const { auto it = tasks.find(n); if (it == tasks.end()) throw std::out_of_range("no task scheduled with the name " + n); return it->second; }
+    void create_and_mark_as_due(const std::string& n) { tasks[n] = {n, 0, 0.0, false}; mark_as_due(n); }
+    void mark_as_due(const std::string& n, double increase_last_performed_by = 0.0) { at(n).is_due = true; at(n).last_performed += increase_last_performed_by; }
+    void mark_as_completed(const std::string& n) { at(n).is_due = false; at(n).num_times_performed += 1; }
+    bool is_due(const std::string& n) const { return at(n).is_due; }
+    // next_schedule of the drivers (subprog_cloud.cpp:720-733): a task is due again once `interval` has passed since it was last due
+    void advance(const std::string& n, double time, double interval) { if (time - at(n).last_performed >= interval) mark_as_due(n, interval); }
+};
+
+inline void write_schedule(const Node& group, const schedule_t& s)
+{
+    for (const auto& kv : s.tasks)
+    {
+        Node t = group.require_group(kv.first);
+        t.write("name", kv.second.name);
+        t.write("num_times_performed", kv.second.num_times_performed);
+        t.write("last_performed", kv.second.last_performed);
+    }
+}
+
+inline schedule_t read_schedule(const Node& group)
+{
+    schedule_t s;
+    for (const auto& name : group.names())
+    {
+        Node t = group.open_group(name);
+        schedule_t::task_t task;
+        task.name = name;
+        task.num_times_performed = t.read_int("num_times_performed");
+        task.last_performed = t.read_double("last_performed");
+        s.tasks[name] = task;                                   // is_due is not stored: false after a restart, as upstream
+    }
+    return s;
+}
+
+inline void write_config(const Node& group, const mara::config_t& cfg)
+{
+    for (const auto& kv : cfg.items())
+    {
+        switch (kv.second.index())
+        {
+            case 0: group.write(kv.first, std::get<int>(kv.second)); break;
+            case 1: group.write(kv.first, std::get<double>(kv.second)); break;
+            case 2: group.write(kv.first, std::get<std::string>(kv.second)); break;
+        }
+    }
+}
+
+// items of a stored run configuration that the template knows, typed by the template (mara::read_config + config_t::update)
+inline void read_config_into(const Node& group, mara::config_t& cfg)
+{
+    for (const auto& name : group.names())
+    {
+        if (! cfg.has(name)) continue;
+        switch (cfg.type_of(name))
+        {
+            case 0: cfg.item(name, group.read_int(name)); break;
+            case 1: cfg.item(name, group.read_double(name)); break;
+            case 2: cfg.item(name, group.read_string(name)); break;
+        }
+    }
+}
+
+inline std::string numbered_filename(const std::string& prefix, int count, const std::string& ext)
+{
+    char buf[1024];
+    std::snprintf(buf, sizeof buf, "%s.%04d.%s", prefix.c_str(), count, ext.c_str());     // mara::create_numbered_filename app_serialize.hpp:170-175
+    return buf;
+}
+
+} // namespace h5io

@@ -11,6 +11,7 @@
 #include "app_config.hpp"
 #include "app_subprogram.hpp"
 #include "host_common.hpp"
+#include "h5_checkpoint.hpp"
 #include "models.hpp"
 
 namespace {
@@ -26,6 +27,9 @@ mara::config_t config_template()
     .item("outdir", "data")
     .item("nr", 256)
     .item("tfinal", 1.0)
+    .item("cpi", 10.0)                // checkpoint interval (chkpt.NNNN.h5, reference layout); tsi / dfi tasks are out of scope
+    .item("tsi", 0.1)
+    .item("dfi", 1.0)
     .item("num_decades", 2.0)
     .item("inner_radius", 3e08)
     .item("cloud_cutoff", 3e10)
@@ -70,7 +74,15 @@ public:
     int main(int argc, const char* argv[]) override
     {
         auto cfg = config_template().update(argc, argv);
-        if (! cfg.get_string("restart").empty()) throw std::invalid_argument("cloud: restart needs the HDF5 checkpoint reader (out of scope)");
+        const std::string restart = cfg.get_string("restart");
+        if (! restart.empty())
+        {
+            // create_run_config :743-752: template <- stored "config" group <- command line
+            auto file = h5io::Node::open_file(restart);
+            cfg = config_template();
+            h5io::read_config_into(file.open_group("config"), cfg);
+            cfg.update(argc, argv);
+        }
         cfg.pretty_print(stdout, "config");
 
         model::cloud_and_envelop envelop;
@@ -147,6 +159,52 @@ public:
         double time = 0.0;
         long iteration = 0;
         std::vector<double> inflow(std::size_t(5) * nq, 0.0), inflow_first;
+        h5io::schedule_t schedule;
+        if (restart.empty())
+        {
+            schedule.create_and_mark_as_due("write_checkpoint");        // new_schedule :703-710
+        }
+        else
+        {
+            auto file = h5io::Node::open_file(restart);
+            auto sol = file.open_group("solution");                    // read_solution :599-608
+            int num = 0, den = 1;
+            sol.read_rational("iteration", num, den);
+            time = sol.read_double("time");
+            iteration = num / den;
+            if (sol.read_vector("radial_vertices") != rv || sol.read_vector("polar_vertices") != qv)
+                throw std::invalid_argument("cloud: the restart file's vertices differ from this configuration's");
+            std::vector<hsize_t> shape;
+            u = sol.read_cells("conserved", 5, shape);
+            if (shape.size() != 2 || shape[0] != hsize_t(nr) || shape[1] != hsize_t(nq)) throw std::invalid_argument("cloud: the restart file holds a different grid");
+            host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+            schedule = h5io::read_schedule(file.open_group("schedule"));
+            if (! schedule.tasks.count("write_checkpoint")) schedule.create_and_mark_as_due("write_checkpoint");
+        }
+        const std::string outdir = cfg.get_string("outdir");
+        auto run_tasks = [&] ()
+        {
+            if (! schedule.is_due("write_checkpoint")) return;
+            // write_checkpoint :758-767, write_solution :590-597
+            host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
+            if (! outdir.empty()) mkdir(outdir.c_str(), 0755);
+            const std::string path = (outdir.empty() ? std::string() : outdir + "/") + h5io::numbered_filename("chkpt", schedule.at("write_checkpoint").num_times_performed, "h5");
+            {
+                auto file = h5io::Node::create_file(path);
+                auto sol = file.require_group("solution");
+                sol.write("time", time);
+                sol.write_rational("iteration", int(iteration), 1);
+                sol.write("radial_vertices", rv);
+                sol.write("polar_vertices", qv);
+                sol.write_cells("conserved", {hsize_t(nr), hsize_t(nq)}, 5, u.data());
+                h5io::write_schedule(file.require_group("schedule"), schedule);
+                h5io::write_config(file.require_group("config"), cfg);
+            }
+            std::printf("write checkpoint: %s\n", path.c_str());
+            schedule.mark_as_completed("write_checkpoint");
+        };
+        const bool checkpoints = cfg.get_double("cpi") > 0.0 && h5io::available();        // cpi <= 0 switches the task off (not upstream: tests and benchmarks)
+        if (checkpoints) run_tasks();
 
         while (time < tfinal && (max_steps == 0 || iteration < max_steps))
         {
@@ -166,6 +224,11 @@ public:
             });
             time += dt;
             iteration += 1;
+            if (checkpoints)
+            {
+                schedule.advance("write_checkpoint", time, cfg.get_double("cpi"));     // next_schedule :720-733
+                run_tasks();
+            }
             int32_t status = 0;
             host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
             if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");

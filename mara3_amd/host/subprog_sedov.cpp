@@ -10,6 +10,7 @@
 #include "app_config.hpp"
 #include "app_subprogram.hpp"
 #include "host_common.hpp"
+#include "h5_checkpoint.hpp"
 
 namespace {
 
@@ -23,6 +24,9 @@ mara::config_t config_template()
     .item("outdir", "data")
     .item("nr", 256)
     .item("tfinal", 1.0)
+    .item("cpi", 1.0)                 // checkpoint interval (chkpt.NNNN.h5, reference layout); tsi / dfi tasks are out of scope
+    .item("tsi", 0.1)
+    .item("dfi", 0.1)
     .item("outer_radius", 100.0)
     .item("explosion_pressure", 1.0)
     .item("explosion_density", 1.0)
@@ -37,7 +41,16 @@ public:
     int main(int argc, const char* argv[]) override
     {
         auto cfg = config_template().update(argc, argv);
-        if (! cfg.get_string("restart").empty()) throw std::invalid_argument("sedov: restart needs the HDF5 checkpoint reader (out of scope)");
+        const std::string restart = cfg.get_string("restart");
+        if (! restart.empty())
+        {
+            // create_run_config :466-475: template <- stored run configuration <- command line. Upstream reads the group
+            // "run_config" but its checkpoints hold "config" (:492), so its own restart fails; both names are accepted here.
+            auto file = h5io::Node::open_file(restart);
+            cfg = config_template();
+            h5io::read_config_into(file.open_group(file.has("run_config") ? "run_config" : "config"), cfg);
+            cfg.update(argc, argv);
+        }
         const bool newtonian = cfg.get_int("newtonian") != 0;
         cfg.pretty_print(stdout, "config");
 
@@ -84,6 +97,50 @@ public:
         const double tfinal = cfg.get_double("tfinal");
         double time = 0.0;
         long iteration = 0;
+        h5io::schedule_t schedule;
+        if (restart.empty())
+        {
+            schedule.create_and_mark_as_due("write_checkpoint");        // new_schedule :427-434
+        }
+        else
+        {
+            auto file = h5io::Node::open_file(restart);
+            auto sol = file.open_group("solution");                    // read_solution :337-345
+            int num = 0, den = 1;
+            sol.read_rational("iteration", num, den);
+            time = sol.read_double("time");
+            iteration = num / den;
+            if (sol.read_vector("vertices") != v) throw std::invalid_argument("sedov: the restart file's vertices differ from this configuration's");
+            std::vector<hsize_t> shape;
+            u = sol.read_cells("conserved", 5, shape);
+            if (shape.size() != 1 || shape[0] != nz) throw std::invalid_argument("sedov: the restart file holds a different number of zones");
+            host::check(mh_upload(ctx, u.data(), nz), ctx, "mh_upload");
+            schedule = h5io::read_schedule(file.open_group("schedule"));
+            if (! schedule.tasks.count("write_checkpoint")) schedule.create_and_mark_as_due("write_checkpoint");
+        }
+        const std::string outdir = cfg.get_string("outdir");
+        auto run_tasks = [&] ()
+        {
+            if (! schedule.is_due("write_checkpoint")) return;
+            // write_checkpoint :486-495, write_solution :329-335
+            host::check(mh_download(ctx, u.data(), nz), ctx, "mh_download");
+            if (! outdir.empty()) mkdir(outdir.c_str(), 0755);
+            const std::string path = (outdir.empty() ? std::string() : outdir + "/") + h5io::numbered_filename("chkpt", schedule.at("write_checkpoint").num_times_performed, "h5");
+            {
+                auto file = h5io::Node::create_file(path);
+                auto sol = file.require_group("solution");
+                sol.write("time", time);
+                sol.write_rational("iteration", int(iteration), 1);
+                sol.write("vertices", v);
+                sol.write_cells("conserved", {hsize_t(nz)}, 5, u.data());
+                h5io::write_schedule(file.require_group("schedule"), schedule);
+                h5io::write_config(file.require_group("config"), cfg);
+            }
+            std::printf("write checkpoint: %s\n", path.c_str());
+            schedule.mark_as_completed("write_checkpoint");
+        };
+        const bool checkpoints = cfg.get_double("cpi") > 0.0 && h5io::available();        // cpi <= 0 switches the task off (not upstream: tests and benchmarks)
+        if (checkpoints) run_tasks();
 
         while (time < tfinal)
         {
@@ -93,6 +150,11 @@ public:
             });
             time += dt;
             iteration += 1;
+            if (checkpoints)
+            {
+                schedule.advance("write_checkpoint", time, cfg.get_double("cpi"));     // next_schedule :445-457
+                run_tasks();
+            }
             if (iteration % 100 == 0)
             {
                 host::throw_on_status(ctx);

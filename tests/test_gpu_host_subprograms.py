@@ -120,3 +120,63 @@ def test_binary_subprogram_rejects_what_is_not_built(tmp_path):
     assert out.returncode == 1 and "uniform-depth" in out.stdout
     out = subprocess.run([EXE, "binary", "reconstruct_method=weno"], cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 1 and "must be plm or pcm" in out.stdout
+
+
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+def _h5_dataset(path, name, dtype=np.float64):
+    """A dataset of an HDF5 file as a flat array, parsed from h5dump's text output with round-trip float formatting (there is
+    no h5py in this image, and h5dump's binary export does not handle array-typed elements)."""
+    import re
+    out = subprocess.run([H5DUMP, "-d", name, "-m", "%.17g", "-w", "65535", path], check=True, capture_output=True, text=True).stdout
+    body = out[out.index("DATA {") + 6:out.rindex("}")]
+    body = re.sub(r"\([0-9,]+\):", " ", body)
+    tokens = [t for t in re.split(r"[\s,\[\]{}]+", body) if t]
+    return np.array([float(t) for t in tokens]).astype(dtype)
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
+def test_sedov_checkpoint_and_restart(tmp_path):
+    """Checkpoints in the reference's layout (src/subprog_sedov.cpp:329-335, :486-495): the file written at iteration 10 holds
+    the reference-generated state bit for bit, and a run restarted from it ends exactly where the uninterrupted run does."""
+    g = golden("sedov_newtonian_nr256")
+    dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
+    common = ["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % float(99.5 * dt), "cpi=%r" % float(9.5 * dt)]
+    stdout = run(common + ["outdir=a"], str(tmp_path))
+    assert "write checkpoint: a/chkpt.0000.h5" in stdout and "write checkpoint: a/chkpt.0001.h5" in stdout
+    chk = os.path.join(tmp_path, "a", "chkpt.0001.h5")
+    assert bits_equal(_h5_dataset(chk, "/solution/conserved").reshape(-1, 5), g["u_10"])
+    assert bits_equal(_h5_dataset(chk, "/solution/vertices"), g["vertices"])
+    assert list(_h5_dataset(chk, "/solution/iteration", np.int32)) == [10, 1]
+    assert _h5_dataset(chk, "/schedule/write_checkpoint/num_times_performed", np.int32)[0] == 1
+    header = subprocess.run([H5DUMP, "-H", chk], check=True, capture_output=True, text=True).stdout
+    assert "H5T_ARRAY { [5] H5T_IEEE_F64LE }" in header and "H5T_ARRAY { [2] H5T_STD_I32LE }" in header
+    assert 'GROUP "config"' in header and 'DATASET "newtonian"' in header and 'GROUP "write_checkpoint"' in header
+    a = read_dump(os.path.join(tmp_path, "a", "final.bin"))
+    assert a["iteration"] == 100 and bits_equal(a["data"], g["u_100"])
+    # restart: the stored run configuration comes back (newtonian, nr, tfinal, cpi); only outdir is overridden
+    stdout = run(["sedov", "restart=a/chkpt.0001.h5", "outdir=b"], str(tmp_path))
+    b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
+    assert b["iteration"] == 100 and b["time"] == a["time"]
+    assert bits_equal(b["data"], a["data"])
+    # upstream's sedov / cloud store the schedule BEFORE marking the task completed (subprog_sedov.cpp:486-495, :565-568), so a
+    # run restarted from checkpoint 1 numbers its next checkpoint 1 again
+    assert "write checkpoint: b/chkpt.0001.h5" in stdout and "b/chkpt.0000.h5" not in stdout
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
+def test_cloud_checkpoint_and_restart(tmp_path):
+    g = golden("cloud_nr32_plm_rk2")
+    args = ["cloud", "nr=32", "num_decades=1", "rk_order=2", "max_steps=3"]
+    run(args + ["outdir=a", "cpi=%r" % float(1.5 * float(g["dt"]))], str(tmp_path))
+    a = read_dump(os.path.join(tmp_path, "a", "final.bin"))
+    assert bits_equal(a["data"], g["un"])
+    chk = os.path.join(tmp_path, "a", "chkpt.0001.h5")          # written after the second step
+    assert list(_h5_dataset(chk, "/solution/iteration", np.int32)) == [2, 1]
+    assert bits_equal(_h5_dataset(chk, "/solution/radial_vertices"), g["rv"]) and bits_equal(_h5_dataset(chk, "/solution/polar_vertices"), g["qv"])
+    header = subprocess.run([H5DUMP, "-H", "-d", "/solution/conserved", chk], check=True, capture_output=True, text=True).stdout
+    assert "H5T_ARRAY { [5] H5T_IEEE_F64LE }" in header and "( 32, 32 )" in header
+    run(["cloud", "restart=a/chkpt.0001.h5", "outdir=b", "max_steps=3"], str(tmp_path))
+    b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
+    assert b["iteration"] == 3 and bits_equal(b["data"], g["un"])
