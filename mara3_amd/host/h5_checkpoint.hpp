@@ -22,10 +22,43 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
-#include <hdf5.h>
 #include "app_config.hpp"
+#if __has_include(<hdf5.h>)
+#include <hdf5.h>
+#define MH_HOST_HAVE_HDF5 1
+#else
+#define MH_HOST_HAVE_HDF5 0
+#endif
+
+#if ! MH_HOST_HAVE_HDF5
+using hsize_t = unsigned long long;
+#endif
 
 namespace h5io {
+
+#if ! MH_HOST_HAVE_HDF5
+// Built where hdf5.h is absent: same interface, no checkpoints (available() is false, restart= reports the reason).
+inline bool available() { std::printf("this build has no HDF5 support (hdf5.h was absent at compile time); no checkpoints will be written\n"); return false; }
+struct Node
+{
+    [[noreturn]] static void none() { throw std::runtime_error("this build has no HDF5 support (hdf5.h was absent at compile time)"); }
+    static Node create_file(const std::string&) { none(); }
+    static Node open_file(const std::string&) { none(); }
+    bool has(const std::string&) const { none(); }
+    Node require_group(const std::string&) const { none(); }
+    Node open_group(const std::string&) const { none(); }
+    std::vector<std::string> names() const { none(); }
+    template<typename T> void write(const std::string&, const T&) const { none(); }
+    void write_rational(const std::string&, int, int) const { none(); }
+    void write_cells(const std::string&, const std::vector<hsize_t>&, int, const double*) const { none(); }
+    double read_double(const std::string&) const { none(); }
+    int read_int(const std::string&) const { none(); }
+    std::string read_string(const std::string&) const { none(); }
+    void read_rational(const std::string&, int&, int&) const { none(); }
+    std::vector<double> read_vector(const std::string&) const { none(); }
+    std::vector<double> read_cells(const std::string&, int, std::vector<hsize_t>&) const { none(); }
+};
+#else
 
 // ---- run-time binding of the HDF5 C library ----------------------------------------------------------------------------
 struct Lib
@@ -243,6 +276,8 @@ struct Node
         return Lib::get().H5Tget_class(d.type);
     }
 };
+
+#endif // MH_HOST_HAVE_HDF5
 
 // ---- mara::schedule_t (src/app_schedule.hpp:55-160) -----------------------------------------------------------------------
 struct schedule_t

@@ -7,7 +7,7 @@
 int main(int argc, char** argv)
 {
     if (argc != 2) return 2;
-    try { h5io::Lib::get(); } catch (const std::exception& e) { std::printf("%s\n", e.what()); return 77; }
+    if (! h5io::available()) return 77;
     const int nz = 7;
     std::vector<double> v(nz + 1), u(5 * nz);
     for (int i = 0; i <= nz; ++i) v[i] = std::pow(10.0, 0.1 * i);
