@@ -1,7 +1,7 @@
 // Shared helpers of the compiled hosts: wall-clock timing of a step (the reference's
 // mara::time_execution, src/app_performance.hpp:76-82, which produces its `kzps`
 // figure), a throwing wrapper around the C ABI, and a raw binary state dump (the
-// HDF5 checkpoint format is out of scope this round).
+// HDF5 checkpoints of sedov and cloud live in h5_checkpoint.hpp; this raw dump is what the parity tests read).
 #pragma once
 #include <chrono>
 #include <cstdio>

@@ -8,7 +8,7 @@
 // Restrictions, stated rather than silently ignored: the tree must be of uniform depth (every node refined; upstream that
 // is `focus_factor` large, here it is the only mode: focus_factor / focus_index are accepted and must describe such a
 // tree), and the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
-// tsi) are out of scope; a raw dump of the final state replaces them.
+// tsi) are out of scope for `binary`; a raw dump of the final state replaces them.
 #include <cmath>
 #include <cstdio>
 #include <vector>
