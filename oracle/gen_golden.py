@@ -241,6 +241,34 @@ def gen_binary():
     return 0
 
 
+BINARY_TREE_CASES = {
+    # graded block trees (refinement towards the origin: prolonged / restricted guard zones, flux correction)
+    "binary_tree_d3_b8": dict(depth=3, block_size=8, domain_radius=4.0, nsteps=2),
+    "binary_tree_d4_b8_default_focus": dict(depth=4, block_size=8, nsteps=1),
+    "binary_tree_d3_b12_nu": dict(depth=3, block_size=12, domain_radius=5.0, focus_factor=1.5, nu=1e-3, mass_ratio=0.5, eccentricity=0.3, rk_order=1,
+                                  fixed_dt=1, nsteps=3, sink_radius=0.2, softening_radius=0.1, density_floor=0.05),
+    "binary_tree_d2_b16_uniform": dict(depth=2, block_size=16, domain_radius=4.0, focus_factor=1e9, nsteps=3),     # == binary_d2_b16, through the tree machinery
+}
+
+
+def gen_binary_tree():
+    import json
+    for name, cfg in BINARY_TREE_CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            prefix = os.path.join(d, "b")
+            run_ref("binary_tree_ref", [prefix] + ["%s=%s" % (k, repr(float(v))) for k, v in cfg.items()])
+            bs = int(cfg["block_size"])
+            blocks = np.fromfile(prefix + ".blocks.i32", dtype=np.int32).reshape(-1, 3)
+            nb = len(blocks)
+            out = {"config": np.array(json.dumps(cfg)), "blocks": blocks}
+            for key, shape in (("xv", (nb, 2, bs + 1)), ("u_init", (nb, bs, bs, 3)), ("br", (nb, bs, bs)), ("u_stage", (nb, bs, bs, 3)),
+                               ("stage_scalars", (-1,)), ("u_final", (nb, bs, bs, 3)), ("scalars", (-1,))):
+                out[key] = np.fromfile(prefix + "." + key + ".f64").reshape(shape)
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+            print(name, "ok", nb, "blocks; levels", np.bincount(blocks[:, 0]), "dt", out["stage_scalars"][0])
+    return 0
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "sedov_srhd":
@@ -282,6 +310,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "two_body.npz"), elements_in=P, state=S, state_in=X, elements=E[:, :10], threw=E[:, 10])
         print("two_body ok; throws:", int(E[:, 10].sum()))
         return 0
+    if len(sys.argv) > 1 and sys.argv[1] == "binary_tree":
+        return gen_binary_tree()
     if len(sys.argv) > 1 and sys.argv[1] == "binary":
         return gen_binary()
     if len(sys.argv) > 1 and sys.argv[1] == "iso2d":
