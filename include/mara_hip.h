@@ -371,6 +371,25 @@ double mh_binary_last_dt(const mh_binary* b);
 const double* mh_binary_field_ptr(mh_binary* b);
 int  mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaunches);
 
+/* ---- `binary` on a GRADED block tree (the sub-program's default: refinement towards the origin) ---------
+ * Leaf blocks of block_size^2 cells at different levels; guard zones are prolonged (piecewise constant) from coarser and
+ * restricted (averaged) from finer neighbours, and the face fluxes of a coarse block next to finer ones are replaced by the sum
+ * of the fine fluxes (src/subprog_binary_scheme.cpp:132-142, :614-720; mesh_tree_operators.hpp:223-258). Linear-momentum form
+ * (advance_u) only. Block data are ordered as the reference traverses its tree (children in orthant order i + 2 j).
+ * Host fields: [nblocks][bs][bs][3]; vertex edges: [nblocks][2][bs + 1] (x of the block's vertex columns, y of its rows). */
+typedef struct mh_tree_block { int32_t level, i, j; } mh_tree_block;
+/* mara::create_vertex_quadtree with the sub-program's refinement predicate (centroid_radius < focus_factor / level^focus_index,
+ * subprog_binary.cpp:174-177) followed by ensure_valid_quadtree (2:1 balance, mesh_tree_operators.hpp:115-139). Returns the number of
+ * leaf blocks (also when out is NULL or capacity too small: then nothing is written), or a negative mh_error. */
+int  mh_binary_tree_build(int block_size, int depth, double focus_factor, double focus_index, mh_tree_block* out, int capacity);
+int  mh_binary_tree_vertices(int block_size, double domain_radius, const mh_tree_block* blocks, int nblocks, double* edges_host);
+int  mh_binary_tree_solver_data(const mh_binary_model* m, int block_size, const mh_tree_block* blocks, int nblocks, const double* edges_host,
+                                double* u_init_host, double* buffer_rate_host, double* recommended_time_step);
+/* Solver object on a graded tree; afterwards mh_binary_set_solution / get_solution / next / last_dt / destroy apply unchanged
+ * (solution arrays in the block layout above). d->n is ignored; d->angmom_form must be 0. */
+int  mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks,
+                           int nblocks, const double* edges_host, const double* u_init_host, const double* buffer_rate_host);
+
 /* device utilities used by bench / tests without torch */
 int  mh_device_count(void);
 int  mh_malloc(void** ptr, size_t bytes);

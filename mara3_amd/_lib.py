@@ -79,6 +79,10 @@ class BinaryModel(C.Structure):
                 ("angmom_form", C.c_int32), ("buffer_damping_rate", C.c_double), ("domain_radius", C.c_double), ("cfl_number", C.c_double)]
 
 
+class TreeBlock(C.Structure):
+    _fields_ = [("level", C.c_int32), ("i", C.c_int32), ("j", C.c_int32)]
+
+
 class BinaryRun(C.Structure):
     _fields_ = [("rk_order", C.c_int32), ("fixed_dt", C.c_int32), ("no_accretion_force", C.c_int32), ("reserved", C.c_int32),
                 ("cfl_number", C.c_double), ("recommended_time_step", C.c_double), ("begin_live_binary", C.c_double)]
@@ -153,6 +157,10 @@ SYMBOLS = [
     ("mh_binary_max_wavespeed", _i, [C.POINTER(BinaryDesc), _dp, _dp, _dp, _vp, _dp, _vp]),
     ("mh_binary_vertices", _i, [_i, _i, _d, _vp]),
     ("mh_binary_solver_data", _i, [C.POINTER(BinaryModel), _i, _vp, _vp, _vp, _vp, C.POINTER(_d)]),
+    ("mh_binary_tree_build", _i, [_i, _i, _d, _d, _vp, _i]),
+    ("mh_binary_tree_vertices", _i, [_i, _d, _vp, _i, _vp]),
+    ("mh_binary_tree_solver_data", _i, [C.POINTER(BinaryModel), _i, _vp, _i, _vp, _vp, _vp, C.POINTER(_d)]),
+    ("mh_binary_tree_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _i, _vp, _vp, _vp]),
     ("mh_binary_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
     ("mh_binary_destroy", None, [_vp]),
     ("mh_binary_set_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),

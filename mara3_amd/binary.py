@@ -10,6 +10,7 @@ from . import _lib as L
 
 # numeric items of binary::create_config_template (src/subprog_binary.cpp:55-99)
 DEFAULTS = dict(
+    focus_factor=2.0, focus_index=2.0,
     cfl_number=0.4, fixed_dt=0, depth=4, begin_live_binary=1e6, block_size=24, rk_order=2, plm_theta=1.8,
     source_term_softening=1.0, softening_radius=0.05, sink_radius=0.05, sink_rate=1.0, buffer_damping_rate=10.0,
     domain_radius=12.0, disk_radius=2.0, disk_mass=1e-3, ambient_density=1e-4, density_floor=0.0, separation=1.0,
@@ -88,6 +89,47 @@ def make_desc(cfg, safe_mode=False, chunk_rows=0, xv=None, yv=None, arith="stric
         yv = xv if yv is None else np.ascontiguousarray(yv, dtype=np.float64)
         d.gst_suppr_radius = gst_suppr_radius(cfg, xv, yv)
     return d
+
+
+# ---- graded block trees (the sub-program's default mesh) ------------------------------------------------------------------
+def tree_blocks(cfg):
+    """Leaf blocks (level, i, j) of the tree the run configuration describes, in the reference's traversal order."""
+    lib = L.load_library()
+    args = (int(cfg["block_size"]), int(cfg["depth"]), float(cfg["focus_factor"]), float(cfg["focus_index"]))
+    n = lib.mh_binary_tree_build(*args, None, 0)
+    if n < 0:
+        L.check(n)
+    out = np.zeros((n, 3), dtype=np.int32)
+    L.check(min(0, lib.mh_binary_tree_build(*args, out.ctypes.data_as(C.c_void_p), n)))
+    return out
+
+
+def tree_is_uniform(blocks):
+    return len(np.unique(blocks[:, 0])) == 1
+
+
+def tree_vertices(cfg, blocks):
+    """[nblocks][2][bs + 1]: x of each block's vertex columns, y of its vertex rows."""
+    lib = L.load_library()
+    bs = int(cfg["block_size"])
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    e = np.zeros((len(blocks), 2, bs + 1))
+    L.check(lib.mh_binary_tree_vertices(bs, float(cfg["domain_radius"]), blocks.ctypes.data_as(C.c_void_p), len(blocks), e.ctypes.data_as(C.c_void_p)))
+    return e
+
+
+def tree_solver_data(cfg, blocks, edges):
+    lib = L.load_library()
+    bs = int(cfg["block_size"])
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+    u = np.zeros((len(blocks), bs, bs, 3))
+    br = np.zeros((len(blocks), bs, bs))
+    dt = C.c_double()
+    m = _model(cfg)
+    L.check(lib.mh_binary_tree_solver_data(C.byref(m), bs, blocks.ctypes.data_as(C.c_void_p), len(blocks), edges.ctypes.data_as(C.c_void_p),
+                                           u.ctypes.data_as(C.c_void_p), br.ctypes.data_as(C.c_void_p), C.byref(dt)))
+    return u, br, dt.value
 
 
 def initial_elements(cfg):
@@ -190,3 +232,44 @@ class BinarySolver:
             self.close()
         except Exception:
             pass
+
+
+class BinaryTreeSolver(BinarySolver):
+    """The same solution object on a GRADED block tree (the sub-program's default mesh). Arrays are block-major:
+    [nblocks][bs][bs][3], blocks in the reference's traversal order (`tree_blocks`)."""
+
+    def __init__(self, cfg, device=0, blocks=None, edges=None, u_init=None, buffer_rate=None, recommended_time_step=None, arith="strict"):
+        self.lib = L.load_library()
+        self.cfg = cfg
+        self.bs = int(cfg["block_size"])
+        self.blocks = tree_blocks(cfg) if blocks is None else np.ascontiguousarray(blocks, dtype=np.int32)
+        self.edges = tree_vertices(cfg, self.blocks) if edges is None else np.ascontiguousarray(edges, dtype=np.float64)
+        if u_init is None or buffer_rate is None or recommended_time_step is None:
+            u_init, buffer_rate, recommended_time_step = tree_solver_data(cfg, self.blocks, self.edges)
+        self.u_init = np.ascontiguousarray(u_init, dtype=np.float64)
+        self.buffer_rate = np.ascontiguousarray(buffer_rate, dtype=np.float64)
+        nb = len(self.blocks)
+        assert self.u_init.shape == (nb, self.bs, self.bs, 3) and self.buffer_rate.shape == (nb, self.bs, self.bs)
+        self.desc = make_desc(config(**{**cfg, "conserve_linear_p": 1}), arith=arith)
+        if not int(cfg["conserve_linear_p"]):
+            raise L.MaraHipError("binary on a graded tree: only conserve_linear_p = 1 is built")
+        run = L.BinaryRun()
+        run.rk_order = int(cfg["rk_order"])
+        run.fixed_dt = int(cfg["fixed_dt"])
+        run.no_accretion_force = int(cfg["no_accretion_force"])
+        run.cfl_number = float(cfg["cfl_number"])
+        run.recommended_time_step = float(recommended_time_step)
+        run.begin_live_binary = float(cfg["begin_live_binary"])
+        self.run = run
+        self.handle = C.c_void_p()
+        L.check(self.lib.mh_binary_tree_create(C.byref(self.handle), device, C.byref(self.desc), C.byref(run), self.blocks.ctypes.data_as(C.c_void_p), nb,
+                                               self.edges.ctypes.data_as(C.c_void_p), self.u_init.ctypes.data_as(C.c_void_p),
+                                               self.buffer_rate.ctypes.data_as(C.c_void_p)))
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
+
+    def solution(self):
+        u = np.empty((len(self.blocks), self.bs, self.bs, 3))
+        L.check(self.lib.mh_binary_get_solution(self.handle, u.ctypes.data_as(C.c_void_p), None))
+        return u

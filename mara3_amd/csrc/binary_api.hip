@@ -23,6 +23,14 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
                               double* result, hipStream_t stream);
 
+// graded trees (binary_tree.hip)
+struct TreeGeom { const int32_t* topo; const int32_t* level; const double* edges; int nb, bs; };
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out; };
+hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
+                                    double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
+                                    double theta, double* totals, int32_t* status, hipStream_t stream);
+hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g, const double* u, const double bodies[10], double* result, hipStream_t stream);
+
 static int check_binary_desc(const mh_binary_desc* d)
 {
     if (! d) { set_error("binary: null descriptor"); return MH_E_INVALID; }
@@ -71,6 +79,14 @@ struct mh_binary
     mh_binary_state maxw_for;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // graded tree (mh_binary_tree_create): block-major fields [nb][3][bs][bs], neighbour table, per-stage work arrays
+    bool tree = false;
+    TreeGeom geom = {nullptr, nullptr, nullptr, 0, 0};
+    TreeBuffers work = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t* topo_dev = nullptr;
+    int32_t* level_dev = nullptr;
+    double* edges_dev = nullptr;
+    std::vector<double> host_staging;
 };
 
 static double* totals_dev(mh_binary* b, int stage) { return b->dev_small + stage * MH_BINARY_NTOTALS; }
@@ -91,8 +107,12 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
         MH_HIP_TRY(hipEventCreate(&e1));
         MH_HIP_TRY(hipEventRecord(e0, b->stream));
     }
-    MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
-                                   totals_dev(b, slot), b->scratch, b->status, b->stream));
+    if (b->tree)
+        MH_HIP_TRY(binary_tree_stage_launch(&b->desc, b->geom, b->work, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
+                                            totals_dev(b, slot), b->status, b->stream));
+    else
+        MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
+                                       totals_dev(b, slot), b->scratch, b->status, b->stream));
     if (b->profile)
     {
         MH_HIP_TRY(hipEventRecord(e1, b->stream));
@@ -161,7 +181,8 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
         mh_two_body_t Bn;
         if (binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK)
         {
-            MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[2], Bn.body1, maxw_dev(b), b->stream));
+            if (b->tree) MH_HIP_TRY(binary_tree_min_dt_launch(&b->desc, b->geom, b->u[2], Bn.body1, maxw_dev(b), b->stream));
+            else         MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[2], Bn.body1, maxw_dev(b), b->stream));
             launched_ahead = true;
         }
     }
@@ -187,6 +208,16 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
         b->maxw_for = ahead;
     }
     return MH_OK;
+}
+
+// host [nb][bs][bs][3] -> device layout [nb][3][bs][bs]
+static void tree_to_device_layout(const mh_binary* b, const double* aos, double* out)
+{
+    const int bs = b->geom.bs;
+    for (int k = 0; k < b->geom.nb; ++k)
+        for (int q = 0; q < 3; ++q)
+            for (int c = 0; c < bs * bs; ++c)
+                out[((size_t) k * 3 + q) * bs * bs + c] = aos[((size_t) k * bs * bs + c) * 3 + q];
 }
 
 extern "C" {
@@ -265,6 +296,60 @@ int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const
     return MH_OK;
 }
 
+int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks, int nblocks,
+                          const double* edges, const double* u_init_aos, const double* br)
+{
+    if (! out || ! d || ! run || ! blocks || ! edges || ! u_init_aos || ! br || nblocks < 1) { set_error("binary tree create: null argument"); return MH_E_INVALID; }
+    if (d->angmom_form) { set_error("binary on a graded tree: only the linear-momentum form (conserve_linear_p = 1) is built"); return MH_E_INVALID; }
+    if (d->block_size < 2 || d->block_size % 2 != 0) { set_error("binary tree: block_size must be even"); return MH_E_INVALID; }
+    if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
+    if (! (d->mach_number > 0.0) || ! (d->sink_radius > 0.0) || ! (d->domain_radius > 0.0)) { set_error("binary: mach_number, sink_radius and domain_radius must be positive"); return MH_E_INVALID; }
+    const int bs = d->block_size, nb = nblocks;
+    std::vector<int32_t> topo((size_t) nb * 12), level(nb);
+    if (int rc = binary_tree_topology(blocks, nb, topo.data())) return rc;
+    for (int k = 0; k < nb; ++k) level[k] = blocks[k].level;
+    MH_HIP_TRY(hipSetDevice(device));
+    mh_binary* b = new mh_binary();
+    b->device = device;
+    b->desc = *d;
+    b->desc.n = 0;
+    b->run = *run;
+    b->tree = true;
+    b->field_doubles = (size_t) nb * 3 * bs * bs;
+    b->host_staging.resize(b->field_doubles);
+    auto fail = [&] (hipError_t e, const char* what) { mh_binary_destroy(b); return hip_fail(e, what); };
+#define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
+    B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->br, (size_t) nb * bs * bs * sizeof(double)));
+    B_TRY(hipMalloc(&b->topo_dev, topo.size() * sizeof(int32_t)));
+    B_TRY(hipMalloc(&b->level_dev, level.size() * sizeof(int32_t)));
+    B_TRY(hipMalloc(&b->edges_dev, (size_t) nb * 2 * (bs + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.prim, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.gx, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.gy, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.fx, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.fy, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
+    B_TRY(hipMalloc(&b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->status, 2 * sizeof(int32_t)));
+    B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
+    b->geom = {b->topo_dev, b->level_dev, b->edges_dev, nb, bs};
+    B_TRY(hipMemcpyAsync(b->topo_dev, topo.data(), topo.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->level_dev, level.data(), level.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->edges_dev, edges, (size_t) nb * 2 * (bs + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->br, br, (size_t) nb * bs * bs * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    tree_to_device_layout(b, u_init_aos, b->host_staging.data());
+    B_TRY(hipMemcpyAsync(b->u_init, b->host_staging.data(), b->field_doubles * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    B_TRY(hipStreamSynchronize(b->stream));
+#undef B_TRY
+    memset(&b->state, 0, sizeof(b->state));
+    *out = b;
+    return MH_OK;
+}
+
 void mh_binary_destroy(mh_binary* b)
 {
     if (! b) return;
@@ -274,6 +359,8 @@ void mh_binary_destroy(mh_binary* b)
     for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
     (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->status); (void) hipFree(b->staging);
+    (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
+    (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out);
     if (b->mirror) (void) hipHostFree(b->mirror);
     if (b->stream) (void) hipStreamDestroy(b->stream);
     delete b;
@@ -284,7 +371,12 @@ int mh_binary_set_solution(mh_binary* b, const double* u_aos, const mh_binary_st
     if (! b || ! state) { set_error("binary set_solution: null argument"); return MH_E_INVALID; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t n = b->desc.n;
-    if (u_aos)
+    if (u_aos && b->tree)
+    {
+        tree_to_device_layout(b, u_aos, b->host_staging.data());
+        MH_HIP_TRY(hipMemcpyAsync(b->u[0], b->host_staging.data(), b->field_doubles * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    else if (u_aos)
     {
         MH_HIP_TRY(hipMemcpyAsync(b->staging, u_aos, n * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
         MH_HIP_TRY(aos_to_soa_launch(b->staging, b->u[0], 3, b->desc.n, n, b->stream));
@@ -304,7 +396,17 @@ int mh_binary_get_solution(mh_binary* b, double* u_aos, mh_binary_state* state)
 {
     if (! b) { set_error("binary get_solution: null solver"); return MH_E_INVALID; }
     MH_HIP_TRY(hipSetDevice(b->device));
-    if (u_aos)
+    if (u_aos && b->tree)
+    {
+        MH_HIP_TRY(hipMemcpyAsync(b->host_staging.data(), b->u[0], b->field_doubles * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        MH_HIP_TRY(hipStreamSynchronize(b->stream));
+        const int bs = b->geom.bs;
+        for (int k = 0; k < b->geom.nb; ++k)                         // device [nb][3][bs][bs] -> host [nb][bs][bs][3]
+            for (int q = 0; q < 3; ++q)
+                for (int c = 0; c < bs * bs; ++c)
+                    u_aos[((size_t) k * bs * bs + c) * 3 + q] = b->host_staging[((size_t) k * 3 + q) * bs * bs + c];
+    }
+    else if (u_aos)
     {
         const size_t n = b->desc.n;
         MH_HIP_TRY(soa_to_aos_launch(b->u[0], b->staging, 3, b->desc.n, n, b->stream));
@@ -332,12 +434,14 @@ int mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps)
             {
                 mh_two_body_t B;
                 if (int rc = binary_bodies(b->state.orbital_elements, b->state.time, &B)) return rc;
-                MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[0], B.body1, maxw_dev(b), b->stream));
+                if (b->tree) MH_HIP_TRY(binary_tree_min_dt_launch(&b->desc, b->geom, b->u[0], B.body1, maxw_dev(b), b->stream));
+                else         MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[0], B.body1, maxw_dev(b), b->stream));
                 MH_HIP_TRY(hipMemcpyAsync(&b->mirror->maxw, maxw_dev(b), sizeof(double), hipMemcpyDeviceToHost, b->stream));
                 MH_HIP_TRY(hipStreamSynchronize(b->stream));
                 maxw = b->mirror->maxw;
             }
-            dt = b->run.cfl_number * (b->h / maxw);
+            // uniform grid: the reduction returns the largest wavespeed; graded tree: already min over blocks of spacing / wavespeed
+            dt = b->tree ? b->run.cfl_number * maxw : b->run.cfl_number * (b->h / maxw);
         }
         b->maxw_ready = false;
         mh_binary_state next;

@@ -1,0 +1,257 @@
+// Device code shared by the two kernel families of the `binary` path (binary.hip: uniform-depth trees as one periodic grid,
+// binary_tree.hip: graded trees block by block): the scheme's constants, the STRICT / FAST arithmetic policies and the
+// inter-cell flux. Reference lines are cited at each function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "euler_device.hpp"
+#include "euler_device_fast.hpp"
+#include "iso2d_device.hpp"
+#include "../../include/mara_hip.h"
+
+namespace mh {
+
+using iso2d::State3;
+
+struct BinaryConsts
+{
+    double h;                 // grid spacing 2 R / block_size / 2^level of the grid or block being processed
+    double h0;                // spacing at the root of the tree, 2 R / block_size (scheme.cpp:793)
+    double mach, alpha, nu, rc_cut;
+    double sink_rate, s2, rs2, floor_sigma;
+    int    axisym;
+    double rd;                // domain radius (the angular-momentum flux through x, y = +-rd is set to zero, scheme.cpp:208-209)
+    double sr2;               // gst_suppr_radius^2: range of the ramp on advance_q's geometrical source term (:421, :440)
+    double body[10];          // (mass, x, y, vx, vy) x 2
+};
+
+
+// ---- arithmetic policies ----------------------------------------------------------------------------------------------
+// BinStrict: reference operation order, IEEE division / sqrt (shared-denominator form), no contraction.
+// BinFast:   MH_ARITH_FAST as in euler_device_fast.hpp: reciprocal + two Newton steps per denominator, rsq-Goldschmidt square
+//            roots (1 / sqrt directly where the reference divides by a root), FMAs, min/max limiter. Tolerance as STRICT's
+//            (which already differs from the reference through libm): 1e-12 of the field scale, tests/test_gpu_binary.py.
+struct BinStrict
+{
+    static constexpr int arith = MH_ARITH_STRICT;
+    struct Ctx { Recip rmach, rh; };
+    static __device__ inline Ctx make(const BinaryConsts& c) { return {make_recip(c.mach, 1.0), make_recip(c.h, 1.0)}; }
+
+    // cs2_at_position :160-175 with grav_phi_field :101-111
+    static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
+    {
+        if (c.axisym)
+        {
+            const double a = 1.0 / sqrt(x * x + y * y);
+            return divide(divide(a, k.rmach), k.rmach);
+        }
+        const double d0 = x - c.body[1], d1 = y - c.body[2];
+        const double e0 = x - c.body[6], e1 = y - c.body[7];
+        const double phi1 = (-1.0 * c.body[0]) / sqrt(d0 * d0 + d1 * d1 + c.rs2);
+        const double phi2 = (-1.0 * c.body[5]) / sqrt(e0 * e0 + e1 * e1 + c.rs2);
+        return divide(divide(-(phi1 + phi2), k.rmach), k.rmach);
+    }
+    // nu_at_position :177-193
+    static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
+    {
+        const double radius = sqrt(x * x + y * y);
+        const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
+        if (c.nu > 0.0)
+            return profile * c.nu;
+        return profile * c.alpha * sqrt(cs2v) * divide(radius, k.rmach);
+    }
+    template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v) { return iso2d::riemann_hlle<AXIS>(pl, pr, cs2v, cs2v); }
+    static __device__ inline State3 plm_per_length(const State3& l, const State3& m, const State3& r, double theta, const Ctx& k)
+    {
+        State3 g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = plm_gradient(l[q], m[q], r[q], theta);
+        divide_group<3>(g.v, k.rh);
+        return g;
+    }
+    // iso2d::recover_primitive(U) physics_iso2d.hpp:351-362, or (Q, x) :376-390 at the centre of the cell the data belongs to
+    template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
+    {
+        State3 P;
+        if constexpr (QFORM) iso2d::recover_primitive_angmom(U, xc, yc, P);
+        else                 iso2d::recover_primitive(U, P);
+        return P;
+    }
+    // grav_vdot_field :85-95 times sigma (:369-370)
+    static __device__ inline void gravity(const BinaryConsts& c, int b, double d0, double d1, double sigma, double (&fg)[2])
+    {
+        const double r2s = d0 * d0 + d1 * d1 + c.rs2;
+        const double den = r2s * sqrt(r2s);                     // pow<3, 2>
+        double a[2] = {-d0, -d1};
+        divide_group<2>(a, make_recip(den, 1.0));
+        fg[0] = (a[0] * 1.0 * c.body[5 * b]) * sigma;
+        fg[1] = (a[1] * 1.0 * c.body[5 * b]) * sigma;
+    }
+    static __device__ inline double sink_a2(const BinaryConsts& c, double d0, double d1) { return (d0 * d0 + d1 * d1) / c.s2 / 2.0; }
+    static __device__ inline void over_area(double (&l)[3], double dA) { divide_group<3>(l, make_recip(dA, 1.0)); }
+};
+
+struct BinFast
+{
+    static constexpr int arith = MH_ARITH_FAST;
+    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2; };
+    static __device__ inline Ctx make(const BinaryConsts& c)
+    {
+        const double im = fast::rcp_nr(c.mach);
+        return {im, im * im, fast::rcp_nr(c.h), fast::rcp_nr(2.0 * c.s2)};
+    }
+    static __device__ inline double rsqrt(double x) { double g, h2; fast::sqrt_rsqrt(x, g, h2); return h2; }
+    static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
+    {
+        if (c.axisym) return rsqrt(__builtin_fma(x, x, y * y)) * k.inv_mach2;
+        const double d0 = x - c.body[1], d1 = y - c.body[2];
+        const double e0 = x - c.body[6], e1 = y - c.body[7];
+        const double r1 = rsqrt(__builtin_fma(d0, d0, __builtin_fma(d1, d1, c.rs2)));
+        const double r2 = rsqrt(__builtin_fma(e0, e0, __builtin_fma(e1, e1, c.rs2)));
+        return __builtin_fma(c.body[0], r1, c.body[5] * r2) * k.inv_mach2;
+    }
+    static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
+    {
+        const double radius = fast::sqrt_fast(__builtin_fma(x, x, y * y));
+        const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
+        if (c.nu > 0.0)
+            return profile * c.nu;
+        return profile * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);
+    }
+    // iso2d::riemann_hlle physics_iso2d.hpp:488-506 with one sound speed for both sides (the scheme passes cs2 twice, :288)
+    template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v)
+    {
+        const double cs = fast::sqrt_fast(cs2v);
+        const double vl = pl[1 + AXIS], vr = pr[1 + AXIS];
+        const double ap = __builtin_fmax(0.0, __builtin_fmax(vl + cs, vr + cs));
+        const double am = __builtin_fmin(0.0, __builtin_fmin(vl - cs, vr - cs));
+        const double rden = fast::rcp_nr(ap - am), apam = ap * am;
+        State3 F;
+        const State3* side[2] = {&pl, &pr};
+        double Ul[3], Ur[3], Fl[3], Fr[3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+        {
+            const State3& P = *side[s];
+            double* U = s == 0 ? Ul : Ur;
+            double* Fx = s == 0 ? Fl : Fr;
+            const double v = P[1 + AXIS], p = P[0] * cs2v;
+            U[0] = P[0]; U[1] = P[0] * P[1]; U[2] = P[0] * P[2];
+            Fx[0] = v * U[0];
+            Fx[1] = AXIS == 0 ? __builtin_fma(v, U[1], p) : v * U[1];
+            Fx[2] = AXIS == 1 ? __builtin_fma(v, U[2], p) : v * U[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            F[q] = __builtin_fma(-(Ul[q] - Ur[q]), apam, __builtin_fma(-Fr[q], am, Fl[q] * ap)) * rden;
+        return F;
+    }
+    static __device__ inline State3 plm_per_length(const State3& l, const State3& m, const State3& r, double theta, const Ctx& k)
+    {
+        State3 g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = fast::plm_gradient(l[q], m[q], r[q], theta) * k.inv_h;
+        return g;
+    }
+    template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
+    {
+        State3 P;
+        const double rs = fast::rcp_nr(U[0]);
+        P[0] = U[0];
+        if constexpr (QFORM)
+        {
+            const double sr = U[1] * rs, lz = U[2] * rs;
+            const double rr2 = fast::rcp_nr(__builtin_fma(xc, xc, yc * yc));
+            P[1] = __builtin_fma(sr, xc, -lz * yc) * rr2;
+            P[2] = __builtin_fma(sr, yc, lz * xc) * rr2;
+        }
+        else
+        {
+            P[1] = U[1] * rs;
+            P[2] = U[2] * rs;
+        }
+        return P;
+    }
+    static __device__ inline void gravity(const BinaryConsts& c, int b, double d0, double d1, double sigma, double (&fg)[2])
+    {
+        const double rs = rsqrt(__builtin_fma(d0, d0, __builtin_fma(d1, d1, c.rs2)));
+        const double w = -(rs * rs * rs) * c.body[5 * b] * sigma;
+        fg[0] = d0 * w;
+        fg[1] = d1 * w;
+    }
+    static __device__ inline double sink_a2(const BinaryConsts& c, double d0, double d1) { return __builtin_fma(d0, d0, d1 * d1) * fast::rcp_nr(2.0 * c.s2); }
+    static __device__ inline void over_area(double (&l)[3], double dA) { const double r = fast::rcp_nr(dA); for (int q = 0; q < 3; ++q) l[q] *= r; }
+};
+
+// strict helpers used by the small kernels (sink sums, maximum wavespeed)
+__device__ inline double binary_cs2(const BinaryConsts& c, const Recip& rmach, double x, double y)
+{
+    BinStrict::Ctx k = {rmach, rmach};
+    return BinStrict::cs2(c, k, x, y);
+}
+
+// intercell_flux_u :268-293 + viscous_flux :220-262 ; g = slopes along AXIS, t = transverse slopes (both per length)
+template<class A, int AXIS, bool QFORM>
+__device__ inline State3 binary_face_flux(const BinaryConsts& c, const typename A::Ctx& k, double xf, double yf,
+    const State3& pl, const State3& pr, const State3& gl, const State3& gr, const State3& tl, const State3& tr)
+{
+    State3 pl_hat, pr_hat;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+    {
+        pl_hat[q] = pl[q] + gl[q] * 0.5 * c.h;
+        pr_hat[q] = pr[q] - gr[q] * 0.5 * c.h;
+    }
+    const double cs2 = A::cs2(c, k, xf, yf);
+    const double nu = A::nu(c, k, xf, yf, cs2);
+    const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
+    State3 F = A::template hlle<AXIS>(pl_hat, pr_hat, cs2);
+    if constexpr (AXIS == 0)
+    {
+        const double dx_ux = 0.5 * (gl[1] + gr[1]);
+        const double dx_uy = 0.5 * (gl[2] + gr[2]);
+        const double dy_ux = 0.5 * (tl[1] + tr[1]);
+        const double dy_uy = 0.5 * (tl[2] + tr[2]);
+        const double tauxx = mu * (dx_ux - dy_uy);
+        const double tauxy = mu * (dx_uy + dy_ux);
+        F[0] = F[0] + 0.0;
+        F[1] = F[1] + -tauxx;
+        F[2] = F[2] + -tauxy;
+    }
+    else
+    {
+        const double dx_ux = 0.5 * (tl[1] + tr[1]);
+        const double dx_uy = 0.5 * (tl[2] + tr[2]);
+        const double dy_ux = 0.5 * (gl[1] + gr[1]);
+        const double dy_uy = 0.5 * (gl[2] + gr[2]);
+        const double tauyx =  mu * (dx_uy + dy_ux);
+        const double tauyy = -mu * (dx_ux - dy_uy);
+        F[0] = F[0] + 0.0;
+        F[1] = F[1] + -tauyx;
+        F[2] = F[2] + -tauyy;
+    }
+    if constexpr (QFORM)
+    {
+        // to_angmom_fluxes scheme.cpp:199-214
+        const double flux_sr = xf * F[1] + yf * F[2];
+        double flux_lz = xf * F[2] - yf * F[1];
+        if (AXIS == 0 && (xf == -c.rd || xf == c.rd)) flux_lz = 0.0;
+        if (AXIS == 1 && (yf == -c.rd || yf == c.rd)) flux_lz = 0.0;
+        F[1] = flux_sr;
+        F[2] = flux_lz;
+    }
+    return F;
+}
+
+// the sink rate of one body at a cell, sink_rate_field :117-126. exp(-a2) == 0 exactly for a2 > 750 (glibc and ocml
+// both underflow to zero below exp(-745.2)), so the call is skipped when no lane of the wave is in range.
+template<class A>
+__device__ inline double binary_sink_rate(const BinaryConsts& c, double d0, double d1)
+{
+    const double a2 = A::sink_a2(c, d0, d1);
+    double e = 0.0;
+    if (__any(a2 < 750.0)) e = exp(-a2);
+    return c.sink_rate * e;
+}
+
+
+} // namespace mh

@@ -5,6 +5,10 @@
 // reference build.
 #include <cmath>
 #include <vector>
+#include <map>
+#include <set>
+#include <array>
+#include <algorithm>
 #include "../../include/mara_hip.h"
 #include "binary_host.hpp"
 
@@ -116,36 +120,17 @@ void binary_combine_scalars(const mh_binary_state& a, const mh_binary_state& b, 
 
 } // namespace mh
 
-extern "C" {
+namespace mh {
 
-int mh_binary_vertices(int block_size, int depth, double domain_radius, double* out)
+// one tensor-product grid (the uniform mesh, or one block of a graded tree): initial field, buffer rate, smallest spacings, largest speed
+void binary_grid_data(const mh_binary_model* m, int n, const double* xv, const double* yv, double* u_init, double* br, double* min_dx_out, double* min_dy_out, double* max_v_out)
 {
-    if (block_size < 1 || depth < 0 || depth > 20 || ! out) return MH_E_INVALID;
-    int n = block_size;
-    std::vector<double> a(n + 1), b;
-    for (int i = 0; i <= n; ++i)
-        a[i] = -1.0 + (1.0 - -1.0) * i / double((n + 1) - 1);          // nd::linspace core_ndarray.hpp:2544-2551
-    for (int l = 0; l < depth; ++l)
-    {
-        b.resize(2 * n + 1);
-        for (int i = 0; i <= 2 * n; ++i)
-            b[i] = (a[i / 2] + a[(i + 1) / 2]) * 0.5;                    // prolong_verts mesh_prolong_restrict.hpp:148-159
-        n *= 2;
-        a.swap(b);
-    }
-    for (int i = 0; i <= n; ++i) out[i] = a[i] * domain_radius;
-    return MH_OK;
-}
-
-int mh_binary_solver_data(const mh_binary_model* m, int n, const double* xv, const double* yv, double* u_init, double* br, double* recommended_dt)
-{
-    if (! m || n < 1 || ! xv || ! yv || ! u_init || ! br || ! recommended_dt) return MH_E_INVALID;
     const double rs = m->softening_radius, rc = m->disk_radius, Ma = m->mach_number;
     const double s0 = m->disk_mass / (17.0618 * rc * rc);
     const double s1 = m->ambient_density * s0;
     auto sigma = [=] (double r) { const double x = r / rc; return s0 * std::exp(-0.5 * (x - 1) * (x - 1)) + s1; };
     auto dp_dr = [=] (double r) { const double x = r / rc; return (1.0 / Ma / Ma / (r + rs)) * (x * (1 - x) * (1 - s1 / sigma(r)) - 1.0); };
-    double min_dx = xv[1] - xv[0], min_dy = yv[1] - yv[0], max_v = 1.0;
+    double min_dx = xv[1] - xv[0], min_dy = yv[1] - yv[0], max_v = 0.0;
     for (int i = 0; i < n; ++i)
     {
         min_dx = std::fmin(min_dx, xv[i + 1] - xv[i]);
@@ -179,6 +164,213 @@ int mh_binary_solver_data(const mh_binary_model* m, int n, const double* xv, con
             const double rcen = std::pow(x * x + y * y, 0.5);
             br[(size_t) i * n + j] = m->buffer_damping_rate * (1.0 + std::tanh(3.0 * (rcen - m->domain_radius)));
         }
+    *min_dx_out = min_dx;
+    *min_dy_out = min_dy;
+    *max_v_out = max_v;
+}
+
+} // namespace mh
+
+extern "C" {
+
+int mh_binary_vertices(int block_size, int depth, double domain_radius, double* out)
+{
+    if (block_size < 1 || depth < 0 || depth > 20 || ! out) return MH_E_INVALID;
+    int n = block_size;
+    std::vector<double> a(n + 1), b;
+    for (int i = 0; i <= n; ++i)
+        a[i] = -1.0 + (1.0 - -1.0) * i / double((n + 1) - 1);          // nd::linspace core_ndarray.hpp:2544-2551
+    for (int l = 0; l < depth; ++l)
+    {
+        b.resize(2 * n + 1);
+        for (int i = 0; i <= 2 * n; ++i)
+            b[i] = (a[i / 2] + a[(i + 1) / 2]) * 0.5;                    // prolong_verts mesh_prolong_restrict.hpp:148-159
+        n *= 2;
+        a.swap(b);
+    }
+    for (int i = 0; i <= n; ++i) out[i] = a[i] * domain_radius;
+    return MH_OK;
+}
+
+int mh_binary_solver_data(const mh_binary_model* m, int n, const double* xv, const double* yv, double* u_init, double* br, double* recommended_dt)
+{
+    if (! m || n < 1 || ! xv || ! yv || ! u_init || ! br || ! recommended_dt) return MH_E_INVALID;
+    double min_dx, min_dy, max_v;
+    mh::binary_grid_data(m, n, xv, yv, u_init, br, &min_dx, &min_dy, &max_v);
+    *recommended_dt = std::fmin(min_dx, min_dy) / std::fmax(1.0, max_v) * m->cfl_number;
+    return MH_OK;
+}
+
+} // extern "C"
+
+// ---- graded block tree ------------------------------------------------------------------------------------------------------
+namespace {
+
+using Key = std::array<int, 3>;      // level, i, j
+
+struct LeafSet
+{
+    std::set<Key> leaves;
+    static Key wrap(Key k) { const int n = 1 << k[0]; k[1] = (k[1] % n + n) % n; k[2] = (k[2] % n + n) % n; return k; }
+    // the level difference to the deepest leaf below node k, or -1 if no node exists there (k lies inside a coarser leaf)
+    int node_depth(const Key& k) const
+    {
+        int best = -1;
+        for (const auto& l : leaves)
+        {
+            if (l[0] < k[0]) continue;
+            const int s = l[0] - k[0];
+            if ((l[1] >> s) == k[1] && (l[2] >> s) == k[2]) best = std::max(best, s);
+        }
+        return best;
+    }
+    void bifurcate(const Key& k)
+    {
+        leaves.erase(k);
+        for (int c = 0; c < 4; ++c) leaves.insert({k[0] + 1, 2 * k[1] + (c & 1), 2 * k[2] + ((c >> 1) & 1)});
+    }
+    // leaves in the order arithmetic_binary_tree_t visits them: depth first, children in orthant order (core_tree.hpp:156-159)
+    void ordered(const Key& node, std::vector<Key>& out) const
+    {
+        if (leaves.count(node)) { out.push_back(node); return; }
+        if (node_depth(node) < 0) return;
+        for (int c = 0; c < 4; ++c) ordered({node[0] + 1, 2 * node[1] + (c & 1), 2 * node[2] + ((c >> 1) & 1)}, out);
+    }
+};
+
+// the level-L refinement of linspace(-1, 1, bs + 1): prolong_verts applied L times (mesh_prolong_restrict.hpp:148-159)
+std::vector<double> level_vertices(int bs, int level)
+{
+    int n = bs;
+    std::vector<double> a(n + 1), b;
+    for (int i = 0; i <= n; ++i) a[i] = -1.0 + (1.0 - -1.0) * i / double((n + 1) - 1);
+    for (int l = 0; l < level; ++l)
+    {
+        b.resize(2 * n + 1);
+        for (int i = 0; i <= 2 * n; ++i) b[i] = (a[i / 2] + a[(i + 1) / 2]) * 0.5;
+        n *= 2;
+        a.swap(b);
+    }
+    return a;
+}
+
+} // namespace
+
+namespace mh {
+
+// neighbour table of the leaf blocks: topo[b][side][3] = {kind, id0, id1 | half}; sides: 0 = -x, 1 = +x, 2 = -y, 3 = +y.
+// kind 0: a leaf of the same level (id0); 1: a coarser leaf (id0) of which this block touches half `half` of the edge;
+// 2: two finer leaves id0, id1 in tangential order. Indices wrap periodically at every level (core_tree.hpp:203-204).
+int binary_tree_topology(const mh_tree_block* blocks, int nb, int32_t* topo)
+{
+    std::map<Key, int> id;
+    for (int b = 0; b < nb; ++b) id[{blocks[b].level, blocks[b].i, blocks[b].j}] = b;
+    for (int b = 0; b < nb; ++b)
+        for (int s = 0; s < 4; ++s)
+        {
+            const int axis = s / 2, up = s % 2;
+            Key n = {blocks[b].level, blocks[b].i, blocks[b].j};
+            const int tangential = axis == 0 ? n[2] : n[1];
+            n[1 + axis] += up ? 1 : -1;
+            n = LeafSet::wrap(n);
+            int32_t* t = topo + ((std::size_t) b * 4 + s) * 3;
+            auto it = id.find(n);
+            if (it != id.end()) { t[0] = 0; t[1] = it->second; t[2] = 0; continue; }
+            it = n[0] > 0 ? id.find({n[0] - 1, n[1] / 2, n[2] / 2}) : id.end();
+            if (it != id.end()) { t[0] = 1; t[1] = it->second; t[2] = tangential & 1; continue; }
+            // the two children of n that touch our face: on the far side of n along `axis` when n is below us, on the near side otherwise
+            Key c0 = {n[0] + 1, 2 * n[1], 2 * n[2]}, c1 = c0;
+            c0[1 + axis] += up ? 0 : 1;
+            c1[1 + axis] += up ? 0 : 1;
+            c1[2 - axis] += 1;
+            auto i0 = id.find(c0), i1 = id.find(c1);
+            if (i0 == id.end() || i1 == id.end()) { set_error("binary tree: block %d has a neighbour more than one level finer or coarser", b); return MH_E_INVALID; }
+            t[0] = 2; t[1] = i0->second; t[2] = i1->second;
+        }
+    return MH_OK;
+}
+
+} // namespace mh
+
+extern "C" {
+
+int mh_binary_tree_build(int bs, int depth, double focus_factor, double focus_index, mh_tree_block* out, int capacity)
+{
+    if (bs < 2 || bs % 2 != 0 || depth < 0 || depth > 12) return MH_E_INVALID;
+    LeafSet T;
+    T.leaves.insert({0, 0, 0});
+    for (int it = 0; it < depth; ++it)
+    {
+        // bifurcate_if over every leaf with level = the loop counter (mesh_tree_operators.hpp:177-188); centroid of the block's
+        // corner vertices, which are exact dyadic points of [-1, 1]
+        std::vector<Key> todo;
+        for (const auto& l : T.leaves)
+        {
+            const double w = 2.0 / (1 << l[0]);
+            const double cx = ((-1.0 + w * l[1]) + (-1.0 + w * (l[1] + 1))) * 0.5, cy = ((-1.0 + w * l[2]) + (-1.0 + w * (l[2] + 1))) * 0.5;
+            const double r = std::sqrt(0.0 + cx * cx + cy * cy);
+            if (r < focus_factor / std::pow(double(it), focus_index)) todo.push_back(l);
+        }
+        for (const auto& k : todo) T.bifurcate(k);
+    }
+    for (;;)      // ensure_valid_quadtree :115-139
+    {
+        std::vector<Key> todo;
+        for (const auto& l : T.leaves)
+        {
+            bool over = false;
+            for (int s = 0; s < 4 && ! over; ++s)
+            {
+                Key n = l;
+                n[1 + s / 2] += (s % 2) ? 1 : -1;
+                over = T.node_depth(LeafSet::wrap(n)) > 1;
+            }
+            if (over) todo.push_back(l);
+        }
+        if (todo.empty()) break;
+        for (const auto& k : todo) T.bifurcate(k);
+    }
+    std::vector<Key> order;
+    T.ordered({0, 0, 0}, order);
+    if (out && capacity >= (int) order.size())
+        for (std::size_t n = 0; n < order.size(); ++n) out[n] = {order[n][0], order[n][1], order[n][2]};
+    return (int) order.size();
+}
+
+int mh_binary_tree_vertices(int bs, double domain_radius, const mh_tree_block* blocks, int nblocks, double* edges)
+{
+    if (! blocks || ! edges || nblocks < 1) return MH_E_INVALID;
+    std::map<int, std::vector<double>> cache;
+    for (int b = 0; b < nblocks; ++b)
+    {
+        const int L = blocks[b].level;
+        if (! cache.count(L)) cache[L] = level_vertices(bs, L);
+        const auto& v = cache[L];
+        double* e = edges + (std::size_t) b * 2 * (bs + 1);
+        for (int a = 0; a <= bs; ++a)
+        {
+            e[a] = v[blocks[b].i * bs + a] * domain_radius;
+            e[bs + 1 + a] = v[blocks[b].j * bs + a] * domain_radius;
+        }
+    }
+    return MH_OK;
+}
+
+int mh_binary_tree_solver_data(const mh_binary_model* m, int bs, const mh_tree_block* blocks, int nblocks, const double* edges,
+                               double* u_init, double* br, double* recommended_dt)
+{
+    if (! m || ! blocks || ! edges || ! u_init || ! br || ! recommended_dt || nblocks < 1) return MH_E_INVALID;
+    if (m->angmom_form) { mh::set_error("binary on a graded tree: only the linear-momentum form is built"); return MH_E_INVALID; }
+    double min_dx = 1e300, min_dy = 1e300, max_v = 1.0;        // std::max(make_velocity(1.0), ...) solver_data.cpp:53-58
+    for (int b = 0; b < nblocks; ++b)
+    {
+        const double* xv = edges + (std::size_t) b * 2 * (bs + 1);
+        double bx, by, bv;
+        mh::binary_grid_data(m, bs, xv, xv + bs + 1, u_init + (std::size_t) b * bs * bs * 3, br + (std::size_t) b * bs * bs, &bx, &by, &bv);
+        min_dx = std::fmin(min_dx, bx);
+        min_dy = std::fmin(min_dy, by);
+        max_v = std::fmax(max_v, bv);
+    }
     *recommended_dt = std::fmin(min_dx, min_dy) / max_v * m->cfl_number;
     return MH_OK;
 }

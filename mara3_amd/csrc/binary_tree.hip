@@ -1,0 +1,380 @@
+// `binary` on a GRADED block tree for gfx950 (the sub-program's default mesh).
+//
+// Leaf blocks of bs x bs cells at different levels. One evaluation of binary::advance_u (src/subprog_binary_scheme.cpp:790-904)
+// runs as four kernels over the blocks, each stage of the reference's tree pipeline being one of them:
+//   tree_c2p_kernel      p0      = recover_primitive(u)                                            :802
+//   tree_grad_kernel     gx, gy  = plm_gradient(p0 extended by one guard zone) / spacing(level)     :794-811
+//   tree_flux_kernel     fhat_x, fhat_y on every face of every block, guard values of p0, gx, gy     :472-516
+//   tree_update_kernel   flux correction at refinement jumps (:614-700), sources, update, totals     :568-587, :345-411
+// Guard zones follow mara::get_cell_block (mesh_tree_operators.hpp:223-258): a neighbour of the same level is copied, a coarser
+// one prolonged piecewise-constant (refine_cells), a finer one restricted - restrict_cells(0) then (1), i.e. pairs averaged
+// along x first, then along y (mesh_prolong_restrict.hpp:124-132). A coarse face next to two fine blocks takes the sum of their
+// two fluxes, even face first (restrict_extrinsic :134-142); fluxes carry their face length already.
+//
+// The per-cell and per-face arithmetic is the same policy code as the uniform kernel (binary.hip: BinStrict / BinFast), so on a
+// uniform tree both kernel families produce identical bits (tests/test_gpu_binary_tree.py). These kernels are written for
+// generality, not for the roofline: the graded runs of the reference are small (64 blocks of 24^2 cells at the defaults);
+// primitives, slopes and fluxes make a round trip through memory between the kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "launch.hpp"
+#include "binary_device.hpp"
+
+namespace mh {
+
+enum { NB_SAME = 0, NB_COARSER = 1, NB_FINER = 2 };
+
+struct TreeGeom
+{
+    const int32_t* topo;      // [nb][4][3]: kind, id0, id1 (FINER: the two fine blocks in tangential order) or half (COARSER: which half of the coarse edge)
+    const int32_t* level;     // [nb]
+    const double*  edges;     // [nb][2][bs + 1]
+    int nb, bs;
+};
+
+__device__ inline long cell_index(int bs, int b, int q, int i, int j) { return (((long) b * 3 + q) * bs + i) * bs + j; }
+
+__device__ inline State3 load3(const double* F, int bs, int b, int i, int j)
+{
+    State3 s;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s[q] = F[cell_index(bs, b, q, i, j)];
+    return s;
+}
+
+// value of a cell-centred field at (i, j) of block b, where ONE of i, j may be -1 or bs: the guard zone of get_cell_block
+__device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i, int j)
+{
+    const int bs = g.bs;
+    if (i >= 0 && i < bs && j >= 0 && j < bs) return load3(F, bs, b, i, j);
+    const int side = i < 0 ? 0 : (i >= bs ? 1 : (j < 0 ? 2 : 3));
+    const int axis = side >> 1;                    // 0: the neighbour lies along x
+    const bool upper = side & 1;
+    const int a = axis == 0 ? j : i;               // tangential index
+    const int32_t* t = g.topo + ((long) b * 4 + side) * 3;
+    const int kind = t[0];
+    if (kind == NB_SAME)
+    {
+        const int n = upper ? 0 : bs - 1;
+        return axis == 0 ? load3(F, bs, t[1], n, a) : load3(F, bs, t[1], a, n);
+    }
+    if (kind == NB_COARSER)
+    {
+        // refine_cells: the fine guard cell takes the value of the coarse cell it lies in
+        const int n = upper ? 0 : bs - 1;
+        const int tc = t[2] * (bs / 2) + a / 2;
+        return axis == 0 ? load3(F, bs, t[1], n, tc) : load3(F, bs, t[1], tc, n);
+    }
+    // finer: coarsen_cells of the 2 x 2 fine cells under the guard cell: average along x, then along y
+    const int fa = 2 * a;                          // first of the two fine tangential indices in the combined (2 bs) edge
+    const int fb = fa >= bs ? t[2] : t[1];
+    const int ta = fa >= bs ? fa - bs : fa;
+    const int n0 = upper ? 0 : bs - 2;             // the two fine layers next to the face
+    State3 r;
+    if (axis == 0)
+    {
+        const State3 c00 = load3(F, bs, fb, n0, ta), c10 = load3(F, bs, fb, n0 + 1, ta), c01 = load3(F, bs, fb, n0, ta + 1), c11 = load3(F, bs, fb, n0 + 1, ta + 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[q] = ((c00[q] + c10[q]) / 2 + (c01[q] + c11[q]) / 2) / 2;
+    }
+    else
+    {
+        const State3 c00 = load3(F, bs, fb, ta, n0), c10 = load3(F, bs, fb, ta + 1, n0), c01 = load3(F, bs, fb, ta, n0 + 1), c11 = load3(F, bs, fb, ta + 1, n0 + 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[q] = ((c00[q] + c10[q]) / 2 + (c01[q] + c11[q]) / 2) / 2;
+    }
+    return r;
+}
+
+__device__ inline double spacing_of(const BinaryConsts& c, int level) { return c.h0 / (1 << level); }     // spacing_at_root / 2^level :793-799
+
+template<class A>
+__global__ __launch_bounds__(256)
+void tree_c2p_kernel(const double* u, double* prim, int nb, int bs)
+{
+    const long total = (long) nb * bs * bs;
+    for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
+    {
+        const int b = (int) (idx / (bs * bs)), c = (int) (idx - (long) b * bs * bs);
+        const int i = c / bs, j = c - i * bs;
+        const State3 P = A::template c2p<false>(load3(u, bs, b, i, j), 0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) prim[cell_index(bs, b, q, i, j)] = P[q];
+    }
+}
+
+template<class A>
+__global__ __launch_bounds__(256)
+void tree_grad_kernel(const double* prim, double* gx, double* gy, TreeGeom g, BinaryConsts c, double theta)
+{
+    const int b = blockIdx.x, bs = g.bs;
+    BinaryConsts cb = c;
+    cb.h = spacing_of(c, g.level[b]);
+    const typename A::Ctx k = A::make(cb);
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    {
+        const int i = idx / bs, j = idx - i * bs;
+        const State3 P0 = load3(prim, bs, b, i, j);
+        const State3 Gx = A::plm_per_length(fetch(prim, g, b, i - 1, j), P0, fetch(prim, g, b, i + 1, j), theta, k);
+        const State3 Gy = A::plm_per_length(fetch(prim, g, b, i, j - 1), P0, fetch(prim, g, b, i, j + 1), theta, k);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { gx[cell_index(bs, b, q, i, j)] = Gx[q]; gy[cell_index(bs, b, q, i, j)] = Gy[q]; }
+    }
+}
+
+// fx: [nb][3][bs + 1][bs], fy: [nb][3][bs][bs + 1]
+__device__ inline long fx_index(int bs, int b, int q, int i, int j) { return (((long) b * 3 + q) * (bs + 1) + i) * bs + j; }
+__device__ inline long fy_index(int bs, int b, int q, int i, int j) { return (((long) b * 3 + q) * bs + i) * (bs + 1) + j; }
+
+template<class A>
+__global__ __launch_bounds__(256)
+void tree_flux_kernel(const double* prim, const double* gx, const double* gy, double* fx, double* fy, TreeGeom g, BinaryConsts c)
+{
+    const int b = blockIdx.x, bs = g.bs;
+    BinaryConsts cb = c;
+    cb.h = spacing_of(c, g.level[b]);
+    const typename A::Ctx k = A::make(cb);
+    const double* xv = g.edges + (long) b * 2 * (bs + 1);
+    const double* yv = xv + bs + 1;
+    for (int idx = threadIdx.x; idx < (bs + 1) * bs; idx += 256)
+    {
+        {   // x-face (i, j), i = 0..bs
+            const int i = idx / bs, j = idx - i * bs;
+            const double xf = (xv[i] + xv[i]) * 0.5, yf = (yv[j] + yv[j + 1]) * 0.5;
+            State3 F = binary_face_flux<A, 0, false>(cb, k, xf, yf, fetch(prim, g, b, i - 1, j), fetch(prim, g, b, i, j),
+                                                     fetch(gx, g, b, i - 1, j), fetch(gx, g, b, i, j), fetch(gy, g, b, i - 1, j), fetch(gy, g, b, i, j));
+            const double dy = yv[j + 1] - yv[j];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fx[fx_index(bs, b, q, i, j)] = F[q] * dy;
+        }
+        {   // y-face (i, j), j = 0..bs
+            const int i = idx / (bs + 1), j = idx - i * (bs + 1);
+            const double xf = (xv[i] + xv[i + 1]) * 0.5, yf = (yv[j] + yv[j]) * 0.5;
+            State3 F = binary_face_flux<A, 1, false>(cb, k, xf, yf, fetch(prim, g, b, i, j - 1), fetch(prim, g, b, i, j),
+                                                     fetch(gy, g, b, i, j - 1), fetch(gy, g, b, i, j), fetch(gx, g, b, i, j - 1), fetch(gx, g, b, i, j));
+            const double dx = xv[i + 1] - xv[i];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fy[fy_index(bs, b, q, i, j)] = F[q] * dx;
+        }
+    }
+}
+
+// the flux through x-face i (0 or bs on the block's edge, anything inside) of row j after correct_fluxes_x
+__device__ inline double corrected_fx(const double* fx, const TreeGeom& g, int b, int q, int i, int j)
+{
+    const int bs = g.bs;
+    if (i == 0 || i == bs)
+    {
+        const int32_t* t = g.topo + ((long) b * 4 + (i == 0 ? 0 : 1)) * 3;
+        if (t[0] == NB_FINER)
+        {
+            const int fa = 2 * j, fb = fa >= bs ? t[2] : t[1], ta = fa >= bs ? fa - bs : fa;
+            const int fi = i == 0 ? bs : 0;                       // the fine blocks' face that coincides with ours
+            return fx[fx_index(bs, fb, q, fi, ta)] + fx[fx_index(bs, fb, q, fi, ta + 1)];
+        }
+    }
+    return fx[fx_index(bs, b, q, i, j)];
+}
+__device__ inline double corrected_fy(const double* fy, const TreeGeom& g, int b, int q, int i, int j)
+{
+    const int bs = g.bs;
+    if (j == 0 || j == bs)
+    {
+        const int32_t* t = g.topo + ((long) b * 4 + (j == 0 ? 2 : 3)) * 3;
+        if (t[0] == NB_FINER)
+        {
+            const int fa = 2 * i, fb = fa >= bs ? t[2] : t[1], ta = fa >= bs ? fa - bs : fa;
+            const int fj = j == 0 ? bs : 0;
+            return fy[fy_index(bs, fb, q, ta, fj)] + fy[fy_index(bs, fb, q, ta + 1, fj)];
+        }
+    }
+    return fy[fy_index(bs, b, q, i, j)];
+}
+
+static constexpr int NTREE_SUMS = 16;      // per block: mass_acc[2], L_acc[2], torque[2], px_acc[2], py_acc[2], fx[2], fy[2], mass_ej, L_ej
+
+template<class A, bool COMBINE>
+__global__ __launch_bounds__(256)
+void tree_update_kernel(const double* u_in, const double* u_base, double* u_out, const double* u_init, const double* br,
+                        const double* fx, const double* fy, TreeGeom g, BinaryConsts c, double dt, double weight, double* block_out, int32_t* status)
+{
+    const int b = blockIdx.x, bs = g.bs;
+    const double* xv = g.edges + (long) b * 2 * (bs + 1);
+    const double* yv = xv + bs + 1;
+    double acc[NTREE_SUMS];
+#pragma unroll
+    for (int k = 0; k < NTREE_SUMS; ++k) acc[k] = 0.0;
+    int bad = 0;
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    {
+        const int i = idx / bs, j = idx - i * bs;
+        const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
+        const double dA = (xv[i + 1] - xv[i]) * (yv[j + 1] - yv[j]);
+        const State3 u0 = load3(u_in, bs, b, i, j);
+        double fg[2][2], s_grav[2][3], s_sink[2][3], s_buffer[3], s_floor[3];
+#pragma unroll
+        for (int bdy = 0; bdy < 2; ++bdy)
+        {
+            const double d0 = xc - c.body[5 * bdy + 1], d1 = yc - c.body[5 * bdy + 2];
+            A::gravity(c, bdy, d0, d1, u0[0], fg[bdy]);
+            s_grav[bdy][0] = 0.0 * dt;
+            s_grav[bdy][1] = fg[bdy][0] * dt;
+            s_grav[bdy][2] = fg[bdy][1] * dt;
+            const double a2 = A::sink_a2(c, d0, d1);
+            const double rate = c.sink_rate * (a2 < 750.0 ? exp(-a2) : 0.0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) s_sink[bdy][q] = -u0[q] * rate * dt;
+        }
+        const double fl = u0[0] < c.floor_sigma ? 1.0 : 0.0;
+        const double brate = br[((long) b * bs + i) * bs + j];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            s_buffer[q] = (u_init[cell_index(bs, b, q, i, j)] - u0[q]) * brate * dt;
+            s_floor[q] = u0[q] * 1e-2 * fl;
+        }
+#pragma unroll
+        for (int bdy = 0; bdy < 2; ++bdy)
+        {
+            acc[0 + bdy]  = acc[0 + bdy] + s_sink[bdy][0] * dA;
+            acc[2 + bdy]  = acc[2 + bdy] + (xc * s_sink[bdy][2] - yc * s_sink[bdy][1]) * dA;
+            acc[4 + bdy]  = acc[4 + bdy] + (xc * s_grav[bdy][2] - yc * s_grav[bdy][1]) * dA;
+            acc[6 + bdy]  = acc[6 + bdy] + s_sink[bdy][1] * dA;
+            acc[8 + bdy]  = acc[8 + bdy] + s_sink[bdy][2] * dA;
+            acc[10 + bdy] = acc[10 + bdy] + fg[bdy][0] * dt * dA;
+            acc[12 + bdy] = acc[12 + bdy] + fg[bdy][1] * dt * dA;
+        }
+        acc[14] = acc[14] + s_buffer[0] * dA;
+        acc[15] = acc[15] + (xc * s_buffer[2] - yc * s_buffer[1]) * dA;
+
+        double l[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            l[q] = ((corrected_fx(fx, g, b, q, i + 1, j) - corrected_fx(fx, g, b, q, i, j)) + (corrected_fy(fy, g, b, q, i, j + 1) - corrected_fy(fy, g, b, q, i, j))) * dt;
+        A::over_area(l, dA);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            const double s = s_grav[0][q] + s_grav[1][q] + s_sink[0][q] + s_sink[1][q] + s_buffer[q] + s_floor[q];
+            const double u1 = u0[q] - l[q] + s;
+            if (q == 0 && !(u1 >= 0.0)) bad = 1;
+            double un = u1;
+            if constexpr (COMBINE) un = u_base[cell_index(bs, b, q, i, j)] * (1.0 - weight) + u1 * weight;
+            u_out[cell_index(bs, b, q, i, j)] = un;
+        }
+    }
+    __shared__ double red[NTREE_SUMS][256];
+#pragma unroll
+    for (int k = 0; k < NTREE_SUMS; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+        if ((int) threadIdx.x < off)
+            for (int k = 0; k < NTREE_SUMS; ++k) red[k][threadIdx.x] = red[k][threadIdx.x] + red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        double* out = block_out + (long) b * MH_BINARY_NTOTALS;
+        // order of mh_binary_total: mass_acc, L_acc, torque, px_acc, py_acc, fx, fy, work, mass_ej, L_ej
+        for (int k = 0; k < 14; ++k) out[k] = -red[k][0];
+        out[MH_T_MASS_EJ] = -red[14][0];
+        out[MH_T_L_EJ] = -red[15][0];
+        for (int bdy = 0; bdy < 2; ++bdy)       // work :356-365 from this block's sink sums
+        {
+            const double M0 = c.body[5 * bdy], px0 = c.body[5 * bdy + 3] * M0, py0 = c.body[5 * bdy + 4] * M0;
+            const double M1 = M0 + out[MH_T_MASS_ACC + bdy], px1 = px0 + out[MH_T_PX_ACC + bdy], py1 = py0 + out[MH_T_PY_ACC + bdy];
+            out[MH_T_WORK + bdy] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+        }
+    }
+    if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, MH_STATUS_NEG_DENSITY);
+}
+
+__global__ __launch_bounds__(64)
+void tree_totals_kernel(const double* block_out, int nb, double* totals)
+{
+    const int t = threadIdx.x;
+    if (t >= MH_BINARY_NTOTALS) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s = s + block_out[(long) b * MH_BINARY_NTOTALS + t];      // blocks in the tree's traversal order
+    totals[t] = s;
+}
+
+// min over blocks of spacing / max over its cells of max_wavespeed (maximum_timestep :1107-1126); *result must hold +inf beforehand
+__global__ __launch_bounds__(256)
+void tree_maxw_kernel(const double* u, TreeGeom g, BinaryConsts c, unsigned long long* result)
+{
+    const int b = blockIdx.x, bs = g.bs;
+    const Recip rmach = make_recip(c.mach, 1.0);
+    const double* xv = g.edges + (long) b * 2 * (bs + 1);
+    const double* yv = xv + bs + 1;
+    double m = 0.0;
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    {
+        const int i = idx / bs, j = idx - i * bs;
+        State3 P;
+        iso2d::recover_primitive(load3(u, bs, b, i, j), P);
+        const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
+        const double w = iso2d::max_wavespeed(P, binary_cs2(c, rmach, xc, yc));
+        m = (m < w) ? w : m;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+        if ((int) threadIdx.x < off) red[threadIdx.x] = red[threadIdx.x] < red[threadIdx.x + off] ? red[threadIdx.x + off] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        const double dtb = spacing_of(c, g.level[b]) / red[0];
+        atomicMin(result, (unsigned long long) __double_as_longlong(dtb));      // positive doubles order as integers
+    }
+}
+
+__global__ void tree_set_inf_kernel(double* x) { *x = __longlong_as_double(0x7ff0000000000000LL); }
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------
+BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]);
+
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out; };
+
+hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
+                                    double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
+                                    double theta, double* totals, int32_t* status, hipStream_t stream)
+{
+    BinaryConsts c = binary_make_consts(d, bodies);
+    const dim3 blk(256), grid(g.nb);
+    const long cells = (long) g.nb * g.bs * g.bs;
+    const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0;
+    const dim3 cgrid((unsigned) ((cells + 255) / 256));
+    if (fast) hipLaunchKernelGGL((tree_c2p_kernel<BinFast>), cgrid, blk, 0, stream, u_in, w.prim, g.nb, g.bs);
+    else      hipLaunchKernelGGL((tree_c2p_kernel<BinStrict>), cgrid, blk, 0, stream, u_in, w.prim, g.nb, g.bs);
+    if (fast)
+    {
+        hipLaunchKernelGGL((tree_grad_kernel<BinFast>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
+        hipLaunchKernelGGL((tree_flux_kernel<BinFast>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
+        if (combine) hipLaunchKernelGGL((tree_update_kernel<BinFast, true>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        else         hipLaunchKernelGGL((tree_update_kernel<BinFast, false>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+    }
+    else
+    {
+        hipLaunchKernelGGL((tree_grad_kernel<BinStrict>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
+        hipLaunchKernelGGL((tree_flux_kernel<BinStrict>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
+        if (combine) hipLaunchKernelGGL((tree_update_kernel<BinStrict, true>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        else         hipLaunchKernelGGL((tree_update_kernel<BinStrict, false>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+    }
+    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(64), 0, stream, w.block_out, g.nb, totals);
+    return hipGetLastError();
+}
+
+hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g, const double* u, const double bodies[10], double* result, hipStream_t stream)
+{
+    const BinaryConsts c = binary_make_consts(d, bodies);
+    hipLaunchKernelGGL(tree_set_inf_kernel, dim3(1), dim3(1), 0, stream, result);
+    hipLaunchKernelGGL(tree_maxw_kernel, dim3(g.nb), dim3(256), 0, stream, u, g, c, reinterpret_cast<unsigned long long*>(result));
+    return hipGetLastError();
+}
+
+} // namespace mh

@@ -1,0 +1,110 @@
+"""GPU parity tests of `binary` on GRADED block trees against vectors produced with the reference's own
+tree machinery (oracle/ref_drivers/binary_tree_ref.cpp: create_vertex_quadtree, ensure_valid_quadtree, get_cell_block,
+restrict_extrinsic). Tolerances as in tests/test_gpu_binary.py: 1e-12 of each field's largest magnitude (device libm)."""
+import json
+import numpy as np
+import pytest
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+CASES = ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d2_b16_uniform"]
+
+
+@pytest.fixture(scope="module")
+def binary():
+    import mara3_amd
+    from mara3_amd import binary
+    assert mara3_amd.load_library().mh_device_count() >= 1
+    return binary
+
+
+def cfg_of(binary, g, **extra):
+    over = json.loads(str(g["config"]))
+    cfg = binary.config(**{k: v for k, v in over.items() if k not in ("nsteps", "safe_mode")})
+    cfg.update(extra)
+    return cfg, over
+
+
+def close(a, b, rel=1e-12):
+    scale = np.abs(b).reshape(-1, 3).max(axis=0)
+    err = np.abs(a - b).reshape(-1, 3).max(axis=0)
+    return bool(np.all(err <= rel * scale)), err / scale
+
+
+def make(binary, cfg, g, dt=None, arith="strict"):
+    return binary.BinaryTreeSolver(cfg, blocks=g["blocks"], edges=g["xv"], u_init=g["u_init"], buffer_rate=g["br"],
+                                   recommended_time_step=g["stage_scalars"][1] if dt is None else dt, arith=arith)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_one_stage_on_a_graded_tree(binary, name):
+    """One advance_u (guard zones across refinement jumps, flux correction, per-block totals): a forward-Euler step with the
+    reference's dt is exactly one stage."""
+    g = golden(name)
+    ss = g["stage_scalars"]
+    cfg, _ = cfg_of(binary, g, rk_order=1, fixed_dt=1)
+    s = make(binary, cfg, g, dt=ss[0])
+    assert s.next(1) == 0 and s.last_dt == ss[0]
+    ok, rel = close(s.solution(), g["u_stage"])
+    assert ok, rel
+    st = binary.state_as_dict(s.state())
+    acc = np.array(st["mass_accreted_on"] + st["angular_momentum_accreted_on"] + st["integrated_torque_on"] + st["work_done_on"] + [st["mass_ejected"], st["angular_momentum_ejected"]])
+    ref = ss[3:13]
+    assert np.all(np.abs(acc - ref) <= 1e-9 * np.abs(ref) + 1e-11 * np.abs(ref).max()), (acc, ref)
+    s.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_next_solution_on_a_graded_tree(binary, name):
+    g = golden(name)
+    cfg, over = cfg_of(binary, g)
+    s = make(binary, cfg, g)
+    nsteps = int(over["nsteps"])
+    dts = []
+    for _ in range(nsteps):
+        assert s.next(1) == 0
+        dts.append(s.last_dt)
+    sc = g["scalars"]
+    assert np.allclose(dts, sc[42:42 + nsteps], rtol=1e-13, atol=0)          # min over blocks of spacing / wavespeed
+    ok, rel = close(s.solution(), g["u_final"])
+    assert ok, rel
+    assert abs(s.state().time - sc[0]) <= 1e-13 * sc[0] and s.state().iteration == int(sc[1])
+    s.close()
+
+
+def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
+    """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
+    policy arithmetic, so the two must agree to the last bit."""
+    g = golden("binary_tree_d2_b16_uniform")
+    gu = golden("binary_d2_b16")
+    cfg, _ = cfg_of(binary, g)
+    for arith in ("strict", "fast"):
+        t = make(binary, cfg, g, arith=arith)
+        u = binary.BinarySolver(cfg, xv=gu["xv"], yv=gu["yv"], u_init=gu["u_init"], buffer_rate=gu["br"], recommended_time_step=gu["stage_scalars"][1], arith=arith)
+        t.next(3)
+        u.next(3)
+        grid = u.solution()
+        blocks = t.solution()
+        for k, (l, i, j) in enumerate(g["blocks"]):
+            assert np.array_equal(blocks[k], grid[i * 16:(i + 1) * 16, j * 16:(j + 1) * 16]), (arith, k)
+        assert t.last_dt == u.last_dt and t.state().time == u.state().time
+        t.close(); u.close()
+
+
+def test_default_configuration_runs_and_stays_symmetric(binary):
+    """The sub-program's default mesh (depth=4 block_size=24 focus_factor=2): 64 blocks over three levels. Equal-mass circular
+    binary => point symmetry (x, y) -> (-x, -y), which maps block (l, i, j) to (l, 2^l - 1 - i, 2^l - 1 - j) reversed."""
+    cfg = binary.config()
+    s = binary.BinaryTreeSolver(cfg)
+    assert len(s.blocks) == 64
+    assert s.next(5) == 0
+    u = s.solution()
+    assert np.isfinite(u).all() and (u[..., 0] > 0).all()
+    index = {tuple(b): k for k, b in enumerate(s.blocks)}
+    scale = np.abs(u).reshape(-1, 3).max(axis=0)
+    for k, (l, i, j) in enumerate(s.blocks):
+        m = index[(l, (1 << l) - 1 - i, (1 << l) - 1 - j)]
+        r = u[m][::-1, ::-1]
+        assert np.abs(u[k][..., 0] - r[..., 0]).max() <= 1e-11 * scale[0]
+        assert np.abs(u[k][..., 1] + r[..., 1]).max() <= 1e-11 * scale[1]
+    s.close()
