@@ -5,9 +5,10 @@
 // subprog_binary_solver_data.cpp:20-102) - evaluated by the library's host functions with the host libm - and the same
 // step semantics including the safe-mode retry (:258-293), which the library performs on the device-resident state.
 //
-// Restrictions, stated rather than silently ignored: the tree must be of uniform depth (every node refined; upstream that
-// is `focus_factor` large, here it is the only mode: focus_factor / focus_index are accepted and must describe such a
-// tree), and the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
+// The tree is built as upstream (refinement predicate + 2:1 balance, mh_binary_tree_build). A tree of uniform depth runs as
+// one periodic grid through the wave-marching kernels (binary.hip); a graded one - the default, focus_factor=2 - block by
+// block with prolonged / restricted guard zones and flux correction (binary_tree.hip, linear-momentum form only).
+// Restrictions, stated rather than silently ignored: the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
 // tsi) are out of scope for `binary`; a raw dump of the final state replaces them.
 #include <cmath>
 #include <cstdio>
@@ -33,7 +34,7 @@ mara::config_t config_template()
     .item("begin_live_binary",    1e6)
     .item("conserve_linear_p",      1)
     .item("block_size",            24)
-    .item("focus_factor",         1e9)          // upstream default 2.0 builds a graded tree; only uniform depth is built here
+    .item("focus_factor",        2.00)
     .item("focus_index",         2.00)
     .item("threaded",               1)          // accepted for command-line compatibility; the device replaces the thread pool
     .item("rk_order",               2)
@@ -84,12 +85,15 @@ public:
         if (cfg.get_string("reconstruct_method") != "plm" && cfg.get_string("reconstruct_method") != "pcm")
             throw std::invalid_argument("invalid reconstruct_method '" + cfg.get_string("reconstruct_method") + "', must be plm or pcm");
         const int depth = cfg.get_int("depth"), bs = cfg.get_int("block_size");
-        // refinement predicate subprog_binary.cpp:174-177: a node at `level` with centroid radius rc refines if
-        // rc < focus_factor / level^focus_index. Uniform depth needs it true up to the corner blocks of the deepest level.
-        for (int level = 1; level < depth; ++level)
-            if (! (std::sqrt(2.0) < cfg.get_double("focus_factor") / std::pow(double(level), cfg.get_double("focus_index"))))
-                throw std::invalid_argument("binary: this build needs a uniform-depth tree (use a large focus_factor, e.g. 1e9)");
-        const int n = bs << depth;
+        const int nblocks = mh_binary_tree_build(bs, depth, cfg.get_double("focus_factor"), cfg.get_double("focus_index"), nullptr, 0);
+        if (nblocks < 0) throw std::invalid_argument("binary: cannot build the block tree (block_size must be even, depth <= 12)");
+        std::vector<mh_tree_block> blocks(nblocks);
+        mh_binary_tree_build(bs, depth, cfg.get_double("focus_factor"), cfg.get_double("focus_index"), blocks.data(), nblocks);
+        bool graded = false;
+        for (const auto& b : blocks) graded = graded || b.level != blocks[0].level;
+        if (graded) return run_graded(cfg, blocks);
+        const int n = bs << blocks[0].level;
+        if (blocks[0].level != depth) throw std::invalid_argument("binary: the refinement predicate stops the tree above the requested depth");
 
         std::vector<double> xv(n + 1), u(std::size_t(3) * n * n), br(std::size_t(n) * n);
         check(mh_binary_vertices(bs, depth, cfg.get_double("domain_radius"), xv.data()), "mh_binary_vertices");
@@ -167,6 +171,83 @@ public:
             std::vector<double> extra = xv;
             extra.insert(extra.end(), scalars.begin(), scalars.end());
             host::dump_state(cfg.get_string("outdir"), "final.bin", {long(n), long(n)}, 3, state.time, state.iteration, extra, u);
+        }
+        mh_binary_destroy(solver);
+        return 0;
+    }
+
+    // the same run loop on a graded tree (block-major arrays)
+    int run_graded(const mara::config_t& cfg, const std::vector<mh_tree_block>& blocks)
+    {
+        const int bs = cfg.get_int("block_size"), nb = int(blocks.size());
+        if (! cfg.get_int("conserve_linear_p")) throw std::invalid_argument("binary: conserve_linear_p=0 on a graded tree is not built");
+        std::vector<double> edges(std::size_t(nb) * 2 * (bs + 1)), u(std::size_t(nb) * bs * bs * 3), br(std::size_t(nb) * bs * bs);
+        check(mh_binary_tree_vertices(bs, cfg.get_double("domain_radius"), blocks.data(), nb, edges.data()), "mh_binary_tree_vertices");
+        mh_binary_model model = {};
+        model.softening_radius = cfg.get_double("softening_radius");
+        model.disk_radius = cfg.get_double("disk_radius");
+        model.mach_number = cfg.get_double("mach_number");
+        model.disk_mass = cfg.get_double("disk_mass");
+        model.ambient_density = cfg.get_double("ambient_density");
+        model.mdot = cfg.get_double("mdot");
+        model.counter_rotate = cfg.get_int("counter_rotate");
+        model.buffer_damping_rate = cfg.get_double("buffer_damping_rate");
+        model.domain_radius = cfg.get_double("domain_radius");
+        model.cfl_number = cfg.get_double("cfl_number");
+        mh_binary_run run = {};
+        check(mh_binary_tree_solver_data(&model, bs, blocks.data(), nb, edges.data(), u.data(), br.data(), &run.recommended_time_step), "mh_binary_tree_solver_data");
+        run.rk_order = cfg.get_int("rk_order");
+        run.fixed_dt = cfg.get_int("fixed_dt");
+        run.no_accretion_force = cfg.get_int("no_accretion_force");
+        run.cfl_number = cfg.get_double("cfl_number");
+        run.begin_live_binary = cfg.get_double("begin_live_binary");
+        mh_binary_desc d = {};
+        d.block_size = bs;
+        d.domain_radius = cfg.get_double("domain_radius");
+        d.mach_number = cfg.get_double("mach_number");
+        d.alpha = cfg.get_double("alpha");
+        d.nu = cfg.get_double("nu");
+        d.alpha_cutoff_radius = cfg.get_double("alpha_cutoff_radius");
+        d.sink_rate = cfg.get_double("sink_rate");
+        d.sink_radius = cfg.get_double("sink_radius");
+        d.softening_radius = cfg.get_double("softening_radius");
+        d.density_floor = cfg.get_double("density_floor") * cfg.get_double("disk_mass");
+        d.axisymmetric_cs2 = cfg.get_int("axisymmetric_cs2");
+        d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
+        d.plm_theta = cfg.get_double("plm_theta");
+
+        mh_binary* solver = nullptr;
+        check(mh_binary_tree_create(&solver, cfg.get_int("device"), &d, &run, blocks.data(), nb, edges.data(), u.data(), br.data()), "mh_binary_tree_create");
+        mh_binary_state state = {};
+        state.orbital_elements.elements.total_mass = 1.0;
+        state.orbital_elements.elements.separation = cfg.get_double("separation");
+        state.orbital_elements.elements.mass_ratio = cfg.get_double("mass_ratio");
+        state.orbital_elements.elements.eccentricity = cfg.get_double("eccentricity");
+        check(mh_binary_set_solution(solver, nullptr, &state), "mh_binary_set_solution");
+
+        const double tfinal = cfg.get_double("tfinal"), cells = double(nb) * bs * bs;
+        const int batch = std::max(1, cfg.get_int("steps_per_call"));
+        const int max_iter = cfg.get_int("max_iterations");
+        std::printf("block tree: %d blocks of %d x %d zones\n", nb, bs, bs);
+        while (state.time / (2 * M_PI) < tfinal && (max_iter == 0 || state.iteration < max_iter))
+        {
+            const int todo = max_iter ? int(std::min<long>(batch, max_iter - state.iteration)) : batch;
+            int safe = 0;
+            const double ms = host::time_ms([&] { check(mh_binary_next(solver, todo, &safe), "mh_binary_next"); });
+            check(mh_binary_get_solution(solver, nullptr, &state), "mh_binary_get_solution");
+            if (safe) std::printf("negative density in updated state\n");
+            std::printf("[%04ld] orbits=%3.7lf kzps=%3.2lf\n", long(state.iteration), state.time / (2 * M_PI), cells * todo / ms);
+            std::fflush(stdout);
+        }
+        if (cfg.get_int("write_final"))
+        {
+            check(mh_binary_get_solution(solver, u.data(), &state), "mh_binary_get_solution");
+            std::vector<double> extra;                 // block list (level, i, j as doubles), then the ten accumulators
+            for (const auto& b : blocks) { extra.push_back(b.level); extra.push_back(b.i); extra.push_back(b.j); }
+            for (double v : {state.mass_accreted_on[0], state.mass_accreted_on[1], state.angular_momentum_accreted_on[0], state.angular_momentum_accreted_on[1],
+                             state.integrated_torque_on[0], state.integrated_torque_on[1], state.work_done_on[0], state.work_done_on[1],
+                             state.mass_ejected, state.angular_momentum_ejected}) extra.push_back(v);
+            host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nb), long(bs), long(bs)}, 3, state.time, state.iteration, extra, u);
         }
         mh_binary_destroy(solver);
         return 0;

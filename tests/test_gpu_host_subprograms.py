@@ -100,6 +100,7 @@ def test_binary_subprogram_matches_reference(tmp_path, case):
     over = json.loads(str(g["config"]))
     nsteps = int(over.pop("nsteps"))
     args = ["%s=%r" % (k, int(v) if float(v).is_integer() and k in ("depth", "block_size", "fixed_dt", "rk_order", "axisymmetric_cs2", "counter_rotate", "no_accretion_force", "conserve_linear_p") else float(v)) for k, v in over.items()]
+    args.append("focus_factor=1e9")          # the uniform-depth tree these vectors were made on (the default, 2.0, grades the tree)
     stdout = run(["binary"] + args + ["max_iterations=%d" % nsteps, "tfinal=100.0"], str(tmp_path))
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     n = g["u_final"].shape[0]
@@ -116,8 +117,8 @@ def test_binary_subprogram_matches_reference(tmp_path, case):
 
 
 def test_binary_subprogram_rejects_what_is_not_built(tmp_path):
-    out = subprocess.run([EXE, "binary", "focus_factor=2.0", "depth=4"], cwd=str(tmp_path), capture_output=True, text=True)
-    assert out.returncode == 1 and "uniform-depth" in out.stdout
+    out = subprocess.run([EXE, "binary", "conserve_linear_p=0"], cwd=str(tmp_path), capture_output=True, text=True)       # the default tree is graded
+    assert out.returncode == 1 and "graded tree" in out.stdout
     out = subprocess.run([EXE, "binary", "reconstruct_method=weno"], cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 1 and "must be plm or pcm" in out.stdout
 
@@ -180,3 +181,31 @@ def test_cloud_checkpoint_and_restart(tmp_path):
     run(["cloud", "restart=a/chkpt.0001.h5", "outdir=b", "max_steps=3"], str(tmp_path))
     b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
     assert b["iteration"] == 3 and bits_equal(b["data"], g["un"])
+
+
+@pytest.mark.parametrize("case", ["binary_tree_d3_b8", "binary_tree_d3_b12_nu"])
+def test_binary_subprogram_on_graded_trees_matches_reference(tmp_path, case):
+    """`mara_hip binary` with a refinement predicate that grades the tree: tree construction, block vertices and solver data on
+    the host, block kernels on the device; against vectors made with the reference's own tree machinery."""
+    import json
+    g = golden(case)
+    over = json.loads(str(g["config"]))
+    nsteps = int(over.pop("nsteps"))
+    ints = ("depth", "block_size", "fixed_dt", "rk_order")
+    args = ["%s=%r" % (k, int(v) if k in ints else float(v)) for k, v in over.items()]
+    stdout = run(["binary"] + args + ["max_iterations=%d" % nsteps, "tfinal=100.0"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    nb = len(g["blocks"])
+    assert "block tree: %d blocks" % nb in stdout
+    assert np.array_equal(d["vertices"][:3 * nb].reshape(nb, 3), g["blocks"])
+    assert d["iteration"] == nsteps and abs(d["time"] - g["scalars"][0]) <= 1e-13 * g["scalars"][0]
+    scale = np.abs(g["u_final"]).reshape(-1, 3).max(axis=0)
+    err = np.abs(d["data"] - g["u_final"]).reshape(-1, 3).max(axis=0)
+    assert np.all(err <= 1e-12 * scale), err / scale
+
+
+def test_binary_subprogram_default_configuration_runs(tmp_path):
+    stdout = run(["binary", "max_iterations=20", "steps_per_call=10"], str(tmp_path))      # depth=4 block_size=24 focus_factor=2: the graded default
+    assert "block tree: 64 blocks of 24 x 24 zones" in stdout and "[0020] orbits=" in stdout
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert np.isfinite(d["data"]).all() and (d["data"][..., 0] > 0).all()
