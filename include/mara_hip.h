@@ -374,8 +374,8 @@ int  mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlau
 /* ---- `binary` on a GRADED block tree (the sub-program's default: refinement towards the origin) ---------
  * Leaf blocks of block_size^2 cells at different levels; guard zones are prolonged (piecewise constant) from coarser and
  * restricted (averaged) from finer neighbours, and the face fluxes of a coarse block next to finer ones are replaced by the sum
- * of the fine fluxes (src/subprog_binary_scheme.cpp:132-142, :614-720; mesh_tree_operators.hpp:223-258). Linear-momentum form
- * (advance_u) only. Block data are ordered as the reference traverses its tree (children in orthant order i + 2 j).
+ * of the fine fluxes (src/subprog_binary_scheme.cpp:132-142, :614-720; mesh_tree_operators.hpp:223-258). Both conserved-variable
+ * forms. Block data are ordered as the reference traverses its tree (children in orthant order i + 2 j).
  * Host fields: [nblocks][bs][bs][3]; vertex edges: [nblocks][2][bs + 1] (x of the block's vertex columns, y of its rows). */
 typedef struct mh_tree_block { int32_t level, i, j; } mh_tree_block;
 /* mara::create_vertex_quadtree with the sub-program's refinement predicate (centroid_radius < focus_factor / level^focus_index,
@@ -386,7 +386,8 @@ int  mh_binary_tree_vertices(int block_size, double domain_radius, const mh_tree
 int  mh_binary_tree_solver_data(const mh_binary_model* m, int block_size, const mh_tree_block* blocks, int nblocks, const double* edges_host,
                                 double* u_init_host, double* buffer_rate_host, double* recommended_time_step);
 /* Solver object on a graded tree; afterwards mh_binary_set_solution / get_solution / next / last_dt / destroy apply unchanged
- * (solution arrays in the block layout above). d->n is ignored; d->angmom_form must be 0. */
+ * (solution arrays in the block layout above). d->n is ignored; with d->angmom_form set, d->gst_suppr_radius is
+ * source_term_softening times the smallest vertex spacing of any block. */
 int  mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks,
                            int nblocks, const double* edges_host, const double* u_init_host, const double* buffer_rate_host);
 

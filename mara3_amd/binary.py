@@ -252,7 +252,8 @@ class BinaryTreeSolver(BinarySolver):
         assert self.u_init.shape == (nb, self.bs, self.bs, 3) and self.buffer_rate.shape == (nb, self.bs, self.bs)
         self.desc = make_desc(config(**{**cfg, "conserve_linear_p": 1}), arith=arith)
         if not int(cfg["conserve_linear_p"]):
-            raise L.MaraHipError("binary on a graded tree: only conserve_linear_p = 1 is built")
+            self.desc.angmom_form = 1
+            self.desc.gst_suppr_radius = float(cfg["source_term_softening"]) * float(np.diff(self.edges, axis=2).min())     # solver_data.cpp:91
         run = L.BinaryRun()
         run.rk_order = int(cfg["rk_order"])
         run.fixed_dt = int(cfg["fixed_dt"])

@@ -300,7 +300,6 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
                           const double* edges, const double* u_init_aos, const double* br)
 {
     if (! out || ! d || ! run || ! blocks || ! edges || ! u_init_aos || ! br || nblocks < 1) { set_error("binary tree create: null argument"); return MH_E_INVALID; }
-    if (d->angmom_form) { set_error("binary on a graded tree: only the linear-momentum form (conserve_linear_p = 1) is built"); return MH_E_INVALID; }
     if (d->block_size < 2 || d->block_size % 2 != 0) { set_error("binary tree: block_size must be even"); return MH_E_INVALID; }
     if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
     if (! (d->mach_number > 0.0) || ! (d->sink_radius > 0.0) || ! (d->domain_radius > 0.0)) { set_error("binary: mach_number, sink_radius and domain_radius must be positive"); return MH_E_INVALID; }

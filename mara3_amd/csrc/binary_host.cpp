@@ -360,7 +360,6 @@ int mh_binary_tree_solver_data(const mh_binary_model* m, int bs, const mh_tree_b
                                double* u_init, double* br, double* recommended_dt)
 {
     if (! m || ! blocks || ! edges || ! u_init || ! br || ! recommended_dt || nblocks < 1) return MH_E_INVALID;
-    if (m->angmom_form) { mh::set_error("binary on a graded tree: only the linear-momentum form is built"); return MH_E_INVALID; }
     double min_dx = 1e300, min_dy = 1e300, max_v = 1.0;        // std::max(make_velocity(1.0), ...) solver_data.cpp:53-58
     for (int b = 0; b < nblocks; ++b)
     {

@@ -11,12 +11,13 @@
 // along x first, then along y (mesh_prolong_restrict.hpp:124-132). A coarse face next to two fine blocks takes the sum of their
 // two fluxes, even face first (restrict_extrinsic :134-142); fluxes carry their face length already.
 //
-// The per-cell and per-face arithmetic is the same policy code as the uniform kernel (binary.hip: BinStrict / BinFast), so on a
+// The per-cell and per-face arithmetic is the same policy code as the uniform kernel (binary.hip: BinStrict / BinFast; both conserved-variable forms), so on a
 // uniform tree both kernel families produce identical bits (tests/test_gpu_binary_tree.py). These kernels are written for
 // generality, not for the roofline: the graded runs of the reference are small (64 blocks of 24^2 cells at the defaults);
 // primitives, slopes and fluxes make a round trip through memory between the kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "launch.hpp"
 #include "binary_device.hpp"
 
@@ -88,16 +89,18 @@ __device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i,
 
 __device__ inline double spacing_of(const BinaryConsts& c, int level) { return c.h0 / (1 << level); }     // spacing_at_root / 2^level :793-799
 
-template<class A>
+template<class A, bool QFORM>
 __global__ __launch_bounds__(256)
-void tree_c2p_kernel(const double* u, double* prim, int nb, int bs)
+void tree_c2p_kernel(const double* u, double* prim, const double* edges, int nb, int bs)
 {
     const long total = (long) nb * bs * bs;
     for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
     {
         const int b = (int) (idx / (bs * bs)), c = (int) (idx - (long) b * bs * bs);
         const int i = c / bs, j = c - i * bs;
-        const State3 P = A::template c2p<false>(load3(u, bs, b, i, j), 0.0, 0.0);
+        const double* xv = edges + (long) b * 2 * (bs + 1);
+        const double* yv = xv + bs + 1;
+        const State3 P = A::template c2p<QFORM>(load3(u, bs, b, i, j), (xv[i] + xv[i + 1]) * 0.5, (yv[j] + yv[j + 1]) * 0.5);
 #pragma unroll
         for (int q = 0; q < 3; ++q) prim[cell_index(bs, b, q, i, j)] = P[q];
     }
@@ -126,7 +129,7 @@ void tree_grad_kernel(const double* prim, double* gx, double* gy, TreeGeom g, Bi
 __device__ inline long fx_index(int bs, int b, int q, int i, int j) { return (((long) b * 3 + q) * (bs + 1) + i) * bs + j; }
 __device__ inline long fy_index(int bs, int b, int q, int i, int j) { return (((long) b * 3 + q) * bs + i) * (bs + 1) + j; }
 
-template<class A>
+template<class A, bool QFORM>
 __global__ __launch_bounds__(256)
 void tree_flux_kernel(const double* prim, const double* gx, const double* gy, double* fx, double* fy, TreeGeom g, BinaryConsts c)
 {
@@ -141,7 +144,7 @@ void tree_flux_kernel(const double* prim, const double* gx, const double* gy, do
         {   // x-face (i, j), i = 0..bs
             const int i = idx / bs, j = idx - i * bs;
             const double xf = (xv[i] + xv[i]) * 0.5, yf = (yv[j] + yv[j + 1]) * 0.5;
-            State3 F = binary_face_flux<A, 0, false>(cb, k, xf, yf, fetch(prim, g, b, i - 1, j), fetch(prim, g, b, i, j),
+            State3 F = binary_face_flux<A, 0, QFORM>(cb, k, xf, yf, fetch(prim, g, b, i - 1, j), fetch(prim, g, b, i, j),
                                                      fetch(gx, g, b, i - 1, j), fetch(gx, g, b, i, j), fetch(gy, g, b, i - 1, j), fetch(gy, g, b, i, j));
             const double dy = yv[j + 1] - yv[j];
 #pragma unroll
@@ -150,7 +153,7 @@ void tree_flux_kernel(const double* prim, const double* gx, const double* gy, do
         {   // y-face (i, j), j = 0..bs
             const int i = idx / (bs + 1), j = idx - i * (bs + 1);
             const double xf = (xv[i] + xv[i + 1]) * 0.5, yf = (yv[j] + yv[j]) * 0.5;
-            State3 F = binary_face_flux<A, 1, false>(cb, k, xf, yf, fetch(prim, g, b, i, j - 1), fetch(prim, g, b, i, j),
+            State3 F = binary_face_flux<A, 1, QFORM>(cb, k, xf, yf, fetch(prim, g, b, i, j - 1), fetch(prim, g, b, i, j),
                                                      fetch(gy, g, b, i, j - 1), fetch(gy, g, b, i, j), fetch(gx, g, b, i, j - 1), fetch(gx, g, b, i, j));
             const double dx = xv[i + 1] - xv[i];
 #pragma unroll
@@ -193,9 +196,9 @@ __device__ inline double corrected_fy(const double* fy, const TreeGeom& g, int b
 
 static constexpr int NTREE_SUMS = 16;      // per block: mass_acc[2], L_acc[2], torque[2], px_acc[2], py_acc[2], fx[2], fy[2], mass_ej, L_ej
 
-template<class A, bool COMBINE>
+template<class A, bool COMBINE, bool QFORM>
 __global__ __launch_bounds__(256)
-void tree_update_kernel(const double* u_in, const double* u_base, double* u_out, const double* u_init, const double* br,
+void tree_update_kernel(const double* u_in, const double* u_base, double* u_out, const double* u_init, const double* br, const double* prim,
                         const double* fx, const double* fy, TreeGeom g, BinaryConsts c, double dt, double weight, double* block_out, int32_t* status)
 {
     const int b = blockIdx.x, bs = g.bs;
@@ -233,19 +236,42 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
             s_buffer[q] = (u_init[cell_index(bs, b, q, i, j)] - u0[q]) * brate * dt;
             s_floor[q] = u0[q] * 1e-2 * fl;
         }
+        double dps[2][2] = {{s_sink[0][1], s_sink[0][2]}, {s_sink[1][1], s_sink[1][2]}};
+        if constexpr (QFORM)
+        {
+            // source_terms_q :417-466 (as in binary.hip)
+            const typename A::Ctx k = A::make(c);
+            const double r2 = 0.0 + xc * xc + yc * yc;
+#pragma unroll
+            for (int bdy = 0; bdy < 2; ++bdy)
+            {
+                s_grav[bdy][1] = (xc * fg[bdy][0] + yc * fg[bdy][1]) * dt;
+                s_grav[bdy][2] = (xc * fg[bdy][1] - yc * fg[bdy][0]) * dt;
+                dps[bdy][0] = (s_sink[bdy][1] * xc - s_sink[bdy][2] * yc) / r2;
+                dps[bdy][1] = (s_sink[bdy][1] * yc + s_sink[bdy][2] * xc) / r2;
+            }
+            const double a = -(xc * xc + yc * yc) / c.sr2;
+            const double ramp = 1.0 - (a > -750.0 ? exp(a) : 0.0);
+            const State3 pc = load3(prim, bs, b, i, j);
+            const double Ek = 0.5 * pc[0] * (pc[1] * pc[1] + pc[2] * pc[2]);
+            const double pg = pc[0] * A::cs2(c, k, xc, yc);
+            s_floor[0] = 0.0 * ramp * dt;
+            s_floor[1] = (Ek + pg) * 2.0 * ramp * dt;
+            s_floor[2] = 0.0 * ramp * dt;
+        }
 #pragma unroll
         for (int bdy = 0; bdy < 2; ++bdy)
         {
             acc[0 + bdy]  = acc[0 + bdy] + s_sink[bdy][0] * dA;
-            acc[2 + bdy]  = acc[2 + bdy] + (xc * s_sink[bdy][2] - yc * s_sink[bdy][1]) * dA;
-            acc[4 + bdy]  = acc[4 + bdy] + (xc * s_grav[bdy][2] - yc * s_grav[bdy][1]) * dA;
-            acc[6 + bdy]  = acc[6 + bdy] + s_sink[bdy][1] * dA;
-            acc[8 + bdy]  = acc[8 + bdy] + s_sink[bdy][2] * dA;
+            acc[2 + bdy]  = acc[2 + bdy] + (QFORM ? s_sink[bdy][2] : (xc * s_sink[bdy][2] - yc * s_sink[bdy][1])) * dA;
+            acc[4 + bdy]  = acc[4 + bdy] + (QFORM ? s_grav[bdy][2] : (xc * s_grav[bdy][2] - yc * s_grav[bdy][1])) * dA;
+            acc[6 + bdy]  = acc[6 + bdy] + dps[bdy][0] * dA;
+            acc[8 + bdy]  = acc[8 + bdy] + dps[bdy][1] * dA;
             acc[10 + bdy] = acc[10 + bdy] + fg[bdy][0] * dt * dA;
             acc[12 + bdy] = acc[12 + bdy] + fg[bdy][1] * dt * dA;
         }
         acc[14] = acc[14] + s_buffer[0] * dA;
-        acc[15] = acc[15] + (xc * s_buffer[2] - yc * s_buffer[1]) * dA;
+        acc[15] = acc[15] + (QFORM ? s_buffer[2] : (xc * s_buffer[2] - yc * s_buffer[1])) * dA;
 
         double l[3];
 #pragma unroll
@@ -284,7 +310,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
         {
             const double M0 = c.body[5 * bdy], px0 = c.body[5 * bdy + 3] * M0, py0 = c.body[5 * bdy + 4] * M0;
             const double M1 = M0 + out[MH_T_MASS_ACC + bdy], px1 = px0 + out[MH_T_PX_ACC + bdy], py1 = py0 + out[MH_T_PY_ACC + bdy];
-            out[MH_T_WORK + bdy] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+            out[MH_T_WORK + bdy] = QFORM ? 0.0 : ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
         }
     }
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, MH_STATUS_NEG_DENSITY);
@@ -302,7 +328,7 @@ void tree_totals_kernel(const double* block_out, int nb, double* totals)
 
 // min over blocks of spacing / max over its cells of max_wavespeed (maximum_timestep :1107-1126); *result must hold +inf beforehand
 __global__ __launch_bounds__(256)
-void tree_maxw_kernel(const double* u, TreeGeom g, BinaryConsts c, unsigned long long* result)
+void tree_maxw_kernel(const double* u, TreeGeom g, BinaryConsts c, int qform, unsigned long long* result)
 {
     const int b = blockIdx.x, bs = g.bs;
     const Recip rmach = make_recip(c.mach, 1.0);
@@ -313,8 +339,9 @@ void tree_maxw_kernel(const double* u, TreeGeom g, BinaryConsts c, unsigned long
     {
         const int i = idx / bs, j = idx - i * bs;
         State3 P;
-        iso2d::recover_primitive(load3(u, bs, b, i, j), P);
         const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
+        if (qform) iso2d::recover_primitive_angmom(load3(u, bs, b, i, j), xc, yc, P);
+        else       iso2d::recover_primitive(load3(u, bs, b, i, j), P);
         const double w = iso2d::max_wavespeed(P, binary_cs2(c, rmach, xc, yc));
         m = (m < w) ? w : m;
     }
@@ -347,24 +374,20 @@ hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, 
     BinaryConsts c = binary_make_consts(d, bodies);
     const dim3 blk(256), grid(g.nb);
     const long cells = (long) g.nb * g.bs * g.bs;
-    const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0;
+    const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0, q = d->angmom_form != 0;
     const dim3 cgrid((unsigned) ((cells + 255) / 256));
-    if (fast) hipLaunchKernelGGL((tree_c2p_kernel<BinFast>), cgrid, blk, 0, stream, u_in, w.prim, g.nb, g.bs);
-    else      hipLaunchKernelGGL((tree_c2p_kernel<BinStrict>), cgrid, blk, 0, stream, u_in, w.prim, g.nb, g.bs);
-    if (fast)
+    auto run = [&] (auto policy, auto qform)
     {
-        hipLaunchKernelGGL((tree_grad_kernel<BinFast>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
-        hipLaunchKernelGGL((tree_flux_kernel<BinFast>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
-        if (combine) hipLaunchKernelGGL((tree_update_kernel<BinFast, true>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-        else         hipLaunchKernelGGL((tree_update_kernel<BinFast, false>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-    }
-    else
-    {
-        hipLaunchKernelGGL((tree_grad_kernel<BinStrict>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
-        hipLaunchKernelGGL((tree_flux_kernel<BinStrict>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
-        if (combine) hipLaunchKernelGGL((tree_update_kernel<BinStrict, true>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-        else         hipLaunchKernelGGL((tree_update_kernel<BinStrict, false>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-    }
+        using A = decltype(policy);
+        constexpr bool Q = decltype(qform)::value;
+        hipLaunchKernelGGL((tree_c2p_kernel<A, Q>), cgrid, blk, 0, stream, u_in, w.prim, g.edges, g.nb, g.bs);
+        hipLaunchKernelGGL((tree_grad_kernel<A>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
+        hipLaunchKernelGGL((tree_flux_kernel<A, Q>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
+        if (combine) hipLaunchKernelGGL((tree_update_kernel<A, true, Q>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        else         hipLaunchKernelGGL((tree_update_kernel<A, false, Q>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+    };
+    if (fast) { if (q) run(BinFast(), std::true_type()); else run(BinFast(), std::false_type()); }
+    else      { if (q) run(BinStrict(), std::true_type()); else run(BinStrict(), std::false_type()); }
     hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(64), 0, stream, w.block_out, g.nb, totals);
     return hipGetLastError();
 }
@@ -373,7 +396,7 @@ hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g,
 {
     const BinaryConsts c = binary_make_consts(d, bodies);
     hipLaunchKernelGGL(tree_set_inf_kernel, dim3(1), dim3(1), 0, stream, result);
-    hipLaunchKernelGGL(tree_maxw_kernel, dim3(g.nb), dim3(256), 0, stream, u, g, c, reinterpret_cast<unsigned long long*>(result));
+    hipLaunchKernelGGL(tree_maxw_kernel, dim3(g.nb), dim3(256), 0, stream, u, g, c, (int) d->angmom_form, reinterpret_cast<unsigned long long*>(result));
     return hipGetLastError();
 }
 

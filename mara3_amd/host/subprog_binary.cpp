@@ -7,7 +7,7 @@
 //
 // The tree is built as upstream (refinement predicate + 2:1 balance, mh_binary_tree_build). A tree of uniform depth runs as
 // one periodic grid through the wave-marching kernels (binary.hip); a graded one - the default, focus_factor=2 - block by
-// block with prolonged / restricted guard zones and flux correction (binary_tree.hip, linear-momentum form only).
+// block with prolonged / restricted guard zones and flux correction (binary_tree.hip).
 // Restrictions, stated rather than silently ignored: the HDF5 tasks (checkpoint, diagnostics, time series: cpi, dfi,
 // tsi) are out of scope for `binary`; a raw dump of the final state replaces them.
 #include <cmath>
@@ -180,7 +180,6 @@ public:
     int run_graded(const mara::config_t& cfg, const std::vector<mh_tree_block>& blocks)
     {
         const int bs = cfg.get_int("block_size"), nb = int(blocks.size());
-        if (! cfg.get_int("conserve_linear_p")) throw std::invalid_argument("binary: conserve_linear_p=0 on a graded tree is not built");
         std::vector<double> edges(std::size_t(nb) * 2 * (bs + 1)), u(std::size_t(nb) * bs * bs * 3), br(std::size_t(nb) * bs * bs);
         check(mh_binary_tree_vertices(bs, cfg.get_double("domain_radius"), blocks.data(), nb, edges.data()), "mh_binary_tree_vertices");
         mh_binary_model model = {};
@@ -191,6 +190,7 @@ public:
         model.ambient_density = cfg.get_double("ambient_density");
         model.mdot = cfg.get_double("mdot");
         model.counter_rotate = cfg.get_int("counter_rotate");
+        model.angmom_form = cfg.get_int("conserve_linear_p") ? 0 : 1;
         model.buffer_damping_rate = cfg.get_double("buffer_damping_rate");
         model.domain_radius = cfg.get_double("domain_radius");
         model.cfl_number = cfg.get_double("cfl_number");
@@ -215,6 +215,15 @@ public:
         d.axisymmetric_cs2 = cfg.get_int("axisymmetric_cs2");
         d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
         d.plm_theta = cfg.get_double("plm_theta");
+        d.angmom_form = model.angmom_form;
+        {
+            double min_d = 1e300;                          // smallest vertex spacing of any block: solver_data.cpp:37-52, :91
+            for (int k = 0; k < nb; ++k)
+                for (int ax = 0; ax < 2; ++ax)
+                    for (int a = 0; a < bs; ++a)
+                        min_d = std::min(min_d, edges[(std::size_t(k) * 2 + ax) * (bs + 1) + a + 1] - edges[(std::size_t(k) * 2 + ax) * (bs + 1) + a]);
+            d.gst_suppr_radius = cfg.get_double("source_term_softening") * min_d;
+        }
 
         mh_binary* solver = nullptr;
         check(mh_binary_tree_create(&solver, cfg.get_int("device"), &d, &run, blocks.data(), nb, edges.data(), u.data(), br.data()), "mh_binary_tree_create");

@@ -247,6 +247,8 @@ BINARY_TREE_CASES = {
     "binary_tree_d4_b8_default_focus": dict(depth=4, block_size=8, nsteps=1),
     "binary_tree_d3_b12_nu": dict(depth=3, block_size=12, domain_radius=5.0, focus_factor=1.5, nu=1e-3, mass_ratio=0.5, eccentricity=0.3, rk_order=1,
                                   fixed_dt=1, nsteps=3, sink_radius=0.2, softening_radius=0.1, density_floor=0.05),
+    "binary_tree_d3_b8_q": dict(depth=3, block_size=8, domain_radius=4.0, conserve_linear_p=0, nsteps=2),
+    "binary_tree_d2_b16_q_uniform": dict(depth=2, block_size=16, domain_radius=4.0, focus_factor=1e9, conserve_linear_p=0, nsteps=3),   # == binary_d2_b16_q
     "binary_tree_d2_b16_uniform": dict(depth=2, block_size=16, domain_radius=4.0, focus_factor=1e9, nsteps=3),     # == binary_d2_b16, through the tree machinery
 }
 

@@ -55,6 +55,12 @@ static cons_t to_ref(vec3 u)
 }
 static vec3 from_ref(const cons_t& U) { return {{mara::get<0>(U).value, mara::get<1>(U).value, mara::get<2>(U).value}}; }
 static loc_t make_loc(double x, double y) { return {{mara::make_length(x), mara::make_length(y)}}; }
+using consq_t = mara::iso2d::conserved_angmom_per_area_t;
+static consq_t to_ref_q(vec3 q)
+{
+    return consq_t().set<0>(mara::make_dimensional<-2, 1, 0>(q[0])).set<1>(mara::make_dimensional<0, 1, -1>(q[1])).set<2>(mara::make_dimensional<0, 1, -1>(q[2]));
+}
+static vec3 from_ref_q(const consq_t& Q) { return {{mara::get<0>(Q).value, mara::get<1>(Q).value, mara::get<2>(Q).value}}; }
 
 enum { T_MASS_ACC = 0, T_L_ACC = 2, T_TORQUE = 4, T_PX_ACC = 6, T_PY_ACC = 8, T_FX = 10, T_FY = 12, T_WORK = 14, T_MASS_EJ = 16, T_L_EJ = 17, NTOT = 18 };
 
@@ -66,7 +72,8 @@ struct params_t
     mara::amr_types::vertex_2d_tree_t vertices;
     tree_of<vec3> u_init;
     tree_of<double> br;
-    double recommended_dt = 0;
+    double recommended_dt = 0, gst = 0;
+    bool qform = false;      // conserve_linear_p == 0: advance_q (scheme.cpp:906-1020), fields are (Sigma, Sigma s_r, Sigma l_z)
     double spacing(const index_t& i) const { return 2.0 * get("domain_radius") / bs / (1 << i.level); }
 };
 
@@ -161,7 +168,17 @@ static vec3 face_flux(const params_t& P, int axis, double h, double xf, double y
         v1 = -(mu * (dx_uy + dy_ux));
         v2 = -(-mu * (dx_ux - dy_uy));
     }
-    return {{f0 + 0.0, f1 + v1, f2 + v2}};
+    vec3 f = {{f0 + 0.0, f1 + v1, f2 + v2}};
+    if (P.qform)
+    {
+        double rd = P.get("domain_radius");
+        double flux_sr = xf * f[1] + yf * f[2];
+        double flux_lz = xf * f[2] - yf * f[1];
+        if (axis == 0 && (xf == -rd || xf == rd)) flux_lz = 0.0;
+        if (axis == 1 && (yf == -rd || yf == rd)) flux_lz = 0.0;
+        f = {{f[0], flux_sr, flux_lz}};
+    }
+    return f;
 }
 
 // flux correction at refinement jumps, scheme.cpp:614-700: where the neighbour across a face is refined, the coarse face flux is
@@ -202,7 +219,15 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
     auto B = mara::compute_two_body_state(S.E, S.time);
     const mara::point_mass_t bodies[2] = {B.body1, B.body2};
 
-    auto p0 = S.u.map([bs] (auto U) { return build<prim_t>(bs, bs, [&] (auto i, auto j) { return mara::iso2d::recover_primitive(to_ref(U(i, j))); }); });
+    auto cell_center = [] (auto xv, std::size_t i, std::size_t j)
+    {
+        double xc = (((xv(i, j)[0] + xv(i + 1, j)[0]) * 0.5 + (xv(i, j + 1)[0] + xv(i + 1, j + 1)[0]) * 0.5) * 0.5).value;
+        double yc = (((xv(i, j)[1] + xv(i + 1, j)[1]) * 0.5 + (xv(i, j + 1)[1] + xv(i + 1, j + 1)[1]) * 0.5) * 0.5).value;
+        return make_loc(xc, yc);
+    };
+    auto p0 = S.u.pair(P.vertices).map([&] (auto ux) { auto U = ux.first; auto xv = ux.second;
+        return build<prim_t>(bs, bs, [&] (auto i, auto j) { return P.qform ? mara::iso2d::recover_primitive(to_ref_q(U(i, j)), cell_center(xv, i, j))
+                                                                            : mara::iso2d::recover_primitive(to_ref(U(i, j))); }); });
     auto p0_ex = extend(p0, 0, 1);
     auto p0_ey = extend(p0, 1, 1);
     auto gx = p0_ex.pair(p0_ex.indexes()).map([&] (auto pi) { auto p = pi.first; double h = P.spacing(pi.second);
@@ -249,7 +274,7 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
     auto u1 = p0.indexes().map([&] (auto index)
     {
         auto xv = P.vertices.at(index); auto U0 = S.u.at(index); auto Ui = P.u_init.at(index); auto Br = P.br.at(index);
-        auto FX = fx.at(index); auto FY = fy.at(index);
+        auto FX = fx.at(index); auto FY = fy.at(index); auto Pc = p0.at(index);
         std::vector<double> t(NTOT, 0.0);
         double sink_sum[2][3] = {{0}};
         auto out = build<vec3>(bs, bs, [&] (auto i, auto j)
@@ -280,18 +305,32 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
             vec3 s_buffer = {{(ui[0] - u0[0]) * br * dt, (ui[1] - u0[1]) * br * dt, (ui[2] - u0[2]) * br * dt}};
             double fl = double(u0[0] < floor_sigma);
             vec3 s_floor = {{u0[0] * 1e-2 * fl, u0[1] * 1e-2 * fl, u0[2] * 1e-2 * fl}};
+            vec3 dps[2] = {s_sink[0], s_sink[1]};
+            if (P.qform)
+            {
+                // source_terms_q :417-466
+                for (int b = 0; b < 2; ++b)
+                {
+                    s_grav[b] = {{0.0 * dt, (xc * fg[b][0] + yc * fg[b][1]) * dt, (xc * fg[b][1] - yc * fg[b][0]) * dt}};
+                    dps[b] = from_ref(mara::iso2d::to_conserved_per_area(to_ref_q(s_sink[b]), make_loc(xc, yc)));
+                }
+                double sr2 = std::pow(P.gst, 2.0);
+                double ramp = 1.0 - std::exp(-(xc * xc + yc * yc) / sr2);
+                auto sg = Pc(i, j).source_terms_conserved_angmom(cs2_at(P, xc, yc, B));
+                s_floor = {{mara::get<0>(sg).value * ramp * dt, mara::get<1>(sg).value * ramp * dt, mara::get<2>(sg).value * ramp * dt}};
+            }
             for (int b = 0; b < 2; ++b)
             {
                 t[T_MASS_ACC + b] = t[T_MASS_ACC + b] + s_sink[b][0] * dA;
-                t[T_L_ACC + b]    = t[T_L_ACC + b] + lz(s_sink[b]) * dA;
-                t[T_TORQUE + b]   = t[T_TORQUE + b] + lz(s_grav[b]) * dA;
+                t[T_L_ACC + b]    = t[T_L_ACC + b] + (P.qform ? s_sink[b][2] : lz(s_sink[b])) * dA;
+                t[T_TORQUE + b]   = t[T_TORQUE + b] + (P.qform ? s_grav[b][2] : lz(s_grav[b])) * dA;
                 t[T_FX + b]       = t[T_FX + b] + fg[b][0] * dt * dA;
                 t[T_FY + b]       = t[T_FY + b] + fg[b][1] * dt * dA;
-                t[T_PX_ACC + b]   = t[T_PX_ACC + b] + s_sink[b][1] * dA;
-                t[T_PY_ACC + b]   = t[T_PY_ACC + b] + s_sink[b][2] * dA;
+                t[T_PX_ACC + b]   = t[T_PX_ACC + b] + dps[b][1] * dA;
+                t[T_PY_ACC + b]   = t[T_PY_ACC + b] + dps[b][2] * dA;
                 for (int q = 0; q < 3; ++q) sink_sum[b][q] = sink_sum[b][q] + s_sink[b][q] * dA;
             }
-            t[T_L_EJ]    = t[T_L_EJ] + lz(s_buffer) * dA;
+            t[T_L_EJ]    = t[T_L_EJ] + (P.qform ? s_buffer[2] : lz(s_buffer)) * dA;
             t[T_MASS_EJ] = t[T_MASS_EJ] + s_buffer[0] * dA;
             vec3 r;
             for (int q = 0; q < 3; ++q)
@@ -309,6 +348,7 @@ static solution_t advance_u(const params_t& P, const solution_t& S, double dt, b
             double M0 = bodies[b].mass, px0 = bodies[b].velocity_x * M0, py0 = bodies[b].velocity_y * M0;
             double M1 = M0 + -sink_sum[b][0], px1 = px0 + -sink_sum[b][1], py1 = py0 + -sink_sum[b][2];
             t[T_WORK + b] = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+            if (P.qform) t[T_WORK + b] = 0.0;
         }
         block_totals[key_of(index)] = t;
         return out;
@@ -374,7 +414,8 @@ static double maximum_timestep(const params_t& P, const solution_t& S)
             {
                 double xc = (((xv(i, j)[0] + xv(i + 1, j)[0]) * 0.5 + (xv(i, j + 1)[0] + xv(i + 1, j + 1)[0]) * 0.5) * 0.5).value;
                 double yc = (((xv(i, j)[1] + xv(i + 1, j)[1]) * 0.5 + (xv(i, j + 1)[1] + xv(i + 1, j + 1)[1]) * 0.5) * 0.5).value;
-                double w = mara::iso2d::recover_primitive(to_ref(U(i, j))).max_wavespeed(cs2_at(P, xc, yc, B));
+                auto pc = P.qform ? mara::iso2d::recover_primitive(to_ref_q(U(i, j)), make_loc(xc, yc)) : mara::iso2d::recover_primitive(to_ref(U(i, j)));
+                double w = pc.max_wavespeed(cs2_at(P, xc, yc, B));
                 a = first ? w : std::max(a, w); first = false;
             }
         return P.spacing(index) / a;
@@ -410,7 +451,7 @@ int main(int argc, char** argv)
         {"buffer_damping_rate", 10.0}, {"domain_radius", 12.0}, {"disk_radius", 2.0}, {"disk_mass", 1e-3}, {"ambient_density", 1e-4},
         {"density_floor", 0.0}, {"separation", 1.0}, {"mass_ratio", 1.0}, {"eccentricity", 0.0}, {"counter_rotate", 0},
         {"mach_number", 10.0}, {"axisymmetric_cs2", 0}, {"no_accretion_force", 0}, {"alpha_cutoff_radius", 0.0}, {"alpha", 0.1},
-        {"nu", 0.0}, {"mdot", 0.0}, {"nsteps", 1}, {"safe_mode", 0}, {"focus_factor", 2.0}, {"focus_index", 2.0}};
+        {"nu", 0.0}, {"mdot", 0.0}, {"nsteps", 1}, {"safe_mode", 0}, {"focus_factor", 2.0}, {"focus_index", 2.0}, {"conserve_linear_p", 1}};
     for (int a = 2; a < argc; ++a)
     {
         std::string kv = argv[a];
@@ -418,6 +459,7 @@ int main(int argc, char** argv)
         if (eq == std::string::npos || ! P.cfg.count(kv.substr(0, eq))) { std::fprintf(stderr, "bad argument %s\n", argv[a]); return 1; }
         P.cfg[kv.substr(0, eq)] = std::atof(kv.substr(eq + 1).data());
     }
+    P.qform = int(P.get("conserve_linear_p")) == 0;
     P.depth = int(P.get("depth"));
     P.bs = int(P.get("block_size"));
     const std::size_t bs = P.bs;
@@ -435,7 +477,8 @@ int main(int argc, char** argv)
         double yc = (((xv(i, j)[1] + xv(i + 1, j)[1]) * 0.5 + (xv(i, j + 1)[1] + xv(i + 1, j + 1)[1]) * 0.5) * 0.5).value;
         return std::make_pair(xc, yc);
     };
-    P.u_init = P.vertices.map([&] (auto xv) { return build<vec3>(bs, bs, [&] (auto i, auto j) { auto c = centers(xv, i, j); return from_ref(disk_profile(P, c.first, c.second).to_conserved_per_area()); }); });
+    P.u_init = P.vertices.map([&] (auto xv) { return build<vec3>(bs, bs, [&] (auto i, auto j) { auto c = centers(xv, i, j); auto p = disk_profile(P, c.first, c.second);
+        return P.qform ? from_ref_q(p.to_conserved_angmom_per_area(make_loc(c.first, c.second))) : from_ref(p.to_conserved_per_area()); }); });
     P.br = P.vertices.map([&] (auto xv) { return build<double>(bs, bs, [&] (auto i, auto j) { auto c = centers(xv, i, j);
         double rc = std::pow(c.first * c.first + c.second * c.second, 0.5); return P.get("buffer_damping_rate") * (1.0 + std::tanh(3.0 * (rc - R))); }); });
     double min_dx = 1e300, min_dy = 1e300, max_v = 1.0;
@@ -455,6 +498,7 @@ int main(int argc, char** argv)
             }
     });
     P.recommended_dt = std::min(min_dx, min_dy) / max_v * P.get("cfl_number");
+    P.gst = P.get("source_term_softening") * std::min(min_dx, min_dy);
 
     solution_t S;
     S.u = P.u_init;

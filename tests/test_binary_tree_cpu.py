@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from conftest import golden, bits_equal
 
-CASES = ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d2_b16_uniform"]
+CASES = ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d2_b16_uniform", "binary_tree_d3_b8_q"]
 
 
 def cfg_of(g):

@@ -7,7 +7,7 @@ import pytest
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
-CASES = ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d2_b16_uniform"]
+CASES = ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d2_b16_uniform", "binary_tree_d3_b8_q", "binary_tree_d2_b16_q_uniform"]
 
 
 @pytest.fixture(scope="module")
@@ -75,8 +75,11 @@ def test_next_solution_on_a_graded_tree(binary, name):
 def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
     """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
     policy arithmetic, so the two must agree to the last bit."""
-    g = golden("binary_tree_d2_b16_uniform")
-    gu = golden("binary_d2_b16")
+    for tname, uname in (("binary_tree_d2_b16_uniform", "binary_d2_b16"), ("binary_tree_d2_b16_q_uniform", "binary_d2_b16_q")):
+        _both_families(binary, golden(tname), golden(uname))
+
+
+def _both_families(binary, g, gu):
     cfg, _ = cfg_of(binary, g)
     for arith in ("strict", "fast"):
         t = make(binary, cfg, g, arith=arith)

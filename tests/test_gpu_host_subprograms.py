@@ -117,8 +117,6 @@ def test_binary_subprogram_matches_reference(tmp_path, case):
 
 
 def test_binary_subprogram_rejects_what_is_not_built(tmp_path):
-    out = subprocess.run([EXE, "binary", "conserve_linear_p=0"], cwd=str(tmp_path), capture_output=True, text=True)       # the default tree is graded
-    assert out.returncode == 1 and "graded tree" in out.stdout
     out = subprocess.run([EXE, "binary", "reconstruct_method=weno"], cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 1 and "must be plm or pcm" in out.stdout
 
@@ -183,7 +181,7 @@ def test_cloud_checkpoint_and_restart(tmp_path):
     assert b["iteration"] == 3 and bits_equal(b["data"], g["un"])
 
 
-@pytest.mark.parametrize("case", ["binary_tree_d3_b8", "binary_tree_d3_b12_nu"])
+@pytest.mark.parametrize("case", ["binary_tree_d3_b8", "binary_tree_d3_b12_nu", "binary_tree_d3_b8_q"])
 def test_binary_subprogram_on_graded_trees_matches_reference(tmp_path, case):
     """`mara_hip binary` with a refinement predicate that grades the tree: tree construction, block vertices and solver data on
     the host, block kernels on the device; against vectors made with the reference's own tree machinery."""
@@ -191,7 +189,7 @@ def test_binary_subprogram_on_graded_trees_matches_reference(tmp_path, case):
     g = golden(case)
     over = json.loads(str(g["config"]))
     nsteps = int(over.pop("nsteps"))
-    ints = ("depth", "block_size", "fixed_dt", "rk_order")
+    ints = ("depth", "block_size", "fixed_dt", "rk_order", "conserve_linear_p")
     args = ["%s=%r" % (k, int(v) if k in ints else float(v)) for k, v in over.items()]
     stdout = run(["binary"] + args + ["max_iterations=%d" % nsteps, "tfinal=100.0"], str(tmp_path))
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
