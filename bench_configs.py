@@ -205,6 +205,20 @@ def run_c5(args):
     return out
 
 
+def attach_traffic(out, key, ok):
+    """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json), mean of the two stage kinds like `achieved`."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if ok:
+            val = 0.5 * (t[key + "_stage1_bytes_per_launch"] + t[key + "_stage2_bytes_per_launch"])
+            out["roofline"]["traffic"] = val
+            if "arith_strict" in out and "roofline" in out["arith_strict"]:
+                out["arith_strict"]["roofline"]["traffic"] = val
+    except Exception:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True, choices=["c3", "c4", "c5"])
@@ -219,6 +233,8 @@ def main():
     if lib.mh_device_count() < 1:
         raise SystemExit("bench_configs.py needs an MI355X; there is no CPU path")
     out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args)
+    out = attach_traffic(out, {"c3": "c3_binary_2048", "c4": "c4_cloud_4096", "c5": "c5_euler3d_384"}[args.config],
+                         args.config == "c3" or (args.config == "c4" and (args.grid or 4096) == 4096) or (args.config == "c5" and args.grid == 384))
     print(json.dumps(out), flush=True)
 
 
