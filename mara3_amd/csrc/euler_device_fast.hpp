@@ -173,27 +173,27 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     }
     else if (sl <= 0.0 && 0.0 <= sstar)
     {
-        const double fac = ml * rcp_nr(sl - sstar);
-        State5 Us;
-        Us[0] = fac;
-        Us[1] = fac * (AXIS == 0 ? sstar : Pl[1]);
-        Us[2] = fac * (AXIS == 1 ? sstar : Pl[2]);
-        Us[3] = fac * (AXIS == 2 ? sstar : Pl[3]);
-        Us[4] = fac * __builtin_fma(sstar - ul, sstar + pl * rcp_nr(ml), Ul[4] * rcp_nr(dl));
+        // F*_L = (S* (S_L U_L - F_L) + S_L p* D) / (S_L - S*), D = (0, n, S*), p* = p_L + rho_L (S_L - u_L)(S* - u_L): Toro eq. 10.41-10.43,
+        // algebraically the same flux as F_L + S_L (U*_L - U_L) of eq. 10.38-10.39 with one division instead of three
+        const double rinv = rcp_nr(sl - sstar);
+        const double sp = sl * __builtin_fma(ml, sstar - ul, pl);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Us[q] - Ul[q], sl, Fl[q]);
+        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sl, Ul[q], -Fl[q]);
+        F[1 + AXIS] += sp;
+        F[4] = __builtin_fma(sp, sstar, F[4]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) F[q] *= rinv;
     }
     else if (sstar <= 0.0 && 0.0 <= sr)
     {
-        const double fac = mr * rcp_nr(sr - sstar);
-        State5 Us;
-        Us[0] = fac;
-        Us[1] = fac * (AXIS == 0 ? sstar : Pr[1]);
-        Us[2] = fac * (AXIS == 1 ? sstar : Pr[2]);
-        Us[3] = fac * (AXIS == 2 ? sstar : Pr[3]);
-        Us[4] = fac * __builtin_fma(sstar - ur, sstar + pr * rcp_nr(mr), Ur[4] * rcp_nr(dr));
+        const double rinv = rcp_nr(sr - sstar);
+        const double sp = sr * __builtin_fma(mr, sstar - ur, pr);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Us[q] - Ur[q], sr, Fr[q]);
+        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sr, Ur[q], -Fr[q]);
+        F[1 + AXIS] += sp;
+        F[4] = __builtin_fma(sp, sstar, F[4]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) F[q] *= rinv;
     }
     else if (sr <= 0.0)
     {
