@@ -147,12 +147,40 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     return F;
 }
 
+// sound speed alone: sqrt(gamma p / d) = gamma p / sqrt(gamma p d)
+__device__ inline double sound_speed(const State5& P, const GammaLawFast& g)
+{
+    const double gp = g.gamma * P[4];
+    double s, rs;
+    sqrt_rsqrt(gp * P[0], s, rs);
+    return gp == 0.0 ? 0.0 : gp * rs;
+}
+
+// conserved state and flux of one face state (what face_quantities computes besides the sound speed)
+template<int AXIS>
+__device__ inline void conserved_and_flux(const State5& P, const GammaLawFast& g, State5& U, State5& F)
+{
+    const double d = P[0], p = P[4], vn = P[1 + AXIS];
+    const double vsq = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    U[0] = d;
+    U[1] = d * P[1];
+    U[2] = d * P[2];
+    U[3] = d * P[3];
+    U[4] = __builtin_fma(0.5 * d, vsq, p * g.inv_gm1);
+    F[0] = vn * U[0];
+    F[1] = AXIS == 0 ? __builtin_fma(vn, U[1], p) : vn * U[1];
+    F[2] = AXIS == 1 ? __builtin_fma(vn, U[2], p) : vn * U[2];
+    F[3] = AXIS == 2 ? __builtin_fma(vn, U[3], p) : vn * U[3];
+    F[4] = vn * (U[4] + p);
+}
+
+// HLLC (Toro 3rd ed. section 10.4-10.6, pressure-based wave speeds as physics_iso2d.hpp:610-687 generalised to a gamma law). The wave
+// speeds need only (d, u_n, p, a) of the two sides; the conserved state and flux are then formed for the ONE side the
+// sampled region belongs to.
 template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, const GammaLawFast& g)
 {
-    State5 Ul, Ur, Fl, Fr;
-    double ul, ur, al, ar;
-    face_quantities<AXIS>(Pl, g, Ul, Fl, ul, al);
-    face_quantities<AXIS>(Pr, g, Ur, Fr, ur, ar);
+    const double ul = Pl[1 + AXIS], ur = Pr[1 + AXIS];
+    const double al = sound_speed(Pl, g), ar = sound_speed(Pr, g);
     const double dl = Pl[0], dr = Pr[0], pl = Pl[4], pr = Pr[4];
     const double dbar = 0.5 * (dl + dr);
     const double abar = 0.5 * (al + ar);
@@ -166,19 +194,21 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     const double mr = dr * (sr - ur);
     const double sstar = (pr - pl + ul * ml - ur * mr) * rcp_nr(ml - mr);
 
-    State5 F;
+    State5 F, U;
     if (0.0 <= sl)
     {
-        F = Fl;
+        conserved_and_flux<AXIS>(Pl, g, U, F);
     }
     else if (sl <= 0.0 && 0.0 <= sstar)
     {
         // F*_L = (S* (S_L U_L - F_L) + S_L p* D) / (S_L - S*), D = (0, n, S*), p* = p_L + rho_L (S_L - u_L)(S* - u_L): Toro eq. 10.41-10.43,
         // algebraically the same flux as F_L + S_L (U*_L - U_L) of eq. 10.38-10.39 with one division instead of three
+        State5 Fl;
+        conserved_and_flux<AXIS>(Pl, g, U, Fl);
         const double rinv = rcp_nr(sl - sstar);
         const double sp = sl * __builtin_fma(ml, sstar - ul, pl);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sl, Ul[q], -Fl[q]);
+        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sl, U[q], -Fl[q]);
         F[1 + AXIS] += sp;
         F[4] = __builtin_fma(sp, sstar, F[4]);
 #pragma unroll
@@ -186,10 +216,12 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     }
     else if (sstar <= 0.0 && 0.0 <= sr)
     {
+        State5 Fr;
+        conserved_and_flux<AXIS>(Pr, g, U, Fr);
         const double rinv = rcp_nr(sr - sstar);
         const double sp = sr * __builtin_fma(mr, sstar - ur, pr);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sr, Ur[q], -Fr[q]);
+        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sr, U[q], -Fr[q]);
         F[1 + AXIS] += sp;
         F[4] = __builtin_fma(sp, sstar, F[4]);
 #pragma unroll
@@ -197,7 +229,7 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     }
     else if (sr <= 0.0)
     {
-        F = Fr;
+        conserved_and_flux<AXIS>(Pr, g, U, F);
     }
     else
     {
