@@ -371,6 +371,15 @@ double mh_binary_last_dt(const mh_binary* b);
 const double* mh_binary_field_ptr(mh_binary* b);
 int  mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaunches);
 
+/* Diagnostics of the device-resident solution, evaluated on the device when a task of the driver is due.
+ * mh_binary_disk_totals: binary::disk_mass and binary::disk_angular_momentum (src/subprog_binary_diagnostics.cpp:21-46), the two
+ * reductions of a time-series sample (subprog_binary.cpp:356-357). mh_binary_diagnostic_fields: binary::diagnostic_fields
+ * (:52-82): sigma, v . rhat, v . phihat per cell into host arrays of n^2 (or nblocks * block_size^2) doubles in the order of
+ * mh_binary_get_solution's cells; any of the three may be NULL. IEEE arithmetic whatever `arith` the stepping uses. Against the
+ * reference: the fields agree to an ulp of the radius (sqrt where the reference calls pow(r2, 0.5)), the sums to reduction order. */
+int  mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_momentum);
+int  mh_binary_diagnostic_fields(mh_binary* b, double* sigma, double* radial_velocity, double* phi_velocity);
+
 /* ---- `binary` on a GRADED block tree (the sub-program's default: refinement towards the origin) ---------
  * Leaf blocks of block_size^2 cells at different levels; guard zones are prolonged (piecewise constant) from coarser and
  * restricted (averaged) from finer neighbours, and the face fluxes of a coarse block next to finer ones are replaced by the sum

@@ -169,6 +169,8 @@ SYMBOLS = [
     ("mh_binary_last_dt", _d, [_vp]),
     ("mh_binary_field_ptr", _vp, [_vp]),
     ("mh_binary_profile", _i, [_vp, _i, C.POINTER(_d), C.POINTER(_i)]),
+    ("mh_binary_disk_totals", _i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
+    ("mh_binary_diagnostic_fields", _i, [_vp, _vp, _vp, _vp]),
     ("mh_device_count", _i, []),
     ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
     ("mh_free", _i, [_vp]),

@@ -217,6 +217,22 @@ class BinarySolver:
     def last_dt(self):
         return self.lib.mh_binary_last_dt(self.handle)
 
+    def disk_totals(self):
+        """binary::disk_mass, binary::disk_angular_momentum (subprog_binary_diagnostics.cpp:21-46), reduced on the device."""
+        m, l = C.c_double(), C.c_double()
+        L.check(self.lib.mh_binary_disk_totals(self.handle, C.byref(m), C.byref(l)))
+        return m.value, l.value
+
+    def diagnostic_fields(self):
+        """binary::diagnostic_fields (:52-82): (sigma, radial_velocity, phi_velocity), each shaped like one component of `solution()`."""
+        shape = self.solution_shape()[:-1]
+        out = [np.empty(shape) for _ in range(3)]
+        L.check(self.lib.mh_binary_diagnostic_fields(self.handle, *[a.ctypes.data_as(C.c_void_p) for a in out]))
+        return tuple(out)
+
+    def solution_shape(self):
+        return (self.n, self.n, 3)
+
     def profile(self, enable=True):
         ms, nl = C.c_double(), C.c_int()
         L.check(self.lib.mh_binary_profile(self.handle, int(enable), C.byref(ms), C.byref(nl)))
@@ -269,6 +285,9 @@ class BinaryTreeSolver(BinarySolver):
         s = L.BinaryState()
         s.orbital_elements = initial_elements(cfg)
         self.set_solution(None, s)
+
+    def solution_shape(self):
+        return (len(self.blocks), self.bs, self.bs, 3)
 
     def solution(self):
         u = np.empty((len(self.blocks), self.bs, self.bs, 3))

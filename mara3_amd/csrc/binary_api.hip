@@ -31,6 +31,12 @@ hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, 
                                     double theta, double* totals, int32_t* status, hipStream_t stream);
 hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g, const double* u, const double bodies[10], double* result, hipStream_t stream);
 
+// diagnostics (binary_diag.hip)
+hipError_t binary_diag_sums_launch(const double* u, const double* xv, const double* yv, const double* edges, int n, int nb, int bs, bool tree,
+                                   bool qform, double* partial, double* out, hipStream_t stream);
+hipError_t binary_diag_fields_launch(const double* u, const double* xv, const double* yv, const double* edges, int n, int nb, int bs, bool tree,
+                                     bool qform, double* fields, hipStream_t stream);
+
 static int check_binary_desc(const mh_binary_desc* d)
 {
     if (! d) { set_error("binary: null descriptor"); return MH_E_INVALID; }
@@ -485,6 +491,39 @@ int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaun
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     b->events.clear();
     b->profile = enable != 0;
+    return MH_OK;
+}
+
+// The stage buffers u[1], u[2] hold nothing between steps: the diagnostics use them as scratch.
+int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_momentum)
+{
+    if (! b) { set_error("binary disk_totals: null solver"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(b->device));
+    const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
+    double* partial = b->u[2];
+    double* out = partial + 2 * ((ncell + 255) / 256);
+    MH_HIP_TRY(binary_diag_sums_launch(b->u[0], b->xv, b->yv, b->edges_dev, b->desc.n, b->geom.nb, b->geom.bs, b->tree, b->desc.angmom_form != 0,
+                                       partial, out, b->stream));
+    double host[2];
+    MH_HIP_TRY(hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, b->stream));
+    MH_HIP_TRY(hipStreamSynchronize(b->stream));
+    if (disk_mass) *disk_mass = host[0];
+    if (disk_angular_momentum) *disk_angular_momentum = host[1];
+    return MH_OK;
+}
+
+int mh_binary_diagnostic_fields(mh_binary* b, double* sigma, double* radial_velocity, double* phi_velocity)
+{
+    if (! b) { set_error("binary diagnostic_fields: null solver"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(b->device));
+    const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
+    double* fields = b->u[1];
+    MH_HIP_TRY(binary_diag_fields_launch(b->u[0], b->xv, b->yv, b->edges_dev, b->desc.n, b->geom.nb, b->geom.bs, b->tree, b->desc.angmom_form != 0,
+                                         fields, b->stream));
+    double* dst[3] = {sigma, radial_velocity, phi_velocity};
+    for (int k = 0; k < 3; ++k)
+        if (dst[k]) MH_HIP_TRY(hipMemcpyAsync(dst[k], fields + k * ncell, ncell * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    MH_HIP_TRY(hipStreamSynchronize(b->stream));
     return MH_OK;
 }
 

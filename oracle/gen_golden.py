@@ -264,7 +264,9 @@ def gen_binary_tree():
             nb = len(blocks)
             out = {"config": np.array(json.dumps(cfg)), "blocks": blocks}
             for key, shape in (("xv", (nb, 2, bs + 1)), ("u_init", (nb, bs, bs, 3)), ("br", (nb, bs, bs)), ("u_stage", (nb, bs, bs, 3)),
-                               ("stage_scalars", (-1,)), ("u_final", (nb, bs, bs, 3)), ("scalars", (-1,))):
+                               ("stage_scalars", (-1,)), ("u_final", (nb, bs, bs, 3)), ("scalars", (-1,)),
+                               # diagnostics of u_final (subprog_binary_diagnostics.cpp): [disk_mass, disk_angular_momentum, x1, y1, x2, y2]; sigma, v_r, v_phi
+                               ("diag_scalars", (6,)), ("diag_fields", (nb, 3, bs, bs))):
                 out[key] = np.fromfile(prefix + "." + key + ".f64").reshape(shape)
             np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
             print(name, "ok", nb, "blocks; levels", np.bincount(blocks[:, 0]), "dt", out["stage_scalars"][0])

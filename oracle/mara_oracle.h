@@ -172,6 +172,8 @@ double mo_binary_nu(const mo_binary_params* P, double x, double y, double cs2);
 void   mo_binary_vertices(int block_size, int depth, double domain_radius, double* v);   /* v[(block_size << depth) + 1] */
 void   mo_binary_disk_profile(const mo_binary_model* m, double x, double y, double prim[3]);
 double mo_binary_solver_data(const mo_binary_model* m, int n, const double* xv, const double* yv, double* u_init, double* br);  /* returns recommended_time_step */
+/* binary::disk_mass, disk_angular_momentum, diagnostic_fields (subprog_binary_diagnostics.cpp:21-82) on a block tree; see the .c file */
+void   mo_binary_diagnostics(int angmom_form, int bs, int nb, const int* blocks, const double* edges, const double* u, double totals[2], double* fields);
 
 #ifdef __cplusplus
 }

@@ -380,6 +380,8 @@ def _binary_lib():
         L.mo_binary_vertices.argtypes = [C.c_int, C.c_int, C.c_double, dp]
         L.mo_binary_solver_data.argtypes = [C.POINTER(_BinaryModel), C.c_int, dp, dp, dp, dp]
         L.mo_binary_solver_data.restype = C.c_double
+        L.mo_binary_diagnostics.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp]
+        L.mo_binary_diagnostics.restype = None
         L._binary_ready = True
     return L
 
@@ -415,3 +417,15 @@ def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False):
 def binary_maximum_timestep(cfg, xv, yv, u, bodies):
     P = _binary_params(cfg, False, xv, yv)
     return _binary_lib().mo_binary_maximum_timestep(C.byref(P), _dp(_f64(xv)), _dp(_f64(yv)), _dp(_f64(u)), _dp(_f64(bodies)))
+
+
+def binary_diagnostics(angmom_form, blocks, edges, u):
+    """subprog_binary_diagnostics.cpp:21-82 on a block tree: blocks [nb][3] (level, i, j) in tree order, edges [nb][2][bs+1],
+    u [nb][bs][bs][3] -> (disk_mass, disk_angular_momentum, fields [nb][3][bs][bs] = sigma, v_r, v_phi)"""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    u = _f64(u)
+    nb, bs = u.shape[0], u.shape[1]
+    tot = np.zeros(2)
+    fields = np.zeros((nb, 3, bs, bs))
+    _binary_lib().mo_binary_diagnostics(int(bool(angmom_form)), bs, nb, blocks.ctypes.data_as(C.POINTER(C.c_int)), _dp(_f64(edges)), _dp(u), _dp(tot), _dp(fields))
+    return tot[0], tot[1], fields

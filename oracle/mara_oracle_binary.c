@@ -364,3 +364,73 @@ double mo_binary_solver_data(const mo_binary_model* m, int n, const double* xv, 
         }
     return (min_dx < min_dy ? min_dx : min_dy) / max_v * m->cfl_number;
 }
+
+
+/* ---- diagnostics: subprog_binary_diagnostics.cpp:21-82 on a block tree ------------------------------
+ * blocks[nb][3] = (level, i, j) in tree order (depth first, children in orthant order), edges[nb][2][bs + 1] = x of the block's
+ * vertex rows then y of its vertex columns, u[nb][bs][bs][3] conserved (or angular-momentum-form) per area.
+ * totals = {disk_mass, disk_angular_momentum}: block sums are nd::sum() (sequential from 0, row-major, core_ndarray.hpp:1882-1898),
+ * combined as arithmetic_binary_tree_t::sum() combines them: recursively, each node 0 + c0 + c1 + c2 + c3 (core_tree.hpp:502,
+ * core_sequence.hpp:216-224). fields[nb][3][bs][bs] = sigma, radial_velocity, phi_velocity (:60-71; r = std::pow(r2, 0.5)). */
+typedef struct { const int* blocks; const double* partial; int nb, next; } tree_sum_t;
+
+static double tree_sum(tree_sum_t* T, int level, int i, int j)
+{
+    if (T->next < T->nb)
+    {
+        const int* b = T->blocks + 3 * T->next;
+        if (b[0] == level && b[1] == i && b[2] == j) return T->partial[T->next++];
+    }
+    double result = 0.0;
+    for (int c = 0; c < 4; ++c) result = result + tree_sum(T, level + 1, 2 * i + (c & 1), 2 * j + ((c >> 1) & 1));
+    return result;
+}
+
+void mo_binary_diagnostics(int angmom_form, int bs, int nb, const int* blocks, const double* edges, const double* u, double totals[2], double* fields)
+{
+    double* mass = (double*) malloc(sizeof(double) * (size_t) nb);
+    double* lz = (double*) malloc(sizeof(double) * (size_t) nb);
+    for (int k = 0; k < nb; ++k)
+    {
+        const double* xe = edges + (size_t) k * 2 * (bs + 1);
+        const double* ye = xe + bs + 1;
+        double m = 0.0, l = 0.0;
+        for (int i = 0; i < bs; ++i)
+            for (int j = 0; j < bs; ++j)
+            {
+                const double* U = u + 3 * (((size_t) k * bs + i) * bs + j);
+                const double xc = (xe[i] + xe[i + 1]) * 0.5, yc = (ye[j] + ye[j + 1]) * 0.5;      /* midpoint of midpoints of a tensor-product block: exact */
+                const double dA = (xe[i + 1] - xe[i]) * (ye[j + 1] - ye[j]);
+                const double x[2] = {xc, yc};
+                double P[3];
+                m = m + U[0] * dA;
+                if (angmom_form)
+                {
+                    l = l + U[2] * dA;
+                    mo_iso2d_recover_primitive_angmom(U, x, P);
+                }
+                else
+                {
+                    l = l + (xc * U[2] - yc * U[1]) * dA;                 /* iso2d::angular_momentum physics_iso2d.hpp:444-447 */
+                    mo_iso2d_recover_primitive(U, P);
+                }
+                if (fields)
+                {
+                    const double rc = pow(xc * xc + yc * yc, 0.5);
+                    const double rhat_x = xc / rc, rhat_y = yc / rc, phat_x = -yc / rc, phat_y = xc / rc;
+                    double* F = fields + (size_t) k * 3 * bs * bs + (size_t) i * bs + j;
+                    F[0] = P[0];
+                    F[(size_t) bs * bs] = P[1] * rhat_x + P[2] * rhat_y;
+                    F[(size_t) 2 * bs * bs] = P[1] * phat_x + P[2] * phat_y;
+                }
+            }
+        mass[k] = m;
+        lz[k] = l;
+    }
+    tree_sum_t T = {blocks, mass, nb, 0};
+    totals[0] = tree_sum(&T, 0, 0, 0);
+    T.partial = lz; T.next = 0;
+    totals[1] = tree_sum(&T, 0, 0, 0);
+    free(mass);
+    free(lz);
+}

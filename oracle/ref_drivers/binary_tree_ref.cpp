@@ -14,7 +14,7 @@
  * guard-zone gather and the flux correction follow scheme.cpp:132-142 and :614-700 call for call.
  *
  * usage: binary_tree_ref <out_prefix> [key=value ...]      (keys as binary_ref, plus focus_factor, focus_index)
- * writes <out_prefix>.{blocks.i32, xv, u_init, br, u_stage, u_final, stage_scalars, scalars}; block data are concatenated in
+ * writes <out_prefix>.{blocks.i32, xv, u_init, br, u_stage, u_final, stage_scalars, scalars, diag_scalars, diag_fields}; block data are concatenated in
  * tree order (arithmetic_binary_tree_t::sink), each block [bs][bs][3] (or [bs+1][2] interleaved x, y for the vertex edges).
  */
 #include <cstdio>
@@ -547,5 +547,60 @@ int main(int argc, char** argv)
     push_elements(fin, S.E_acc); push_elements(fin, S.E_grav); push_elements(fin, S.E);
     for (double d : dts) fin.push_back(d);
     dump(prefix + ".scalars.f64", fin.data(), fin.size() * 8);
+
+    // Diagnostics of the final state, composed as subprog_binary_diagnostics.cpp:21-82 composes them:
+    // disk_mass, disk_angular_momentum (time series) and sigma, radial_velocity, phi_velocity (diagnostics file).
+    {
+        auto dA = P.vertices.map([] (auto block)                // subprog_binary_solver_data.cpp:29-34
+        {
+            auto dx = block | nd::map([] (auto p) { return p[0]; }) | nd::difference_on_axis(0) | nd::midpoint_on_axis(1);
+            auto dy = block | nd::map([] (auto p) { return p[1]; }) | nd::difference_on_axis(1) | nd::midpoint_on_axis(0);
+            return (dx * dy) | nd::to_shared();
+        });
+        auto cc = P.vertices.map([] (auto block) { return block | nd::midpoint_on_axis(0) | nd::midpoint_on_axis(1) | nd::to_shared(); });
+        double disk_mass = 0, disk_lz = 0;
+        std::vector<double> fields;                              // per block: sigma [bs][bs], then v_r, then v_phi
+        auto push_fields = [&] (auto p0)
+        {
+            auto xc = cc.map([] (auto b) { return b | nd::map([] (auto x) { return x[0]; }) | nd::to_shared(); });
+            auto yc = cc.map([] (auto b) { return b | nd::map([] (auto x) { return x[1]; }) | nd::to_shared(); });
+            auto rc = (xc * xc + yc * yc).map(nd::map([] (mara::unit_area<double> r2) { return r2.pow<1, 2>(); }));
+            auto rhat_x =  xc / rc;
+            auto rhat_y =  yc / rc;
+            auto phat_x = -yc / rc;
+            auto phat_y =  xc / rc;
+            auto sigma = p0.map(nd::map(std::mem_fn(&prim_t::sigma)));
+            auto vx    = p0.map(nd::map(std::mem_fn(&prim_t::velocity_x)));
+            auto vy    = p0.map(nd::map(std::mem_fn(&prim_t::velocity_y)));
+            auto vr    = vx * rhat_x + vy * rhat_y;
+            auto vp    = vx * phat_x + vy * phat_y;
+            auto s_ = sigma.map(nd::to_shared()), r_ = vr.map(nd::to_shared()), p_ = vp.map(nd::to_shared());
+            s_.indexes().sink([&] (auto index)
+            {
+                for (auto v : s_.at(index)) fields.push_back(v);
+                for (auto v : r_.at(index)) fields.push_back(v);
+                for (auto v : p_.at(index)) fields.push_back(v);
+            });
+        };
+        if (! P.qform)
+        {
+            auto U = S.u.map([] (auto b) { return b | nd::map([] (vec3 u) { return to_ref(u); }) | nd::to_shared(); });
+            disk_mass = (U.map(nd::map([] (auto u) { return mara::get<0>(u); })) * dA).map(nd::sum()).sum().value;
+            auto lz = U.pair(cc).apply([] (auto Ub, auto X) { return nd::zip(Ub, X) | nd::apply(mara::iso2d::angular_momentum); });
+            disk_lz = (lz * dA).map(nd::sum()).sum().value;
+            push_fields(U.map([] (auto Ub) { return Ub | nd::map([] (auto u) { return mara::iso2d::recover_primitive(u); }) | nd::to_shared(); }));
+        }
+        else
+        {
+            auto Q = S.u.map([] (auto b) { return b | nd::map([] (vec3 u) { return to_ref_q(u); }) | nd::to_shared(); });
+            disk_mass = (Q.map(nd::map([] (auto q) { return mara::get<0>(q); })) * dA).map(nd::sum()).sum().value;
+            disk_lz = (Q * dA).map(nd::map([] (auto q) { return mara::get<2>(q); })).map(nd::sum()).sum().value;
+            push_fields(Q.pair(cc).apply([] (auto Qb, auto X) { return nd::zip(Qb, X) | nd::apply([] (auto q, auto x) { return mara::iso2d::recover_primitive(q, x); }) | nd::to_shared(); }));
+        }
+        auto B = mara::compute_two_body_state(S.E, S.time);
+        std::vector<double> dg = {disk_mass, disk_lz, B.body1.position_x, B.body1.position_y, B.body2.position_x, B.body2.position_y};
+        dump(prefix + ".diag_scalars.f64", dg.data(), dg.size() * 8);
+        dump(prefix + ".diag_fields.f64", fields.data(), fields.size() * 8);
+    }
     return 0;
 }

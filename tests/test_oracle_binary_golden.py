@@ -40,3 +40,16 @@ def test_one_stage(name, oracle):
     # the accumulators after one stage from zero are the totals themselves (scheme.cpp:893-898)
     acc = ss[3:13]
     assert bits_equal(acc, tot[[0, 1, 2, 3, 4, 5, 14, 15, 16, 17]] + 0.0)
+
+
+@pytest.mark.parametrize("name", ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b12_nu", "binary_tree_d3_b8_q",
+                                  "binary_tree_d2_b16_q_uniform", "binary_tree_d2_b16_uniform"])
+def test_diagnostics_vs_reference_composition(name, oracle):
+    """disk_mass, disk_angular_momentum and the diagnostic fields (sigma, v_r, v_phi) of the final state, bit for bit against the
+    reference's own array / tree operators composed as subprog_binary_diagnostics.cpp composes them (sum order included)."""
+    import json
+    g = golden(name)
+    q = int(json.loads(str(g["config"])).get("conserve_linear_p", 1)) == 0
+    mass, lz, fields = oracle.binary_diagnostics(q, g["blocks"], g["xv"], g["u_final"])
+    assert mass == g["diag_scalars"][0] and lz == g["diag_scalars"][1]
+    assert bits_equal(fields, g["diag_fields"])
