@@ -8,7 +8,9 @@
 //     /schedule/<task>/{name (C string), num_times_performed (int), last_performed (f64)}   (write_schedule :61-70)
 //     /config/<item>                  int | f64 | fixed-length C string (size max(1, len)), scalar   (write_config :90-96, core_hdf5.hpp:474-477)
 //
-// written by subprog_sedov.cpp:329-335,486-495 and subprog_cloud.cpp:590-597,758-767 upstream. The reference wraps the HDF5 C
+// written by subprog_sedov.cpp:329-335,486-495 and subprog_cloud.cpp:590-597,758-767 upstream. `binary`'s files (checkpoint with one
+// dataset per tree block, compound orbital elements, the time series; diagnostics) are laid out in subprog_binary.cpp from the
+// same pieces: scalar H5T_ARRAY datasets, 2-D datasets, and compound types (Compound below = h5::Datatype::compound, core_hdf5.hpp:197-210). The reference wraps the HDF5 C
 // API in core_hdf5.hpp; here the C API is called directly. libhdf5 is bound at run time (dlopen), like RCCL in slab.hip: the
 // host executable has no link-time dependency on it and runs without it as long as no checkpoint is requested.
 //
@@ -57,6 +59,21 @@ struct Node
     void read_rational(const std::string&, int&, int&) const { none(); }
     std::vector<double> read_vector(const std::string&) const { none(); }
     std::vector<double> read_cells(const std::string&, int, std::vector<hsize_t>&) const { none(); }
+    void write_array(const std::string&, const double*, int) const { none(); }
+    void read_array(const std::string&, double*, int) const { none(); }
+    void write_grid(const std::string&, hsize_t, hsize_t, const double*) const { none(); }
+    template<typename C> void write_record(const std::string&, const C&, const void*) const { none(); }
+    template<typename C> void write_records(const std::string&, const C&, hsize_t, const void*) const { none(); }
+    template<typename C> void read_record(const std::string&, const C&, void*) const { none(); }
+    hsize_t count_of(const std::string&) const { none(); }
+    template<typename C> void read_records(const std::string&, const C&, void*) const { none(); }
+};
+struct Compound
+{
+    explicit Compound(std::size_t) {}
+    void insert_double(const char*, std::size_t) {}
+    void insert_array(const char*, std::size_t, int) {}
+    void insert(const char*, std::size_t, const Compound&) {}
 };
 #else
 
@@ -69,7 +86,8 @@ struct Lib
     H5IO_FN(H5Lexists); H5IO_FN(H5Screate); H5IO_FN(H5Screate_simple); H5IO_FN(H5Sclose); H5IO_FN(H5Sget_simple_extent_ndims);
     H5IO_FN(H5Sget_simple_extent_dims); H5IO_FN(H5Tcopy); H5IO_FN(H5Tset_size); H5IO_FN(H5Tarray_create2); H5IO_FN(H5Tclose);
     H5IO_FN(H5Tget_size); H5IO_FN(H5Tget_class); H5IO_FN(H5Dcreate2); H5IO_FN(H5Dopen2); H5IO_FN(H5Dwrite); H5IO_FN(H5Dread);
-    H5IO_FN(H5Dget_space); H5IO_FN(H5Dget_type); H5IO_FN(H5Dclose); H5IO_FN(H5Literate);
+    H5IO_FN(H5Dget_space); H5IO_FN(H5Dget_type); H5IO_FN(H5Dclose); H5IO_FN(H5Literate); H5IO_FN(H5Tcreate); H5IO_FN(H5Tinsert);
+    H5IO_FN(H5Sget_simple_extent_npoints);
 #undef H5IO_FN
     hid_t native_double = -1, native_int = -1, c_s1 = -1;
 
@@ -86,7 +104,8 @@ struct Lib
             H5IO_SYM(H5Lexists); H5IO_SYM(H5Screate); H5IO_SYM(H5Screate_simple); H5IO_SYM(H5Sclose); H5IO_SYM(H5Sget_simple_extent_ndims);
             H5IO_SYM(H5Sget_simple_extent_dims); H5IO_SYM(H5Tcopy); H5IO_SYM(H5Tset_size); H5IO_SYM(H5Tarray_create2); H5IO_SYM(H5Tclose);
             H5IO_SYM(H5Tget_size); H5IO_SYM(H5Tget_class); H5IO_SYM(H5Dcreate2); H5IO_SYM(H5Dopen2); H5IO_SYM(H5Dwrite); H5IO_SYM(H5Dread);
-            H5IO_SYM(H5Dget_space); H5IO_SYM(H5Dget_type); H5IO_SYM(H5Dclose); H5IO_SYM(H5Literate);
+            H5IO_SYM(H5Dget_space); H5IO_SYM(H5Dget_type); H5IO_SYM(H5Dclose); H5IO_SYM(H5Literate); H5IO_SYM(H5Tcreate); H5IO_SYM(H5Tinsert);
+            H5IO_SYM(H5Sget_simple_extent_npoints);
 #undef H5IO_SYM
             lib.H5open();
             auto global = [&] (const char* sym) { auto p = static_cast<hid_t*>(dlsym(lib.handle, sym)); if (! p) throw std::runtime_error(std::string("libhdf5 lacks ") + sym); return *p; };
@@ -106,6 +125,26 @@ inline bool available()
 }
 
 inline void check(hid_t id, const std::string& what) { if (id < 0) throw std::runtime_error("HDF5: " + what + " failed"); }
+
+// h5::Datatype::compound (core_hdf5.hpp:197-210): a struct of doubles, arrays of doubles and nested compounds, members at the
+// offsets of the in-memory struct
+struct Compound
+{
+    hid_t id = -1;
+    explicit Compound(std::size_t size) : id(Lib::get().H5Tcreate(H5T_COMPOUND, size)) { check(id, "create compound type"); }
+    Compound(const Compound&) = delete;
+    ~Compound() { if (id >= 0) Lib::get().H5Tclose(id); }
+    void insert_double(const char* name, std::size_t offset) { Lib::get().H5Tinsert(id, name, offset, Lib::get().native_double); }
+    void insert_array(const char* name, std::size_t offset, int n)
+    {
+        auto& L = Lib::get();
+        const hsize_t q = n;
+        hid_t t = L.H5Tarray_create2(L.native_double, 1, &q);
+        L.H5Tinsert(id, name, offset, t);
+        L.H5Tclose(t);
+    }
+    void insert(const char* name, std::size_t offset, const Compound& member) { Lib::get().H5Tinsert(id, name, offset, member.id); }
+};
 
 // a file or group handle
 struct Node
@@ -198,6 +237,28 @@ struct Node
         L.H5Tclose(t);
     }
 
+    // a scalar dataset whose element is an array of n doubles: mara::arithmetic_sequence_t (app_serialize.hpp:240-252)
+    void write_array(const std::string& name, const double* v, int n) const
+    {
+        auto& L = Lib::get();
+        const hsize_t q = n;
+        hid_t t = L.H5Tarray_create2(L.native_double, 1, &q);
+        write_raw(name, t, 0, nullptr, v);
+        L.H5Tclose(t);
+    }
+    void write_grid(const std::string& name, hsize_t n0, hsize_t n1, const double* data) const
+    {
+        const hsize_t dims[2] = {n0, n1};
+        write_raw(name, Lib::get().native_double, 2, dims, data);
+    }
+    void write_record(const std::string& name, const Compound& type, const void* data) const { write_raw(name, type.id, 0, nullptr, data); }
+    // std::vector<record> (core_hdf5.hpp:487-497): a 1-D dataset, possibly of extent 0
+    void write_records(const std::string& name, const Compound& type, hsize_t n, const void* data) const
+    {
+        static const char nothing[8] = {0};
+        write_raw(name, type.id, 1, &n, n ? data : nothing);
+    }
+
     // ---- readers
     struct Dataset
     {
@@ -269,6 +330,29 @@ struct Node
         std::vector<double> v(n);
         if (Lib::get().H5Dread(d.ds, d.type, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data()) < 0) throw std::runtime_error("HDF5: read " + name);
         return v;
+    }
+    void read_array(const std::string& name, double* v, int n) const
+    {
+        Dataset d; open(name, d);
+        if (Lib::get().H5Tget_size(d.type) != std::size_t(n) * sizeof(double)) throw std::runtime_error("HDF5: " + name + " is not an array of " + std::to_string(n) + " doubles");
+        if (Lib::get().H5Dread(d.ds, d.type, H5S_ALL, H5S_ALL, H5P_DEFAULT, v) < 0) throw std::runtime_error("HDF5: read " + name);
+    }
+    void read_record(const std::string& name, const Compound& type, void* data) const
+    {
+        Dataset d; open(name, d);
+        if (Lib::get().H5Dread(d.ds, type.id, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) throw std::runtime_error("HDF5: read " + name);
+    }
+    hsize_t count_of(const std::string& name) const
+    {
+        Dataset d; open(name, d);
+        const auto n = Lib::get().H5Sget_simple_extent_npoints(d.space);
+        return n < 0 ? 0 : hsize_t(n);
+    }
+    void read_records(const std::string& name, const Compound& type, void* data) const
+    {
+        Dataset d; open(name, d);
+        if (Lib::get().H5Sget_simple_extent_npoints(d.space) <= 0) return;
+        if (Lib::get().H5Dread(d.ds, type.id, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) throw std::runtime_error("HDF5: read " + name);
     }
     H5T_class_t class_of(const std::string& name) const
     {

@@ -203,7 +203,98 @@ def test_binary_subprogram_on_graded_trees_matches_reference(tmp_path, case):
 
 
 def test_binary_subprogram_default_configuration_runs(tmp_path):
-    stdout = run(["binary", "max_iterations=20", "steps_per_call=10"], str(tmp_path))      # depth=4 block_size=24 focus_factor=2: the graded default
+    # depth=4 block_size=24 focus_factor=2: the graded default; with the three tasks switched off the iterations are batched
+    stdout = run(["binary", "max_iterations=20", "steps_per_call=10", "cpi=0", "dfi=0", "tsi=0"], str(tmp_path))
     assert "block tree: 64 blocks of 24 x 24 zones" in stdout and "[0020] orbits=" in stdout
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     assert np.isfinite(d["data"]).all() and (d["data"][..., 0] > 0).all()
+
+
+def _binary_args(over):
+    ints = ("depth", "block_size", "fixed_dt", "rk_order", "axisymmetric_cs2", "counter_rotate", "no_accretion_force", "conserve_linear_p")
+    return ["%s=%r" % (k, int(v) if k in ints else float(v)) for k, v in over.items()]
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
+@pytest.mark.parametrize("case", ["binary_tree_d2_b16_uniform", "binary_tree_d3_b8", "binary_tree_d3_b8_q"])
+def test_binary_tasks_checkpoint_diagnostics_time_series_and_restart(tmp_path, case):
+    """`mara_hip binary` with its three tasks (src/subprog_binary.cpp:296-385): file layout as subprog_binary_io.cpp writes it (one
+    dataset per tree block named level:ii-jj, compound orbital elements and time-series samples), contents against the
+    reference-generated vectors, and restart == uninterrupted run. With tiny intervals a task falls due from the second
+    iteration on (the schedule looks at the time the step started from), so files number 0000 (initial), 0001 (after step 2)..."""
+    import json
+    g = golden(case)
+    over = json.loads(str(g["config"]))
+    nsteps = int(over.pop("nsteps"))
+    assert nsteps >= 2
+    qform = int(over.get("conserve_linear_p", 1)) == 0
+    args = ["binary"] + _binary_args(over) + ["max_iterations=%d" % nsteps, "tfinal=100.0", "cpi=1e-9", "dfi=1e-9", "tsi=1e-9"]
+    stdout = run(args + ["outdir=a"], str(tmp_path))
+    last = nsteps - 1
+    for prefix in ("chkpt", "diagnostics"):
+        for k in range(last + 1):
+            assert "write %s: a/%s.%04d.h5" % ("checkpoint" if prefix == "chkpt" else "diagnostics", prefix, k) in stdout
+    chk = os.path.join(tmp_path, "a", "chkpt.%04d.h5" % last)
+    header = subprocess.run([H5DUMP, "-H", chk], check=True, capture_output=True, text=True).stdout
+    for name in ('GROUP "solution"', 'GROUP "conserved_u"', 'GROUP "conserved_q"', 'GROUP "schedule"', 'GROUP "run_config"', 'DATASET "time_series"',
+                 'DATASET "orbital_elements_grav"', '"cm_velocity_y"', '"eccentricity"', '"disk_angular_momentum"', '"position_of_mass2"',
+                 'GROUP "record_time_series"', "H5T_ARRAY { [3] H5T_IEEE_F64LE }", "H5T_ARRAY { [2] H5T_IEEE_F64LE }"):
+        assert name in header, name
+    assert list(_h5_dataset(chk, "/solution/iteration", np.int32)) == [nsteps, 1]
+    assert abs(_h5_dataset(chk, "/solution/time")[0] - g["scalars"][0]) <= 1e-13 * g["scalars"][0]
+    bs = int(over["block_size"])
+    scale = np.abs(g["u_final"]).reshape(-1, 3).max(axis=0)
+    form = "conserved_q" if qform else "conserved_u"
+    for k, (level, i, j) in enumerate(g["blocks"]):
+        width = 1 + int(np.log10(1 << level))
+        name = "%d:%0*d-%0*d" % (level, width, i, width, j)
+        cells = _h5_dataset(chk, "/solution/%s/%s" % (form, name)).reshape(bs, bs, 3)[..., ::-1]       # std::tuple storage order of libstdc++
+        assert np.all(np.abs(cells - g["u_final"][k]).reshape(-1, 3).max(axis=0) <= 1e-12 * scale), name
+    # the time series: samples at t = 0 and after every step from the second on; the last one belongs to the final state
+    series = _h5_dataset(chk, "/time_series").reshape(-1, 47)
+    assert len(series) == nsteps and series[0, 0] == 0.0
+    assert abs(series[-1, 0] - g["scalars"][0]) <= 1e-13 * g["scalars"][0]
+    assert abs(series[-1, 1] - g["diag_scalars"][0]) <= 1e-12 * g["diag_scalars"][0]          # disk_mass
+    assert abs(series[-1, 2] - g["diag_scalars"][1]) <= 1e-11 * abs(g["diag_scalars"][1])     # disk_angular_momentum
+    assert np.allclose(series[-1, 43:47], g["diag_scalars"][2:6], rtol=0, atol=1e-13)         # positions of the two masses
+    assert np.allclose(series[-1, 33:43], g["scalars"][32:42], rtol=1e-13, atol=1e-15)        # orbital_elements
+    sched = _h5_dataset(chk, "/schedule/write_checkpoint/num_times_performed", np.int32)[0]
+    assert sched == nsteps                                                                     # completed before the state is written (:333-335)
+    # diagnostics file of the final state
+    dg = os.path.join(tmp_path, "a", "diagnostics.%04d.h5" % last)
+    vscale = np.abs(g["diag_fields"][:, 1:]).max()
+    for k, (level, i, j) in enumerate(g["blocks"][:6]):
+        width = 1 + int(np.log10(1 << level))
+        name = "%d:%0*d-%0*d" % (level, width, i, width, j)
+        sig = _h5_dataset(dg, "/sigma/" + name).reshape(bs, bs)
+        assert np.all(np.abs(sig - g["diag_fields"][k, 0]) <= 1e-12 * scale[0])
+        vp = _h5_dataset(dg, "/phi_velocity/" + name).reshape(bs, bs)
+        assert np.all(np.abs(vp - g["diag_fields"][k, 2]) <= 1e-10 * vscale)
+        verts = _h5_dataset(dg, "/vertices/" + name).reshape(bs + 1, bs + 1, 2)
+        assert bits_equal(verts[:, 0, 0], g["xv"][k, 0]) and bits_equal(verts[0, :, 1], g["xv"][k, 1])
+    assert np.allclose(_h5_dataset(dg, "/position_of_mass1"), g["diag_scalars"][2:4], rtol=0, atol=1e-13)
+    # restart from the checkpoint written after step 2 and compare with the uninterrupted run
+    a = read_dump(os.path.join(tmp_path, "a", "final.bin"))
+    if nsteps > 2:
+        stdout = run(["binary", "restart=a/chkpt.0001.h5", "outdir=b"], str(tmp_path))
+        b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
+        assert b["iteration"] == nsteps and b["time"] == a["time"]
+        assert bits_equal(b["data"], a["data"]) and bits_equal(b["vertices"], a["vertices"])
+        assert "write checkpoint: b/chkpt.0002.h5" in stdout and "b/chkpt.0000.h5" not in stdout
+        series_b = _h5_dataset(os.path.join(tmp_path, "b", "chkpt.0002.h5"), "/time_series").reshape(-1, 47)
+        assert bits_equal(series_b, series)
+    else:
+        stdout = run(["binary", "restart=a/chkpt.0001.h5", "outdir=b", "max_iterations=%d" % (nsteps + 1)], str(tmp_path))
+        b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
+        assert b["iteration"] == nsteps + 1
+        stdout = run(args[:-3] + ["outdir=c", "cpi=0", "dfi=0", "tsi=0", "max_iterations=%d" % (nsteps + 1)], str(tmp_path))
+        c = read_dump(os.path.join(tmp_path, "c", "final.bin"))
+        assert bits_equal(b["data"], c["data"]) and b["time"] == c["time"]
+
+
+def test_binary_runs_to_tfinal_with_the_closing_step(tmp_path):
+    """Without max_iterations the loop is upstream's: run while orbits < tfinal, then one closing `tasks(next(state))`."""
+    stdout = run(["binary", "depth=2", "block_size=8", "focus_factor=1e9", "domain_radius=4.0", "tfinal=0.02", "cpi=0", "dfi=0", "tsi=0"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    lines = [l for l in stdout.splitlines() if l.startswith("[")]
+    assert d["iteration"] == len(lines) + 1 and d["time"] / (2 * np.pi) > 0.02
