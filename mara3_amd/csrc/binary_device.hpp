@@ -99,7 +99,7 @@ struct BinFast
         const double im = fast::rcp_nr(c.mach);
         return {im, im * im, fast::rcp_nr(c.h), fast::rcp_nr(2.0 * c.s2)};
     }
-    static __device__ inline double rsqrt(double x) { double g, h2; fast::sqrt_rsqrt(x, g, h2); return h2; }
+    static __device__ inline double rsqrt(double x) { return fast::rsqrt_fast(x); }
     static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
     {
         if (c.axisym) return rsqrt(__builtin_fma(x, x, y * y)) * k.inv_mach2;

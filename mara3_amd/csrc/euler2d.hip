@@ -164,7 +164,9 @@ void euler2d_stage_kernel(Stage2dParams p)
     // row loop, unrolled by three, needs no register-to-register rotation at all.
     //   U[k]: conserved of rows r, r+1, r+2        P[k]: primitives of rows r, r+1, r+2
     //   G[k]: axis-0 slope of rows r, r+1          Fx[k]: axis-0 flux through faces r-1/2, r+1/2
-    State5 U[3], P[3], G[3], Fx[3];
+    //   D[k]: (FAST) theta * (P of row r+1 - P of row r), the limiter's one-sided difference across face r+1/2
+    State5 U[3], P[3], G[3], Fx[3], D[3];
+    const double half_over_theta = 0.5 / theta;
     {
         const State5 Pa = A::c2p(load_row(in + row_off(r0 - 2), p.plane_stride, jc8), gl);
         const State5 Pb = A::c2p(load_row(in + row_off(r0 - 1), p.plane_stride, jc8), gl);
@@ -173,7 +175,15 @@ void euler2d_stage_kernel(Stage2dParams p)
         U[2] = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
         P[0] = A::c2p(U[0], gl);
         P[1] = A::c2p(U[1], gl);
-        if constexpr (PLM)
+        if constexpr (PLM && A::shared_differences)
+        {
+            const State5 Dab = A::scaled_difference(Pa, Pb, theta), Db0 = A::scaled_difference(Pb, P[0], theta);
+            D[0] = A::scaled_difference(P[0], P[1], theta);
+            const State5 Gb = A::plm_from_differences(Dab, Db0, half_over_theta);
+            G[0] = A::plm_from_differences(Db0, D[0], half_over_theta);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
+        }
+        else if constexpr (PLM)
         {
             const State5 Gb = A::plm(Pa, Pb, P[0], theta);
             G[0] = A::plm(Pb, P[0], P[1], theta);
@@ -204,7 +214,13 @@ void euler2d_stage_kernel(Stage2dParams p)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(U[K2], gl);
-        if constexpr (PLM)
+        if constexpr (PLM && A::shared_differences)
+        {
+            D[K1] = A::scaled_difference(P[K1], P[K2], theta);
+            G[K1] = A::plm_from_differences(D[K0], D[K1], half_over_theta);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
+        }
+        else if constexpr (PLM)
         {
             G[K1] = A::plm(P[K0], P[K1], P[K2], theta);
             Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
@@ -216,7 +232,14 @@ void euler2d_stage_kernel(Stage2dParams p)
 
         // ---- axis 1: this lane computes the flux through its LEFT face (between lane-1 and lane)
         State5 Fy_lo, Fy_hi;
-        if constexpr (PLM)
+        if constexpr (PLM && A::shared_differences)
+        {
+            const State5 Dr = A::scaled_difference(P[K0], from_right(P[K0]), theta);
+            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, half_over_theta);
+            const State5 SL = from_left(A::plus(P[K0], Gy));
+            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy), gl);
+        }
+        else if constexpr (PLM)
         {
             const State5 Gy = A::plm(from_left(P[K0]), P[K0], from_right(P[K0]), theta);
             const State5 SL = from_left(A::plus(P[K0], Gy));       // left neighbour's right-going face state
