@@ -117,7 +117,7 @@ __device__ inline void store_row(double* row, long plane_stride, unsigned lane_b
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, A::min_waves_per_simd)
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, (COMBINE ? A::min_waves_per_simd : A::min_waves_first_stage))
 void euler2d_stage_kernel(Stage2dParams p)
 {
     // ---- which (chunk, strip) does this wave own? XCD-aware: consecutive work
@@ -175,6 +175,9 @@ void euler2d_stage_kernel(Stage2dParams p)
         U[2] = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
         P[0] = A::c2p(U[0], gl);
         P[1] = A::c2p(U[1], gl);
+        // (recompute_conserved: U[] is the ring of LOADED rows instead - slot (row - r0) mod 3 holds row r+2, r+3 or r+4 until its
+        // conversion; rows r0, r0+1 are converted already and their slots take rows r0+3, r0+4)
+        if constexpr (A::recompute_conserved) U[0] = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
         if constexpr (PLM && A::shared_differences)
         {
             const State5 Dab = A::scaled_difference(Pa, Pb, theta), Db0 = A::scaled_difference(Pb, P[0], theta);
@@ -199,7 +202,8 @@ void euler2d_stage_kernel(Stage2dParams p)
     // second prefetch stage: row r+3 is in flight in Upre while row r is processed, row r+4 is issued at its top.
     // Two rows (10 loads of 512 B) in flight per wave keep ~40 KB outstanding per CU, enough to cover HBM latency
     // at this kernel's bandwidth (one row in flight left the first RK stage latency-bound).
-    State5 Upre = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
+    State5 Upre;
+    if constexpr (! A::recompute_conserved) Upre = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
 
     // one row; K0 = ring slot of row r (compile-time), K1 / K2 = slots of rows r+1 / r+2
     auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
@@ -208,7 +212,9 @@ void euler2d_stage_kernel(Stage2dParams p)
 
         // issue the load of row r+4 (clamped to the stored ghost range; unused past the chunk end)
         const int rp = min(r + 4, p.n0 + 1);
-        const State5 Unext = load_row(in + row_off(rp), p.plane_stride, jc8);
+        State5 Unext;
+        if constexpr (A::recompute_conserved) U[K1] = load_row(in + row_off(rp), p.plane_stride, jc8);      // row r+1 was converted a row ago
+        else                                  Unext = load_row(in + row_off(rp), p.plane_stride, jc8);
         State5 Ubase;
         if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);
 
@@ -252,11 +258,13 @@ void euler2d_stage_kernel(Stage2dParams p)
         Fy_hi = from_right(Fy_lo);
 
         // ---- conservative update (+ RK combine)
-        State5 Un;
+        State5 Un, Uc;
+        if constexpr (A::recompute_conserved) Uc = A::p2c(P[K0], gl);
+        else                                  Uc = U[K0];
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double u1 = A::update2(U[K0][q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+            const double u1 = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
@@ -274,8 +282,11 @@ void euler2d_stage_kernel(Stage2dParams p)
                 if (p.bc_lo0 == 1 && r >= p.n0 - HALO) store_row(p.u_out + row_off(r - p.n0), p.plane_stride, col8, Un);
             }
         }
-        U[K0] = Upre;       // slot of row r now holds row r+3 ...
-        Upre = Unext;       // ... and row r+4 stays in flight
+        if constexpr (! A::recompute_conserved)
+        {
+            U[K0] = Upre;       // slot of row r now holds row r+3 ...
+            Upre = Unext;       // ... and row r+4 stays in flight
+        }
     };
 
     int r = r0;

@@ -169,6 +169,19 @@ __device__ inline void conserved_and_flux(const State5& P, const GammaLawFast& g
     F[4] = vn * (U[4] + p);
 }
 
+// primitive_t::to_conserved_density (physics_euler.hpp:209-220)
+__device__ inline State5 to_conserved(const State5& P, const GammaLawFast& g)
+{
+    const double vsq = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    State5 U;
+    U[0] = P[0];
+    U[1] = P[0] * P[1];
+    U[2] = P[0] * P[2];
+    U[3] = P[0] * P[3];
+    U[4] = __builtin_fma(0.5 * P[0], vsq, P[4] * g.inv_gm1);
+    return U;
+}
+
 // HLLC (Toro 3rd ed. section 10.4-10.6, pressure-based wave speeds as physics_iso2d.hpp:610-687 generalised to a gamma law). The wave
 // speeds need only (d, u_n, p, a) of the two sides; the conserved state and flux are then formed for the ONE side the
 // sampled region belongs to.
@@ -189,48 +202,27 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     const double mr = dr * (sr - ur);
     const double sstar = (pr - pl + ul * ml - ur * mr) * rcp_nr(ml - mr);
 
-    State5 F, U;
-    if (0.0 <= sl)
-    {
-        conserved_and_flux<AXIS>(Pl, g, U, F);
-    }
-    else if (sl <= 0.0 && 0.0 <= sstar)
-    {
-        // F*_L = (S* (S_L U_L - F_L) + S_L p* D) / (S_L - S*), D = (0, n, S*), p* = p_L + rho_L (S_L - u_L)(S* - u_L): Toro eq. 10.41-10.43,
-        // algebraically the same flux as F_L + S_L (U*_L - U_L) of eq. 10.38-10.39 with one division instead of three
-        State5 Fl;
-        conserved_and_flux<AXIS>(Pl, g, U, Fl);
-        const double rinv = rcp_nr(sl - sstar);
-        const double sp = sl * __builtin_fma(ml, sstar - ul, pl);
+    // Region selection without control flow (four-way branches cost more in instruction-fetch stalls than the selects do in issue
+    // slots): K = the side of the contact the face lies on; its own flux if the K wave moves away from the face, else the star flux
+    //   F*_K = (S* (S_K U_K - F_K) + S_K p* D) / (S_K - S*), D = (0, n, S*), p* = p_K + rho_K (S_K - u_K)(S* - u_K)   (Toro eq. 10.41-10.43),
+    // algebraically F_K + S_K (U*_K - U_K) of eq. 10.38-10.39 with one division instead of three. Conditions in the reference's
+    // order (physics_iso2d.hpp:576-583): 0 <= S_L, S_L <= 0 <= S*, S* <= 0 <= S_R, S_R <= 0.
+    const bool left = 0.0 <= sstar;
+    State5 Pk;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sl, U[q], -Fl[q]);
-        F[1 + AXIS] += sp;
-        F[4] = __builtin_fma(sp, sstar, F[4]);
+    for (int q = 0; q < 5; ++q) Pk[q] = left ? Pl[q] : Pr[q];
+    const double sk = left ? sl : sr, mk = left ? ml : mr;
+    const bool star = left ? ! (0.0 <= sl) : (0.0 <= sr);
+    State5 U, Fk, F;
+    conserved_and_flux<AXIS>(Pk, g, U, Fk);
+    const double rinv = rcp_nr(sk - sstar);
+    const double sp = sk * __builtin_fma(mk, sstar - Pk[1 + AXIS], Pk[4]);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] *= rinv;
-    }
-    else if (sstar <= 0.0 && 0.0 <= sr)
-    {
-        State5 Fr;
-        conserved_and_flux<AXIS>(Pr, g, U, Fr);
-        const double rinv = rcp_nr(sr - sstar);
-        const double sp = sr * __builtin_fma(mr, sstar - ur, pr);
+    for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sk, U[q], -Fk[q]);
+    F[1 + AXIS] += sp;
+    F[4] = __builtin_fma(sp, sstar, F[4]);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sr, U[q], -Fr[q]);
-        F[1 + AXIS] += sp;
-        F[4] = __builtin_fma(sp, sstar, F[4]);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] *= rinv;
-    }
-    else if (sr <= 0.0)
-    {
-        conserved_and_flux<AXIS>(Pr, g, U, F);
-    }
-    else
-    {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) F[q] = __builtin_nan("");
-    }
+    for (int q = 0; q < 5; ++q) F[q] = star ? F[q] * rinv : Fk[q];
     return F;
 }
 
@@ -240,7 +232,9 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
 struct StrictArith
 {
     static constexpr int min_waves_per_simd = 2;
+    static constexpr int min_waves_first_stage = 2;
     static constexpr bool shared_differences = false;       // the reference's plm_gradient takes the three values, bit for bit
+    static constexpr bool recompute_conserved = false;      // the update starts from the stored conserved state, bit for bit
     using Gamma = GammaLaw;
     static __device__ inline Gamma gamma_law(double gamma) { return make_gamma_law(gamma); }
     static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return recover_primitive(U, g.gamma, 0.0); }
@@ -273,10 +267,19 @@ struct FastArith
 #define MH_FAST_MIN_WAVES 2
 #endif
     static constexpr int min_waves_per_simd = MH_FAST_MIN_WAVES;
+#ifndef MH_FAST_MIN_WAVES_STAGE1
+#define MH_FAST_MIN_WAVES_STAGE1 2          // 3 (168 VGPRs, ~40 spills) was measured: no faster, DESIGN.md §6
+#endif
+    static constexpr int min_waves_first_stage = MH_FAST_MIN_WAVES_STAGE1;
     // The limiter's one-sided differences theta (y_{i+1} - y_i) belong to a FACE: each is formed once and used by the two cells it
     // separates (carried in the register ring along the marching axis, passed by DPP across lanes); the central difference is
     // their sum times 1 / (2 theta). 4 instead of 6 fp64 instructions per variable and axis in front of the min/max.
     static constexpr bool shared_differences = true;
+    // The 2-D stage kernel converts a loaded row to primitives once and keeps only those; the conserved state the update starts
+    // from is formed again from the primitives (8 instructions, equal to the stored one to rounding) instead of being carried through
+    // the register window: no register-to-register moves in the row loop and 20 VGPRs fewer.
+    static constexpr bool recompute_conserved = true;
+    static __device__ inline State5 p2c(const State5& P, const fast::GammaLawFast& g) { return fast::to_conserved(P, g); }
     static __device__ inline State5 scaled_difference(const State5& P, const State5& Pnext, double theta)
     {
         State5 D;
