@@ -30,6 +30,7 @@
 // Algorithmic HBM bytes per cell per stage: 80 (first stage) / 120 (second
 // stage of RK2) => 200 B per zone-update for RK2.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 #include "euler_device.hpp"
@@ -306,12 +307,25 @@ void euler2d_stage_kernel(Stage2dParams p)
     }
 }
 
+// The slab stepper orders its two streams with events. An event recorded by hipEventRecord is a separate marker packet behind
+// the kernel; handed to the launch itself (hipExtLaunchKernel's stopEvent) it rides on the dispatch packet's own completion signal,
+// one packet less on the chain between consecutive stages.
+static thread_local hipEvent_t g_stop_event = nullptr;
+void euler2d_next_launch_signals(hipEvent_t stop) { g_stop_event = stop; }
+
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
 static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
 {
     const int nwaves = p.nstrips * p.nchunks;
     const int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    hipLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
+    if (g_stop_event)
+    {
+        hipEvent_t stop = g_stop_event;
+        g_stop_event = nullptr;
+        hipExtLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, nullptr, stop, 0, p);
+    }
+    else
+        hipLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -362,7 +376,11 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     p.cx = dt / d->dl[0];
     p.cy = dt / d->dl[1];
     p.weight = weight;
-    if (p.nchunks <= 0) return hipSuccess;
+    if (p.nchunks <= 0)
+    {
+        if (g_stop_event) { hipEvent_t stop = g_stop_event; g_stop_event = nullptr; return hipEventRecord(stop, stream); }     // nothing to launch: the event still has to fire
+        return hipSuccess;
+    }
 
     const bool plm = d->plm_theta >= 0.0;
     const bool combine = weight != 1.0;

@@ -14,6 +14,7 @@
 // RCCL is bound at run time (dlopen "librccl.so.1": inside a torch process that is the copy torch already
 // loaded), so the library has no link-time dependency on it and single-GPU hosts never touch it.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstring>
@@ -87,6 +88,9 @@ struct mh_slab
     int device = 0, rank = 0, world = 1, rk_order = 2;
     int lo = -1, hi = -1;                 // neighbour ranks on the low / high side of axis 0 (-1: physical boundary)
     int row0 = 0, row1 = 0, n0 = 0, n1 = 0, edge_rows = 0;
+    int stagger = 0;                  // stages per stagger period (0: every stage synchronises both ways), see slab_stage
+    int phase = 0;                    // stage index within the period
+    bool event_on_launch = true;      // the stage kernels signal the cross-stream events themselves (hipExtLaunchKernel's stopEvent)
     mh_euler_cart_desc desc, edge_desc;
     double* field[2] = {nullptr, nullptr};       // [0] solution, [1] stage scratch; layout of include/mara_hip.h
     double* staging = nullptr;
@@ -127,7 +131,14 @@ static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
 
 static int slab_stage(mh_slab* s, const double* in, const double* base, double* out, double dt, double w, int which)
 {
-    const int n0 = s->n0, e = s->edge_rows;
+    // Staggered edges (2-D): over a period of S stages the edge strips grow by two rows per stage (2, 4, .., 2S) and the interior
+    // shrinks accordingly. Stage k's interior [e_k, n0 - e_k) then reads only rows the previous interior wrote (k >= 1), and the
+    // first edge of the next period (rows 0,1) reads only rows 0..3, which the last edge wrote: per PERIOD the main stream waits for
+    // the side stream once (before interior 0); the side stream waits for the main stream before edges 1..S-1, off the interior's
+    // critical path. Hazards are checked in the comment at the waits.
+    const int S = s->stagger, k = S ? s->phase : 0;
+    if (S) s->phase = (s->phase + 1) % S;
+    const int n0 = s->n0, e = s->edge_rows * (k + 1);
     std::pair<hipEvent_t, hipEvent_t> ev;
     auto bulk = [&] (int a, int b) -> hipError_t
     {
@@ -156,10 +167,17 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     // The interior rows [8, n0-8) read rows 6..n0-7 of the previous stage: edge and interior output, never ghost rows,
     // so the main stream does not wait for RCCL at all; the exchange latency only sits on the (short) edge chain.
     // The waits are issued BEFORE the events are re-recorded, so they bind to the previous stage's records.
-    MH_HIP_TRY(hipStreamWaitEvent(s->main, s->ev_edge, 0));
-    MH_HIP_TRY(hipStreamWaitEvent(s->side, s->ev_interior, 0));
+    // Staggered, stage k of the period, e_k = 2 (k + 1), buffers alternate (out(k) = in(k-1)):
+    //   interior(k) reads in rows >= e_k - 2 = e_{k-1}: interior(k-1)'s, stream order; for k = 0 rows >= 0: edge(S-1)'s -> the one wait.
+    //   interior(k) writes out rows >= e_k; edge(k-1) read that buffer up to row e_{k-1} + 1 < e_k: no overlap, no wait.
+    //   edge(k) reads in rows up to e_k + 1: [0, e_{k-1}) edge(k-1)'s (stream order), the rest interior(k-1)'s -> wait (k >= 1); it
+    //   overwrites out rows [0, e_k), of which interior(k-1) read rows >= e_{k-1} - 2 -> the same wait. For k = 0 it reads rows 0..3
+    //   (edge(S-1)'s, stream order) and writes rows 0,1, while interior(S-1) reads rows >= 2S - 2 >= 2 of that buffer: no wait.
+    if (! S || k == 0) MH_HIP_TRY(hipStreamWaitEvent(s->main, s->ev_edge, 0));
+    if (! S || k >= 1) MH_HIP_TRY(hipStreamWaitEvent(s->side, s->ev_interior, 0));
     if (s->desc.rank == 2)
     {
+        if (s->event_on_launch) euler2d_next_launch_signals(s->ev_edge);
         MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
     }
     else
@@ -167,10 +185,12 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
         MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, 0, e, s->status, s->side));
         MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, n0 - e, n0, s->status, s->side));
     }
-    MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
+    const bool on_launch = s->desc.rank == 2 && s->event_on_launch;
+    if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
     if (int rc = slab_exchange(s, out, s->side)) return rc;
+    if (on_launch) euler2d_next_launch_signals(s->ev_interior);
     MH_HIP_TRY(bulk(e, n0 - e));
-    MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
+    if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
     return MH_OK;
 }
 
@@ -230,16 +250,26 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     s->desc.n[0] = s->n0;
     s->desc.bc_lo0 = s->lo >= 0 ? MH_BC_EXTERNAL : global->bc_lo0;
     s->desc.bc_hi0 = s->hi >= 0 ? MH_BC_EXTERNAL : global->bc_hi0;
+    // Edge strips: the rows whose results are sent. In 2-D exactly the two ghost layers' worth (rows 0,1 and n0-2,n0-1): the edge
+    // launch sits on the stage's critical chain (exchange(k-1) -> edge(k) -> exchange(k)) while it shares the SIMDs with the interior
+    // launch, so its latency - rows per wave - is what matters: 8-row strips took 35 us per stage at 512 x 4096 per rank and made the
+    // side chain, not the interior, set the step time (rocprofv3 kernel trace, scripts/slab_trace.py); 2-row strips take ~15 us.
+    const int edge = global->rank == 2 ? 2 : 8;
     s->edge_desc = s->desc;
-    s->edge_desc.chunk_rows = 8;
-    s->edge_rows = (s->lo >= 0 || s->hi >= 0) ? 8 : 0;
+    s->edge_desc.chunk_rows = edge;
+    s->edge_rows = (s->lo >= 0 || s->hi >= 0) ? edge : 0;
     if (2 * s->edge_rows > s->n0) s->edge_rows = s->n0 / 2;
+    s->stagger = 4;          // measured at 512 / 1024 / 2048 rows per rank (scripts/slab_ab.py): 4 stages per period is ~1 us per step better than 2
+    if (const char* v = getenv("MH_SLAB_STAGGER")) s->stagger = atoi(v);          // measurement switches
+    if (global->rank != 2 || s->edge_rows != 2 || s->stagger < 2 || s->n0 < 4 * s->stagger + 4) s->stagger = 0;
     if (s->edge_rows > 0 && global->rank == 2 && global->chunk_rows == 0)
     {
-        // The interior launch and the concurrent edge launch (2 chunks per strip) should together fit one residency
-        // round of 2048 waves, otherwise a handful of waves run alone in a second round (see euler2d.hip's default).
+        // The interior launch alone should fill one residency round of 2048 waves and no more (a handful of waves in a second
+        // round run alone, see euler2d.hip's default). The concurrent edge launch is NOT counted: it has priority, squeezes in at
+        // the start and is gone long before the round ends. Measured at 512 x 4096 per rank, exchange to self, us per step:
+        // 18 rows per chunk (29 chunks, 2001 waves) 118; 21 (25 chunks) 125; 16 (32 chunks, 2208 waves) 139; 24 (22 chunks) 136.
         const long nstrips = (global->n[1] + 59) / 60;
-        const long chunks_max = 2048 / nstrips - 2;
+        const long chunks_max = 2048 / nstrips;
         const long rows = s->n0 - 2 * s->edge_rows;
         if (chunks_max > 0)
         {
@@ -247,13 +277,14 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
             if (c <= 96) s->desc.chunk_rows = (int) (c < 4 ? 4 : c);
         }
     }
+    if (const char* v = getenv("MH_SLAB_EVENT_ON_LAUNCH")) s->event_on_launch = atoi(v) != 0;
     if ((s->lo >= 0 || s->hi >= 0) && s->n0 < 4) { delete s; set_error("slab of %d rows is thinner than two ghost layers", s->n0); return MH_E_INVALID; }
 
     auto cleanup = [&] () { mh_slab_destroy(s); };
     if (hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
     { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
     const size_t doubles = mh_euler_cart_field_doubles(&s->desc);
@@ -320,6 +351,7 @@ int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
     if (int rc = slab_exchange(s, s->field[0], s->main)) return slab_fail(s, rc);
     MH_HIP_TRY(hipStreamSynchronize(s->main));
     MH_HIP_TRY(hipStreamSynchronize(s->side));
+    s->phase = 0;
     MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));      // both dependency chains start from "everything done"
     MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
     return MH_OK;
@@ -420,7 +452,8 @@ int mh_slab_profile_read(mh_slab* s, double avg_ms[2], int nlaunches[2], int* bu
         if (avg_ms) avg_ms[k] = s->events[k].empty() ? 0.0 : total / s->events[k].size();
         if (nlaunches) nlaunches[k] = (int) s->events[k].size();
     }
-    if (bulk_rows) *bulk_rows = s->n0 - 2 * s->edge_rows;
+    // rows of a bulk launch; with staggered edges the average over the period (edges of 2 (k + 1) rows per side, k = 0 .. S-1)
+    if (bulk_rows) *bulk_rows = s->n0 - 2 * (s->stagger ? s->edge_rows * (s->stagger + 1) / 2 : s->edge_rows);
     return MH_OK;
 }
 
