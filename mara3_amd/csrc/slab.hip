@@ -283,7 +283,8 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     auto cleanup = [&] () { mh_slab_destroy(s); };
     if (hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess ||            // followed by the RCCL send of those rows: system-scope release
+        // ev_interior is consumed by the edge launches of this device only: device-scope release
         hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
     { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
