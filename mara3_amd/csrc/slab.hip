@@ -90,6 +90,7 @@ struct mh_slab
     int row0 = 0, row1 = 0, n0 = 0, n1 = 0, edge_rows = 0;
     int stagger = 0;                  // stages per stagger period (0: every stage synchronises both ways), see slab_stage
     int phase = 0;                    // stage index within the period
+    int test_delay = 0;               // MH_SLAB_TEST_DELAY, see slab_test_delay_kernel
     bool event_on_launch = true;      // the stage kernels signal the cross-stream events themselves (hipExtLaunchKernel's stopEvent)
     mh_euler_cart_desc desc, edge_desc;
     double* field[2] = {nullptr, nullptr};       // [0] solution, [1] stage scratch; layout of include/mara_hip.h
@@ -127,6 +128,14 @@ static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
     if (s->lo >= 0) MH_RCCL_TRY(a->Recv(f, blk, ncclDouble, s->lo, s->comm, stream));                                   // ghosts -2,-1
     MH_RCCL_TRY(a->GroupEnd());
     return MH_OK;
+}
+
+// Test instrument (MH_SLAB_TEST_DELAY, tests/test_gpu_rccl.py): one wave that sleeps a bounded ~150 us, queued in front of the edge
+// launch (bit 0) and / or the interior launch (bit 1). It shifts the relative timing of the two chains by more than a stage, so a
+// dependency that only held by luck of timing shows up as a wrong result on one GPU.
+__global__ void slab_test_delay_kernel(int iters)
+{
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
 }
 
 static int slab_stage(mh_slab* s, const double* in, const double* base, double* out, double dt, double w, int which)
@@ -175,6 +184,8 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     //   (edge(S-1)'s, stream order) and writes rows 0,1, while interior(S-1) reads rows >= 2S - 2 >= 2 of that buffer: no wait.
     if (! S || k == 0) MH_HIP_TRY(hipStreamWaitEvent(s->main, s->ev_edge, 0));
     if (! S || k >= 1) MH_HIP_TRY(hipStreamWaitEvent(s->side, s->ev_interior, 0));
+    if (s->test_delay & 1) hipLaunchKernelGGL(slab_test_delay_kernel, dim3(1), dim3(64), 0, s->side, 40);
+    if (s->test_delay & 2) hipLaunchKernelGGL(slab_test_delay_kernel, dim3(1), dim3(64), 0, s->main, 40);
     if (s->desc.rank == 2)
     {
         if (s->event_on_launch) euler2d_next_launch_signals(s->ev_edge);
@@ -278,6 +289,7 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
         }
     }
     if (const char* v = getenv("MH_SLAB_EVENT_ON_LAUNCH")) s->event_on_launch = atoi(v) != 0;
+    if (const char* v = getenv("MH_SLAB_TEST_DELAY")) s->test_delay = atoi(v);
     if ((s->lo >= 0 || s->hi >= 0) && s->n0 < 4) { delete s; set_error("slab of %d rows is thinner than two ghost layers", s->n0); return MH_E_INVALID; }
 
     auto cleanup = [&] () { mh_slab_destroy(s); };

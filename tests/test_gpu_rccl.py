@@ -129,3 +129,30 @@ def test_native_slab_staggered_edges_survive_interruptions(rk_order, shape):
         assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64)), (done, nsteps)
     assert st.status() == 0
     st.close()
+
+
+@pytest.mark.parametrize("delay", [1, 2, 3])
+@pytest.mark.parametrize("stagger", [0, 4])
+def test_native_slab_dependencies_hold_under_shifted_timing(delay, stagger, monkeypatch):
+    """The two-chain schedule of the native stepper (edge -> exchange on one stream, interior on the other) with a ~150 us sleeping
+    wave queued in front of the edge launches (1), the interior launches (2) or both (3): whatever the relative timing of the chains,
+    the events alone must order them. With and without staggered edges."""
+    import numpy as np
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabStepper, native_comm_id
+    from mara3_amd.engine import EulerCartSolver
+    monkeypatch.setenv("MH_SLAB_TEST_DELAY", str(delay))
+    monkeypatch.setenv("MH_SLAB_STAGGER", str(stagger))
+    shape, gamma = (192, 260), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=12)
+    ref = EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, "periodic", arith="fast")
+    ref.upload(u0)
+    ref.step(5e-4, 7)
+    st = NativeSlabStepper(shape, dl, gamma, 1.5, "hllc", 2, "periodic", rank=0, world=1, arith="fast",
+                           comm_id=native_comm_id(0, 1), self_exchange=True)
+    st.load_slab(u0)
+    st.step(5e-4, 7)
+    st.synchronize()
+    assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64))
+    st.close()
