@@ -179,6 +179,15 @@ int  mh_cloud_stage(const mh_cloud_desc* d, const double* geom_dev, const double
  * mh_download act on the cloud state (AoS [nr][nq][5]); mh_cloud_set_inflow takes host AoS [nq][5] primitives. */
 int  mh_cloud_configure(mh_ctx* ctx, const mh_cloud_desc* d, const double* r_vertices_host, const double* q_vertices_host, int rk_order);
 int  mh_cloud_set_inflow(mh_ctx* ctx, const double* inflow_prims_host);
+/* CloudProblem::make_diagnostic_fields (src/subprog_cloud.cpp:334-433) of the device-resident solution, evaluated on the device
+ * when the driver's write_diagnostics task is due. units = {length (cm), mass (g), time (s)} of
+ * make_reference_units (:318-326). Host outputs, either may be NULL:
+ *   fields  [5][nr][nq]: mass_density, gas_pressure, specific_entropy, radial_gamma_beta, radial_energy_flow   (cgs but the entropy)
+ *   columns [15][nq]   : total_energy_at_theta, solid_angle_at_theta, shock_midpoint_radius, shock_upstream_radius, shock_pressure_radius,
+ *                        shock_luminosity_radius, postshock_flow_gamma, postshock_flow_power, ..power02, 04, 08, 16, 32, 64, ..power_max
+ * (the member order of diagnostic_fields_t, :147-161; the shock locator is post_shock_locator.hpp:73-170). Primitive recovery and
+ * fluxes are the STRICT ones; log / pow are the device library's, so the entropy agrees with the reference to an ulp or two. */
+int  mh_cloud_diagnostics(mh_ctx* ctx, const double units[3], double* fields_host, double* columns_host);
 
 int  mh_upload(mh_ctx* ctx, const double* u_aos_host, size_t ncell);     /* host AoS -> device SoA (+ ghosts) */
 int  mh_download(mh_ctx* ctx, double* u_aos_host, size_t ncell);         /* device SoA -> host AoS */

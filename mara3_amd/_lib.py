@@ -111,6 +111,7 @@ SYMBOLS = [
     ("mh_cloud_stage", _i, [C.POINTER(CloudDesc), _dp, _dp, _dp, _dp, _dp, _d, _d, _i, _i, _vp, _vp]),
     ("mh_cloud_configure", _i, [_vp, C.POINTER(CloudDesc), _vp, _vp, _i]),
     ("mh_cloud_set_inflow", _i, [_vp, _vp]),
+    ("mh_cloud_diagnostics", _i, [_vp, _vp, _vp, _vp]),
     ("mh_upload", _i, [_vp, _vp, _sz]),
     ("mh_download", _i, [_vp, _vp, _sz]),
     ("mh_step", _i, [_vp, _d, _i]),

@@ -420,6 +420,25 @@ int mh_cloud_configure(mh_ctx* c, const mh_cloud_desc* d, const double* rv, cons
     return MH_OK;
 }
 
+int mh_cloud_diagnostics(mh_ctx* c, const double units[3], double* fields_host, double* columns_host)
+{
+    if (! c || c->kind != mh_ctx::KIND_CLOUD || ! c->uploaded || ! units) { set_error("cloud diagnostics: needs a cloud context holding a solution"); return ctx_fail(c, MH_E_STATE); }
+    if (! (units[0] > 0.0) || ! (units[1] > 0.0) || ! (units[2] > 0.0)) { set_error("cloud diagnostics: reference units must be positive"); return ctx_fail(c, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    const size_t ncell = (size_t) c->cloud.nr * c->cloud.nq, nq = (size_t) c->cloud.nq;
+    double* fields = c->field[1];                      // the stage scratch holds nothing between steps: 5 (nr + 4) nq doubles
+    double* work = nullptr;
+    if (hipMalloc((void**) &work, (4 * ncell + 15 * nq) * sizeof(double)) != hipSuccess) { set_error("cloud diagnostics: hipMalloc failed"); return ctx_fail(c, MH_E_NOMEM); }
+    double* columns = work + 4 * ncell;
+    hipError_t e = cloud_diagnostics_launch(&c->cloud, c->geom, c->field[0], units, fields, work, columns, c->status, c->stream);
+    if (e == hipSuccess && fields_host) e = hipMemcpyAsync(fields_host, fields, 5 * ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && columns_host) e = hipMemcpyAsync(columns_host, columns, 15 * nq * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void) hipFree(work);
+    if (e != hipSuccess) return hip_fail(e, "cloud diagnostics");
+    return MH_OK;
+}
+
 int mh_cloud_set_inflow(mh_ctx* c, const double* inflow_aos)
 {
     if (! c || c->kind != mh_ctx::KIND_CLOUD || ! inflow_aos) { set_error("set_inflow: not a cloud context"); return ctx_fail(c, MH_E_STATE); }

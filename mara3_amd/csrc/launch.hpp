@@ -30,6 +30,10 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
                               const double* u_in, const double* u_base, double* u_out, double dt, double weight,
                               int row_begin, int row_end, int32_t* status, hipStream_t stream);
 
+// cloud_diag.hip: make_diagnostic_fields of a device-resident cloud state; fields [5][nr][nq], work [4][nr][nq], columns [15][nq] (device)
+hipError_t cloud_diagnostics_launch(const mh_cloud_desc* d, const double* geom_dev, const double* u, const double units[3],
+                                    double* fields, double* work, double* columns, int32_t* status, hipStream_t stream);
+
 // thread-local error text for the C ABI
 void set_error(const char* fmt, ...);
 int  hip_fail(hipError_t e, const char* what);

@@ -158,6 +158,15 @@ class CloudSolver:
         L.check(self.lib.mh_download(self.ctx, u.ctypes.data_as(C.c_void_p), self.nr * self.nq), self.ctx)
         return u
 
+    def diagnostics(self, units):
+        """CloudProblem::make_diagnostic_fields (subprog_cloud.cpp:334-433) of the resident state; units = (length, mass, time) in cgs.
+        -> (fields [5][nr][nq]: mass_density, gas_pressure, specific_entropy, radial_gamma_beta, radial_energy_flow; columns [15][nq])"""
+        un = np.ascontiguousarray(units, dtype=np.float64)
+        fields, columns = np.empty((5, self.nr, self.nq)), np.empty((15, self.nq))
+        L.check(self.lib.mh_cloud_diagnostics(self.ctx, un.ctypes.data_as(C.c_void_p), fields.ctypes.data_as(C.c_void_p),
+                                              columns.ctypes.data_as(C.c_void_p)), self.ctx)
+        return fields, columns
+
     def step(self, dt, nsteps=1):
         L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
 

@@ -27,9 +27,9 @@ mara::config_t config_template()
     .item("outdir", "data")
     .item("nr", 256)
     .item("tfinal", 1.0)
-    .item("cpi", 10.0)                // checkpoint interval (chkpt.NNNN.h5, reference layout); tsi / dfi tasks are out of scope
-    .item("tsi", 0.1)
-    .item("dfi", 1.0)
+    .item("cpi", 10.0)                // checkpoint interval (chkpt.NNNN.h5, reference layout)
+    .item("tsi", 0.1)                 // time-series interval: the task exists upstream but writes nothing (:801-803)
+    .item("dfi", 1.0)                 // diagnostics interval (diagnostics.NNNN.h5, make_diagnostic_fields evaluated on the device)
     .item("num_decades", 2.0)
     .item("inner_radius", 3e08)
     .item("cloud_cutoff", 3e10)
@@ -163,6 +163,8 @@ public:
         if (restart.empty())
         {
             schedule.create_and_mark_as_due("write_checkpoint");        // new_schedule :703-710
+            schedule.create_and_mark_as_due("write_diagnostics");
+            schedule.create_and_mark_as_due("write_time_series");
         }
         else
         {
@@ -179,16 +181,21 @@ public:
             if (shape.size() != 2 || shape[0] != hsize_t(nr) || shape[1] != hsize_t(nq)) throw std::invalid_argument("cloud: the restart file holds a different grid");
             host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
             schedule = h5io::read_schedule(file.open_group("schedule"));
-            if (! schedule.tasks.count("write_checkpoint")) schedule.create_and_mark_as_due("write_checkpoint");
+            for (const char* task : {"write_checkpoint", "write_diagnostics", "write_time_series"})
+                if (! schedule.tasks.count(task)) schedule.create_and_mark_as_due(task);
         }
         const std::string outdir = cfg.get_string("outdir");
-        auto run_tasks = [&] ()
+        const double units[3] = {ref_length, ref_mass, ref_time};
+        auto path_of = [&] (const char* prefix, int count)
         {
-            if (! schedule.is_due("write_checkpoint")) return;
+            if (! outdir.empty()) mkdir(outdir.c_str(), 0755);
+            return (outdir.empty() ? std::string() : outdir + "/") + h5io::numbered_filename(prefix, count, "h5");
+        };
+        auto write_checkpoint = [&] ()
+        {
             // write_checkpoint :758-767, write_solution :590-597
             host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
-            if (! outdir.empty()) mkdir(outdir.c_str(), 0755);
-            const std::string path = (outdir.empty() ? std::string() : outdir + "/") + h5io::numbered_filename("chkpt", schedule.at("write_checkpoint").num_times_performed, "h5");
+            const std::string path = path_of("chkpt", schedule.at("write_checkpoint").num_times_performed);
             {
                 auto file = h5io::Node::create_file(path);
                 auto sol = file.require_group("solution");
@@ -201,10 +208,48 @@ public:
                 h5io::write_config(file.require_group("config"), cfg);
             }
             std::printf("write checkpoint: %s\n", path.c_str());
-            schedule.mark_as_completed("write_checkpoint");
         };
-        const bool checkpoints = cfg.get_double("cpi") > 0.0 && h5io::available();        // cpi <= 0 switches the task off (not upstream: tests and benchmarks)
-        if (checkpoints) run_tasks();
+        auto write_diagnostics = [&] ()
+        {
+            // write_diagnostics :769-799: make_diagnostic_fields (:334-433) is evaluated on the device, the file gets its results
+            std::vector<double> fields(std::size_t(5) * nr * nq), columns(std::size_t(15) * nq);
+            host::check(mh_cloud_diagnostics(ctx, units, fields.data(), columns.data()), ctx, "mh_cloud_diagnostics");
+            const std::string path = path_of("diagnostics", schedule.at("write_diagnostics").num_times_performed);
+            {
+                auto file = h5io::Node::create_file(path);
+                const std::size_t plane = std::size_t(nr) * nq;
+                file.write("time", time * ref_time);
+                file.write_grid("gas_pressure", nr, nq, &fields[1 * plane]);
+                file.write_grid("mass_density", nr, nq, &fields[0 * plane]);
+                file.write_grid("specific_entropy", nr, nq, &fields[2 * plane]);
+                file.write_grid("radial_energy_flow", nr, nq, &fields[4 * plane]);
+                file.write_grid("radial_gamma_beta", nr, nq, &fields[3 * plane]);
+                std::vector<double> rv_cm(rv);
+                for (auto& r : rv_cm) r = r * ref_length;
+                file.write("radial_vertices", rv_cm);
+                file.write("polar_vertices", qv);
+                const char* names[15] = {"total_energy_at_theta", "solid_angle_at_theta", "shock_midpoint_radius", "shock_upstream_radius",
+                                         "shock_pressure_radius", "shock_luminosity_radius", "postshock_flow_gamma", "postshock_flow_power",
+                                         "postshock_flow_power02", "postshock_flow_power04", "postshock_flow_power08", "postshock_flow_power16",
+                                         "postshock_flow_power32", "postshock_flow_power64", "postshock_flow_power_max"};
+                for (int k = 0; k < 15; ++k) file.write(names[k], std::vector<double>(columns.begin() + std::size_t(k) * nq, columns.begin() + std::size_t(k + 1) * nq));
+            }
+            std::printf("write diagnostics: %s\n", path.c_str());
+        };
+        // run_tasks :826-849: which tasks run is read from the incoming schedule; a task interval <= 0 switches that task off
+        // (not upstream: tests and benchmarks)
+        const bool tasks_on = h5io::available();
+        const double cpi = cfg.get_double("cpi"), dfi = cfg.get_double("dfi"), tsi = cfg.get_double("tsi");
+        auto run_tasks = [&] ()
+        {
+            if (! tasks_on) return;
+            const bool chk = cpi > 0.0 && schedule.is_due("write_checkpoint"), diag = dfi > 0.0 && schedule.is_due("write_diagnostics"),
+                       series = tsi > 0.0 && schedule.is_due("write_time_series");
+            if (chk) { write_checkpoint(); schedule.mark_as_completed("write_checkpoint"); }
+            if (diag) { write_diagnostics(); schedule.mark_as_completed("write_diagnostics"); }
+            if (series) schedule.mark_as_completed("write_time_series");                 // write_time_series is empty upstream (:801-803)
+        };
+        run_tasks();
 
         while (time < tfinal && (max_steps == 0 || iteration < max_steps))
         {
@@ -222,13 +267,16 @@ public:
                 host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
                 host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
             });
+            if (tasks_on)
+            {
+                // next_schedule :720-733 looks at the time of the state the step STARTED from (CloudProblem::next :811-817)
+                schedule.advance("write_checkpoint", time, cpi);
+                schedule.advance("write_diagnostics", time, dfi);
+                schedule.advance("write_time_series", time, tsi);
+            }
             time += dt;
             iteration += 1;
-            if (checkpoints)
-            {
-                schedule.advance("write_checkpoint", time, cfg.get_double("cpi"));     // next_schedule :720-733
-                run_tasks();
-            }
+            run_tasks();
             int32_t status = 0;
             host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
             if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");

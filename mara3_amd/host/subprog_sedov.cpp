@@ -148,13 +148,11 @@ public:
                 host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
                 host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
             });
+            // next_schedule :445-457 looks at the time of the state the step STARTED from (SedovProblem::next :542-549)
+            if (checkpoints) schedule.advance("write_checkpoint", time, cfg.get_double("cpi"));
             time += dt;
             iteration += 1;
-            if (checkpoints)
-            {
-                schedule.advance("write_checkpoint", time, cfg.get_double("cpi"));     // next_schedule :445-457
-                run_tasks();
-            }
+            if (checkpoints) run_tasks();
             if (iteration % 100 == 0)
             {
                 host::throw_on_status(ctx);

@@ -112,6 +112,26 @@ def ref_cloud(nr, num_decades, rk, method, theta, nsteps):
                     rk=rk, method=method, theta=theta, nsteps=nsteps)
 
 
+def gen_cloud_diag():
+    """CloudProblem::make_diagnostic_fields of evolved states (the jet has entered the grid in the longer case)."""
+    for name, (nr, num_decades, rk, method, theta, nsteps) in (("clouddiag_nr48_150steps", (48, 1.0, 2, 2, 1.2, 150)),
+                                                             ("clouddiag_nr40_pcm_60steps", (40, 1.0, 1, 1, 1.2, 60)),
+                                                             ("clouddiag_nr32_4steps", (32, 1.0, 1, 2, 1.2, 4))):
+        with tempfile.TemporaryDirectory() as d:
+            prefix = os.path.join(d, "c")
+            run_ref("cloud_ref", [nr, hexf(num_decades), rk, method, hexf(theta), nsteps, prefix])
+            rv, qv = np.fromfile(prefix + ".rv.f64"), np.fromfile(prefix + ".qv.f64")
+            n0, n1 = rv.size - 1, qv.size - 1
+            meta = np.fromfile(prefix + ".meta.f64")
+            out = dict(rv=rv, qv=qv, un=np.fromfile(prefix + ".un.f64").reshape(n0, n1, 5), tfloor=meta[1], nsteps=nsteps, dt=meta[0],
+                       diag_fields=np.fromfile(prefix + ".diag_fields.f64").reshape(5, n0, n1),
+                       diag_columns=np.fromfile(prefix + ".diag_columns.f64").reshape(15, n1),
+                       diag_meta=np.fromfile(prefix + ".diag_meta.f64"))
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+            print(name, "ok", n0, n1, "shock radii (cm)", out["diag_columns"][2, ::max(1, n1 // 4)])
+    return 0
+
+
 def random_srhd_prims(rng, n):
     P = np.empty((n, 5))
     P[:, 0] = 10.0 ** rng.uniform(-3, 2, n)
@@ -287,6 +307,8 @@ def main():
             np.savez_compressed(os.path.join(OUT, "sedov_srhd_nr256.npz"), **sed)
             print("sedov srhd ok", sed["u0"].shape)
         return 0
+    if len(sys.argv) > 1 and sys.argv[1] == "cloud_diag":
+        return gen_cloud_diag()
     if len(sys.argv) > 1 and sys.argv[1] == "two_body":
         rng = np.random.default_rng(20260404)
         n = 2048

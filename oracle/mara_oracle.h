@@ -109,6 +109,9 @@ void mo_cloud_geometry(size_t nr, size_t nq, const double* rv, const double* qv,
 /* subprog_cloud.cpp:511-584 ; u = cell-integrated conserved AoS [nr][nq][5]; inflow [nq][5] primitives */
 int  mo_cloud_advance(size_t nr, size_t nq, const double* rv, const double* qv, const double* inflow,
                       double gamma, double plm_theta, double temperature_floor, double dt, const double* u0, double* u1);
+/* subprog_cloud.cpp:334-433 make_diagnostic_fields; units = {length, mass, time}; fields [5][nr][nq], columns [15][nq] (see the .c file) */
+int  mo_cloud_diagnostics(size_t nr, size_t nq, const double* rv, const double* qv, const double* u, double gamma, double tfloor,
+                          const double units[3], double* fields, double* columns);
 /* subprog_cloud.cpp:676-697 ; inflow [nsteps][nq][5] */
 int  mo_cloud_run(size_t nr, size_t nq, const double* rv, const double* qv, const double* inflow, double gamma,
                   double plm_theta, double temperature_floor, int rk_order, double dt, int nsteps, double* u);

@@ -251,6 +251,19 @@ def cloud_run(u, rv, qv, inflow, dt, nsteps, rk=1, theta=1.2, tfloor=1e-8, gamma
     return u, st
 
 
+def cloud_diagnostics(u, rv, qv, units, tfloor=1e-8, gamma=4.0 / 3):
+    """CloudProblem::make_diagnostic_fields: u [nr][nq][5], units (length, mass, time) -> (fields [5][nr][nq], columns [15][nq], status)"""
+    u, rv, qv = _f64(u), _f64(rv), _f64(qv)
+    nr, nq = u.shape[0], u.shape[1]
+    fields, columns = np.zeros((5, nr, nq)), np.zeros((15, nq))
+    L = lib()
+    L.mo_cloud_diagnostics.restype = C.c_int
+    L.mo_cloud_diagnostics.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                       C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    st = L.mo_cloud_diagnostics(nr, nq, _dp(rv), _dp(qv), _dp(u), gamma, tfloor, _dp(_f64(np.array(units, dtype=np.float64))), _dp(fields), _dp(columns))
+    return fields, columns, st
+
+
 # ---- mara::iso2d ---------------------------------------------------------------------------------------------
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))

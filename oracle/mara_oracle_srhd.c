@@ -330,3 +330,112 @@ int mo_cloud_run(size_t nr, size_t nq, const double* rv, const double* qv, const
     free(b);
     return status;
 }
+
+
+/* ---- CloudProblem::make_diagnostic_fields, subprog_cloud.cpp:334-433 -------------------------------------
+ * u [nr][nq][5] cell-integrated conserved; units = {length, mass, time} of make_reference_units (:318-326, unit_system_t :177-195).
+ * fields [5][nr][nq] = mass_density, gas_pressure, specific_entropy, radial_gamma_beta, radial_energy_flow;
+ * columns [15][nq] in the order of diagnostic_fields_t (:147-161). The shock locator is post_shock_locator.hpp:73-170: the first
+ * minimum of the entropy difference; scans that end in the reference's bounds_check exception return index 0. */
+static double srhd_energy_flux_radial(const double P[5], double gamma)
+{
+    double U[5], F[5];
+    mo_srhd_to_conserved_density(P, gamma, U);
+    mo_srhd_flux(P, U, 0, F);
+    return F[4];
+}
+
+int mo_cloud_diagnostics(size_t nr, size_t nq, const double* rv, const double* qv, const double* u, double gamma, double tfloor,
+                         const double units[3], double* fields, double* columns)
+{
+    const double light_speed_cgs = 2.998e10;
+    const double u_length = units[0], u_mass = units[1], u_time = units[2];
+    const double u_energy = u_mass * pow(light_speed_cgs, 2);
+    const double u_mass_density = u_mass / pow(u_length, 3);
+    const double u_energy_density = u_energy / pow(u_length, 3);
+    const double u_power = u_energy / u_time;
+    double* dAr = (double*) malloc(sizeof(double) * (nr + 1) * nq);
+    double* dAq = (double*) malloc(sizeof(double) * nr * (nq + 1));
+    double* dv = (double*) malloc(sizeof(double) * nr * nq);
+    double* P = (double*) malloc(sizeof(double) * nr * nq * 5);
+    double* s0 = (double*) malloc(sizeof(double) * nr);
+    double* L = (double*) malloc(sizeof(double) * nr);
+    int status = 0;
+    mo_cloud_geometry(nr, nq, rv, qv, dAr, dAq, dv);
+    for (size_t c = 0; c < nr * nq; ++c)
+    {
+        double Ud[5];
+        for (int q = 0; q < 5; ++q) Ud[q] = u[5 * c + q] / dv[c];
+        status |= mo_srhd_recover_primitive(Ud, gamma, tfloor, P + 5 * c);
+    }
+    for (size_t i = 0; i < nr; ++i)
+        for (size_t j = 0; j < nq; ++j)
+        {
+            const double* p = P + 5 * (i * nq + j);
+            const size_t c = i * nq + j;
+            fields[0 * nr * nq + c] = p[0] * u_mass_density;
+            fields[1 * nr * nq + c] = p[4] * u_energy_density;
+            fields[2 * nr * nq + c] = log(p[4] / pow(p[0], gamma));
+            fields[3 * nr * nq + c] = p[1];
+            fields[4 * nr * nq + c] = (srhd_energy_flux_radial(p, gamma) * dAr[i * nq + j]) * u_power;
+        }
+    for (size_t j = 0; j < nq; ++j)
+    {
+        for (size_t i = 0; i < nr; ++i)
+        {
+            const double* p = P + 5 * (i * nq + j);
+            const double Aj = (dAr[i * nq + j] + dAr[(i + 1) * nq + j]) * 0.5;
+            s0[i] = log(p[4] / pow(p[0], gamma));
+            L[i] = (srhd_energy_flux_radial(p, gamma) * Aj) * u_power;
+        }
+#define PRESSURE(i) P[5 * ((i) * nq + j) + 4]
+        /* find_shock_index: first index of the minimum entropy difference */
+        size_t mid = 0;
+        {
+            double dsmin = s0[1] - s0[0];
+            for (size_t i = 1; i + 1 < nr; ++i) { const double ds = s0[i + 1] - s0[i]; if (ds < dsmin) { dsmin = ds; mid = i; } }
+        }
+        /* find_index_of_pressure_plateau_ahead: dlogp has nr - 1 entries; an index outside them ends the scan with 0 */
+        size_t up = mid;
+        for (;;)
+        {
+            const size_t a = up - 1, b = up - 2;                      /* wrap like std::size_t */
+            if (a >= nr - 1 || b >= nr - 1) { up = 0; break; }
+            const double da = log(PRESSURE(a + 1)) - log(PRESSURE(a));
+            const double db = log(PRESSURE(b + 1)) - log(PRESSURE(b));
+            if (da < 0.5 * db) ++up; else break;
+        }
+        /* find_index_of_maximum_pressure_behind / find_index_of_maximum_behind */
+        size_t pi = mid;
+        for (;;)
+        {
+            const size_t a = pi - 1;
+            if (a >= nr || pi >= nr) { pi = 0; break; }
+            if (PRESSURE(a) > PRESSURE(pi)) --pi; else break;
+        }
+        size_t li = mid;
+        for (;;)
+        {
+            const size_t a = li - 1;
+            if (a >= nr || li >= nr) { li = 0; break; }
+            if (L[a] > L[li]) --li; else break;
+        }
+#undef PRESSURE
+        const size_t back[6] = {2, 4, 8, 16, 32, 64};
+        double total = 0.0;
+        for (size_t i = 0; i < nr; ++i) total = total + u[5 * (i * nq + j) + 4] * u_energy;
+        const double* pp = P + 5 * (pi * nq + j);
+        columns[0 * nq + j] = total;
+        columns[1 * nq + j] = dAr[j] / rv[0] / rv[0];
+        columns[2 * nq + j] = ((rv[mid] + rv[mid + 1]) * 0.5) * u_length;
+        columns[3 * nq + j] = ((rv[up] + rv[up + 1]) * 0.5) * u_length;
+        columns[4 * nq + j] = ((rv[pi] + rv[pi + 1]) * 0.5) * u_length;
+        columns[5 * nq + j] = ((rv[li] + rv[li + 1]) * 0.5) * u_length;
+        columns[6 * nq + j] = sqrt(1.0 + (pp[1] * pp[1] + pp[2] * pp[2] + pp[3] * pp[3]));
+        columns[7 * nq + j] = L[pi];
+        for (int k = 0; k < 6; ++k) columns[(8 + k) * nq + j] = L[mid > back[k] ? mid - back[k] : 0];
+        columns[14 * nq + j] = L[li];
+    }
+    free(dAr); free(dAq); free(dv); free(P); free(s0); free(L);
+    return status;
+}

@@ -141,7 +141,7 @@ def test_sedov_checkpoint_and_restart(tmp_path):
     the reference-generated state bit for bit, and a run restarted from it ends exactly where the uninterrupted run does."""
     g = golden("sedov_newtonian_nr256")
     dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
-    common = ["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % float(99.5 * dt), "cpi=%r" % float(9.5 * dt)]
+    common = ["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % float(99.5 * dt), "cpi=%r" % float(8.5 * dt)]      # due once a step STARTS at t >= 8.5 dt: after step 10
     stdout = run(common + ["outdir=a"], str(tmp_path))
     assert "write checkpoint: a/chkpt.0000.h5" in stdout and "write checkpoint: a/chkpt.0001.h5" in stdout
     chk = os.path.join(tmp_path, "a", "chkpt.0001.h5")
@@ -168,7 +168,7 @@ def test_sedov_checkpoint_and_restart(tmp_path):
 def test_cloud_checkpoint_and_restart(tmp_path):
     g = golden("cloud_nr32_plm_rk2")
     args = ["cloud", "nr=32", "num_decades=1", "rk_order=2", "max_steps=3"]
-    run(args + ["outdir=a", "cpi=%r" % float(1.5 * float(g["dt"]))], str(tmp_path))
+    run(args + ["outdir=a", "cpi=%r" % float(0.5 * float(g["dt"])), "dfi=0"], str(tmp_path))        # due once a step starts at t >= 0.5 dt
     a = read_dump(os.path.join(tmp_path, "a", "final.bin"))
     assert bits_equal(a["data"], g["un"])
     chk = os.path.join(tmp_path, "a", "chkpt.0001.h5")          # written after the second step
@@ -298,3 +298,31 @@ def test_binary_runs_to_tfinal_with_the_closing_step(tmp_path):
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     lines = [l for l in stdout.splitlines() if l.startswith("[")]
     assert d["iteration"] == len(lines) + 1 and d["time"] / (2 * np.pi) > 0.02
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
+def test_cloud_diagnostics_files(tmp_path):
+    """`mara_hip cloud` write_diagnostics task (src/subprog_cloud.cpp:769-799): diagnostics.NNNN.h5 with the reference's dataset names,
+    contents = make_diagnostic_fields evaluated on the device, against the reference-composed vectors after 150 steps."""
+    g = golden("clouddiag_nr48_150steps")
+    dt = float(g["dt"])
+    stdout = run(["cloud", "nr=48", "num_decades=1", "rk_order=2", "max_steps=150", "tfinal=100.0", "cpi=0", "dfi=%r" % (148.5 * dt)], str(tmp_path))
+    assert "write diagnostics: data/diagnostics.0000.h5" in stdout and "write diagnostics: data/diagnostics.0001.h5" in stdout
+    assert "diagnostics.0002" not in stdout and "chkpt" not in stdout
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert d["iteration"] == 150 and bits_equal(d["data"], g["un"])
+    f = os.path.join(tmp_path, "data", "diagnostics.0001.h5")            # a step started at t = 149 dt >= dfi: written after step 150
+    names = ["mass_density", "gas_pressure", "specific_entropy", "radial_gamma_beta", "radial_energy_flow"]
+    for k, name in enumerate(names):
+        got = _h5_dataset(f, "/" + name).reshape(48, 48)
+        if name == "specific_entropy":
+            assert np.all(np.abs(got - g["diag_fields"][k]) <= 1e-13 * np.maximum(1.0, np.abs(g["diag_fields"][k])))
+        else:
+            assert bits_equal(got, g["diag_fields"][k]), name
+    cols = ["total_energy_at_theta", "solid_angle_at_theta", "shock_midpoint_radius", "shock_upstream_radius", "shock_pressure_radius",
+            "shock_luminosity_radius", "postshock_flow_gamma", "postshock_flow_power", "postshock_flow_power02", "postshock_flow_power04",
+            "postshock_flow_power08", "postshock_flow_power16", "postshock_flow_power32", "postshock_flow_power64", "postshock_flow_power_max"]
+    for k, name in enumerate(cols):
+        assert bits_equal(_h5_dataset(f, "/" + name), g["diag_columns"][k]), name
+    assert _h5_dataset(f, "/time")[0] == g["diag_meta"][0]
+    assert bits_equal(_h5_dataset(f, "/radial_vertices"), g["rv"] * g["diag_meta"][1]) and bits_equal(_h5_dataset(f, "/polar_vertices"), g["qv"])

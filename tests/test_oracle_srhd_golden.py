@@ -57,3 +57,17 @@ def test_sedov_srhd_bit_exact(oracle):
         assert st == 0
         if "u_%d" % n in g.files:
             assert bits_equal(u, g["u_%d" % n]), n
+
+
+CLOUD_DIAG_CASES = ["clouddiag_nr48_150steps", "clouddiag_nr40_pcm_60steps", "clouddiag_nr32_4steps"]
+
+
+@pytest.mark.parametrize("case", CLOUD_DIAG_CASES)
+def test_cloud_diagnostic_fields_bit_exact(oracle, case):
+    """CloudProblem::make_diagnostic_fields (subprog_cloud.cpp:334-433): the five 2-D fields and the fifteen per-angle arrays (shock
+    locator of post_shock_locator.hpp included) against the reference's own operators composed the same way (cloud_ref.cpp)."""
+    g = golden(case)
+    fields, columns, status = oracle.cloud_diagnostics(g["un"], g["rv"], g["qv"], g["diag_meta"][1:4], float(g["tfloor"]))
+    assert status == 0
+    assert bits_equal(fields, g["diag_fields"])
+    assert bits_equal(columns, g["diag_columns"])
