@@ -145,6 +145,12 @@ typedef struct
     int    arith;           /* MH_ARITH_STRICT */
 } mh_sedov_desc;
 int  mh_sedov_configure(mh_ctx* ctx, const mh_sedov_desc* d, const double* vertices_host);
+/* SedovProblem::make_diagnostic_fields and the shock locator of compute_time_series_data (src/subprog_sedov.cpp:252-308,
+ * post_shock_locator.hpp:73-170) of the device-resident state. fields_host [4][nz]: specific_entropy,
+ * gas_pressure, mass_density, radial velocity (Euler) or gamma-beta (SRHD); indices_host = {shock_index, downstream_index
+ * (maximum pressure behind), upstream_index (pressure plateau ahead)}. The scalar time-series entries are a few host operations on
+ * these (parabola_vertex, solve_for_shock_velocity) and stay in the driver. Either pointer may be NULL. */
+int  mh_sedov_diagnostics(mh_ctx* ctx, double* fields_host, int32_t indices_host[3]);
 
 /* `cloud` sub-program (BASELINE config 4): 2-D axisymmetric spherical-polar SRHD, PCM/PLM + HLLE, RK1/RK2,
  * cell-integrated conserved variables (D, S_r, S_theta, S_phi, tau). Replaces CloudProblem::advance and

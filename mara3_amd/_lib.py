@@ -112,6 +112,7 @@ SYMBOLS = [
     ("mh_cloud_configure", _i, [_vp, C.POINTER(CloudDesc), _vp, _vp, _i]),
     ("mh_cloud_set_inflow", _i, [_vp, _vp]),
     ("mh_cloud_diagnostics", _i, [_vp, _vp, _vp, _vp]),
+    ("mh_sedov_diagnostics", _i, [_vp, _vp, _vp]),
     ("mh_upload", _i, [_vp, _vp, _sz]),
     ("mh_download", _i, [_vp, _vp, _sz]),
     ("mh_step", _i, [_vp, _d, _i]),

@@ -420,6 +420,23 @@ int mh_cloud_configure(mh_ctx* c, const mh_cloud_desc* d, const double* rv, cons
     return MH_OK;
 }
 
+int mh_sedov_diagnostics(mh_ctx* c, double* fields_host, int32_t indices_host[3])
+{
+    if (! c || c->kind != mh_ctx::KIND_SEDOV || ! c->uploaded) { set_error("sedov diagnostics: needs a sedov context holding a solution"); return ctx_fail(c, MH_E_STATE); }
+    MH_HIP_TRY(hipSetDevice(c->device));
+    const int n = c->sedov.nz;
+    double* fields = c->field[1];                      // the stage buffer (5 n doubles) holds nothing between steps
+    int32_t* indices = nullptr;
+    if (hipMalloc((void**) &indices, 3 * sizeof(int32_t)) != hipSuccess) { set_error("sedov diagnostics: hipMalloc failed"); return ctx_fail(c, MH_E_NOMEM); }
+    hipError_t e = sedov_diagnostics_launch(c->sedov.system, c->field[0], c->geom, n, c->sedov.gamma, fields, indices, c->status, c->stream);
+    if (e == hipSuccess && fields_host) e = hipMemcpyAsync(fields_host, fields, (size_t) 4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && indices_host) e = hipMemcpyAsync(indices_host, indices, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void) hipFree(indices);
+    if (e != hipSuccess) return hip_fail(e, "sedov diagnostics");
+    return MH_OK;
+}
+
 int mh_cloud_diagnostics(mh_ctx* c, const double units[3], double* fields_host, double* columns_host)
 {
     if (! c || c->kind != mh_ctx::KIND_CLOUD || ! c->uploaded || ! units) { set_error("cloud diagnostics: needs a cloud context holding a solution"); return ctx_fail(c, MH_E_STATE); }

@@ -26,6 +26,9 @@ hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, siz
 hipError_t sedov_stage_launch(int system, const double* u0, double* u1, const double* dv, const double* da, const double* rc,
                               int n, double gamma, double dt, int32_t* status, hipStream_t stream);
 
+hipError_t sedov_diagnostics_launch(int system, const double* u, const double* dv, int n, double gamma, double* fields, int32_t* indices,
+                                    int32_t* status, hipStream_t stream);
+
 hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev,
                               const double* u_in, const double* u_base, double* u_out, double dt, double weight,
                               int row_begin, int row_end, int32_t* status, hipStream_t stream);

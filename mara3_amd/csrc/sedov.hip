@@ -93,6 +93,69 @@ void sedov_stage_kernel(const double* __restrict__ u0, double* __restrict__ u1, 
     if (bad && status) atomicOr(status, bad);
 }
 
+// SedovProblem::make_diagnostic_fields and the indices of compute_time_series_data (src/subprog_sedov.cpp:252-308; the shock locator is
+// post_shock_locator.hpp:73-170) of the device-resident state. fields [4][n]: specific_entropy, gas_pressure, mass_density, radial
+// velocity (Euler) or gamma-beta (SRHD). STRICT primitive recovery; log / pow from the device library.
+template<class S>
+__global__ __launch_bounds__(64)
+void sedov_diag_fields_kernel(const double* __restrict__ u, const double* __restrict__ dv, int n, double gamma, double* fields, int32_t* status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const typename S::Gamma g = S::gamma(gamma);
+    int bad = 0;
+    const State5 P = sedov_primitive<S>(u, dv, n, i, g, bad);
+    fields[i] = log(P[4] / pow(P[0], gamma));
+    fields[(size_t) n + i] = P[4];
+    fields[(size_t) 2 * n + i] = P[0];
+    fields[(size_t) 3 * n + i] = P[1];
+    if (bad) atomicOr(status, bad);
+}
+
+// indices[3] = shock, downstream (maximum pressure behind), upstream (pressure plateau ahead); one thread: the scans are sequential
+__global__ void sedov_diag_indices_kernel(const double* __restrict__ fields, int n, int32_t* indices)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const unsigned nn = (unsigned) n;
+    const double* s0 = fields;
+    const double* pr = fields + n;
+    unsigned mid = 0;
+    double dsmin = 0.0;
+    for (unsigned i = 0; i + 1 < nn; ++i)
+    {
+        const double ds = s0[i + 1] - s0[i];
+        if (i == 0 || ds < dsmin) { dsmin = ds; mid = i; }
+    }
+    unsigned down = mid;
+    for (;;)
+    {
+        const unsigned a = down - 1;
+        if (a >= nn || down >= nn) { down = 0; break; }
+        if (pr[a] > pr[down]) --down; else break;
+    }
+    unsigned up = mid;
+    for (;;)
+    {
+        const unsigned a = up - 1, b = up - 2;
+        if (a >= nn - 1 || b >= nn - 1) { up = 0; break; }
+        const double da = log(pr[a + 1]) - log(pr[a]);
+        const double db = log(pr[b + 1]) - log(pr[b]);
+        if (da < 0.5 * db) ++up; else break;
+    }
+    indices[0] = (int32_t) mid;
+    indices[1] = (int32_t) down;
+    indices[2] = (int32_t) up;
+}
+
+hipError_t sedov_diagnostics_launch(int system, const double* u, const double* dv, int n, double gamma, double* fields, int32_t* indices,
+                                    int32_t* status, hipStream_t stream)
+{
+    if (system == MH_SYSTEM_SRHD) hipLaunchKernelGGL(sedov_diag_fields_kernel<SedovSrhd>, dim3((n + 63) / 64), dim3(64), 0, stream, u, dv, n, gamma, fields, status);
+    else                          hipLaunchKernelGGL(sedov_diag_fields_kernel<SedovEuler>, dim3((n + 63) / 64), dim3(64), 0, stream, u, dv, n, gamma, fields, status);
+    hipLaunchKernelGGL(sedov_diag_indices_kernel, dim3(1), dim3(64), 0, stream, fields, n, indices);
+    return hipGetLastError();
+}
+
 hipError_t sedov_stage_launch(int system, const double* u0, double* u1, const double* dv, const double* da, const double* rc,
                               int n, double gamma, double dt, int32_t* status, hipStream_t stream)
 {

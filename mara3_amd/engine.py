@@ -105,6 +105,13 @@ class SedovSolver:
     def step(self, dt, nsteps=1):
         L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
 
+    def diagnostics(self):
+        """SedovProblem::make_diagnostic_fields and the shock locator (subprog_sedov.cpp:252-308) of the resident state ->
+        (fields [4][nz]: specific_entropy, gas_pressure, mass_density, radial velocity / gamma-beta; indices: shock, downstream, upstream)"""
+        fields, indices = np.empty((4, self.nz)), np.zeros(3, dtype=np.int32)
+        L.check(self.lib.mh_sedov_diagnostics(self.ctx, fields.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p)), self.ctx)
+        return fields, indices
+
     def status(self):
         s = C.c_int32()
         L.check(self.lib.mh_status_word(self.ctx, C.byref(s)), self.ctx)

@@ -67,6 +67,9 @@ struct Node
     template<typename C> void read_record(const std::string&, const C&, void*) const { none(); }
     hsize_t count_of(const std::string&) const { none(); }
     template<typename C> void read_records(const std::string&, const C&, void*) const { none(); }
+    static Node open_file_rw(const std::string&) { none(); }
+    void create_unlimited(const std::string&, hsize_t) const { none(); }
+    void append(const std::string&, hsize_t, double) const { none(); }
 };
 struct Compound
 {
@@ -87,9 +90,10 @@ struct Lib
     H5IO_FN(H5Sget_simple_extent_dims); H5IO_FN(H5Tcopy); H5IO_FN(H5Tset_size); H5IO_FN(H5Tarray_create2); H5IO_FN(H5Tclose);
     H5IO_FN(H5Tget_size); H5IO_FN(H5Tget_class); H5IO_FN(H5Dcreate2); H5IO_FN(H5Dopen2); H5IO_FN(H5Dwrite); H5IO_FN(H5Dread);
     H5IO_FN(H5Dget_space); H5IO_FN(H5Dget_type); H5IO_FN(H5Dclose); H5IO_FN(H5Literate); H5IO_FN(H5Tcreate); H5IO_FN(H5Tinsert);
-    H5IO_FN(H5Sget_simple_extent_npoints);
+    H5IO_FN(H5Sget_simple_extent_npoints); H5IO_FN(H5Pcreate); H5IO_FN(H5Pset_chunk); H5IO_FN(H5Pclose); H5IO_FN(H5Dset_extent);
+    H5IO_FN(H5Sselect_hyperslab);
 #undef H5IO_FN
-    hid_t native_double = -1, native_int = -1, c_s1 = -1;
+    hid_t native_double = -1, native_int = -1, c_s1 = -1, dataset_create = -1;
 
     static Lib& get()
     {
@@ -105,13 +109,15 @@ struct Lib
             H5IO_SYM(H5Sget_simple_extent_dims); H5IO_SYM(H5Tcopy); H5IO_SYM(H5Tset_size); H5IO_SYM(H5Tarray_create2); H5IO_SYM(H5Tclose);
             H5IO_SYM(H5Tget_size); H5IO_SYM(H5Tget_class); H5IO_SYM(H5Dcreate2); H5IO_SYM(H5Dopen2); H5IO_SYM(H5Dwrite); H5IO_SYM(H5Dread);
             H5IO_SYM(H5Dget_space); H5IO_SYM(H5Dget_type); H5IO_SYM(H5Dclose); H5IO_SYM(H5Literate); H5IO_SYM(H5Tcreate); H5IO_SYM(H5Tinsert);
-            H5IO_SYM(H5Sget_simple_extent_npoints);
+            H5IO_SYM(H5Sget_simple_extent_npoints); H5IO_SYM(H5Pcreate); H5IO_SYM(H5Pset_chunk); H5IO_SYM(H5Pclose); H5IO_SYM(H5Dset_extent);
+            H5IO_SYM(H5Sselect_hyperslab);
 #undef H5IO_SYM
             lib.H5open();
             auto global = [&] (const char* sym) { auto p = static_cast<hid_t*>(dlsym(lib.handle, sym)); if (! p) throw std::runtime_error(std::string("libhdf5 lacks ") + sym); return *p; };
             lib.native_double = global("H5T_NATIVE_DOUBLE_g");
             lib.native_int = global("H5T_NATIVE_INT_g");
             lib.c_s1 = global("H5T_C_S1_g");
+            lib.dataset_create = global("H5P_CLS_DATASET_CREATE_ID_g");
         }
         return lib;
     }
@@ -166,6 +172,12 @@ struct Node
     static Node open_file(const std::string& path)
     {
         hid_t f = Lib::get().H5Fopen(path.c_str(), 0x0000u /* H5F_ACC_RDONLY */, H5P_DEFAULT);
+        check(f, "open " + path);
+        return Node(f, true);
+    }
+    static Node open_file_rw(const std::string& path)
+    {
+        hid_t f = Lib::get().H5Fopen(path.c_str(), 0x0001u /* H5F_ACC_RDWR */, H5P_DEFAULT);
         check(f, "open " + path);
         return Node(f, true);
     }
@@ -257,6 +269,37 @@ struct Node
     {
         static const char nothing[8] = {0};
         write_raw(name, type.id, 1, &n, n ? data : nothing);
+    }
+
+    // An empty, extendible 1-D f64 dataset (sedov's time_series.h5 columns: Dataspace::unlimited(0) with chunks of 1000,
+    // src/subprog_sedov.cpp:605-612) and one value written at `index` after growing it (write_time_series :516-529)
+    void create_unlimited(const std::string& name, hsize_t chunk) const
+    {
+        auto& L = Lib::get();
+        const hsize_t zero = 0, unlimited = ~hsize_t(0) /* H5S_UNLIMITED */;
+        hid_t space = L.H5Screate_simple(1, &zero, &unlimited);
+        hid_t plist = L.H5Pcreate(L.dataset_create);
+        L.H5Pset_chunk(plist, 1, &chunk);
+        hid_t ds = L.H5Dcreate2(id, name.c_str(), L.native_double, space, H5P_DEFAULT, plist, H5P_DEFAULT);
+        check(ds, "create dataset " + name);
+        L.H5Dclose(ds);
+        L.H5Pclose(plist);
+        L.H5Sclose(space);
+    }
+    void append(const std::string& name, hsize_t index, double value) const
+    {
+        auto& L = Lib::get();
+        hid_t ds = L.H5Dopen2(id, name.c_str(), H5P_DEFAULT);
+        check(ds, "open dataset " + name);
+        const hsize_t size = index + 1, one = 1;
+        if (L.H5Dset_extent(ds, &size) < 0) throw std::runtime_error("HDF5: cannot extend " + name);
+        hid_t fspace = L.H5Dget_space(ds);
+        L.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, &index, nullptr, &one, nullptr);
+        hid_t mspace = L.H5Screate_simple(1, &one, nullptr);
+        if (L.H5Dwrite(ds, L.native_double, mspace, fspace, H5P_DEFAULT, &value) < 0) throw std::runtime_error("HDF5: write " + name + " failed");
+        L.H5Sclose(mspace);
+        L.H5Sclose(fspace);
+        L.H5Dclose(ds);
     }
 
     // ---- readers

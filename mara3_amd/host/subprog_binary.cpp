@@ -74,7 +74,7 @@ mara::config_t config_template()
     .item("mdot",                 0.0)
     // not upstream:
     .item("arith",           "strict")          // strict | fast (see include/mara_hip.h)
-    .item("max_iterations",         0)          // stop after this many iterations (0 = run to tfinal, then upstream's one closing step)
+    .item("max_iterations",         0)          // stop after this many iterations (0 = run to tfinal, then upstream's closing step for its tasks)
     .item("steps_per_call",         1)          // iterations per mh_binary_next call; used only when all three tasks are switched off (interval <= 0)
     .item("write_final",            1)
     .item("device",                 0);
@@ -474,8 +474,6 @@ public:
         };
         while (state.time / (2 * M_PI) < tfinal && (max_iter == 0 || state.iteration < max_iter))
             advance(max_iter ? int(std::min<long>(batch, max_iter - state.iteration)) : batch, true);
-        if (max_iter == 0) advance(1, false);                // upstream's closing `tasks(next(state))`
-
         if (cfg.get_int("write_final"))
         {
             check(mh_binary_get_solution(solver, u.data(), &state), "mh_binary_get_solution");
@@ -488,6 +486,9 @@ public:
             if (mesh.graded) host::dump_state(outdir, "final.bin", {long(nb), long(bs), long(bs)}, 3, state.time, state.iteration, extra, u);
             else             host::dump_state(outdir, "final.bin", {long(n), long(n)}, 3, state.time, state.iteration, extra, u);
         }
+        // upstream's closing `tasks(next(state))` (:437): one more step whose only visible effect is a task that falls due on it; final.bin
+        // above is the state the loop ended with. A run cut short by max_iterations (not upstream) ends there.
+        if (max_iter == 0 && any_task) advance(1, false);
         mh_binary_destroy(solver);
         return 0;
     }

@@ -251,7 +251,8 @@ public:
         };
         run_tasks();
 
-        while (time < tfinal && (max_steps == 0 || iteration < max_steps))
+        // one `run_tasks(next(state))` (:811-849)
+        auto advance = [&] (bool verbose)
         {
             // nozzle row at the step-start time (:466-493); both RK stages use it (:524)
             const double t_seconds = time * ref_time;
@@ -280,8 +281,9 @@ public:
             int32_t status = 0;
             host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
             if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");
-            std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
-        }
+            if (verbose) std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
+        };
+        while (time < tfinal && (max_steps == 0 || iteration < max_steps)) advance(true);
         if (cfg.get_int("profile"))
         {
             double avg_ms = 0.0;
@@ -295,6 +297,9 @@ public:
         host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nr), long(nq)}, 5, time, iteration, vertices, u);
         if (cfg.get_int("write_inflow"))
             host::dump_state(cfg.get_string("outdir"), "inflow0.bin", {long(nq)}, 5, 0.0, 0, {}, inflow_first);
+        // upstream's closing `run_tasks_on_next(state)` (:935): one more step whose only visible effect is a task that falls due on it.
+        // final.bin above is the state the loop ended with; a run cut short by max_steps (not upstream) ends there.
+        if (max_steps == 0 && tasks_on) advance(false);
         mh_destroy(ctx);
         return 0;
     }

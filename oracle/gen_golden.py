@@ -309,6 +309,25 @@ def main():
         return 0
     if len(sys.argv) > 1 and sys.argv[1] == "cloud_diag":
         return gen_cloud_diag()
+    if len(sys.argv) > 1 and sys.argv[1] == "sedov_diag":
+        # make_diagnostic_fields / compute_time_series_data of evolved sedov states, both hydro systems (new files: the step vectors stay as they are)
+        for name, extra in (("sedovdiag_newtonian_nr256", []), ("sedovdiag_srhd_nr256", ["srhd"])):
+            with tempfile.TemporaryDirectory() as d:
+                out = {}
+                for ns in (100, 400):
+                    fv, f0, fn = (os.path.join(d, x) for x in ("v", "u0", "un"))
+                    run_ref("sedov_ref", [256, hexf(100.0), ns, fv, f0, fn] + extra)
+                    out["vertices"] = np.fromfile(fv)
+                    u = np.fromfile(fn).reshape(-1, 5)
+                    diag = np.fromfile(fn + ".diag")
+                    nz = u.shape[0]
+                    out["u_%d" % ns] = u
+                    out["fields_%d" % ns] = diag[:4 * nz].reshape(4, nz)
+                    out["indices_%d" % ns] = diag[4 * nz:4 * nz + 3].astype(np.int32)
+                    out["series_%d" % ns] = diag[4 * nz + 3:]
+                    print(name, ns, "indices", out["indices_%d" % ns], "series", out["series_%d" % ns])
+                np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == "two_body":
         rng = np.random.default_rng(20260404)
         n = 2048

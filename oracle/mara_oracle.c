@@ -580,3 +580,78 @@ void mo_block_extent(size_t n, size_t nblocks, size_t b, size_t* start, size_t* 
 {
     mo_partition_rows(n, nblocks, b, start, final_);
 }
+
+
+/* ---- sedov diagnostics: SedovProblem::make_diagnostic_fields / compute_time_series_data, subprog_sedov.cpp:252-308 ---------------
+ * fields [4][nz]: specific_entropy, gas_pressure, mass_density, radial velocity (Euler) or gamma-beta (SRHD); indices = shock,
+ * downstream (maximum pressure behind), upstream (pressure plateau ahead) by post_shock_locator.hpp:73-170; series = time,
+ * shock_radius, shock_radius_upstream, shock_radius_downstream, shock_radius_interpolated (math_polynomial.hpp:206-215),
+ * shock_velocity (:96-114). The interpolated radius is NaN where the reference would index outside the array. */
+int mo_sedov_diagnostics(int srhd, size_t nz, const double* v, const double* u, double gamma, double time, double* fields, int* indices, double* series)
+{
+    double* P = (double*) malloc(sizeof(double) * 5 * nz);
+    int status = 0;
+    for (size_t i = 0; i < nz; ++i)
+    {
+        const double dv = (pow(v[i + 1], 3) - pow(v[i], 3)) / 3;
+        double U[5];
+        for (int q = 0; q < 5; ++q) U[q] = u[5 * i + q] / dv;
+        if (srhd) status |= mo_srhd_recover_primitive(U, gamma, 0.0, P + 5 * i);
+        else      mo_euler_recover_primitive(U, gamma, 0.0, P + 5 * i);
+        fields[0 * nz + i] = log(P[5 * i + 4] / pow(P[5 * i], gamma));
+        fields[1 * nz + i] = P[5 * i + 4];
+        fields[2 * nz + i] = P[5 * i];
+        fields[3 * nz + i] = P[5 * i + 1];
+    }
+    const double* s0 = fields;
+    const double* pr = fields + nz;
+    size_t mid = 0;
+    {
+        double dsmin = s0[1] - s0[0];
+        for (size_t i = 1; i + 1 < nz; ++i) { const double ds = s0[i + 1] - s0[i]; if (ds < dsmin) { dsmin = ds; mid = i; } }
+    }
+    size_t down = mid;
+    for (;;)
+    {
+        const size_t a = down - 1;
+        if (a >= nz || down >= nz) { down = 0; break; }
+        if (pr[a] > pr[down]) --down; else break;
+    }
+    size_t up = mid;
+    for (;;)
+    {
+        const size_t a = up - 1, b = up - 2;
+        if (a >= nz - 1 || b >= nz - 1) { up = 0; break; }
+        if (log(pr[a + 1]) - log(pr[a]) < 0.5 * (log(pr[b + 1]) - log(pr[b]))) ++up; else break;
+    }
+    indices[0] = (int) mid; indices[1] = (int) down; indices[2] = (int) up;
+#define RC(i) ((v[i] + v[(i) + 1]) * 0.5)
+#define VC(i) (P[5 * (i) + 1])
+    series[0] = time;
+    series[1] = v[mid];
+    series[2] = RC(up);
+    series[3] = RC(down);
+    if (down >= 1 && down + 1 < nz)
+    {
+        const double x1 = RC(down - 1), x2 = RC(down), x3 = RC(down + 1), y1 = VC(down - 1), y2 = VC(down), y3 = VC(down + 1);
+        const double d = (x1 - x2) * (x1 - x3) * (x2 - x3);
+        const double A = (x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2)) / d;
+        const double B = (x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1) + x1 * x1 * (y2 - y3)) / d;
+        series[4] = -B / (2 * A);
+    }
+    else series[4] = NAN;
+    {
+        const double* p1 = P + 5 * up;
+        const double* p2 = P + 5 * down;
+        if (srhd)
+        {
+            const double g1 = sqrt(1.0 + (p1[1] * p1[1] + p1[2] * p1[2] + p1[3] * p1[3])), g2 = sqrt(1.0 + (p2[1] * p2[1] + p2[2] * p2[2] + p2[3] * p2[3]));
+            series[5] = (p2[0] * p2[1] - p1[0] * p1[1]) / (p2[0] * g2 - p1[0] * g1);
+        }
+        else series[5] = (p2[0] * p2[1] - p1[0] * p1[1]) / (p2[0] - p1[0]);
+    }
+#undef RC
+#undef VC
+    free(P);
+    return status;
+}

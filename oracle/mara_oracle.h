@@ -84,6 +84,8 @@ void mo_sedov_advance(size_t nz, const double* vertices, double gamma, double dt
 /* HydroSystem = mara::srhd (the sub-program's default system) */
 void mo_sedov_initial_system(int srhd, size_t nz, const double* vertices, double gamma, double explosion_density,
                              double explosion_pressure, double density_index, double* u);
+/* make_diagnostic_fields / compute_time_series_data (subprog_sedov.cpp:252-308): fields [4][nz], indices[3], series[6]; see the .c file */
+int  mo_sedov_diagnostics(int srhd, size_t nz, const double* vertices, const double* u, double gamma, double time, double* fields, int* indices, double* series);
 int  mo_sedov_advance_srhd(size_t nz, const double* vertices, double gamma, double dt, const double* u0, double* u1);
 
 /* ---- mara::srhd and the `cloud` stage (mara_oracle_srhd.c) ------------------ */

@@ -180,6 +180,19 @@ def sedov_advance_srhd(vertices, u0, dt, gamma=4.0 / 3):
     return u1, st
 
 
+def sedov_diagnostics(vertices, u, time, srhd=False, gamma=4.0 / 3):
+    """-> (fields [4][nz], indices [3] int32, series [6], status); subprog_sedov.cpp:252-308"""
+    v, u = _f64(vertices), _f64(u)
+    nz = u.shape[0]
+    fields, indices, series = np.zeros((4, nz)), np.zeros(3, dtype=np.int32), np.zeros(6)
+    L = lib()
+    L.mo_sedov_diagnostics.restype = C.c_int
+    L.mo_sedov_diagnostics.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    st = L.mo_sedov_diagnostics(int(bool(srhd)), nz, _dp(v), _dp(u), gamma, float(time), _dp(fields), indices.ctypes.data_as(C.POINTER(C.c_int)), _dp(series))
+    return fields, indices, series, st
+
+
 def sedov_timestep(vertices, cfl=0.4):
     return lib().mo_sedov_timestep(_dp(_f64(vertices)), cfl)
 

@@ -9,8 +9,15 @@
  *
  * usage: sedov_ref <nr> <outer_radius> <nsteps> <out_vertices.f64> <out_u0.f64> <out_uN.f64> [srhd]
  * (the optional last argument selects mara::srhd, the sub-program's default system, instead of mara::euler)
+ * Also writes <out_uN.f64>.diag: make_diagnostic_fields / compute_time_series_data of the final state (subprog_sedov.cpp:252-308,
+ * composed from the same header functions): [4][nz] specific_entropy, gas_pressure, mass_density, radial velocity or gamma-beta;
+ * then shock, downstream, upstream index (as doubles); then time, shock_radius, shock_radius_upstream, shock_radius_downstream,
+ * shock_radius_interpolated, shock_velocity.
  */
 #include <cstdio>
+#include <string>
+#include <vector>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -24,10 +31,25 @@
 #include "core_rational.hpp"
 #include "physics_euler.hpp"
 #include "physics_srhd.hpp"
+#include "post_shock_locator.hpp"
+#include "math_polynomial.hpp"
 
 static const double gamma_law = 4. / 3;
 static const double cfl = 0.4;
 
+static double radial_u(const mara::srhd::primitive_t& p) { return p.gamma_beta_1(); }          // subprog_sedov.cpp:76-84
+static double radial_u(const mara::euler::primitive_t& p) { return p.velocity_1(); }
+static double shock_velocity(const mara::srhd::primitive_t& p1, const mara::srhd::primitive_t& p2)   // :96-105
+{
+    auto d1 = p1.mass_density(), d2 = p2.mass_density(), u1 = p1.gamma_beta_1(), u2 = p2.gamma_beta_1();
+    auto g1 = p1.lorentz_factor(), g2 = p2.lorentz_factor();
+    return (d2 * u2 - d1 * u1) / (d2 * g2 - d1 * g1);
+}
+static double shock_velocity(const mara::euler::primitive_t& p1, const mara::euler::primitive_t& p2)   // :107-114
+{
+    auto d1 = p1.mass_density(), d2 = p2.mass_density(), v1 = p1.velocity_1(), v2 = p2.velocity_1();
+    return (d2 * v2 - d1 * v1) / (d2 - d1);
+}
 static auto negate_radial(const mara::euler::primitive_t& p) { return p.with_velocity_1(-p.velocity_1()); }
 static auto negate_radial(const mara::srhd::primitive_t& p) { return p.with_gamma_beta_1(-p.gamma_beta_1()); }
 
@@ -72,8 +94,10 @@ static int run(int argc, char** argv)
     auto u = xc | nd::map(initial_p) | nd::map(to_cons) | nd::multiply(cell_volumes(vertices)) | nd::to_shared();
     auto u_init = u;
 
+    double time = 0.0;
     for (int n = 0; n < nsteps; ++n)
     {
+        time += cfl * (vertices(1) - vertices(0));
         auto dr_min = vertices | nd::difference_on_axis(0) | nd::read_index(0);
         auto dt = mara::make_time(cfl * dr_min);
         auto dv = cell_volumes(vertices) | nd::to_shared();
@@ -98,6 +122,29 @@ static int run(int argc, char** argv)
     dump(argv[4], vertices.data(), vertices.size() * sizeof(double));
     dump(argv[5], u_init.data(), u_init.size() * sizeof(cons_t));
     dump(argv[6], u.data(), u.size() * sizeof(cons_t));
+    {
+        using namespace std::placeholders;
+        auto primitive = u | nd::divide(cell_volumes(vertices)) | nd::map(c2p) | nd::to_shared();
+        std::vector<double> out;
+        for (auto p : primitive) out.push_back(p.specific_entropy(gamma_law));
+        for (auto p : primitive) out.push_back(p.gas_pressure());
+        for (auto p : primitive) out.push_back(p.mass_density());
+        for (auto p : primitive) out.push_back(radial_u(p));
+        auto shock_index      = mara::find_shock_index(primitive, gamma_law)[0];
+        auto downstream_index = mara::find_index_of_maximum_pressure_behind(primitive, shock_index);
+        auto upstream_index   = mara::find_index_of_pressure_plateau_ahead(primitive, shock_index);
+        auto rc = vertices | nd::midpoint_on_axis(0);
+        auto vc = primitive | nd::map([] (auto p) { return radial_u(p); });
+        auto find_vertex = [rc, vc] (auto i) { return mara::parabola_vertex(rc(i - 1), rc(i), rc(i + 1), vc(i - 1), vc(i), vc(i + 1)).first; };
+        out.push_back(double(shock_index)); out.push_back(double(downstream_index)); out.push_back(double(upstream_index));
+        out.push_back(time);
+        out.push_back(vertices(shock_index));
+        out.push_back(rc(upstream_index));
+        out.push_back(rc(downstream_index));
+        out.push_back(downstream_index >= 1 && downstream_index + 1 < rc.size() ? find_vertex(downstream_index) : std::nan(""));   // upstream reads out of range there
+        out.push_back(shock_velocity(primitive(upstream_index), primitive(downstream_index)));
+        dump((std::string(argv[6]) + ".diag").c_str(), out.data(), out.size() * sizeof(double));
+    }
     return 0;
 }
 

@@ -55,3 +55,21 @@ def test_cloud_diagnostics_after_stepping_match_the_oracle(eng, oracle):
     f0, c0, st = oracle.cloud_diagnostics(u, g["rv"], g["qv"], g["diag_meta"][1:4], float(g["tfloor"]))
     assert st == 0
     check(fields, columns, f0, c0)
+
+
+@pytest.mark.parametrize("name,system", [("sedovdiag_newtonian_nr256", "euler"), ("sedovdiag_srhd_nr256", "srhd")])
+def test_sedov_diagnostics_vs_reference_composition(eng, name, system):
+    """mh_sedov_diagnostics: pressure, density, velocity bit-exact; entropy to a few ulp (device log / pow); the three shock-locator
+    indices equal to the reference's."""
+    g = golden(name)
+    s = eng.SedovSolver(g["vertices"], system=system)
+    for ns in (100, 400):
+        s.upload(g["u_%d" % ns])
+        fields, indices = s.diagnostics()
+        ref = g["fields_%d" % ns]
+        for k in (1, 2, 3):
+            assert bits_equal(fields[k], ref[k]), k
+        assert np.all(np.abs(fields[0] - ref[0]) <= 32 * np.spacing(np.maximum(np.abs(ref[0]), 1.0)))
+        assert np.array_equal(indices, g["indices_%d" % ns])
+        assert bits_equal(s.download(), g["u_%d" % ns])
+    assert s.status() == 0

@@ -292,37 +292,47 @@ def test_binary_tasks_checkpoint_diagnostics_time_series_and_restart(tmp_path, c
         assert bits_equal(b["data"], c["data"]) and b["time"] == c["time"]
 
 
-def test_binary_runs_to_tfinal_with_the_closing_step(tmp_path):
-    """Without max_iterations the loop is upstream's: run while orbits < tfinal, then one closing `tasks(next(state))`."""
-    stdout = run(["binary", "depth=2", "block_size=8", "focus_factor=1e9", "domain_radius=4.0", "tfinal=0.02", "cpi=0", "dfi=0", "tsi=0"], str(tmp_path))
+def test_closing_step_runs_the_tasks_once_more(tmp_path):
+    """Upstream's run loops end with one more `run_tasks(next(state))` (subprog_binary.cpp:437, subprog_sedov.cpp:644, subprog_cloud.cpp:935):
+    the state it produces is dropped, but a task that falls due on it still writes its file - numbered after the loop's last one and
+    holding iteration N + 1. final.bin is the state the loop ended with."""
+    stdout = run(["binary", "depth=2", "block_size=8", "focus_factor=1e9", "domain_radius=4.0", "tfinal=0.02", "cpi=1e-9", "dfi=0", "tsi=0"], str(tmp_path))
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
     lines = [l for l in stdout.splitlines() if l.startswith("[")]
-    assert d["iteration"] == len(lines) + 1 and d["time"] / (2 * np.pi) > 0.02
+    n = len(lines)
+    assert d["iteration"] == n and d["time"] / (2 * np.pi) >= 0.02
+    last = os.path.join(tmp_path, "data", "chkpt.%04d.h5" % n)                 # 0000 initial, then one per step from the second on, then the closing one
+    assert os.path.exists(last) and not os.path.exists(os.path.join(tmp_path, "data", "chkpt.%04d.h5" % (n + 1)))
+    if os.path.exists(H5DUMP):
+        assert list(_h5_dataset(last, "/solution/iteration", np.int32)) == [n + 1, 1]
 
 
 @pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
-def test_cloud_diagnostics_files(tmp_path):
-    """`mara_hip cloud` write_diagnostics task (src/subprog_cloud.cpp:769-799): diagnostics.NNNN.h5 with the reference's dataset names,
-    contents = make_diagnostic_fields evaluated on the device, against the reference-composed vectors after 150 steps."""
-    g = golden("clouddiag_nr48_150steps")
-    dt = float(g["dt"])
-    stdout = run(["cloud", "nr=48", "num_decades=1", "rk_order=2", "max_steps=150", "tfinal=100.0", "cpi=0", "dfi=%r" % (148.5 * dt)], str(tmp_path))
+@pytest.mark.parametrize("name,extra", [("sedovdiag_newtonian_nr256", ["newtonian=1"]), ("sedovdiag_srhd_nr256", [])])
+def test_sedov_diagnostics_and_time_series_files(tmp_path, name, extra):
+    """`mara_hip sedov` write_diagnostics and write_time_series (src/subprog_sedov.cpp:497-529): diagnostics.NNNN.h5 with the reference's
+    dataset names and time_series.h5 with one row per sample in extendible datasets; the sample taken after step 100 against the
+    reference-composed vectors (entropy to a few ulp, everything else bit for bit)."""
+    g = golden(name)
+    dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
+    # tasks fall due when a step STARTS at t >= interval: interval 98.5 dt -> sampled after step 100
+    stdout = run(["sedov", "nr=256", "outer_radius=100", "tfinal=%r" % float(99.5 * dt), "cpi=0", "dfi=%r" % float(98.5 * dt), "tsi=%r" % float(98.5 * dt)] + extra, str(tmp_path))
     assert "write diagnostics: data/diagnostics.0000.h5" in stdout and "write diagnostics: data/diagnostics.0001.h5" in stdout
-    assert "diagnostics.0002" not in stdout and "chkpt" not in stdout
     d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
-    assert d["iteration"] == 150 and bits_equal(d["data"], g["un"])
-    f = os.path.join(tmp_path, "data", "diagnostics.0001.h5")            # a step started at t = 149 dt >= dfi: written after step 150
-    names = ["mass_density", "gas_pressure", "specific_entropy", "radial_gamma_beta", "radial_energy_flow"]
-    for k, name in enumerate(names):
-        got = _h5_dataset(f, "/" + name).reshape(48, 48)
-        if name == "specific_entropy":
-            assert np.all(np.abs(got - g["diag_fields"][k]) <= 1e-13 * np.maximum(1.0, np.abs(g["diag_fields"][k])))
-        else:
-            assert bits_equal(got, g["diag_fields"][k]), name
-    cols = ["total_energy_at_theta", "solid_angle_at_theta", "shock_midpoint_radius", "shock_upstream_radius", "shock_pressure_radius",
-            "shock_luminosity_radius", "postshock_flow_gamma", "postshock_flow_power", "postshock_flow_power02", "postshock_flow_power04",
-            "postshock_flow_power08", "postshock_flow_power16", "postshock_flow_power32", "postshock_flow_power64", "postshock_flow_power_max"]
-    for k, name in enumerate(cols):
-        assert bits_equal(_h5_dataset(f, "/" + name), g["diag_columns"][k]), name
-    assert _h5_dataset(f, "/time")[0] == g["diag_meta"][0]
-    assert bits_equal(_h5_dataset(f, "/radial_vertices"), g["rv"] * g["diag_meta"][1]) and bits_equal(_h5_dataset(f, "/polar_vertices"), g["qv"])
+    assert d["iteration"] == 100 and bits_equal(d["data"], g["u_100"])
+    f = os.path.join(tmp_path, "data", "diagnostics.0001.h5")
+    ref = g["fields_100"]
+    for k, key in ((1, "gas_pressure"), (2, "mass_density"), (3, "radial_gamma_beta")):
+        assert bits_equal(_h5_dataset(f, "/" + key), ref[k]), key
+    ent = _h5_dataset(f, "/specific_entropy")
+    assert np.all(np.abs(ent - ref[0]) <= 32 * np.spacing(np.maximum(np.abs(ref[0]), 1.0)))
+    assert bits_equal(_h5_dataset(f, "/radial_coordinates"), (g["vertices"][:-1] + g["vertices"][1:]) * 0.5)
+    cols = ["time", "shock_radius", "shock_radius_upstream", "shock_radius_downstream", "shock_radius_interpolated", "shock_velocity"]
+    series = g["series_100"]
+    ts = os.path.join(tmp_path, "data", "time_series.h5")
+    for k, key in enumerate(cols):
+        assert abs(_h5_dataset(f, "/" + key)[0] - series[k]) <= 1e-13 * abs(series[k]), key      # time: 100 additions of dt against n * dt
+        column = _h5_dataset(ts, "/" + key)
+        assert len(column) == 2 and abs(column[1] - series[k]) <= 1e-13 * abs(series[k]), key
+    header = subprocess.run([H5DUMP, "-H", "-p", ts], check=True, capture_output=True, text=True).stdout
+    assert "CHUNKED" in header and "( 1000 )" in header and "H5S_UNLIMITED" in header and 'GROUP "run_config"' in header

@@ -118,3 +118,14 @@ def test_decomposition_integers(oracle):
                     assert b - a == size and (size == 0 or a == start), key
                 else:
                     assert (a, b) == tuple(g[key][p]), key
+
+
+@pytest.mark.parametrize("name,srhd", [("sedovdiag_newtonian_nr256", False), ("sedovdiag_srhd_nr256", True)])
+def test_sedov_diagnostics_bit_exact(oracle, name, srhd):
+    """SedovProblem::make_diagnostic_fields / compute_time_series_data (subprog_sedov.cpp:252-308: entropy, shock locator, parabola vertex,
+    shock velocity) against the reference's own functions composed the same way (sedov_ref.cpp), both hydro systems, two epochs."""
+    g = golden(name)
+    for ns in (100, 400):
+        fields, indices, series, status = oracle.sedov_diagnostics(g["vertices"], g["u_%d" % ns], g["series_%d" % ns][0], srhd)
+        assert status == 0
+        assert bits_equal(fields, g["fields_%d" % ns]) and np.array_equal(indices, g["indices_%d" % ns]) and bits_equal(series, g["series_%d" % ns])
