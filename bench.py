@@ -250,9 +250,47 @@ def main():
             st.close()
         return res, final
 
+    def slab_checksum(t):
+        """Order-independent fingerprint of a slab's bits: (wrapping sum, xor) of the doubles viewed as int64."""
+        v = t.contiguous().view(torch.int64).reshape(-1)
+        x = v.clone()
+        while x.numel() > 1:                      # xor reduction by halving
+            h = x.numel() // 2
+            x = torch.cat([x[:h] ^ x[h:2 * h], x[2 * h:]])
+        return [int(v.sum().item()), int(x[0].item())]
+
+    def partition_check(arith, u_slab):
+        """N > 1: the union of the ranks' slabs against the SAME run on one GPU (rank 0 repeats it alone, outside the timed region):
+        per-arithmetic results do not depend on the partition, so the slab fingerprints must match bit for bit."""
+        nsteps_total = args.warmup + args.steps + 3
+        mine = torch.tensor(slab_checksum(u_slab), dtype=torch.int64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ok = None
+        if rank == 0:
+            try:                                   # nothing here may keep rank 0 from the barrier below
+                from mara3_amd.slab import partition_rows
+                one = NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=0, world=1, device=local_rank,
+                                        chunk_rows=args.chunk_rows, arith=arith)
+                one.load_slab(setups.blast_ic((n, n), gamma))
+                one.step(dt, nsteps_total)
+                one.synchronize()
+                whole = torch.from_numpy(one.slab_host())
+                one.close()
+                ok = True
+                for r in range(world):
+                    a, b = partition_rows(n, world, r)
+                    ok = ok and slab_checksum(whole[a:b]) == [int(x) for x in every[r].tolist()]
+            except Exception as e:
+                print("bench.py: partition check not completed: %r" % (e,), file=sys.stderr)
+                ok = None
+        dist.barrier()
+        return ok
+
     primary = args.arith
     other = "strict" if primary == "fast" else "fast"
     res, u_primary = run_mode(primary)
+    partition_ok = partition_check(primary, u_primary) if world > 1 and state["stepper"] == "native" else None
     res_other, u_other = (None, None) if args.single_arith else run_mode(other)
     l1 = None
     if u_other is not None:
@@ -285,6 +323,8 @@ def main():
                        "arith": arith_note[primary], "status_word": res["status_word"]},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
+        if partition_ok is not None:
+            out["slabs_bit_identical_to_one_gpu_run"] = bool(partition_ok)
         if res_other:
             out["arith_" + other] = {"note": arith_note[other], "value": res_other["value"], "ms_per_step": res_other["ms_per_step"],
                                      "roofline": res_other["roofline"], "roofline_step": res_other["roofline_step"],
