@@ -19,6 +19,7 @@
 // with h5dump, and the round trip (write, restart, continue) is tested to reproduce an uninterrupted run bit for bit.
 #pragma once
 #include <dlfcn.h>
+#include <cmath>
 #include <cstdio>
 #include <map>
 #include <stdexcept>
@@ -474,6 +475,16 @@ inline void read_config_into(const Node& group, mara::config_t& cfg)
             case 2: cfg.item(name, group.read_string(name)); break;
         }
     }
+}
+
+// mara::format_tree_index (app_serialize_tree.hpp:74-90): "level:ii-jj", coordinates zero-padded to 1 + log10(2^level) digits
+// (known answers of app_test.cpp:377-384: level 3 -> "3:5-6", level 5 -> "5:01-16", level 8 -> "8:001-002")
+inline std::string format_tree_index(int level, int i, int j)
+{
+    const int width = int(1 + std::log10(double(1 << level)));
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%d:%0*d-%0*d", level, width, i, width, j);
+    return buf;
 }
 
 inline std::string numbered_filename(const std::string& prefix, int count, const std::string& ext)

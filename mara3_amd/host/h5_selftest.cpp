@@ -2,6 +2,8 @@
 // usage: h5_selftest <file.h5>   (exit code 0 = round trip exact; 77 = libhdf5 not available)
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <cstddef>
 #include "h5_checkpoint.hpp"
 
 int main(int argc, char** argv)
@@ -39,6 +41,41 @@ int main(int argc, char** argv)
     mara::config_t c2 = mara::config_t().item("outdir", "x").item("restart", "y").item("nr", 1).item("tfinal", 0.0).item("not_stored", 3);
     h5io::read_config_into(file.open_group("config"), c2);
     ok = ok && c2.get_string("outdir") == "data" && c2.get_string("restart") == "" && c2.get_int("nr") == 256 && c2.get_double("tfinal") == 1.5 && c2.get_int("not_stored") == 3;
+    // tree dataset names: the reference's own known answers (src/app_test.cpp:377-384, two of the three coordinates)
+    ok = ok && h5io::format_tree_index(0, 0, 0) == "0:0-0" && h5io::format_tree_index(3, 5, 6) == "3:5-6"
+            && h5io::format_tree_index(5, 1, 16) == "5:01-16" && h5io::format_tree_index(8, 1, 2) == "8:001-002";
+    // compound records (binary's orbital elements / time series) and extendible columns (sedov's time_series.h5)
+    struct inner_t { double a, b; };
+    struct record_t { double x; double v[2]; inner_t in; };
+    {
+        h5io::Compound inner(sizeof(inner_t)), rec(sizeof(record_t));
+        inner.insert_double("a", offsetof(inner_t, a));
+        inner.insert_double("b", offsetof(inner_t, b));
+        rec.insert_double("x", offsetof(record_t, x));
+        rec.insert_array("v", offsetof(record_t, v), 2);
+        rec.insert("in", offsetof(record_t, in), inner);
+        const record_t rows[3] = {{1, {2, 3}, {4, 5}}, {6, {7, 8}, {9, 10}}, {11, {12, 13}, {14, 15}}};
+        const std::string path2 = std::string(argv[1]) + ".records.h5";
+        {
+            auto f2 = h5io::Node::create_file(path2);
+            f2.write_records("rows", rec, 3, rows);
+            f2.write_records("none", rec, 0, nullptr);
+            f2.write_record("one", rec, &rows[1]);
+            f2.create_unlimited("column", 1000);
+        }
+        {
+            auto f2 = h5io::Node::open_file_rw(path2);
+            f2.append("column", 0, 1.5);
+            f2.append("column", 1, 2.5);
+            f2.append("column", 4, 5.5);          // rows 2, 3 stay at the fill value
+        }
+        auto f2 = h5io::Node::open_file(path2);
+        record_t back[3] = {}, one = {};
+        f2.read_records("rows", rec, back);
+        f2.read_record("one", rec, &one);
+        ok = ok && f2.count_of("rows") == 3 && f2.count_of("none") == 0 && std::memcmp(back, rows, sizeof rows) == 0 && std::memcmp(&one, &rows[1], sizeof one) == 0;
+        ok = ok && f2.read_vector("column") == std::vector<double>({1.5, 2.5, 0.0, 0.0, 5.5});
+    }
     std::printf(ok ? "round trip ok\n" : "round trip FAILED\n");
     return ok ? 0 : 1;
 }

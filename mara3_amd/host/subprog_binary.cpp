@@ -141,14 +141,7 @@ struct record_types_t
     }
 };
 
-// mara::format_tree_index (app_serialize_tree.hpp:74-90): "level:ii-jj", coordinates zero-padded to 1 + log10(2^level) digits
-std::string format_tree_index(const mh_tree_block& b)
-{
-    const int width = int(1 + std::log10(double(1 << b.level)));
-    char buf[64];
-    std::snprintf(buf, sizeof buf, "%d:%0*d-%0*d", b.level, width, b.i, width, b.j);
-    return buf;
-}
+std::string format_tree_index(const mh_tree_block& b) { return h5io::format_tree_index(b.level, b.i, b.j); }
 
 // The leaf blocks in tree order and the order in which the solver object hands cells over: one grid [n][n] (uniform depth) or
 // block-major [nb][bs][bs] (graded). Files are always per block.
