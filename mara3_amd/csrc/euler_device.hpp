@@ -240,12 +240,11 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     using N = Normal<AXIS>;
     const double nh[3] = {N::n1, N::n2, N::n3};
     const double gamma = g.gamma;
-    State5 Ul, Ur;
-    to_conserved_pair(Pl, Pr, g, Ul, Ur);
+    // The wave speeds need the primitives only; the conserved state and the flux are formed for the side the sampled region belongs
+    // to, inside its branch (same expressions, same bits as forming both sides up front - a division gives the same result alone
+    // or in a group - and about 25 instructions fewer per face where a wave takes one branch).
     const double ul = velocity_along<AXIS>(Pl);
     const double ur = velocity_along<AXIS>(Pr);
-    const State5 Fl = flux<AXIS>(Pl, Ul, ul);
-    const State5 Fr = flux<AXIS>(Pr, Ur, ur);
     const double dl = Pl[0], dr = Pr[0], pl = Pl[4], pr = Pr[4];
     const double dbar = 0.5 * (dl + dr);
     const double al = sqrt(gamma * pl / dl);
@@ -264,10 +263,12 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     State5 F;
     if (0.0 <= sl)
     {
-        F = Fl;
+        F = flux<AXIS>(Pl, to_conserved_density(Pl, g), ul);
     }
     else if (sl <= 0.0 && 0.0 <= sstar)
     {
+        const State5 Ul = to_conserved_density(Pl, g);
+        const State5 Fl = flux<AXIS>(Pl, Ul, ul);
         const double fac = dl * (sl - ul) / (sl - sstar);
         State5 Us;
         Us[0] = fac;
@@ -279,6 +280,8 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     }
     else if (sstar <= 0.0 && 0.0 <= sr)
     {
+        const State5 Ur = to_conserved_density(Pr, g);
+        const State5 Fr = flux<AXIS>(Pr, Ur, ur);
         const double fac = dr * (sr - ur) / (sr - sstar);
         State5 Us;
         Us[0] = fac;
@@ -290,7 +293,7 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     }
     else if (sr <= 0.0)
     {
-        F = Fr;
+        F = flux<AXIS>(Pr, to_conserved_density(Pr, g), ur);
     }
     else
     {
