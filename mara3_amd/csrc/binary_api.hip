@@ -25,7 +25,7 @@ hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const d
 
 // graded trees (binary_tree.hip)
 struct TreeGeom { const int32_t* topo; const int32_t* level; const double* edges; int nb, bs; };
-struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out; };
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals; };
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
                                     double theta, double* totals, int32_t* status, hipStream_t stream);
@@ -88,7 +88,7 @@ struct mh_binary
     // graded tree (mh_binary_tree_create): block-major fields [nb][3][bs][bs], neighbour table, per-stage work arrays
     bool tree = false;
     TreeGeom geom = {nullptr, nullptr, nullptr, 0, 0};
-    TreeBuffers work = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    TreeBuffers work = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t* topo_dev = nullptr;
     int32_t* level_dev = nullptr;
     double* edges_dev = nullptr;
@@ -336,7 +336,8 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     B_TRY(hipMalloc(&b->work.gy, b->field_doubles * sizeof(double)));
     B_TRY(hipMalloc(&b->work.fx, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
     B_TRY(hipMalloc(&b->work.fy, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
-    B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * ((bs * bs + 255) / 256) * 16 * sizeof(double)));      // [nb][tiles of 256 cells][16 partial sums]
+    B_TRY(hipMalloc(&b->work.block_vals, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
     B_TRY(hipMalloc(&b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double)));
     B_TRY(hipMalloc(&b->status, 2 * sizeof(int32_t)));
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
@@ -365,7 +366,7 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
     (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->status); (void) hipFree(b->staging);
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
-    (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out);
+    (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals);
     if (b->mirror) (void) hipHostFree(b->mirror);
     if (b->stream) (void) hipStreamDestroy(b->stream);
     delete b;

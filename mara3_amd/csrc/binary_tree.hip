@@ -114,7 +114,7 @@ void tree_grad_kernel(const double* prim, double* gx, double* gy, TreeGeom g, Bi
     BinaryConsts cb = c;
     cb.h = spacing_of(c, g.level[b]);
     const typename A::Ctx k = A::make(cb);
-    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < bs * bs; idx += 256 * gridDim.y)      // grid = (blocks, tiles of 256 cells)
     {
         const int i = idx / bs, j = idx - i * bs;
         const State3 P0 = load3(prim, bs, b, i, j);
@@ -139,8 +139,12 @@ void tree_flux_kernel(const double* prim, const double* gx, const double* gy, do
     const typename A::Ctx k = A::make(cb);
     const double* xv = g.edges + (long) b * 2 * (bs + 1);
     const double* yv = xv + bs + 1;
-    for (int idx = threadIdx.x; idx < (bs + 1) * bs; idx += 256)
+    // grid = (blocks, 2 x tiles of 256 faces): even blockIdx.y -> x-faces, odd -> y-faces. A 64-block tree would otherwise occupy 64 of
+    // the 256 CUs with three sequential passes of two face fluxes each.
+    const bool xfaces = (blockIdx.y & 1) == 0;
+    for (int idx = (blockIdx.y >> 1) * 256 + threadIdx.x; idx < (bs + 1) * bs; idx += 256 * (gridDim.y >> 1))
     {
+        if (xfaces)
         {   // x-face (i, j), i = 0..bs
             const int i = idx / bs, j = idx - i * bs;
             const double xf = (xv[i] + xv[i]) * 0.5, yf = (yv[j] + yv[j + 1]) * 0.5;
@@ -150,6 +154,7 @@ void tree_flux_kernel(const double* prim, const double* gx, const double* gy, do
 #pragma unroll
             for (int q = 0; q < 3; ++q) fx[fx_index(bs, b, q, i, j)] = F[q] * dy;
         }
+        else
         {   // y-face (i, j), j = 0..bs
             const int i = idx / (bs + 1), j = idx - i * (bs + 1);
             const double xf = (xv[i] + xv[i + 1]) * 0.5, yf = (yv[j] + yv[j]) * 0.5;
@@ -208,7 +213,8 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
 #pragma unroll
     for (int k = 0; k < NTREE_SUMS; ++k) acc[k] = 0.0;
     int bad = 0;
-    for (int idx = threadIdx.x; idx < bs * bs; idx += 256)
+    // grid = (blocks, tiles of 256 cells): one cell per thread, a partial sum per tile (a 64-block tree would otherwise run on 64 CUs)
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < bs * bs; idx += 256 * gridDim.y)
     {
         const int i = idx / bs, j = idx - i * bs;
         const double xc = (xv[i] + xv[i + 1]) * 0.5, yc = (yv[j] + yv[j + 1]) * 0.5;
@@ -301,39 +307,58 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
     }
     if (threadIdx.x == 0)
     {
-        double* out = block_out + (long) b * MH_BINARY_NTOTALS;
-        // order of mh_binary_total: mass_acc, L_acc, torque, px_acc, py_acc, fx, fy, work, mass_ej, L_ej
-        for (int k = 0; k < 14; ++k) out[k] = -red[k][0];
-        out[MH_T_MASS_EJ] = -red[14][0];
-        out[MH_T_L_EJ] = -red[15][0];
-        for (int bdy = 0; bdy < 2; ++bdy)       // work :356-365 from this block's sink sums
-        {
-            const double M0 = c.body[5 * bdy], px0 = c.body[5 * bdy + 3] * M0, py0 = c.body[5 * bdy + 4] * M0;
-            const double M1 = M0 + out[MH_T_MASS_ACC + bdy], px1 = px0 + out[MH_T_PX_ACC + bdy], py1 = py0 + out[MH_T_PY_ACC + bdy];
-            out[MH_T_WORK + bdy] = QFORM ? 0.0 : ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
-        }
+        double* out = block_out + ((long) b * gridDim.y + blockIdx.y) * NTREE_SUMS;       // raw partial sums of this tile; signs and work: tree_totals_kernel
+        for (int k = 0; k < NTREE_SUMS; ++k) out[k] = red[k][0];
     }
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, MH_STATUS_NEG_DENSITY);
 }
 
-__global__ __launch_bounds__(64)
-void tree_totals_kernel(const double* block_out, int nb, double* totals)
+// totals[18] in the order of mh_binary_total (mass_acc, L_acc, torque, px_acc, py_acc, fx, fy, work, mass_ej, L_ej): per block the tile
+// partials are added in tile order, the block values in the tree's traversal order (scheme.cpp:829-830 sums the blocks' results
+// with tree.sum()); work_done_on :356-365 is a per-block function of that block's sink sums.
+// One workgroup. Phase 1: all threads form the nb x 18 block values (independent loads, into block_vals); phase 2: one thread per
+// entry adds them in block order, the loads of eight blocks issued together - a plain loop is a chain of dependent load latencies
+// (13 us for 64 blocks, 100 us with the tile sums inside it).
+__global__ __launch_bounds__(1024)
+void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c, int qform, double* block_vals, double* totals)
 {
+    auto block_sum = [&] (int b, int k)
+    {
+        double v = 0.0;
+        for (int tile = 0; tile < tiles; ++tile) v = v + partial[((long) b * tiles + tile) * NTREE_SUMS + k];
+        return -v;
+    };
+    for (int idx = threadIdx.x; idx < nb * MH_BINARY_NTOTALS; idx += blockDim.x)
+    {
+        const int b = idx / MH_BINARY_NTOTALS, t = idx - b * MH_BINARY_NTOTALS;
+        double val;
+        if (t < MH_T_WORK) val = block_sum(b, t);
+        else if (t >= MH_T_MASS_EJ) val = block_sum(b, 14 + (t - MH_T_MASS_EJ));
+        else if (qform) val = 0.0;
+        else
+        {
+            const int bdy = t - MH_T_WORK;
+            const double M0 = c.body[5 * bdy], px0 = c.body[5 * bdy + 3] * M0, py0 = c.body[5 * bdy + 4] * M0;
+            const double M1 = M0 + block_sum(b, MH_T_MASS_ACC + bdy), px1 = px0 + block_sum(b, MH_T_PX_ACC + bdy), py1 = py0 + block_sum(b, MH_T_PY_ACC + bdy);
+            val = ((px1 * px1 + py1 * py1) / M1 - (px0 * px0 + py0 * py0) / M0) * 0.5;
+        }
+        block_vals[idx] = val;
+    }
+    __threadfence_block();
+    __syncthreads();
     const int t = threadIdx.x;
     if (t >= MH_BINARY_NTOTALS) return;
-    // blocks in the tree's traversal order; the loads of eight blocks are issued together (the additions stay sequential): the loop
-    // was a chain of 64 dependent load latencies, 13 us per stage of a 64-block run
     double s = 0.0;
     int b = 0;
     for (; b + 8 <= nb; b += 8)
     {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = block_out[(long) (b + k) * MH_BINARY_NTOTALS + t];
+        for (int k = 0; k < 8; ++k) v[k] = block_vals[(long) (b + k) * MH_BINARY_NTOTALS + t];
 #pragma unroll
         for (int k = 0; k < 8; ++k) s = s + v[k];
     }
-    for (; b < nb; ++b) s = s + block_out[(long) b * MH_BINARY_NTOTALS + t];
+    for (; b < nb; ++b) s = s + block_vals[(long) b * MH_BINARY_NTOTALS + t];
     totals[t] = s;
 }
 
@@ -376,7 +401,7 @@ __global__ void tree_set_inf_kernel(double* x) { *x = __longlong_as_double(0x7ff
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
 BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]);
 
-struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out; };
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals; };
 
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
@@ -392,14 +417,15 @@ hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, 
         using A = decltype(policy);
         constexpr bool Q = decltype(qform)::value;
         hipLaunchKernelGGL((tree_c2p_kernel<A, Q>), cgrid, blk, 0, stream, u_in, w.prim, g.edges, g.nb, g.bs);
-        hipLaunchKernelGGL((tree_grad_kernel<A>), grid, blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
-        hipLaunchKernelGGL((tree_flux_kernel<A, Q>), grid, blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
-        if (combine) hipLaunchKernelGGL((tree_update_kernel<A, true, Q>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-        else         hipLaunchKernelGGL((tree_update_kernel<A, false, Q>), grid, blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        const unsigned cell_tiles = (unsigned) ((g.bs * g.bs + 255) / 256), face_tiles = (unsigned) (((g.bs + 1) * g.bs + 255) / 256);
+        hipLaunchKernelGGL((tree_grad_kernel<A>), dim3(g.nb, cell_tiles), blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
+        hipLaunchKernelGGL((tree_flux_kernel<A, Q>), dim3(g.nb, 2 * face_tiles), blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
+        if (combine) hipLaunchKernelGGL((tree_update_kernel<A, true, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        else         hipLaunchKernelGGL((tree_update_kernel<A, false, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
     };
     if (fast) { if (q) run(BinFast(), std::true_type()); else run(BinFast(), std::false_type()); }
     else      { if (q) run(BinStrict(), std::true_type()); else run(BinStrict(), std::false_type()); }
-    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(64), 0, stream, w.block_out, g.nb, totals);
+    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(1024), 0, stream, w.block_out, g.nb, (g.bs * g.bs + 255) / 256, c, (int) q, w.block_vals, totals);
     return hipGetLastError();
 }
 
