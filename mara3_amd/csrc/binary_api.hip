@@ -48,7 +48,7 @@ static int check_binary_desc(const mh_binary_desc* d)
     return MH_OK;
 }
 
-struct HostMirror        // pinned: what one step brings back
+struct HostMirror        // pinned: what one step brings back; dev_small on the device has the same layout
 {
     double  totals[2][MH_BINARY_NTOTALS];
     double  maxw;
@@ -146,8 +146,8 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
 
     auto fetch = [b] () -> int
     {
-        MH_HIP_TRY(hipMemcpyAsync(b->mirror->totals, b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        MH_HIP_TRY(hipMemcpyAsync(b->mirror->status, b->status, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+        // totals, maximum wavespeed and the status words are one device block laid out like HostMirror: one copy per synchronisation
+        MH_HIP_TRY(hipMemcpyAsync(b->mirror, b->dev_small, sizeof(HostMirror), hipMemcpyDeviceToHost, b->stream));
         MH_HIP_TRY(hipStreamSynchronize(b->stream));
         return MH_OK;
     };
@@ -284,8 +284,8 @@ int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const
     B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
     B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
     B_TRY(hipMalloc(&b->scratch, binary_scratch_doubles(d) * sizeof(double)));
-    B_TRY(hipMalloc(&b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double)));
-    B_TRY(hipMalloc(&b->status, 2 * sizeof(int32_t)));
+    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
+    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
     B_TRY(hipMalloc(&b->staging, n * n * 3 * sizeof(double)));
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
     B_TRY(hipMemcpyAsync(b->xv, xv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -338,8 +338,8 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     B_TRY(hipMalloc(&b->work.fy, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
     B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * ((bs * bs + 255) / 256) * 16 * sizeof(double)));      // [nb][tiles of 256 cells][16 partial sums]
     B_TRY(hipMalloc(&b->work.block_vals, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
-    B_TRY(hipMalloc(&b->dev_small, (2 * MH_BINARY_NTOTALS + 1) * sizeof(double)));
-    B_TRY(hipMalloc(&b->status, 2 * sizeof(int32_t)));
+    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
+    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
     b->geom = {b->topo_dev, b->level_dev, b->edges_dev, nb, bs};
     B_TRY(hipMemcpyAsync(b->topo_dev, topo.data(), topo.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
@@ -364,7 +364,7 @@ void mh_binary_destroy(mh_binary* b)
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
-    (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->status); (void) hipFree(b->staging);
+    (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->staging);      // status lives inside dev_small
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
     (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals);
     if (b->mirror) (void) hipHostFree(b->mirror);
