@@ -428,11 +428,22 @@ void binary_reduce_kernel(const double* partials, int nwaves, const double* bloc
         else if (t < 14) from_wave = t - 8;
         else if (t < 16) from_block = t - 6;
         else from_wave = t - 10;
+        // each lane adds its entries in index order; the loads of eight of them are issued together (a plain loop is a chain of
+        // dependent load latencies: 12 us per stage at 2048^2)
+        const double* src = from_block >= 0 ? block_out + from_block : partials + from_wave;
+        const long pitch = from_block >= 0 ? NBLK : NPART;
+        const int count = from_block >= 0 ? nblocks : nwaves;
         double s = 0.0;
-        if (from_block >= 0)
-            for (int k = lane; k < nblocks; k += 64) s = s + block_out[(long) k * NBLK + from_block];
-        else
-            for (int k = lane; k < nwaves; k += 64) s = s + partials[(long) k * NPART + from_wave];
+        int k = lane;
+        for (; k + 7 * 64 < count; k += 8 * 64)
+        {
+            double v[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = src[(long) (k + 64 * m) * pitch];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) s = s + v[m];
+        }
+        for (; k < count; k += 64) s = s + src[(long) k * pitch];
         s = wave_sum(s);
         if (lane == 0) totals[t] = from_block >= 0 ? s : -s;
     }
