@@ -21,6 +21,8 @@
 // neighbours move through DPP wave shifts. Conserved variables are
 // cell-integrated; device layout as in include/mara_hip.h.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "launch.hpp"
 #include "euler_device.hpp"
@@ -49,6 +51,7 @@ struct CloudParams
     int    n0, n1;             // local radial rows, polar columns
     int    row_offset;         // global index of local row 0
     int    row_begin, row_end, chunk_rows, nstrips, nchunks;
+    int    row_begin2, row_end2, chunk_rows2, nchunks_a, tail_blocks_per_xcd;   // graded tail: chunks >= nchunks_a are short and march [row_begin2, row_end2)
     int    bc_lo0, bc_hi0;     // MH_BC_INFLOW / MH_BC_OUTFLOW (physical) or MH_BC_EXTERNAL (slab cut)
     double gamma, theta, tfloor, dt, weight;
 };
@@ -104,16 +107,26 @@ void cloud_stage_kernel(CloudParams p)
 {
     int b = blockIdx.x;
     {
-        const int per_xcd = gridDim.x >> 3;
-        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
+        // XCD-aware order; each XCD's share ends on the short waves of the graded tail (as euler2d.hip)
+        const int per_xcd = gridDim.x >> 3, tail = p.tail_blocks_per_xcd, body = per_xcd - tail;
+        if (b < per_xcd * 8)
+        {
+            const int x = b & 7, s = b >> 3;
+            b = s < body ? x * body + s : 8 * body + x * tail + (s - body);
+        }
     }
     const int w = __builtin_amdgcn_readfirstlane(b * CWAVES_PER_BLOCK + (int) (threadIdx.x >> 6));   // wave-uniform -> scalar registers
     if (w >= p.nstrips * p.nchunks) return;
     const int lane = threadIdx.x & 63;
     const int chunk = w / p.nstrips;
     const int strip = w - chunk * p.nstrips;
-    const int r0 = p.row_begin + chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, p.row_end);
+    int r0 = p.row_begin + chunk * p.chunk_rows;
+    int r1 = min(r0 + p.chunk_rows, p.row_end);
+    if (chunk >= p.nchunks_a)
+    {
+        r0 = p.row_begin2 + (chunk - p.nchunks_a) * p.chunk_rows2;
+        r1 = min(r0 + p.chunk_rows2, p.row_end2);
+    }
 
     const int col = strip * CSTRIP - CHALO + lane;
     const int jc = min(max(col, 0), p.n1 - 1);
@@ -302,7 +315,25 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     p.row_begin = row_begin; p.row_end = row_end;
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     p.nstrips = (p.n1 + CSTRIP - 1) / CSTRIP;
-    p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    // graded tail (see euler2d.hip): the last rows of a large launch go to short waves, so that the ragged end of the last residency
+    // round lasts a short wave's duration. MH_CLOUD_TAIL="rows,chunk" overrides (0 rows = off).
+    p.row_begin2 = p.row_end2 = row_end;
+    p.chunk_rows2 = p.chunk_rows;
+    if (d->chunk_rows == 0)
+    {
+        int tail_rows = 512, tail_chunk = 8;
+        if (const char* v = getenv("MH_CLOUD_TAIL")) sscanf(v, "%d,%d", &tail_rows, &tail_chunk);
+        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= 4 * tail_rows)
+        {
+            p.row_begin2 = row_end - tail_rows;
+            p.row_end2 = row_end;
+            p.row_end = p.row_begin2;
+            p.chunk_rows2 = tail_chunk;
+        }
+    }
+    p.nchunks_a = (p.row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
+    p.nchunks = p.nchunks_a + (p.row_end2 - p.row_begin2 + p.chunk_rows2 - 1) / p.chunk_rows2;
+    p.tail_blocks_per_xcd = p.chunk_rows2 != p.chunk_rows ? (int) (((long) p.nstrips * (p.nchunks - p.nchunks_a) / CWAVES_PER_BLOCK) >> 3) : 0;
     p.bc_lo0 = d->bc_lo0; p.bc_hi0 = d->bc_hi0;
     p.gamma = d->gamma; p.theta = d->plm_theta; p.tfloor = d->temperature_floor;
     p.dt = dt; p.weight = weight;
