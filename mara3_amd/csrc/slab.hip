@@ -189,7 +189,9 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     if (s->desc.rank == 2)
     {
         if (s->event_on_launch) euler2d_next_launch_signals(s->ev_edge);
-        MH_HIP_TRY(euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side));   // both edges, one launch
+        const hipError_t le = euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side);   // both edges, one launch
+        euler2d_next_launch_signals(nullptr);          // consumed by the launch; never left armed for an unrelated one if it failed early
+        MH_HIP_TRY(le);
     }
     else
     {
@@ -200,7 +202,9 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
     if (int rc = slab_exchange(s, out, s->side)) return rc;
     if (on_launch) euler2d_next_launch_signals(s->ev_interior);
-    MH_HIP_TRY(bulk(e, n0 - e));
+    const hipError_t be = bulk(e, n0 - e);
+    euler2d_next_launch_signals(nullptr);
+    MH_HIP_TRY(be);
     if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
     return MH_OK;
 }
