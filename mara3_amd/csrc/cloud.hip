@@ -319,11 +319,12 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     // round lasts a short wave's duration. MH_CLOUD_TAIL="rows,chunk" overrides (0 rows = off).
     p.row_begin2 = p.row_end2 = row_end;
     p.chunk_rows2 = p.chunk_rows;
-    if (d->chunk_rows == 0)
+    const char* tail_env = getenv("MH_CLOUD_TAIL");          // explicit: applies to any launch with more rows than the tail (tests on small grids)
+    if (tail_env || d->chunk_rows == 0)
     {
         int tail_rows = 512, tail_chunk = 8;
-        if (const char* v = getenv("MH_CLOUD_TAIL")) sscanf(v, "%d,%d", &tail_rows, &tail_chunk);
-        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= 4 * tail_rows)
+        if (tail_env) sscanf(tail_env, "%d,%d", &tail_rows, &tail_chunk);
+        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= (tail_env ? tail_rows + 1 : 4 * tail_rows))
         {
             p.row_begin2 = row_end - tail_rows;
             p.row_end2 = row_end;
