@@ -261,14 +261,7 @@ def main():
             st.close()
         return res, final
 
-    def slab_checksum(t):
-        """Order-independent fingerprint of a slab's bits: (wrapping sum, xor) of the doubles viewed as int64."""
-        v = t.contiguous().view(torch.int64).reshape(-1)
-        x = v.clone()
-        while x.numel() > 1:                      # xor reduction by halving
-            h = x.numel() // 2
-            x = torch.cat([x[:h] ^ x[h:2 * h], x[2 * h:]])
-        return [int(v.sum().item()), int(x[0].item())]
+    from mara3_amd.slab import slab_fingerprint as slab_checksum
 
     def partition_check(arith, u_slab):
         """N > 1: the union of the ranks' slabs against the SAME run on one GPU (rank 0 repeats it alone, outside the timed region):

@@ -20,6 +20,17 @@ HALO = 2
 NQ = 5
 
 
+def slab_fingerprint(t):
+    """Order-independent fingerprint of a slab's bits: [wrapping sum, xor] of its doubles viewed as int64 (bench.py compares the
+    ranks' slabs with a one-GPU run through it)."""
+    v = t.contiguous().view(torch.int64).reshape(-1)
+    x = v.clone()
+    while x.numel() > 1:                      # xor reduction by halving
+        h = x.numel() // 2
+        x = torch.cat([x[:h] ^ x[h:2 * h], x[2 * h:]])
+    return [int(v.sum().item()), int(x[0].item()) if x.numel() else 0]
+
+
 def partition_rows(count, nparts, part):
     """Rows [start, final) of slab `part` (calls the C ABI's host-side mh_partition_rows)."""
     lib = L.load_library()

@@ -106,3 +106,18 @@ def test_cloud_radial_slabs_over_gloo_match_the_reference(tmp_path, oracle, worl
         covered += b - a
     assert covered == g["un"].shape[0]
     assert bits_equal(got, g["un"]), np.abs(got - g["un"]).max()
+
+
+def test_slab_fingerprint_detects_a_single_bit():
+    """bench.py's N > 1 determinism check compares fingerprints of the ranks' slabs with those of a one-GPU run."""
+    import numpy as np
+    import torch
+    from mara3_amd.slab import slab_fingerprint
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.standard_normal((37, 11, 5)))
+    assert slab_fingerprint(a) == slab_fingerprint(a.clone())
+    assert slab_fingerprint(a)[1] == int(np.bitwise_xor.reduce(a.numpy().view(np.int64).reshape(-1)))
+    b = a.clone()
+    b.view(torch.int64)[3, 4, 1] ^= 1                      # flip the last mantissa bit of one value
+    assert slab_fingerprint(b) != slab_fingerprint(a)
+    assert slab_fingerprint(a[5:9]) == slab_fingerprint(a[5:9].contiguous())
