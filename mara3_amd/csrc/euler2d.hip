@@ -320,8 +320,10 @@ void euler2d_stage_kernel(Stage2dParams p)
 // The slab stepper orders its two streams with events. An event recorded by hipEventRecord is a separate marker packet behind
 // the kernel; handed to the launch itself (hipExtLaunchKernel's stopEvent) it rides on the dispatch packet's own completion signal,
 // one packet less on the chain between consecutive stages.
-static thread_local hipEvent_t g_stop_event = nullptr;
-void euler2d_next_launch_signals(hipEvent_t stop) { g_stop_event = stop; }
+static thread_local hipEvent_t g_stop_event = nullptr, g_start_event = nullptr;
+void euler2d_next_launch_signals(hipEvent_t stop) { g_stop_event = stop; g_start_event = nullptr; }
+// the same with a start event: the pair brackets exactly the kernel (profiling without marker packets around the launch)
+void euler2d_next_launch_events(hipEvent_t start, hipEvent_t stop) { g_start_event = start; g_stop_event = stop; }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
 static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
@@ -330,9 +332,10 @@ static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
     const int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (g_stop_event)
     {
-        hipEvent_t stop = g_stop_event;
+        hipEvent_t stop = g_stop_event, start = g_start_event;
         g_stop_event = nullptr;
-        hipExtLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, nullptr, stop, 0, p);
+        g_start_event = nullptr;
+        hipExtLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, start, stop, 0, p);
     }
     else
         hipLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
@@ -410,7 +413,14 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     p.weight = weight;
     if (p.nchunks <= 0)
     {
-        if (g_stop_event) { hipEvent_t stop = g_stop_event; g_stop_event = nullptr; return hipEventRecord(stop, stream); }     // nothing to launch: the event still has to fire
+        if (g_stop_event)          // nothing to launch: the events still have to fire
+        {
+            hipEvent_t stop = g_stop_event, start = g_start_event;
+            g_stop_event = nullptr;
+            g_start_event = nullptr;
+            if (start) (void) hipEventRecord(start, stream);
+            return hipEventRecord(stop, stream);
+        }
         return hipSuccess;
     }
 

@@ -149,18 +149,24 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     if (S) s->phase = (s->phase + 1) % S;
     const int n0 = s->n0, e = s->edge_rows * (k + 1);
     std::pair<hipEvent_t, hipEvent_t> ev;
+    // profiling events of the bulk launch. Without neighbours (2-D) they ride on the launch itself (hipExtLaunchKernel's start / stop
+    // events: the dispatch packet's own timestamps, no marker packets between consecutive stage kernels of the timed region); with
+    // neighbours the stop slot of the launch belongs to the stream-ordering event, so they are recorded around it.
+    const bool events_on_launch = s->profile && s->desc.rank == 2 && s->lo < 0 && s->hi < 0;
     auto bulk = [&] (int a, int b) -> hipError_t
     {
         if (s->profile)
         {
             hipEventCreate(&ev.first);
             hipEventCreate(&ev.second);
-            hipEventRecord(ev.first, s->main);
+            if (events_on_launch) euler2d_next_launch_events(ev.first, ev.second);
+            else                  hipEventRecord(ev.first, s->main);
         }
         hipError_t r = stage_launch(&s->desc, in, base, out, dt, w, a, b, s->status, s->main);
         if (s->profile)
         {
-            hipEventRecord(ev.second, s->main);
+            if (events_on_launch) euler2d_next_launch_signals(nullptr);
+            else                  hipEventRecord(ev.second, s->main);
             s->events[which].push_back(ev);
         }
         return r;
