@@ -82,3 +82,30 @@ def test_euler3d_blast_128_properties(eng, oracle):
     sub = oracle.euler_cart_run(u0[a - pad:b + pad, a - pad:b + pad, 30 - pad:100 + pad], dl, dt, 3, gamma, 1.5, 2,
                                 oracle.RIEMANN_HLLE, oracle.BC_OUTFLOW, nthreads=8)
     assert bits_equal(got[a:b, a:b, 30:100], sub[pad:-pad, pad:-pad, pad:-pad])
+
+
+@pytest.mark.timeout(600)
+def test_config5_full_rank_size_symmetry_and_conservation(eng):
+    """BASELINE config 5 at one rank's full size (512^3 of the 1024^3 / 8-GPU case; PLM 1.5 + HLLE, RK2, fast arithmetic): a centred blast
+    stays mirror-symmetric about the three mid-planes (to rounding: a reflection swaps the left / right roles inside the Riemann solver,
+    so the last bits may differ) and, as long as the wave is far from the outflow boundaries, mass and energy are conserved to rounding."""
+    from mara3_amd import setups
+    n, gamma = 512, 5.0 / 3
+    u0 = setups.blast_ic((n, n, n), gamma)
+    s = eng.EulerCartSolver((n, n, n), (1.0 / n,) * 3, gamma, 1.5, "hlle", 2, "outflow", arith="fast")
+    s.upload(u0)
+    mass0, energy0 = float(u0[..., 0].sum()), float(u0[..., 4].sum())
+    del u0
+    s.step(0.3 / n / 6, 3)
+    u = s.download()
+    assert s.status() == 0
+    s.close()
+    assert abs(float(u[..., 0].sum()) - mass0) <= 1e-12 * mass0 and abs(float(u[..., 4].sum()) - energy0) <= 1e-12 * energy0
+    scale = np.abs(u[..., 4]).max()
+    for axis in range(3):
+        sign = np.ones(5)
+        sign[1 + axis] = -1.0                                   # the momentum along the mirrored axis changes sign
+        mirror = np.flip(u, axis=axis) * sign
+        assert np.abs(u - mirror).max() <= 1e-12 * scale, axis
+        del mirror
+    assert (u[..., 0] > 0).all() and np.abs(u[n // 2, n // 2, :, 3]).max() > 0      # the blast edge on the central line is moving

@@ -336,3 +336,22 @@ def test_sedov_diagnostics_and_time_series_files(tmp_path, name, extra):
         assert len(column) == 2 and abs(column[1] - series[k]) <= 1e-13 * abs(series[k]), key
     header = subprocess.run([H5DUMP, "-H", "-p", ts], check=True, capture_output=True, text=True).stdout
     assert "CHUNKED" in header and "( 1000 )" in header and "H5S_UNLIMITED" in header and 'GROUP "run_config"' in header
+
+
+@pytest.mark.timeout(600)
+def test_cloud_full_size_equatorial_symmetry(tmp_path):
+    """BASELINE config 4 at full size (`mara_hip cloud nr=4096 num_decades=1 rk_order=2 plm_theta=1.2`, strict arithmetic): the nozzle model
+    is symmetric about the equator (model_jet_nozzle: gamma_beta(q) + gamma_beta(pi - q)), so after three steps the state mirrors about
+    theta = pi / 2 - the polar momentum changes sign - to the rounding of the polar grid (linspace(0, pi) is not exactly mirror-symmetric),
+    and every cell keeps a positive density and energy."""
+    run(["cloud", "nr=4096", "num_decades=1", "rk_order=2", "plm_theta=1.2", "max_steps=3", "tfinal=100.0", "cpi=0", "dfi=0", "tsi=0"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    u = d["data"]
+    assert d["iteration"] == 3 and u.shape == (4096, 4096, 5)
+    assert (u[..., 0] > 0).all() and (u[..., 4] > 0).all()
+    sign = np.array([1.0, 1.0, -1.0, 1.0, 1.0])
+    mirror = u[:, ::-1, :] * sign
+    scale = np.abs(u).reshape(-1, 5).max(axis=0)
+    scale[2] = scale[1]                                        # the polar momentum is measured against the radial one
+    err = np.abs(u - mirror).reshape(-1, 5).max(axis=0)
+    assert np.all(err <= 1e-9 * scale), err / scale
