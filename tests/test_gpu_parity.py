@@ -338,3 +338,27 @@ def test_euler2d_graded_tail_is_bit_exact(eng, case, tail, monkeypatch):
             got = s.download()
             assert s.status() == 0
             assert bits_equal(got, g["u_%d" % ns]), (case, ns, tail)
+
+
+@pytest.mark.timeout(600)
+def test_beyond_baseline_size_8192_symmetry_and_conservation(eng):
+    """Four times the BASELINE grid (8192^2, 2.7 GB per field; the layout is sized for 288 GB of HBM): the graded-tail launch path at its
+    default settings, fast arithmetic, PLM + HLLC RK2. The centred blast stays symmetric under both mirror images and the transpose (to
+    rounding) and conserves mass and energy while the wave is far from the boundary."""
+    from mara3_amd import setups
+    n, gamma = 8192, 5.0 / 3
+    u0 = setups.blast_ic((n, n), gamma)
+    mass0, energy0 = float(u0[..., 0].sum()), float(u0[..., 4].sum())
+    s = eng.EulerCartSolver((n, n), (1.0 / n, 1.0 / n), gamma, 1.5, "hllc", 2, "outflow", arith="fast")
+    s.upload(u0)
+    del u0
+    s.step(setups.baseline_dt(n), 3)
+    u = s.download()
+    assert s.status() == 0
+    s.close()
+    assert abs(float(u[..., 0].sum()) - mass0) <= 1e-12 * mass0 and abs(float(u[..., 4].sum()) - energy0) <= 1e-12 * energy0
+    scale = np.abs(u[..., 4]).max()
+    assert np.abs(u - u[::-1] * np.array([1.0, -1.0, 1.0, 1.0, 1.0])).max() <= 1e-12 * scale
+    assert np.abs(u - u[:, ::-1] * np.array([1.0, 1.0, -1.0, 1.0, 1.0])).max() <= 1e-12 * scale
+    assert np.abs(u - u.transpose(1, 0, 2)[..., [0, 2, 1, 3, 4]]).max() <= 1e-12 * scale
+    assert np.abs(u[..., 1]).max() > 0
