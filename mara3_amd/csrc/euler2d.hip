@@ -210,6 +210,7 @@ void euler2d_stage_kernel(Stage2dParams p)
     }
 
     int32_t bad = 0;
+    if (!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)) bad |= 1;      // the chunk's first two rows (the row loop checks rows r + 2)
     // second prefetch stage: row r+3 is in flight in Upre while row r is processed, row r+4 is issued at its top.
     // Two rows (10 loads of 512 B) in flight per wave keep ~40 KB outstanding per CU, enough to cover HBM latency
     // at this kernel's bandwidth (one row in flight left the first RK stage latency-bound).
@@ -231,6 +232,9 @@ void euler2d_stage_kernel(Stage2dParams p)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(U[K2], gl);
+        // a negative (or NaN) pressure: the strict arithmetic turns it into NaN sound speeds that reach the density check below, the fast
+        // arithmetic's guarded inverse root would not - so it is flagged where it appears (once per cell and stage)
+        if (!(P[K2][4] >= 0.0)) bad |= 1;
         if constexpr (PLM && A::shared_differences)
         {
             D[K1] = A::scaled_difference(P[K1], P[K2], theta);

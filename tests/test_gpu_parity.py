@@ -362,3 +362,29 @@ def test_beyond_baseline_size_8192_symmetry_and_conservation(eng):
     assert np.abs(u - u[:, ::-1] * np.array([1.0, 1.0, -1.0, 1.0, 1.0])).max() <= 1e-12 * scale
     assert np.abs(u - u.transpose(1, 0, 2)[..., [0, 2, 1, 3, 4]]).max() <= 1e-12 * scale
     assert np.abs(u[..., 1]).max() > 0
+
+
+@pytest.mark.parametrize("where", [(33, 64), (0, 5), (69, 129), (1, 60)])
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+@pytest.mark.parametrize("poison", ["nan", "negative_density", "negative_energy"])
+def test_bad_states_raise_the_status_word_and_nothing_else(eng, poison, arith, where):
+    """Where the reference would end in `negative density in updated state` or carry NaNs on, the device cannot throw: the status word
+    (MH_STATUS_NEG_DENSITY covers NaN too) is raised, it reads back once (cleared by the read), and a clean state afterwards leaves it at 0."""
+    from mara3_amd import setups
+    shape, gamma = (70, 130), 5.0 / 3
+    u0 = setups.blast_ic(shape, gamma, radius=0.3)
+    bad = u0.copy()
+    if poison == "nan":
+        bad[where + (0,)] = np.nan
+    elif poison == "negative_density":
+        bad[where + (0,)] = -1.0
+    else:
+        bad[where + (4,)] = -50.0                  # negative pressure: sound speeds become NaN around the cell
+    s = eng.EulerCartSolver(shape, (1.0 / shape[0], 1.0 / shape[1]), gamma, 1.5, "hllc", 2, "outflow", arith=arith)
+    s.upload(bad)
+    s.step(1e-3, 1)
+    assert s.status() != 0
+    s.upload(u0)
+    s.step(1e-3, 2)
+    assert s.status() == 0
+    s.close()
