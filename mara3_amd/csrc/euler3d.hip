@@ -187,6 +187,7 @@ void euler3d_stage_kernel(Stage3dParams p)
     }
     State5 Uin = load_plane(in + row_off(r0 + 2), plane, c0);      // plane r+2, in flight for one iteration
     int32_t bad = 0;
+    if (!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)) bad |= 1;      // negative / NaN pressure is flagged where it appears (see euler2d.hip)
 
     // One plane. ONE workgroup barrier: before it every wave publishes the primitives of its row of plane r (and the helper
     // waves those of the outside rows) and does the axis-0 and axis-2 work, which needs no other wave; after it every wave
@@ -207,6 +208,7 @@ void euler3d_stage_kernel(Stage3dParams p)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(Uin, gl);
+        if (!(P[K2][4] >= 0.0)) bad |= 1;
         lds_put(tile.U[row][K2], lane, Uin);
         Uin = Unext;
         if constexpr (PLM)

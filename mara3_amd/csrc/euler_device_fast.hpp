@@ -34,12 +34,13 @@ __device__ inline double rsqrt_fast(double x)
     return __builtin_fma(y, __builtin_fma(0.375, e, 0.5) * e, y); // y (1 + e / 2 + 3 e^2 / 8)
 }
 
-// returns g ~ sqrt(x) and h2 ~ 1/sqrt(x) (x > 0; x == 0 gives g = 0, h2 = NaN)
+// returns g ~ sqrt(x) and h2 ~ 1/sqrt(x) (x > 0; x == 0 gives g = 0, h2 = NaN; x < 0 gives NaN for both, as sqrt does)
 __device__ inline void sqrt_rsqrt(double x, double& g, double& h2)
 {
     h2 = rsqrt_fast(x);
     const double gg = x * h2;
-    g = __builtin_fmax(__builtin_fma(__builtin_fma(-gg, gg, x), 0.5 * h2, gg), 0.0);      // one correction step; NaN (x == 0) -> 0
+    const double gc = __builtin_fma(__builtin_fma(-gg, gg, x), 0.5 * h2, gg);             // one correction step
+    g = x == 0.0 ? 0.0 : gc;                                                               // a negative x keeps its NaN
 }
 
 __device__ inline double sqrt_fast(double x)

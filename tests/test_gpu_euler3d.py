@@ -109,3 +109,26 @@ def test_config5_full_rank_size_symmetry_and_conservation(eng):
         assert np.abs(u - mirror).max() <= 1e-12 * scale, axis
         del mirror
     assert (u[..., 0] > 0).all() and np.abs(u[n // 2, n // 2, :, 3]).max() > 0      # the blast edge on the central line is moving
+
+
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+@pytest.mark.parametrize("poison", ["nan", "negative_density", "negative_energy"])
+def test_bad_states_raise_the_status_word_3d(eng, poison, arith):
+    from mara3_amd import setups
+    shape, gamma = (24, 20, 70), 5.0 / 3
+    u0 = setups.blast_ic(shape, gamma, radius=0.3)
+    bad = u0.copy()
+    if poison == "nan":
+        bad[11, 9, 33, 0] = np.nan
+    elif poison == "negative_density":
+        bad[0, 3, 64, 0] = -1.0
+    else:
+        bad[23, 19, 1, 4] = -50.0
+    s = eng.EulerCartSolver(shape, tuple(1.0 / n for n in shape), gamma, 1.5, "hlle", 2, "outflow", arith=arith)
+    s.upload(bad)
+    s.step(1e-3, 1)
+    assert s.status() != 0
+    s.upload(u0)
+    s.step(1e-3, 2)
+    assert s.status() == 0
+    s.close()
