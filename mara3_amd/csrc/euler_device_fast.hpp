@@ -3,12 +3,13 @@
 // BASELINE.json's tolerance allows (conserved-variable L1 <= 1e-12 vs the
 // reference; NOT bit-exact):
 //   * explicit fused multiply-adds,
-//   * x / d  ->  x * r with r = v_rcp_f64(d) + two Newton steps (~1 ulp), one r per denominator,
-//   * sqrt via v_rsq_f64 + Goldschmidt (the correctly-rounded fix-up steps dropped),
+//   * x / d  ->  x * r with r = v_rcp_f64(d) + one third-order step (0.5 ulp measured), one r per denominator,
+//   * inverse roots via v_rsq_f64 + one third-order step (< 1 ulp); sqrt(x) = x * rsqrt(x) + one correction,
 //   * the literal 0.0 / 1.0 normal-vector products removed (exact for finite data),
-//   * the PLM sign factor 0.25*|sgn a + sgn b|*(sgn a + sgn c) evaluated with integer sign-bit
-//     logic (identical except for the sign of an exact zero).
-// Roughly half the fp64 issue slots of the strict path; see DESIGN.md for the measured difference.
+//   * the limiter as max(0, min(a, b, c)) + min(0, max(a, b, c)) (identical to the sign-product form for finite arguments except for
+//     the sign of an exact zero), its one-sided differences formed once per face where the kernel can share them,
+//   * HLLC with wave speeds from the primitives, the conserved state and flux of the sampled side only, region choice by selects.
+// Less than half the executed instructions of the strict path; see DESIGN.md §5.2 / §6 for the measured difference.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "euler_device.hpp"
