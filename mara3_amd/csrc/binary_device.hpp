@@ -27,7 +27,7 @@ struct BinaryConsts
 
 // ---- arithmetic policies ----------------------------------------------------------------------------------------------
 // BinStrict: reference operation order, IEEE division / sqrt (shared-denominator form), no contraction.
-// BinFast:   MH_ARITH_FAST as in euler_device_fast.hpp: reciprocal + two Newton steps per denominator, rsq-Goldschmidt square
+// BinFast:   MH_ARITH_FAST as in euler_device_fast.hpp: reciprocal and inverse root = hardware estimate + one third-order step, one per denominator; square
 //            roots (1 / sqrt directly where the reference divides by a root), FMAs, min/max limiter. Tolerance as STRICT's
 //            (which already differs from the reference through libm): 1e-12 of the field scale, tests/test_gpu_binary.py.
 struct BinStrict

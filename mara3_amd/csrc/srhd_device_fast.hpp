@@ -1,6 +1,6 @@
 // MH_ARITH_FAST device physics for mara::srhd on gfx950: the formulas of srhd_device.hpp (same reference lines) with the
-// arithmetic freedoms of euler_device_fast.hpp - x / d as x * (v_rcp_f64 + two Newton steps), sqrt via v_rsq_f64 +
-// Goldschmidt, explicit FMAs, no literal 0/1 normal-vector products. NOT bit-exact: bound by the north star's tolerance
+// arithmetic freedoms of euler_device_fast.hpp - x / d as x * (v_rcp_f64 + one third-order step), sqrt via v_rsq_f64 +
+// one third-order step and a correction, explicit FMAs, no literal 0/1 normal-vector products. NOT bit-exact: bound by the north star's tolerance
 // (conserved-variable L1 <= 1e-12 relative to the field scale, asserted in tests/test_gpu_srhd_cloud.py::test_fast_*).
 // The Newton iteration of recover_primitive keeps the reference's start value, update and stopping rule, so it walks the
 // same sequence of iterates up to rounding; where |f| lands within rounding of the 1e-10 threshold one more or one fewer
