@@ -6,7 +6,7 @@
 // form) plus, when stage_weight != 1, the RK combine of
 // src/subprog_cloud.cpp:682-695.
 //
-// Design (HBM-bound stencil with ~800 fp64 issue slots per cell, no MFMA):
+// Design (HBM-bound stencil with ~400 (fast) to ~900 (strict) issue slots per cell-row, no MFMA):
 //  * One 64-lane wavefront owns a strip of 60 columns (+2 halo lanes on each
 //    side) and MARCHES along axis 0 over `chunk_rows` rows. Lanes run along
 //    axis 1, the contiguous axis, so every plane access is one coalesced 512 B
@@ -26,6 +26,12 @@
 //  * Boundary conditions need no branches in the row loop: axis-1 ghosts are
 //    clamped / wrapped column indices computed once per wave; axis-0 ghosts are
 //    two stored rows per side, refreshed by whichever wave writes the edge rows.
+//  * Launch order: workgroups are dealt round-robin over the 8 XCDs, so the
+//    work-item order keeps neighbouring tiles on one XCD (halo re-reads hit its
+//    L2); a large launch ends on short waves (graded tail) in every XCD's share.
+//  * Arithmetic is a template policy: StrictArith (bit-identical to the
+//    reference) or FastArith (euler_device_fast.hpp; there the register window
+//    holds primitives only and limiter differences are shared between cells).
 //
 // Algorithmic HBM bytes per cell per stage: 80 (first stage) / 120 (second
 // stage of RK2) => 200 B per zone-update for RK2.
