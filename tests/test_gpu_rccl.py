@@ -131,9 +131,10 @@ def test_native_slab_staggered_edges_survive_interruptions(rk_order, shape):
     st.close()
 
 
+@pytest.mark.parametrize("on_launch", [1, 0])
 @pytest.mark.parametrize("delay", [1, 2, 3])
 @pytest.mark.parametrize("stagger", [0, 4])
-def test_native_slab_dependencies_hold_under_shifted_timing(delay, stagger, monkeypatch):
+def test_native_slab_dependencies_hold_under_shifted_timing(delay, stagger, on_launch, monkeypatch):
     """The two-chain schedule of the native stepper (edge -> exchange on one stream, interior on the other) with a ~150 us sleeping
     wave queued in front of the edge launches (1), the interior launches (2) or both (3): whatever the relative timing of the chains,
     the events alone must order them. With and without staggered edges."""
@@ -143,6 +144,7 @@ def test_native_slab_dependencies_hold_under_shifted_timing(delay, stagger, monk
     from mara3_amd.engine import EulerCartSolver
     monkeypatch.setenv("MH_SLAB_TEST_DELAY", str(delay))
     monkeypatch.setenv("MH_SLAB_STAGGER", str(stagger))
+    monkeypatch.setenv("MH_SLAB_EVENT_ON_LAUNCH", str(on_launch))      # events carried by the launches, or recorded behind them
     shape, gamma = (192, 260), 1.4
     dl = (1.0 / shape[0], 1.0 / shape[1])
     u0 = setups.wave_ic(shape, gamma, seed=12)
