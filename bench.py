@@ -8,10 +8,21 @@
 One process per GPU. The global 4096^2 grid is cut into axis-0 slabs with the reference's partition formula
 (strong scaling: total work fixed), ghost rows travel as RCCL send/recv. A "step" is one full RK2 time step
 of the whole grid; inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line with the
-contract keys plus `roofline` (dominant kernel: the second, combining RK2 stage) and, at N=1, `cpu_baseline`
-(the parity-pinned plain-C restatement of the reference's thread-slab CPU path, timed on the host cores).
+contract keys plus
+
+  roofline, roofline_stage1, roofline_step   the headline leg (FAST arithmetic, HLLC, blast): its two stage kernels against HBM
+  repeat_blocks                              4 more timed blocks of K steps of the same leg (spread of the measurement)
+  legs                                       the same measurement for the other variants, each with its own rooflines:
+                                             strict+HLLE (the variant pinned bit for bit to the reference), fast+HLLE, strict+HLLC, and
+                                             the smooth periodic wave of SURVEY.md §8d (every face in a shock / rarefaction branch)
+  extra_configs                              BASELINE configs 3, 4, 5 on this GPU (bench_configs.py), N = 1 only
+  cpu_baseline / cpu_reference               N = 1 only: the oracle and the reference's own lazy-array composition on the host cores
+
+Timing: the timed region is the product path (HIP-graph replay at N = 1, eager two-stream issue with RCCL at N > 1), no events in it.
+The per-kernel durations behind the rooflines come from HIP events riding on the launches, in a short separate pass right after it.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -50,10 +61,32 @@ def host_cores():
     return min(cores, int(os.environ.get("MARA_BENCH_CPU_THREADS", "64")))
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources: PMC traffic recorded for other sources is not reported (see `traffic`)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mara3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC runs (profiles/pmc_traffic.json), or None when the kernel sources have
+    changed since they were taken. Never measured inside this run: PMC collection needs its own rocprofv3 passes."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if table.get("csrc_sha16") != csrc_fingerprint():
+            return None
+        return table.get(key)
+    except Exception:
+        return None
+
+
 def cpu_baseline(n, gamma, theta, riemann, budget_s=15.0):
     """Time the oracle (test infrastructure, used here ONLY as the reported CPU baseline) on the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import mara_oracle
     from mara3_amd import setups
     cores = host_cores()
@@ -68,17 +101,15 @@ def cpu_baseline(n, gamma, theta, riemann, budget_s=15.0):
     t0 = time.perf_counter()
     mara_oracle.euler_cart_run(u, dl, dt, steps, gamma, theta, 2, kind, mara_oracle.BC_OUTFLOW, nthreads=cores)
     t = time.perf_counter() - t0
-    out = {"value": n * n * steps / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
-           "sample": "%d RK2 steps of the same %dx%d PLM+%s workload, oracle/mara_oracle.c with %d slab threads"
-                     % (steps, n, n, riemann.upper(), cores)}
-    return out
+    return {"value": n * n * steps / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+            "sample": "%d RK2 steps of the same %dx%d PLM+%s workload, oracle/mara_oracle.c with %d slab threads"
+                      % (steps, n, n, riemann.upper(), cores)}
 
 
 def cpu_reference(gamma, theta):
     """If the reference-composed driver was prebuilt (oracle/_ref), time Mara3's own lazy-array path (1 thread)."""
     import subprocess
     import tempfile
-    import numpy as np
     from mara3_amd import setups
     exe = os.path.join(ROOT, "oracle", "_ref", "euler_cart_ref")
     if not os.path.exists(exe):
@@ -104,11 +135,26 @@ def cpu_reference(gamma, theta):
             "sample": "%d RK2 steps at %dx%d PLM+HLLE, reference headers composed as in oracle/ref_drivers/euler_cart_ref.cpp" % (steps, n, n)}
 
 
+def extra_configs(steps, warmup):
+    """BASELINE configs 3, 4, 5 on this GPU, each as a child process of bench_configs.py (its JSON line is embedded as is)."""
+    import subprocess
+    out = {}
+    for cfg in ("c3", "c4", "c5"):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py"), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup)],
+                               capture_output=True, text=True, timeout=900)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            out[cfg] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": (p.stderr or p.stdout)[-400:]}
+        except Exception as e:
+            out[cfg] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=4096, help="cells per axis of the global grid")
     ap.add_argument("--riemann", default="hllc", choices=["hllc", "hlle"])
     ap.add_argument("--theta", type=float, default=1.5)
@@ -116,26 +162,32 @@ def main():
     ap.add_argument("--arith", default="fast", choices=["strict", "fast"], help="arithmetic contract of the headline value")
     ap.add_argument("--stepper", default="native", choices=["native", "torch"],
                     help="native: C++ slab stepper of libmara_hip.so (RCCL called from the library); torch: Python stepper over torch.distributed")
-    ap.add_argument("--single-arith", action="store_true", help="do not also time the other arithmetic mode")
+    ap.add_argument("--single-arith", action="store_true", help="headline leg only: no other variants (legs), no extra configs")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of K steps of the headline leg (the first one is `value`)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--loopback-slabs", type=int, default=0,
+                    help="rehearsal on ONE GPU of the N > 1 code path: the grid as this many slab objects of the native stepper exchanging through its "
+                         "loopback backend (RCCL refuses two ranks on one device), incl. the partition check against the one-domain run")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import mara3_amd
     from mara3_amd import setups
-    from mara3_amd.slab import SlabEulerStepper
+    from mara3_amd.slab import SlabEulerStepper, NativeSlabStepper, NativeSlabGroup, native_comm_id, partition_rows
+    from mara3_amd.slab import slab_fingerprint as slab_checksum
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "MARA_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N>1 code path on a one-GPU box
-        local_rank = int(os.environ["MARA_BENCH_FORCE_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.loopback_slabs and world != 1:
+        raise SystemExit("--loopback-slabs is a one-GPU rehearsal")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     mara3_amd.load_library()           # fails loudly if the HIP library is missing
@@ -147,6 +199,7 @@ def main():
     n, gamma = args.n, 5.0 / 3
     dl = (1.0 / n, 1.0 / n)
     dt = setups.baseline_dt(n)
+    nslabs = args.loopback_slabs if args.loopback_slabs else world
 
     def fence():
         torch.cuda.synchronize()
@@ -154,24 +207,47 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from mara3_amd.slab import NativeSlabStepper, native_comm_id
-
     state = {"stepper": args.stepper}
 
-    def make_stepper(arith):
+    class GroupAsStepper:
+        """--loopback-slabs: the N slab objects of one process behind the stepper interface the timing code uses"""
+        def __init__(self, arith, riemann, bc):
+            self.g = NativeSlabGroup((n, n), dl, gamma, args.theta, riemann, 2, bc, world=nslabs, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+            self.row0, self.row1 = 0, n
+            self.member = NativeSlabStepper((n, n), dl, gamma, handle=torch_free_handle(self.g, nslabs // 2))      # profiled member: an inner rank
+        def load_slab(self, u): self.g.upload(u)
+        def step(self, dt_, k): self.g.step(dt_, k)
+        def synchronize(self): self.g.synchronize()
+        def profile(self, on): self.member.profile(on)
+        def profile_read(self): return self.member.profile_read()
+        def status(self): return self.g.status()[0]
+        def slab_host(self): return self.g.download()
+        def close(self):
+            self.member.handle = None
+            self.g.close()
+
+    def torch_free_handle(group, r):
+        import ctypes
+        return ctypes.c_void_p(group.handles[r])
+
+    def make_stepper(arith, riemann, bc):
+        if args.loopback_slabs:
+            return GroupAsStepper(arith, riemann, bc)
         if state["stepper"] == "native":
             st, err = None, None
             try:
-                # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
-                comm_id = native_comm_id(rank, world, device="cuda") if world > 1 else None
-                st = NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
-                                       comm_id=comm_id, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+                # without a communicator first: ncclCommInitRank is collective, so every rank must have got this far before any enters it
+                st = NativeSlabStepper((n, n), dl, gamma, args.theta, riemann, 2, bc, rank=rank, world=world,
+                                       comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
             except mara3_amd.MaraHipError as e:
                 err = e
             ok = torch.tensor([0 if st is None else 1], device="cuda")
             if world > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must take the same path
             if int(ok.item()) == 1:
+                if world > 1:
+                    # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
+                    st.connect(native_comm_id(rank, world, device="cuda"))
                 return st
             if world == 1:
                 raise err
@@ -180,52 +256,60 @@ def main():
             if st is not None:
                 st.close()
             state["stepper"] = "torch"
-        return SlabEulerStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=rank, world=world,
+        return SlabEulerStepper((n, n), dl, gamma, args.theta, riemann, 2, bc, rank=rank, world=world,
                                 device="cuda", overlap=not args.no_overlap, chunk_rows=args.chunk_rows, arith=arith)
 
-    def prime(arith):
+    def prime(arith, riemann):
         """One step of a 128 x 128 throw-away problem: first-use costs of the library (code-object load, stream and event creation) are
         initialisation, not part of a step of the workload - they must not land in the timed region when the caller asks for W = 0."""
-        tiny = NativeSlabStepper((128, 128), (1.0 / 128, 1.0 / 128), gamma, args.theta, args.riemann, 2, "outflow", device=local_rank, arith=arith)
+        tiny = NativeSlabStepper((128, 128), (1.0 / 128, 1.0 / 128), gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith)
         tiny.load_slab(setups.blast_ic((128, 128), gamma))
         tiny.step(setups.baseline_dt(128), 1)
         tiny.synchronize()
         tiny.close()
 
-    def run_mode(arith):
-        """W untimed + K timed steps of the whole (slab-decomposed) grid in one arithmetic mode."""
-        if state["stepper"] == "native" and args.warmup == 0:      # with W >= 1 the warm-up steps do this (and a profile of the run shows the workload's launches only)
-            prime(arith)
-        st = make_stepper(arith)
-        st.load_slab(setups.blast_ic((n, n), gamma, row_range=(st.row0, st.row1)))
-        native = isinstance(st, NativeSlabStepper)
+    def initial_state(workload, row0, row1):
+        if workload == "blast":
+            return setups.blast_ic((n, n), gamma, row_range=(row0, row1))
+        return setups.smooth_wave_ic((n, n), gamma, row_range=(row0, row1))
+
+    def run_leg(arith, riemann, workload, nblocks=1, keep_state=False):
+        """W untimed + K timed steps (+ nblocks - 1 further timed blocks of K) of the whole grid, then a short profiled pass."""
+        bc = "outflow" if workload == "blast" else "periodic"
+        native = state["stepper"] == "native" or bool(args.loopback_slabs)
+        if native and args.warmup == 0:      # with W >= 1 the warm-up steps do this (and a profile of the run shows the workload's launches only)
+            prime(arith, riemann)
+        st = make_stepper(arith, riemann, bc)
+        native = not isinstance(st, SlabEulerStepper)
+        st.load_slab(initial_state(workload, st.row0, st.row1))
         st.step(dt, args.warmup)
         if native:
             st.synchronize()
-        fence()
-        # HIP events around every bulk stage launch, on the stream it is launched on. At N = 1 they are recorded in
-        # the timed region itself; at N > 1 in a short extra pass, so that the timed region carries no event traffic.
-        live = world == 1
-        if live:
-            if native:
-                st.profile(True)
-            else:
-                st.timers = []
-        t0 = time.perf_counter()
-        st.step(dt, args.steps)
-        if native:
-            st.synchronize()
-        fence()
-        elapsed = time.perf_counter() - t0
-        if not live:
-            if native:
-                st.profile(True)
-            else:
-                st.timers = []
-            st.step(dt, 3)
+        block_ms = []
+        for b in range(nblocks):
+            fence()
+            t0 = time.perf_counter()
+            st.step(dt, args.steps)
             if native:
                 st.synchronize()
             fence()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            block_ms.append(elapsed / args.steps * 1e3)
+        # HIP events around every bulk stage launch, on the stream it is launched on: a separate short pass, so that the timed region
+        # is the un-instrumented product path (graph replay without neighbours)
+        nprof = 5
+        if native:
+            st.profile(True)
+        else:
+            st.timers = []
+        st.step(dt, nprof)
+        if native:
+            st.synchronize()
+        fence()
         if native:
             (avg1, avg2), (nl1, nl2), bulk_rows = st.profile_read()
             st.profile(False)
@@ -237,44 +321,56 @@ def main():
             avg1 = sum(dur[1.0]) / max(1, len(dur[1.0]))
             avg2 = sum(dur[0.5]) / max(1, len(dur[0.5]))
             nl1, nl2, bulk_rows = len(dur[1.0]), len(dur[0.5]), st.n0 - 2 * st.edge_rows
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
         cells_launch = bulk_rows * n
-        value = n * n * args.steps / elapsed / 1e6
+        ms = block_ms[0]
+        value = n * n / ms / 1e3
+        timing = "HIP events riding on the launches, %d extra steps right after the timed region" % nprof
+
+        def kernel_roofline(nbytes, avg, nl, name, traffic_key):
+            ach = cells_launch * nbytes / (avg * 1e-3) / 1e9 if avg > 0 else None
+            r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+                 "traffic": recorded_traffic(traffic_key) if (world == 1 and not args.loopback_slabs and n == 4096 and workload == "blast") else None,
+                 "kernel": name, "algorithmic_bytes_per_launch": cells_launch * nbytes, "avg_launch_ms": avg, "launches": nl, "timing": timing}
+            if r["traffic"] is None:
+                r["traffic_note"] = "no rocprofv3 PMC record for this kernel build / workload (profiles/pmc_traffic.json is keyed by the kernel sources' hash)"
+            else:
+                r["traffic_note"] = "recorded: rocprofv3 PMC passes of these kernel sources (profiles/pmc_traffic.json), not measured in this run"
+            return r
+
         res = {
-            "value": value, "ms_per_step": elapsed / args.steps * 1e3, "status_word": st.status(),
-            "roofline": {"bound": "hbm", "achieved": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": cells_launch * BYTES_STAGE2 / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, args.riemann),
-                         "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE2, "avg_launch_ms": avg2, "launches": nl2,
-                         "timing": "HIP events on the launch stream, %s" % ("inside the timed region" if live else "3 extra steps after the timed region")},
-            "roofline_stage1": {"achieved": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9,
-                                "frac": cells_launch * BYTES_STAGE1 / (avg1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "algorithmic_bytes_per_launch": cells_launch * BYTES_STAGE1, "avg_launch_ms": avg1, "launches": nl1},
+            "value": value, "ms_per_step": ms, "status_word": st.status(),
+            "roofline": kernel_roofline(BYTES_STAGE2, avg2, nl2, "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, riemann),
+                                        "stage2_%s_%s_bytes_per_launch" % (arith, riemann)),
+            "roofline_stage1": kernel_roofline(BYTES_STAGE1, avg1, nl1, "euler2d_stage_kernel<%s,%s,PLM> (first RK2 stage)" % (arith, riemann),
+                                               "stage1_%s_%s_bytes_per_launch" % (arith, riemann)),
             "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
                               "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
         }
-        final = torch.from_numpy(st.slab_host()) if native else st.u[2:2 + st.n0].permute(0, 2, 1).contiguous().cpu()
+        if nblocks > 1:
+            rest = sorted(block_ms[1:])
+            res["repeat_blocks"] = {"ms_per_step": block_ms[1:], "median_ms_per_step": rest[len(rest) // 2], "min": rest[0], "max": rest[-1],
+                                    "note": "%d further timed blocks of %d steps of the same leg, same bracketing" % (nblocks - 1, args.steps)}
+        final = None
+        if keep_state:
+            final = torch.from_numpy(st.slab_host()) if native else st.u[2:2 + st.n0].permute(0, 2, 1).contiguous().cpu()
         if native:
             st.close()
-        return res, final
+        return res, final, args.warmup + nblocks * args.steps + nprof
 
-    from mara3_amd.slab import slab_fingerprint as slab_checksum
-
-    def partition_check(arith, u_slab):
-        """N > 1: the union of the ranks' slabs against the SAME run on one GPU (rank 0 repeats it alone, outside the timed region):
-        per-arithmetic results do not depend on the partition, so the slab fingerprints must match bit for bit."""
-        nsteps_total = args.warmup + args.steps + 3
-        mine = torch.tensor(slab_checksum(u_slab), dtype=torch.int64, device="cuda")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
+    def partition_check(arith, riemann, u_mine, nsteps_total):
+        """N > 1 (or --loopback-slabs): the union of the ranks' slabs against the SAME run on one GPU (rank 0 repeats it alone, outside the
+        timed region): per-arithmetic results do not depend on the partition, so the slab fingerprints must match bit for bit."""
+        if args.loopback_slabs:
+            every = [slab_checksum(u_mine[slice(*partition_rows(n, nslabs, r))]) for r in range(nslabs)]
+        else:
+            mine = torch.tensor(slab_checksum(u_mine), dtype=torch.int64, device="cuda")
+            gathered = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            every = [[int(x) for x in g.tolist()] for g in gathered]
         ok = None
         if rank == 0:
             try:                                   # nothing here may keep rank 0 from the barrier below
-                from mara3_amd.slab import partition_rows
-                one = NativeSlabStepper((n, n), dl, gamma, args.theta, args.riemann, 2, "outflow", rank=0, world=1, device=local_rank,
+                one = NativeSlabStepper((n, n), dl, gamma, args.theta, riemann, 2, "outflow", rank=0, world=1, device=local_rank,
                                         chunk_rows=args.chunk_rows, arith=arith)
                 one.load_slab(setups.blast_ic((n, n), gamma))
                 one.step(dt, nsteps_total)
@@ -282,40 +378,51 @@ def main():
                 whole = torch.from_numpy(one.slab_host())
                 one.close()
                 ok = True
-                for r in range(world):
-                    a, b = partition_rows(n, world, r)
-                    ok = ok and slab_checksum(whole[a:b]) == [int(x) for x in every[r].tolist()]
+                for r in range(nslabs):
+                    a, b = partition_rows(n, nslabs, r)
+                    ok = ok and slab_checksum(whole[a:b]) == every[r]
             except Exception as e:
                 print("bench.py: partition check not completed: %r" % (e,), file=sys.stderr)
                 ok = None
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         return ok
 
     primary = args.arith
     other = "strict" if primary == "fast" else "fast"
-    res, u_primary = run_mode(primary)
-    partition_ok = partition_check(primary, u_primary) if world > 1 and state["stepper"] == "native" else None
-    res_other, u_other = (None, None) if args.single_arith else run_mode(other)
-    l1 = None
-    if u_other is not None:
-        s = (u_primary - u_other).abs().sum().to("cuda")
-        if world > 1:
-            dist.all_reduce(s)
-        l1 = float(s.item()) / (n * n * 5)
-    del u_primary, u_other
+    decomposed = world > 1 or bool(args.loopback_slabs)
+    res, u_primary, nsteps_primary = run_leg(primary, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True)
+    partition_ok = partition_check(primary, args.riemann, u_primary, nsteps_primary) if decomposed and state["stepper"] == "native" else None
+
+    arith_note = {"strict": "strict: bit-identical to the reference CPU path (tests/test_gpu_parity.py, golden vectors from reference headers)",
+                  "fast": "fast: FMA + shared reciprocals, conserved-variable L1 <= 1e-12 vs the reference CPU path (tests/test_gpu_parity.py::test_fast_*)"}
+    pin_note = {"hlle": "HLLE: pinned to the reference (golden vectors from its own headers)",
+                "hllc": "HLLC: parity unpinned - no Euler HLLC exists upstream; GPU == the repo's C restatement bit for bit + exact-Riemann-solver tests"}
+    legs, l1 = {}, None
+    if not args.single_arith:
+        # same workload, other arithmetic (and the L1 distance between the two after the same number of steps)
+        r2, u_other, nsteps_other = run_leg(other, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True)
+        legs["%s_%s_blast" % (other, args.riemann)] = r2
+        if nsteps_other == nsteps_primary:
+            s = (u_primary - u_other).abs().sum().to("cuda")
+            if world > 1:
+                dist.all_reduce(s)
+            l1 = float(s.item()) / (n * n * 5)
+        del u_other
+        other_riemann = "hlle" if args.riemann == "hllc" else "hllc"
+        more = [("strict", other_riemann, "blast"), ("fast", other_riemann, "blast")]
+        if n % 2 == 0:
+            more += [(primary, args.riemann, "smooth_wave"), ("strict", "hlle", "smooth_wave")]
+        for (a, r, w) in more:
+            legs["%s_%s_%s" % (a, r, w)] = run_leg(a, r, w)[0]
+        for key, leg in legs.items():
+            a, r, w = key.split("_", 2)
+            leg["note"] = "%s; %s; workload: %s" % (arith_note[a], pin_note[r],
+                                                    "Sedov-type blast, outflow" if w == "blast" else
+                                                    "smooth periodic wave rho = 1 + 0.2 sin(2 pi x) sin(2 pi y), p = rho^gamma, v = (0.5, 0.25) (SURVEY.md §8d)")
+    del u_primary
 
     if rank == 0:
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and world == 1 and n == 4096:
-            try:
-                table = json.load(open(pmc))
-                res["roofline"]["traffic"] = table.get("stage2_%s_%s_bytes_per_launch" % (primary, args.riemann))
-                if res_other:
-                    res_other["roofline"]["traffic"] = table.get("stage2_%s_%s_bytes_per_launch" % (other, args.riemann))
-            except Exception:
-                pass
-        arith_note = {"strict": "strict: bit-identical to the reference CPU path (tests/test_gpu_parity.py, golden vectors from reference headers)",
-                      "fast": "fast: FMA + shared reciprocals, conserved-variable L1 <= 1e-12 vs the reference CPU path (tests/test_gpu_parity.py::test_fast_*)"}
         out = {
             "metric": "zone-updates/sec (Mcells/s) whole node, 2D Euler %d^2 PLM+%s RK2" % (n, args.riemann.upper()),
             "value": res["value"], "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,23 +430,30 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
-                       "decomposition": "axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, state["stepper"]),
-                       "arith": arith_note[primary], "status_word": res["status_word"]},
+                       "decomposition": ("axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, state["stepper"]))
+                                        if not args.loopback_slabs else
+                                        ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
+                       "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
+                       "timed_region": "HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage"},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
+        if "repeat_blocks" in res:
+            out["repeat_blocks"] = res["repeat_blocks"]
         if partition_ok is not None:
             out["slabs_bit_identical_to_one_gpu_run"] = bool(partition_ok)
-        if res_other:
-            out["arith_" + other] = {"note": arith_note[other], "value": res_other["value"], "ms_per_step": res_other["ms_per_step"],
-                                     "roofline": res_other["roofline"], "roofline_step": res_other["roofline_step"],
-                                     "status_word": res_other["status_word"]}
-            out["l1_fast_vs_strict_after_%d_steps" % (args.steps + args.warmup)] = l1
-        if world == 1 and not args.no_cpu_baseline:
+        if legs:
+            out["legs"] = legs
+        if l1 is not None:
+            out["l1_fast_vs_strict_after_%d_steps" % nsteps_primary] = l1
+        if world == 1 and not args.loopback_slabs:
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(n, gamma, args.theta, args.riemann)
-            ref = cpu_reference(gamma, args.theta)
-            if ref:
-                out["cpu_reference"] = ref
+            if not args.single_arith and not args.no_extra_configs and n == 4096:
+                out["extra_configs"] = extra_configs(20, 3)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(n, gamma, args.theta, args.riemann)
+                ref = cpu_reference(gamma, args.theta)
+                if ref:
+                    out["cpu_reference"] = ref
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -66,6 +66,18 @@ enum mh_status
 {
     MH_STATUS_NEG_DENSITY = 1, MH_STATUS_NEG_PRESSURE = 2, MH_STATUS_C2P_FAILED = 4, MH_STATUS_NAN = 8
 };
+/* What a step reports back: the OR of the mh_status bits raised by any cell, and the flat index (row-major, the
+ * order of the host array handed to mh_upload / mh_slab_upload / mh_binary_set_solution) of the FIRST cell that raised one;
+ * UINT64_MAX when status == 0. The Euler kernels raise NEG_DENSITY (updated density <= 0), NEG_PRESSURE (recovered pressure < 0)
+ * and NAN (either is NaN); the SRHD kernels raise the bit of each `throw` of mara::srhd::recover_primitive
+ * (src/physics_srhd.hpp:430-449); `binary` raises NEG_DENSITY where validate_u throws (src/subprog_binary_scheme.cpp:726-752).
+ * On the device this is int32[2] = {bits, 0xFFFFFFFF - first local flat index (0: none)}, both order-independent atomics. */
+typedef struct
+{
+    int32_t  status;
+    int32_t  reserved;
+    uint64_t first_bad_index;
+} mh_step_result;
 
 /* ------------------------------------------------------------------------ */
 /* Uniform cartesian Euler (BASELINE configs 2 and 5): stateless launchers.   */
@@ -88,6 +100,8 @@ typedef struct
     int    bc_transverse;   /* MH_BC_OUTFLOW or MH_BC_PERIODIC on axes 1 (and 2) */
     int    arith;           /* enum mh_arith */
     int    chunk_rows;      /* rows marched per wave (0 = default) */
+    int    tail_rows;       /* graded tail: the LAST tail_rows rows of a launch go to short waves of tail_chunk_rows rows */
+    int    tail_chunk_rows; /* (0, 0 = the measured default on large grids; tail_rows < 0 = off). Read at configure time. */
 } mh_euler_cart_desc;
 
 /* number of doubles one device field of this description occupies: (n0+4) * 5 * row_pitch */
@@ -169,6 +183,8 @@ typedef struct
     int    bc_lo0, bc_hi0;      /* MH_BC_INFLOW / MH_BC_OUTFLOW on physical sides, MH_BC_EXTERNAL on slab cuts */
     int    arith;               /* MH_ARITH_STRICT */
     int    chunk_rows;          /* rows marched per wave (0 = default) */
+    int    tail_rows;           /* graded tail, as in the cartesian descriptor: 0, 0 = default; tail_rows < 0 = off */
+    int    tail_chunk_rows;
 } mh_cloud_desc;
 
 /* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] */
@@ -200,8 +216,15 @@ int  mh_download(mh_ctx* ctx, double* u_aos_host, size_t ncell);         /* devi
 /* nsteps full time steps (all RK stages) with fixed dt, like the reference's cloud/sedov drivers. */
 int  mh_step(mh_ctx* ctx, double dt, int nsteps);
 int  mh_synchronize(mh_ctx* ctx);
-/* OR of mh_status bits since the last call (reads back 4 bytes; synchronises). */
+/* OR of mh_status bits since the last call (reads back 8 bytes; synchronises) / the same with the first failing cell. Both clear. */
 int  mh_status_word(mh_ctx* ctx, int32_t* status);
+int  mh_status(mh_ctx* ctx, mh_step_result* result);
+/* ONE full time step as a transaction (Euler and cloud contexts): the step's result goes to a third buffer and becomes the
+ * solution only if no cell raised a status bit; otherwise the call returns MH_E_PHYSICS, `result` says what and where, and the
+ * previous solution stays in place and downloadable, bit for bit - what the reference's callers rely on when they catch the
+ * exception and retry from the OLD solution (src/subprog_binary.cpp:285-292). Synchronises (one 8-byte read-back per step);
+ * mh_step stays the asynchronous in-place form for drivers that, like upstream's cloud / sedov, do not retry. */
+int  mh_step_checked(mh_ctx* ctx, double dt, mh_step_result* result);
 /* Raw device pointer of the current solution field (SoA with ghosts) and of the scratch field, for halo exchange. */
 double* mh_field_ptr(mh_ctx* ctx, int which /* 0 = current solution, 1 = stage scratch */);
 /* Average kernel time in ms of the stage launches since the last reset, measured with HIP events
@@ -210,12 +233,13 @@ int  mh_profile_enable(mh_ctx* ctx, int on);
 int  mh_profile_read(mh_ctx* ctx, double* avg_stage_ms, int* nlaunches);
 
 /* ------------------------------------------------------------------------ */
-/* Native slab stepper (one process per GPU): the 2-D Euler step with the     */
-/* axis-0 ghost exchange as RCCL send/recv over xGMI, overlapped with the     */
-/* interior update on a second stream and captured into one HIP graph.        */
-/* The cut is nd::partition_shape (src/core_ndarray.hpp:820-836), the         */
-/* execution policy it replaces is mara::evaluate_on<N> (src/app_parallel.hpp */
-/* :75-103) - thread slabs that share one address space upstream.             */
+/* Native slab stepper (one process per GPU): the Euler step (2-D, 3-D) and    */
+/* the `cloud` step (radial slabs) with the axis-0 ghost exchange as RCCL      */
+/* send/recv over xGMI, overlapped with the interior update on a second        */
+/* stream; without neighbours the Euler step is replayed from one HIP graph.   */
+/* The cut is nd::partition_shape (src/core_ndarray.hpp:820-836), the          */
+/* execution policy it replaces is mara::evaluate_on<N> (src/app_parallel.hpp  */
+/* :75-103) - thread slabs that share one address space upstream.              */
 /* ------------------------------------------------------------------------ */
 typedef struct mh_slab mh_slab;
 
@@ -226,6 +250,31 @@ int  mh_comm_unique_id(void* id128);
  * periodic axis 0 makes the rank exchange with itself (exercises the whole path on one GPU). */
 int  mh_slab_create(mh_slab** slab, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
                     const void* comm_id128, int self_exchange, int device_id);
+/* comm_id128 == NULL for a rank WITH neighbours defers the RCCL communicator: the host first lets every rank agree that creation
+ * succeeded and only then calls mh_slab_connect on all of them (ncclCommInitRank is collective: a rank that failed earlier would
+ * leave the others blocked inside it). */
+int  mh_slab_connect(mh_slab* slab, const void* comm_id128);
+/* `cloud` sub-program (BASELINE config 4: radial slabs + RCCL halo): CloudProblem::advance / next_solution
+ * (src/subprog_cloud.cpp:511-584, :676-697) on rows partition_shape(nr, world)[rank] of the global grid. `global` describes the
+ * WHOLE grid (nr == nr_global, row_offset 0); rank 0 keeps the nozzle-inflow boundary, the last rank the zero-gradient one, cut
+ * sides are MH_BC_EXTERNAL. Geometry is evaluated from the GLOBAL vertex arrays, so every cell sees the same bits as in the
+ * single-domain run. mh_slab_set_inflow: host AoS [nq][5] primitives of the inner ghost row at the step-start time (:466-493);
+ * every rank may call it, only the rank owning row 0 reads it. Stepping: mh_slab_step(slab, dt, 1, 0) per time step. */
+int  mh_slab_cloud_create(mh_slab** slab, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                          int rk_order, int rank, int world, const void* comm_id128, int device_id);
+int  mh_slab_set_inflow(mh_slab* slab, const double* inflow_prims_aos_host);
+/* LOOPBACK groups: all `world` slabs of a decomposition as objects of ONE process on one GPU. A "receive" is a stream-ordered
+ * device-to-device copy out of the neighbour object's field under the same event protocol; cut, ghost layout, edge / interior
+ * split and staggering are the code the RCCL ranks run. (RCCL itself refuses two ranks on one device.) This is how the multi-rank
+ * stepper is executed - ranks with lo != hi, mixed physical / external sides, uneven cuts - and compared bit for bit with the
+ * single-domain run on a one-GPU box. slabs[world] receives the handles (destroy each with mh_slab_destroy); the group calls take
+ * the global host array [N0][row_pitch][5] and drive the members in lockstep; mh_slab_download / _status / _rows work per member. */
+int  mh_slab_group_create(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, int device_id);
+int  mh_slab_cloud_group_create(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                                int rk_order, int world, int device_id);
+int  mh_slab_group_upload(mh_slab** slabs, int world, const double* u_aos_global_host);
+int  mh_slab_group_download(mh_slab** slabs, int world, double* u_aos_global_host);
+int  mh_slab_group_step(mh_slab** slabs, int world, double dt, int nsteps);
 void mh_slab_destroy(mh_slab* slab);
 int  mh_slab_rows(const mh_slab* slab, int* row0, int* row1);                 /* this rank's rows [row0, row1) */
 int  mh_slab_upload(mh_slab* slab, const double* u_aos_slab_host);            /* host AoS [n0][n1][5] of this rank's rows */
@@ -233,6 +282,7 @@ int  mh_slab_download(mh_slab* slab, double* u_aos_slab_host);
 int  mh_slab_step(mh_slab* slab, double dt, int nsteps, int use_graph);       /* use_graph: replay one captured step (RK2) */
 int  mh_slab_synchronize(mh_slab* slab);
 int  mh_slab_status_word(mh_slab* slab, int32_t* status);
+int  mh_slab_status(mh_slab* slab, mh_step_result* result);                   /* first_bad_index in the GLOBAL host array */
 double* mh_slab_field_ptr(mh_slab* slab, int which);
 /* HIP-event timing of the bulk (interior) stage launches in eager mode: avg_ms[0|1] = first | second RK stage */
 int  mh_slab_profile_enable(mh_slab* slab, int on);

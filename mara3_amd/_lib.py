@@ -30,7 +30,13 @@ class EulerCartDesc(C.Structure):
         ("bc_transverse", C.c_int),
         ("arith", C.c_int),
         ("chunk_rows", C.c_int),
+        ("tail_rows", C.c_int),
+        ("tail_chunk_rows", C.c_int),
     ]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("reserved", C.c_int32), ("first_bad_index", C.c_uint64)]
 
 
 class SedovDesc(C.Structure):
@@ -40,7 +46,7 @@ class SedovDesc(C.Structure):
 class CloudDesc(C.Structure):
     _fields_ = [("nr", C.c_int), ("nq", C.c_int), ("nr_global", C.c_int), ("row_offset", C.c_int), ("gamma", C.c_double),
                 ("plm_theta", C.c_double), ("temperature_floor", C.c_double), ("bc_lo0", C.c_int), ("bc_hi0", C.c_int),
-                ("arith", C.c_int), ("chunk_rows", C.c_int)]
+                ("arith", C.c_int), ("chunk_rows", C.c_int), ("tail_rows", C.c_int), ("tail_chunk_rows", C.c_int)]
 
 
 class BinaryDesc(C.Structure):
@@ -118,11 +124,22 @@ SYMBOLS = [
     ("mh_step", _i, [_vp, _d, _i]),
     ("mh_synchronize", _i, [_vp]),
     ("mh_status_word", _i, [_vp, C.POINTER(C.c_int32)]),
+    ("mh_status", _i, [_vp, C.POINTER(StepResult)]),
+    ("mh_step_checked", _i, [_vp, _d, C.POINTER(StepResult)]),
     ("mh_field_ptr", _vp, [_vp, _i]),
     ("mh_profile_enable", _i, [_vp, _i]),
     ("mh_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     ("mh_comm_unique_id", _i, [_vp]),
     ("mh_slab_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i, _i]),
+    ("mh_slab_connect", _i, [_vp, _vp]),
+    ("mh_slab_cloud_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i, _vp, _i]),
+    ("mh_slab_set_inflow", _i, [_vp, _vp]),
+    ("mh_slab_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
+    ("mh_slab_cloud_group_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i]),
+    ("mh_slab_group_upload", _i, [C.POINTER(_vp), _i, _vp]),
+    ("mh_slab_group_download", _i, [C.POINTER(_vp), _i, _vp]),
+    ("mh_slab_group_step", _i, [C.POINTER(_vp), _i, _d, _i]),
+    ("mh_slab_status", _i, [_vp, C.POINTER(StepResult)]),
     ("mh_slab_destroy", None, [_vp]),
     ("mh_slab_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     ("mh_slab_upload", _i, [_vp, _vp]),

@@ -183,6 +183,7 @@ struct mh_ctx
     int rk_order = 2;
     size_t field_doubles = 0;
     double* field[2] = {nullptr, nullptr};   // [0] current solution, [1] stage scratch
+    double* third = nullptr;                 // mh_step_checked: the step's result before it is committed (allocated on first use)
     double* staging = nullptr;               // AoS staging for upload/download
     size_t staging_doubles = 0;
     int32_t* status = nullptr;
@@ -268,6 +269,8 @@ int mh_create(mh_ctx** out, int device_id)
 static void release_fields(mh_ctx* c)
 {
     for (auto& f : c->field) { if (f) hipFree(f); f = nullptr; }
+    if (c->third) hipFree(c->third);
+    c->third = nullptr;
     if (c->geom) hipFree(c->geom);
     c->geom = nullptr;
     if (c->inflow) hipFree(c->inflow);
@@ -629,15 +632,69 @@ int mh_synchronize(mh_ctx* c)
     return MH_OK;
 }
 
-int mh_status_word(mh_ctx* c, int32_t* status)
+int mh_status(mh_ctx* c, mh_step_result* result)
 {
-    if (! c || ! status) return MH_E_INVALID;
+    if (! c || ! result) return MH_E_INVALID;
     MH_HIP_TRY(hipSetDevice(c->device));
-    int32_t h[2] = {0, 0};
+    uint32_t h[2] = {0, 0};
     MH_HIP_TRY(hipMemcpyAsync(h, c->status, sizeof h, hipMemcpyDeviceToHost, c->stream));
     MH_HIP_TRY(hipMemsetAsync(c->status, 0, sizeof h, c->stream));
     MH_HIP_TRY(hipStreamSynchronize(c->stream));
-    *status = h[0];
+    result->status = (int32_t) h[0];
+    result->reserved = 0;
+    result->first_bad_index = h[1] ? (uint64_t) (0xFFFFFFFFu - h[1]) : UINT64_MAX;      // device word: status_device.hpp
+    return MH_OK;
+}
+
+int mh_status_word(mh_ctx* c, int32_t* status)
+{
+    if (! status) return MH_E_INVALID;
+    mh_step_result r;
+    if (int rc = mh_status(c, &r)) return rc;
+    *status = r.status;
+    return MH_OK;
+}
+
+int mh_step_checked(mh_ctx* c, double dt, mh_step_result* result)
+{
+    if (! c || ! c->uploaded) { set_error("step before upload"); return ctx_fail(c, MH_E_STATE); }
+    if (! result) return MH_E_INVALID;
+    MH_HIP_TRY(hipSetDevice(c->device));
+    MH_HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int32_t), c->stream));       // the result speaks about THIS step only
+    double* committed = nullptr;              // the buffer that holds the step's result
+    if (c->kind == mh_ctx::KIND_SEDOV)
+    {
+        const int n = c->sedov.nz;
+        const double* dv = c->geom;
+        const double* da = dv + n;
+        const double* rc = da + n + 1;
+        MH_HIP_TRY(sedov_stage_launch(c->sedov.system, c->field[0], c->field[1], dv, da, rc, n, c->sedov.gamma, dt, c->status, c->stream));
+        committed = c->field[1];
+    }
+    else if (c->rk_order == 1)
+    {
+        MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+        committed = c->field[1];
+    }
+    else
+    {
+        if (! c->third)
+        {
+            if (hipMalloc((void**) &c->third, c->field_doubles * sizeof(double)) != hipSuccess) { set_error("hipMalloc of the third field (%zu bytes) failed", c->field_doubles * sizeof(double)); return ctx_fail(c, MH_E_NOMEM); }
+            MH_HIP_TRY(hipMemsetAsync(c->third, 0, c->field_doubles * sizeof(double), c->stream));
+        }
+        MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+        MH_HIP_TRY(timed_stage(c, c->field[1], c->field[0], c->third, dt, 0.5));       // NOT in place: field[0] survives a failed step
+        committed = c->third;
+    }
+    if (int rc = mh_status(c, result)) return ctx_fail(c, rc);
+    if (result->status != 0)
+    {
+        set_error("step rejected: status 0x%x, first failing cell %llu; the previous solution is unchanged", result->status, (unsigned long long) result->first_bad_index);
+        return ctx_fail(c, MH_E_PHYSICS);
+    }
+    if (committed == c->third) std::swap(c->field[0], c->third);
+    else                       std::swap(c->field[0], c->field[1]);
     return MH_OK;
 }
 

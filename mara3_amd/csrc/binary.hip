@@ -39,6 +39,7 @@
 #include <type_traits>
 #include "launch.hpp"
 #include "binary_device.hpp"
+#include "status_device.hpp"
 
 namespace mh {
 
@@ -178,7 +179,8 @@ void binary_stage_kernel(BinaryStageParams p)
     double part[NPART];
 #pragma unroll
     for (int k = 0; k < NPART; ++k) part[k] = 0.0;
-    int32_t bad = 0;
+    StatusAcc acc;        // validate_u (scheme.cpp:726-752) as status bits + first failing cell r * n + col (status_device.hpp)
+    double sigma_new = 0.0;
 
     auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
     {
@@ -279,8 +281,12 @@ void binary_stage_kernel(BinaryStageParams p)
                 const double u1 = u0[q] - l[q] + s;
                 if constexpr (COMBINE) Un[q] = Ubase[q] * (1.0 - p.weight) + u1 * p.weight;
                 else                   Un[q] = u1;
-                if (q == 0 && !(u1 >= 0.0)) bad |= 1;          // validate_u :726-752 (and NaN)
+                if (q == 0) sigma_new = u1;
             }
+        }
+        if (__any(!(sigma_new >= 0.0)))          // validate_u :726-752 (and NaN); a scalar branch never taken in a healthy run
+        {
+            if (writes && !(sigma_new >= 0.0)) acc.note_value(sigma_new, MH_STATUS_NEG_DENSITY, (uint32_t) r * (uint32_t) n + (uint32_t) col);
         }
         if (writes)
         {
@@ -308,11 +314,7 @@ void binary_stage_kernel(BinaryStageParams p)
         const double s = wave_sum(part[k]);
         if (lane == 0) p.partials[(long) w * NPART + k] = s;
     }
-    if (p.status)
-    {
-        const bool any_bad = __any(writes && bad);
-        if (any_bad && lane == 0) atomicOr(p.status, MH_STATUS_NEG_DENSITY);
-    }
+    acc.commit(p.status);
 }
 
 // ---- per-block sink sums and work --------------------------------------------------------------------------------

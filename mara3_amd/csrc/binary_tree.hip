@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "launch.hpp"
 #include "binary_device.hpp"
+#include "status_device.hpp"
 
 namespace mh {
 
@@ -212,7 +213,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
     double acc[NTREE_SUMS];
 #pragma unroll
     for (int k = 0; k < NTREE_SUMS; ++k) acc[k] = 0.0;
-    int bad = 0;
+    StatusAcc sacc;       // validate_u as status bits + first failing cell (block * bs + i) * bs + j, the order of mh_binary_get_solution
     // grid = (blocks, tiles of 256 cells): one cell per thread, a partial sum per tile (a 64-block tree would otherwise run on 64 CUs)
     for (int idx = blockIdx.y * 256 + threadIdx.x; idx < bs * bs; idx += 256 * gridDim.y)
     {
@@ -289,7 +290,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
         {
             const double s = s_grav[0][q] + s_grav[1][q] + s_sink[0][q] + s_sink[1][q] + s_buffer[q] + s_floor[q];
             const double u1 = u0[q] - l[q] + s;
-            if (q == 0 && !(u1 >= 0.0)) bad = 1;
+            if (q == 0 && !(u1 >= 0.0)) sacc.note_value(u1, MH_STATUS_NEG_DENSITY, ((uint32_t) b * (uint32_t) bs + (uint32_t) i) * (uint32_t) bs + (uint32_t) j);
             double un = u1;
             if constexpr (COMBINE) un = u_base[cell_index(bs, b, q, i, j)] * (1.0 - weight) + u1 * weight;
             u_out[cell_index(bs, b, q, i, j)] = un;
@@ -310,7 +311,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
         double* out = block_out + ((long) b * gridDim.y + blockIdx.y) * NTREE_SUMS;       // raw partial sums of this tile; signs and work: tree_totals_kernel
         for (int k = 0; k < NTREE_SUMS; ++k) out[k] = red[k][0];
     }
-    if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, MH_STATUS_NEG_DENSITY);
+    sacc.commit(status);
 }
 
 // totals[18] in the order of mh_binary_total (mass_acc, L_acc, torque, px_acc, py_acc, fx, fy, work, mass_ej, L_ej): per block the tile

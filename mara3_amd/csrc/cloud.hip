@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include "launch.hpp"
+#include "status_device.hpp"
 #include "euler_device.hpp"
 #include "srhd_device.hpp"
 #include "srhd_device_fast.hpp"
@@ -141,7 +142,7 @@ void cloud_stage_kernel(CloudParams p)
     const long row_stride = p.row_stride, plane = p.plane_stride;
     const double* in = p.u_in + jc;
     auto row_off = [row_stride] (int r) { return (long) (r + CHALO) * row_stride; };
-    int bad = 0;
+    StatusAcc acc;        // error contract (status_device.hpp): recover_primitive's status bits + the flat index r * n1 + col of the cell
 
     // the five conserved variables of a stored row (clamped to the stored range: rows -2 .. n0+1)
     auto load_raw = [&] (int r) -> State5
@@ -164,7 +165,10 @@ void cloud_stage_kernel(CloudParams p)
 #pragma unroll
         for (int q = 0; q < 5; ++q) U[q] = x[q];
         const int st = S::c2p(U, g, tfloor, P);
-        if (r >= 0 && r < p.n0) bad |= st;
+        if (__any(st != 0))       // where the reference throws (physics_srhd.hpp:430-449); a scalar branch never taken in a healthy run
+        {
+            if (writes && st != 0 && r >= 0 && r < p.n0) acc.note((uint32_t) st, (uint32_t) r * (uint32_t) p.n1 + (uint32_t) col);
+        }
         return P;
     };
     auto prim_of_row = [&] (int r) -> State5 { return prim_of_raw(r, load_raw(r)); };
@@ -288,11 +292,7 @@ void cloud_stage_kernel(CloudParams p)
         Fx_lo = Fx_hi;
     }
 
-    if (p.status)
-    {
-        const int mine = writes ? bad : 0;
-        if (__any(mine != 0)) atomicOr(p.status, mine);
-    }
+    acc.commit(p.status);
 }
 
 hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev,
@@ -316,15 +316,15 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     p.nstrips = (p.n1 + CSTRIP - 1) / CSTRIP;
     // graded tail (see euler2d.hip): the last rows of a large launch go to short waves, so that the ragged end of the last residency
-    // round lasts a short wave's duration. MH_CLOUD_TAIL="rows,chunk" overrides (0 rows = off).
+    // round lasts a short wave's duration. The descriptor's tail_rows / tail_chunk_rows override (tail_rows < 0 = off).
     p.row_begin2 = p.row_end2 = row_end;
     p.chunk_rows2 = p.chunk_rows;
-    const char* tail_env = getenv("MH_CLOUD_TAIL");          // explicit: applies to any launch with more rows than the tail (tests on small grids)
-    if (tail_env || d->chunk_rows == 0)
+    const bool tail_given = d->tail_rows != 0;          // explicit: applies to any launch with more rows than the tail (tests on small grids)
+    if (tail_given || d->chunk_rows == 0)
     {
         int tail_rows = 512, tail_chunk = 8;
-        if (tail_env) sscanf(tail_env, "%d,%d", &tail_rows, &tail_chunk);
-        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= (tail_env ? tail_rows + 1 : 4 * tail_rows))
+        if (tail_given) { tail_rows = d->tail_rows; tail_chunk = d->tail_chunk_rows > 0 ? d->tail_chunk_rows : 8; }
+        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= (tail_given ? tail_rows + 1 : 4 * tail_rows))
         {
             p.row_begin2 = row_end - tail_rows;
             p.row_end2 = row_end;

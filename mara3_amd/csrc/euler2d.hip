@@ -44,6 +44,7 @@
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
 #include "launch.hpp"
+#include "status_device.hpp"
 
 namespace mh {
 
@@ -215,8 +216,15 @@ void euler2d_stage_kernel(Stage2dParams p)
         }
     }
 
-    int32_t bad = 0;
-    if (!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)) bad |= 1;      // the chunk's first two rows (the row loop checks rows r + 2)
+    // Error contract (status_device.hpp): an updated density that is not > 0 and a recovered pressure that is not >= 0 are recorded with
+    // their kind (NaN apart) and flat cell index row * n1 + col. The tests are wave-wide votes - scalar branches never taken in a healthy run.
+    StatusAcc acc;
+    const uint32_t n1u = (uint32_t) p.n1, colu = (uint32_t) col;
+    if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))      // the chunk's first two rows (the row loop checks rows r + 2)
+    {
+        if (writes && !(P[0][4] >= 0.0)) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) r0 * n1u + colu);
+        if (writes && !(P[1][4] >= 0.0) && r0 + 1 < p.n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r0 + 1) * n1u + colu);
+    }
     // second prefetch stage: row r+3 is in flight in Upre while row r is processed, row r+4 is issued at its top.
     // Two rows (10 loads of 512 B) in flight per wave keep ~40 KB outstanding per CU, enough to cover HBM latency
     // at this kernel's bandwidth (one row in flight left the first RK stage latency-bound).
@@ -240,7 +248,7 @@ void euler2d_stage_kernel(Stage2dParams p)
         P[K2] = A::c2p(U[K2], gl);
         // a negative (or NaN) pressure: the strict arithmetic turns it into NaN sound speeds that reach the density check below, the fast
         // arithmetic's guarded inverse root would not - so it is flagged where it appears (once per cell and stage)
-        if (!(P[K2][4] >= 0.0)) bad |= 1;
+        const bool bad_pressure = !(P[K2][4] >= 0.0);
         if constexpr (PLM && A::shared_differences)
         {
             D[K1] = A::scaled_difference(P[K1], P[K2], theta);
@@ -289,7 +297,12 @@ void euler2d_stage_kernel(Stage2dParams p)
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
-        if (!(Un[0] > 0.0)) bad |= 1;          // catches <= 0 and NaN
+        const bool bad_density = !(Un[0] > 0.0);          // catches <= 0 and NaN
+        if (__any(bad_pressure || bad_density))
+        {
+            if (writes && bad_pressure && r + 2 < p.n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r + 2) * n1u + colu);
+            if (writes && bad_density) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) r * n1u + colu);
+        }
 
         if (writes)
         {
@@ -320,47 +333,34 @@ void euler2d_stage_kernel(Stage2dParams p)
     if (r < r1) row_step(r, std::integral_constant<int, 0>());
     if (r + 1 < r1) row_step(r + 1, std::integral_constant<int, 1>());
 
-    if (p.status)
-    {
-        const bool any_bad = __any(writes && bad);
-        if (any_bad && lane == 0) atomicOr(p.status, 1);
-    }
+    acc.commit(p.status);
 }
 
 // The slab stepper orders its two streams with events. An event recorded by hipEventRecord is a separate marker packet behind
 // the kernel; handed to the launch itself (hipExtLaunchKernel's stopEvent) it rides on the dispatch packet's own completion signal,
-// one packet less on the chain between consecutive stages.
-static thread_local hipEvent_t g_stop_event = nullptr, g_start_event = nullptr;
-void euler2d_next_launch_signals(hipEvent_t stop) { g_stop_event = stop; g_start_event = nullptr; }
-// the same with a start event: the pair brackets exactly the kernel (profiling without marker packets around the launch)
-void euler2d_next_launch_events(hipEvent_t start, hipEvent_t stop) { g_start_event = start; g_stop_event = stop; }
-
+// one packet less on the chain between consecutive stages. With a start event too the pair brackets exactly the kernel (profiling
+// without marker packets around the launch). Both arrive as launch parameters (LaunchEvents, launch.hpp).
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
-static hipError_t launch(const Stage2dParams& p, hipStream_t stream)
+static hipError_t launch(const Stage2dParams& p, hipStream_t stream, const LaunchEvents& ev)
 {
     const int nwaves = p.nstrips * p.nchunks;
     const int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    if (g_stop_event)
-    {
-        hipEvent_t stop = g_stop_event, start = g_start_event;
-        g_stop_event = nullptr;
-        g_start_event = nullptr;
-        hipExtLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, start, stop, 0, p);
-    }
+    if (ev.stop)
+        hipExtLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, ev.start, ev.stop, 0, p);
     else
         hipLaunchKernelGGL((euler2d_stage_kernel<A, RIEMANN, PLM, COMBINE>), dim3(nblocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
-                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream, LaunchEvents ev)
 {
-    return euler2d_stage_launch2(d, u_in, u_base, u_out, dt, weight, row_begin, row_end, 0, 0, status, stream);
+    return euler2d_stage_launch2(d, u_in, u_base, u_out, dt, weight, row_begin, row_end, 0, 0, status, stream, ev);
 }
 
 hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                  double dt, double weight, int row_begin, int row_end, int row_begin2, int row_end2,
-                                 int32_t* status, hipStream_t stream)
+                                 int32_t* status, hipStream_t stream, LaunchEvents ev)
 {
     Stage2dParams p;
     p.u_in = u_in;
@@ -391,15 +391,15 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     // Graded tail (large single-range launches only). The workgroups of a launch are dispatched in index order and the last residency
     // round ends ragged: for about one wave duration the chip runs half empty (measured: the same kernels reach 59 / 67 % of the HBM
     // roofline at 16384^2 against 50 / 61 % at 4096^2). Giving the LAST rows to short waves shortens that window; their extra prologue
-    // work is paid on a small fraction of the rows only. MH_E2D_TAIL="rows,chunk" overrides (0 rows = off).
-    // An explicit MH_E2D_TAIL applies to any single-range launch with more rows than the tail (that is how the tests reach this path on
+    // work is paid on a small fraction of the rows only. The descriptor's tail_rows / tail_chunk_rows override (tail_rows < 0 = off).
+    // An explicit tail applies to any single-range launch with more rows than the tail (that is how the tests reach this path on
     // small grids); the default applies to large launches only.
-    const char* tail_env = getenv("MH_E2D_TAIL");
-    if (row_end2 == row_begin2 && (tail_env || (d->chunk_rows == 0 && p.chunk_rows == 32)))
+    const bool tail_given = d->tail_rows != 0;
+    if (row_end2 == row_begin2 && (tail_given || (d->chunk_rows == 0 && p.chunk_rows == 32)))
     {
         int tail_rows = 512, tail_chunk = 8;          // measured at 4096^2 (3 alternating runs): 0.752 -> 0.739 ms per step; 384,8 the same; 256,16 and 1024,16 no gain
-        if (tail_env) sscanf(tail_env, "%d,%d", &tail_rows, &tail_chunk);
-        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= (tail_env ? tail_rows + 1 : 4 * tail_rows))
+        if (tail_given) { tail_rows = d->tail_rows; tail_chunk = d->tail_chunk_rows > 0 ? d->tail_chunk_rows : 8; }
+        if (tail_rows > 0 && tail_chunk >= 2 && row_end - row_begin >= (tail_given ? tail_rows + 1 : 4 * tail_rows))
         {
             row_begin2 = row_end - tail_rows;
             row_end2 = row_end;
@@ -423,13 +423,10 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     p.weight = weight;
     if (p.nchunks <= 0)
     {
-        if (g_stop_event)          // nothing to launch: the events still have to fire
+        if (ev.stop)          // nothing to launch: the events still have to fire
         {
-            hipEvent_t stop = g_stop_event, start = g_start_event;
-            g_stop_event = nullptr;
-            g_start_event = nullptr;
-            if (start) (void) hipEventRecord(start, stream);
-            return hipEventRecord(stop, stream);
+            if (ev.start) (void) hipEventRecord(ev.start, stream);
+            return hipEventRecord(ev.stop, stream);
         }
         return hipSuccess;
     }
@@ -439,22 +436,22 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     const int key = (d->arith == MH_ARITH_FAST ? 8 : 0) | (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
     switch (key)
     {
-        case 0:  return launch<StrictArith, 0, false, false>(p, stream);
-        case 1:  return launch<StrictArith, 0, false, true >(p, stream);
-        case 2:  return launch<StrictArith, 0, true,  false>(p, stream);
-        case 3:  return launch<StrictArith, 0, true,  true >(p, stream);
-        case 4:  return launch<StrictArith, 1, false, false>(p, stream);
-        case 5:  return launch<StrictArith, 1, false, true >(p, stream);
-        case 6:  return launch<StrictArith, 1, true,  false>(p, stream);
-        case 7:  return launch<StrictArith, 1, true,  true >(p, stream);
-        case 8:  return launch<FastArith, 0, false, false>(p, stream);
-        case 9:  return launch<FastArith, 0, false, true >(p, stream);
-        case 10: return launch<FastArith, 0, true,  false>(p, stream);
-        case 11: return launch<FastArith, 0, true,  true >(p, stream);
-        case 12: return launch<FastArith, 1, false, false>(p, stream);
-        case 13: return launch<FastArith, 1, false, true >(p, stream);
-        case 14: return launch<FastArith, 1, true,  false>(p, stream);
-        case 15: return launch<FastArith, 1, true,  true >(p, stream);
+        case 0:  return launch<StrictArith, 0, false, false>(p, stream, ev);
+        case 1:  return launch<StrictArith, 0, false, true >(p, stream, ev);
+        case 2:  return launch<StrictArith, 0, true,  false>(p, stream, ev);
+        case 3:  return launch<StrictArith, 0, true,  true >(p, stream, ev);
+        case 4:  return launch<StrictArith, 1, false, false>(p, stream, ev);
+        case 5:  return launch<StrictArith, 1, false, true >(p, stream, ev);
+        case 6:  return launch<StrictArith, 1, true,  false>(p, stream, ev);
+        case 7:  return launch<StrictArith, 1, true,  true >(p, stream, ev);
+        case 8:  return launch<FastArith, 0, false, false>(p, stream, ev);
+        case 9:  return launch<FastArith, 0, false, true >(p, stream, ev);
+        case 10: return launch<FastArith, 0, true,  false>(p, stream, ev);
+        case 11: return launch<FastArith, 0, true,  true >(p, stream, ev);
+        case 12: return launch<FastArith, 1, false, false>(p, stream, ev);
+        case 13: return launch<FastArith, 1, false, true >(p, stream, ev);
+        case 14: return launch<FastArith, 1, true,  false>(p, stream, ev);
+        case 15: return launch<FastArith, 1, true,  true >(p, stream, ev);
     }
     return hipErrorInvalidValue;
 }

@@ -28,7 +28,9 @@
 #include <type_traits>
 #include "euler_device.hpp"
 #include "euler_device_fast.hpp"
+#include <atomic>
 #include "launch.hpp"
+#include "status_device.hpp"
 
 namespace mh {
 
@@ -186,8 +188,14 @@ void euler3d_stage_kernel(Stage3dParams p)
         }
     }
     State5 Uin = load_plane(in + row_off(r0 + 2), plane, c0);      // plane r+2, in flight for one iteration
-    int32_t bad = 0;
-    if (!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)) bad |= 1;      // negative / NaN pressure is flagged where it appears (see euler2d.hip)
+    // error contract as in euler2d.hip: kind + flat cell index (r * n1 + j) * n2 + col behind wave-wide votes
+    StatusAcc acc;
+    const uint32_t cellu = (uint32_t) j * (uint32_t) p.n2 + (uint32_t) col, planeu = (uint32_t) p.n1 * (uint32_t) p.n2;
+    if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))
+    {
+        if (writes && !(P[0][4] >= 0.0)) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) r0 * planeu + cellu);
+        if (writes && !(P[1][4] >= 0.0) && r0 + 1 < p.n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r0 + 1) * planeu + cellu);
+    }
 
     // One plane. ONE workgroup barrier: before it every wave publishes the primitives of its row of plane r (and the helper
     // waves those of the outside rows) and does the axis-0 and axis-2 work, which needs no other wave; after it every wave
@@ -208,7 +216,7 @@ void euler3d_stage_kernel(Stage3dParams p)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(Uin, gl);
-        if (!(P[K2][4] >= 0.0)) bad |= 1;
+        const bool bad_pressure = !(P[K2][4] >= 0.0);
         lds_put(tile.U[row][K2], lane, Uin);
         Uin = Unext;
         if constexpr (PLM)
@@ -275,7 +283,12 @@ void euler3d_stage_kernel(Stage3dParams p)
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
-        if (!(Un[0] > 0.0)) bad |= 1;
+        const bool bad_density = !(Un[0] > 0.0);
+        if (__any(bad_pressure || bad_density))
+        {
+            if (writes && bad_pressure && r + 2 < p.n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r + 2) * planeu + cellu);
+            if (writes && bad_density) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) r * planeu + cellu);
+        }
 
         if (writes)
         {
@@ -300,10 +313,7 @@ void euler3d_stage_kernel(Stage3dParams p)
     if (r < r1) plane_step(r, std::integral_constant<int, 0>());
     if (r + 1 < r1) plane_step(r + 1, std::integral_constant<int, 1>());
 
-    if (p.status)
-    {
-        if (__any(writes && bad) && lane == 0) atomicOr(p.status, 1);
-    }
+    acc.commit(p.status);
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
@@ -311,12 +321,16 @@ static hipError_t launch3(const Stage3dParams& p, hipStream_t stream)
 {
     const int nblocks = p.nstrips * p.ntiles1 * p.nchunks;
     auto kernel = euler3d_stage_kernel<A, RIEMANN, PLM, COMBINE>;
-    static bool attr_set = false;           // 120 KB of LDS per workgroup: dynamic + opt-in
-    if (! attr_set)
+    // 120 KB of LDS per workgroup: dynamic + opt-in, once per DEVICE (a process may hold contexts on several)
+    static std::atomic<uint64_t> attr_set_on(0);
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (! (attr_set_on.load(std::memory_order_acquire) & bit))
     {
         hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Tile3d));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set_on.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(W3 * ROWS3), sizeof(Tile3d), stream, p);
     return hipGetLastError();

@@ -6,15 +6,18 @@
 
 namespace mh {
 
+// Events carried by a stage launch itself (hipExtLaunchKernel): `stop` fires on the dispatch packet's own completion signal, `start`
+// (optional) on its start - no marker packets on the stream. With nothing to launch they are recorded on the stream instead.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+
 hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
-                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream,
+                                LaunchEvents ev = LaunchEvents());
 
 // two disjoint row ranges [a0,a1) and [b0,b1) in one launch (the two edge strips of a slab)
-// the next euler2d stage launch of this thread signals `stop` on completion (see euler2d.hip)
-void euler2d_next_launch_signals(hipEvent_t stop);
-void euler2d_next_launch_events(hipEvent_t start, hipEvent_t stop);
 hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
-                                 double dt, double weight, int a0, int a1, int b0, int b1, int32_t* status, hipStream_t stream);
+                                 double dt, double weight, int a0, int a1, int b0, int b1, int32_t* status, hipStream_t stream,
+                                 LaunchEvents ev = LaunchEvents());
 
 hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);

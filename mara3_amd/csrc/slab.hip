@@ -1,5 +1,13 @@
-// Native slab stepper: one rank's share of a 2-D uniform-cartesian Euler run, with the ghost-row exchange as
-// RCCL point-to-point send/recv over xGMI, driven from C++ (HIP graph replay when the rank has no neighbours).
+// Native slab stepper: one rank's share of a uniform-cartesian Euler run (2-D, 3-D) or of the `cloud` sub-program's
+// spherical-polar SRHD grid (radial slabs), with the ghost-row exchange as RCCL point-to-point send/recv over xGMI,
+// driven from C++ (HIP graph replay when the rank has no neighbours).
+//
+// Exchange backends. RCCL: one process per GPU, ncclSend/ncclRecv in one group per stage. LOOPBACK: the slabs of a GROUP
+// live in one process (on one GPU) and a "receive" is a stream-ordered device-to-device copy out of the neighbour
+// object's field, ordered by the same events; every other line of the stepper - cut, ghost layout, edge / interior
+// split, staggered edges, event protocol - is shared. RCCL refuses two ranks on one device ("Duplicate GPU detected"),
+// so the loopback group is how ranks with lo != hi, mixed physical / external sides and uneven cuts are executed and
+// compared bit for bit with the single-domain run on a one-GPU box (tests/test_gpu_slab_group.py).
 //
 // Why native: at 8 GPUs a 4096^2 grid leaves ~60 us of device work per stage; issuing the launches and a P2P
 // group per stage from a host language costs several times that. Here the whole multi-step loop - edge launch,
@@ -83,22 +91,34 @@ static int rccl_fail(ncclResult_t r, const char* what)
 
 using namespace mh;
 
+enum { SLAB_EULER = 0, SLAB_CLOUD = 1 };
+enum { EXCHANGE_NONE = 0, EXCHANGE_RCCL = 1, EXCHANGE_LOOPBACK = 2 };
+
 struct mh_slab
 {
+    int kind = SLAB_EULER;
+    int backend = EXCHANGE_NONE;
     int device = 0, rank = 0, world = 1, rk_order = 2;
     int lo = -1, hi = -1;                 // neighbour ranks on the low / high side of axis 0 (-1: physical boundary)
     int row0 = 0, row1 = 0, n0 = 0, n1 = 0, edge_rows = 0;
-    int stagger = 0;                  // stages per stagger period (0: every stage synchronises both ways), see slab_stage
+    int stagger = 0;                  // stages per stagger period (0: every stage synchronises both ways), see stage_begin
     int phase = 0;                    // stage index within the period
     int test_delay = 0;               // MH_SLAB_TEST_DELAY, see slab_test_delay_kernel
     bool event_on_launch = true;      // the stage kernels signal the cross-stream events themselves (hipExtLaunchKernel's stopEvent)
     mh_euler_cart_desc desc, edge_desc;
+    mh_cloud_desc cloud, cloud_edge;             // SLAB_CLOUD: this rank's rows of the global radial grid
+    double* geom = nullptr;                      // SLAB_CLOUD: packed geometry of the GLOBAL grid (mh_cloud_pack_geometry)
+    double* inflow = nullptr;                    // SLAB_CLOUD: [5][nq] nozzle primitives (read by the rank that owns row 0)
     double* field[2] = {nullptr, nullptr};       // [0] solution, [1] stage scratch; layout of include/mara_hip.h
     double* staging = nullptr;
     int32_t* status = nullptr;
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t ev_edge = nullptr, ev_interior = nullptr, join = nullptr;
     ncclComm_t comm = nullptr;
+    mh_slab* peer_lo = nullptr;                  // EXCHANGE_LOOPBACK: the neighbour objects
+    mh_slab* peer_hi = nullptr;
+    hipEvent_t ev_copied = nullptr;              // EXCHANGE_LOOPBACK: this slab's copies out of its peers' rows have completed
+    double* cur_out = nullptr;                   // output field of the stage being issued (read by the peers' loopback copies)
     hipGraphExec_t exec = nullptr;
     double graph_dt = 0.0;
     bool profile = false;
@@ -107,19 +127,38 @@ struct mh_slab
 };
 
 static int slab_fail(mh_slab* s, int code) { if (s) s->error = mh_last_error(nullptr); return code; }
+static bool has_neighbours(const mh_slab* s) { return s->lo >= 0 || s->hi >= 0; }
 
-static hipError_t stage_launch(const mh_euler_cart_desc* d, const double* in, const double* base, double* out, double dt, double w,
-                               int a, int b, int32_t* status, hipStream_t stream)
+// one launch of the stage kernel over rows [a, b) (and, 2-D Euler only, a second range [a2, b2) in the same launch)
+static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const double* base, double* out, double dt, double w,
+                               int a, int b, int a2, int b2, hipStream_t stream, LaunchEvents ev)
 {
-    return d->rank == 3 ? euler3d_stage_launch(d, in, base, out, dt, w, a, b, status, stream)
-                        : euler2d_stage_launch(d, in, base, out, dt, w, a, b, status, stream);
+    if (s->kind == SLAB_CLOUD)
+    {
+        const mh_cloud_desc* d = edge ? &s->cloud_edge : &s->cloud;
+        if (hipError_t e = cloud_stage_launch(d, s->geom, s->inflow, in, base, out, dt, w, a, b, s->status, stream)) return e;
+        if (b2 > a2) if (hipError_t e = cloud_stage_launch(d, s->geom, s->inflow, in, base, out, dt, w, a2, b2, s->status, stream)) return e;
+    }
+    else
+    {
+        const mh_euler_cart_desc* d = edge ? &s->edge_desc : &s->desc;
+        if (d->rank == 2) return euler2d_stage_launch2(d, in, base, out, dt, w, a, b, a2, b2, s->status, stream, ev);
+        if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a, b, s->status, stream)) return e;
+        if (b2 > a2) if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a2, b2, s->status, stream)) return e;
+    }
+    // launchers that do not carry events: record them behind the launch
+    if (ev.stop) return hipEventRecord(ev.stop, stream);
+    return hipSuccess;
 }
+static bool launch_carries_events(const mh_slab* s) { return s->kind == SLAB_EULER && s->desc.rank == 2; }
 
-static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
+static size_t ghost_block_doubles(const mh_slab* s) { return (size_t) 2 * 5 * s->n1; }      // two rows, all variables: contiguous
+
+static int exchange_rccl(mh_slab* s, double* f, hipStream_t stream)
 {
-    if (s->lo < 0 && s->hi < 0) return MH_OK;
     RcclApi* a = rccl();
-    const size_t blk = (size_t) 2 * 5 * s->n1;             // two rows, all variables: contiguous
+    if (! a || ! s->comm) { set_error("mh_slab: neighbours exist but the RCCL communicator was not connected (mh_slab_connect)"); return MH_E_STATE; }
+    const size_t blk = ghost_block_doubles(s);
     MH_RCCL_TRY(a->GroupStart());
     if (s->lo >= 0) MH_RCCL_TRY(a->Send(f + blk, blk, ncclDouble, s->lo, s->comm, stream));                             // rows 0,1
     if (s->hi >= 0) MH_RCCL_TRY(a->Send(f + (size_t) s->n0 * 5 * s->n1, blk, ncclDouble, s->hi, s->comm, stream));      // rows n0-2,n0-1
@@ -130,6 +169,38 @@ static int slab_exchange(mh_slab* s, double* f, hipStream_t stream)
     return MH_OK;
 }
 
+// LOOPBACK "receive": copy the neighbour object's edge rows of ITS current output field into this slab's ghost rows, on this slab's
+// stream, after the neighbour's edge launch (its ev_edge, as recorded for the current stage: the group driver issues every slab's edge
+// launch before any slab's exchange). peer_field == nullptr: use the peers' cur_out.
+static int exchange_loopback(mh_slab* s, double* f, hipStream_t stream, bool initial)
+{
+    const size_t blk = ghost_block_doubles(s), bytes = blk * sizeof(double);
+    if (s->hi >= 0)
+    {
+        mh_slab* p = s->peer_hi;
+        if (! p) { set_error("mh_slab: loopback peer missing"); return MH_E_STATE; }
+        const double* src = (initial ? p->field[0] : p->cur_out) + blk;                                  // peer rows 0,1
+        if (! initial) MH_HIP_TRY(hipStreamWaitEvent(stream, p->ev_edge, 0));
+        MH_HIP_TRY(hipMemcpyAsync(f + (size_t) (s->n0 + 2) * 5 * s->n1, src, bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    if (s->lo >= 0)
+    {
+        mh_slab* p = s->peer_lo;
+        if (! p) { set_error("mh_slab: loopback peer missing"); return MH_E_STATE; }
+        const double* src = (initial ? p->field[0] : p->cur_out) + (size_t) p->n0 * 5 * p->n1;           // peer rows n0-2,n0-1
+        if (! initial) MH_HIP_TRY(hipStreamWaitEvent(stream, p->ev_edge, 0));
+        MH_HIP_TRY(hipMemcpyAsync(f, src, bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    MH_HIP_TRY(hipEventRecord(s->ev_copied, stream));
+    return MH_OK;
+}
+
+static int slab_exchange(mh_slab* s, double* f, hipStream_t stream, bool initial)
+{
+    if (! has_neighbours(s)) return MH_OK;
+    return s->backend == EXCHANGE_LOOPBACK ? exchange_loopback(s, f, stream, initial) : exchange_rccl(s, f, stream);
+}
+
 // Test instrument (MH_SLAB_TEST_DELAY, tests/test_gpu_rccl.py): one wave that sleeps a bounded ~150 us, queued in front of the edge
 // launch (bit 0) and / or the interior launch (bit 1). It shifts the relative timing of the two chains by more than a stage, so a
 // dependency that only held by luck of timing shows up as a wrong result on one GPU.
@@ -138,49 +209,34 @@ __global__ void slab_test_delay_kernel(int iters)
     for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
 }
 
-static int slab_stage(mh_slab* s, const double* in, const double* base, double* out, double dt, double w, int which)
+// One Runge-Kutta stage of one slab, issued in two halves so that the slabs of a loopback group can be driven in lockstep
+// (every slab's first half, then every slab's second half); a single slab simply runs them back to back.
+struct StageArgs
 {
-    // Staggered edges (2-D): over a period of S stages the edge strips grow by two rows per stage (2, 4, .., 2S) and the interior
-    // shrinks accordingly. Stage k's interior [e_k, n0 - e_k) then reads only rows the previous interior wrote (k >= 1), and the
-    // first edge of the next period (rows 0,1) reads only rows 0..3, which the last edge wrote: per PERIOD the main stream waits for
-    // the side stream once (before interior 0); the side stream waits for the main stream before edges 1..S-1, off the interior's
-    // critical path. Hazards are checked in the comment at the waits.
+    const double* in; const double* base; double* out; double dt, w; int which;
+    int e = 0;       // edge rows per side of this stage (filled by stage_begin)
+};
+
+// Staggered edges (2-D): over a period of S stages the edge strips grow by two rows per stage (2, 4, .., 2S) and the interior
+// shrinks accordingly. Stage k's interior [e_k, n0 - e_k) then reads only rows the previous interior wrote (k >= 1), and the
+// first edge of the next period (rows 0,1) reads only rows 0..3, which the last edge wrote: per PERIOD the main stream waits for
+// the side stream once (before interior 0); the side stream waits for the main stream before edges 1..S-1, off the interior's
+// critical path. Hazards are checked in the comment at the waits.
+//
+// first half: stream waits, edge launch (side stream) - after it the rows that the neighbours need exist (ev_edge)
+static int stage_begin(mh_slab* s, StageArgs& st)
+{
+    s->cur_out = st.out;
+    if (! has_neighbours(s)) return MH_OK;
     const int S = s->stagger, k = S ? s->phase : 0;
     if (S) s->phase = (s->phase + 1) % S;
     const int n0 = s->n0, e = s->edge_rows * (k + 1);
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    // profiling events of the bulk launch. Without neighbours (2-D) they ride on the launch itself (hipExtLaunchKernel's start / stop
-    // events: the dispatch packet's own timestamps, no marker packets between consecutive stage kernels of the timed region); with
-    // neighbours the stop slot of the launch belongs to the stream-ordering event, so they are recorded around it.
-    const bool events_on_launch = s->profile && s->desc.rank == 2 && s->lo < 0 && s->hi < 0;
-    auto bulk = [&] (int a, int b) -> hipError_t
-    {
-        if (s->profile)
-        {
-            hipEventCreate(&ev.first);
-            hipEventCreate(&ev.second);
-            if (events_on_launch) euler2d_next_launch_events(ev.first, ev.second);
-            else                  hipEventRecord(ev.first, s->main);
-        }
-        hipError_t r = stage_launch(&s->desc, in, base, out, dt, w, a, b, s->status, s->main);
-        if (s->profile)
-        {
-            if (events_on_launch) euler2d_next_launch_signals(nullptr);
-            else                  hipEventRecord(ev.second, s->main);
-            s->events[which].push_back(ev);
-        }
-        return r;
-    };
-    if (s->lo < 0 && s->hi < 0)
-    {
-        MH_HIP_TRY(bulk(0, n0));
-        return MH_OK;
-    }
+    st.e = e;
     // Two dependency chains instead of a fork/join per stage:
     //   side stream:  edge(k) -> exchange(k)          edge(k) needs interior(k-1) [event] and exchange(k-1) [stream order]
     //   main stream:  interior(k)                      needs edge(k-1) [event] and interior(k-1) [stream order]
     // The interior rows [8, n0-8) read rows 6..n0-7 of the previous stage: edge and interior output, never ghost rows,
-    // so the main stream does not wait for RCCL at all; the exchange latency only sits on the (short) edge chain.
+    // so the main stream does not wait for the exchange at all; its latency only sits on the (short) edge chain.
     // The waits are issued BEFORE the events are re-recorded, so they bind to the previous stage's records.
     // Staggered, stage k of the period, e_k = 2 (k + 1), buffers alternate (out(k) = in(k-1)):
     //   interior(k) reads in rows >= e_k - 2 = e_{k-1}: interior(k-1)'s, stream order; for k = 0 rows >= 0: edge(S-1)'s -> the one wait.
@@ -190,100 +246,170 @@ static int slab_stage(mh_slab* s, const double* in, const double* base, double* 
     //   (edge(S-1)'s, stream order) and writes rows 0,1, while interior(S-1) reads rows >= 2S - 2 >= 2 of that buffer: no wait.
     if (! S || k == 0) MH_HIP_TRY(hipStreamWaitEvent(s->main, s->ev_edge, 0));
     if (! S || k >= 1) MH_HIP_TRY(hipStreamWaitEvent(s->side, s->ev_interior, 0));
+    if (s->backend == EXCHANGE_LOOPBACK)
+    {
+        // edge(k) overwrites rows of out(k) = out(k-2)'s buffer, which the peers' copies of stage k-2 read; their copies of stage k-1
+        // are later on the same streams, so waiting for those (the latest record of ev_copied) covers it
+        if (s->peer_lo) MH_HIP_TRY(hipStreamWaitEvent(s->side, s->peer_lo->ev_copied, 0));
+        if (s->peer_hi) MH_HIP_TRY(hipStreamWaitEvent(s->side, s->peer_hi->ev_copied, 0));
+    }
     if (s->test_delay & 1) hipLaunchKernelGGL(slab_test_delay_kernel, dim3(1), dim3(64), 0, s->side, 40);
     if (s->test_delay & 2) hipLaunchKernelGGL(slab_test_delay_kernel, dim3(1), dim3(64), 0, s->main, 40);
-    if (s->desc.rank == 2)
-    {
-        if (s->event_on_launch) euler2d_next_launch_signals(s->ev_edge);
-        const hipError_t le = euler2d_stage_launch2(&s->edge_desc, in, base, out, dt, w, 0, e, n0 - e, n0, s->status, s->side);   // both edges, one launch
-        euler2d_next_launch_signals(nullptr);          // consumed by the launch; never left armed for an unrelated one if it failed early
-        MH_HIP_TRY(le);
-    }
-    else
-    {
-        MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, 0, e, s->status, s->side));
-        MH_HIP_TRY(stage_launch(&s->edge_desc, in, base, out, dt, w, n0 - e, n0, s->status, s->side));
-    }
-    const bool on_launch = s->desc.rank == 2 && s->event_on_launch;
+    // both edge strips; the event rides on the launch where the launcher can carry it, else it is recorded behind it
+    LaunchEvents ev;
+    const bool on_launch = launch_carries_events(s) && s->event_on_launch;
+    if (on_launch) ev.stop = s->ev_edge;
+    MH_HIP_TRY(stage_launch(s, true, st.in, st.base, st.out, st.dt, st.w, 0, e, n0 - e, n0, s->side, ev));
     if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
-    if (int rc = slab_exchange(s, out, s->side)) return rc;
-    if (on_launch) euler2d_next_launch_signals(s->ev_interior);
-    const hipError_t be = bulk(e, n0 - e);
-    euler2d_next_launch_signals(nullptr);
+    return MH_OK;
+}
+
+// second half: ghost exchange (side stream) and the interior launch (main stream)
+static int stage_finish(mh_slab* s, StageArgs& st)
+{
+    const int n0 = s->n0, e = st.e;
+    const bool alone = ! has_neighbours(s);
+    std::pair<hipEvent_t, hipEvent_t> pe;
+    // profiling events of the bulk launch. Without neighbours (2-D) they ride on the launch itself (hipExtLaunchKernel's start / stop
+    // events: the dispatch packet's own timestamps, no marker packets between consecutive stage kernels of the timed region); with
+    // neighbours the stop slot of the launch belongs to the stream-ordering event, so they are recorded around it.
+    const bool profile_on_launch = s->profile && alone && launch_carries_events(s);
+    if (! alone) if (int rc = slab_exchange(s, st.out, s->side, false)) return rc;
+    LaunchEvents ev;
+    const bool on_launch = ! alone && launch_carries_events(s) && s->event_on_launch;
+    if (on_launch) ev.stop = s->ev_interior;
+    if (s->profile)
+    {
+        hipEventCreate(&pe.first);
+        hipEventCreate(&pe.second);
+        if (profile_on_launch) { ev.start = pe.first; ev.stop = pe.second; }
+        else                   hipEventRecord(pe.first, s->main);
+    }
+    const hipError_t be = stage_launch(s, false, st.in, st.base, st.out, st.dt, st.w, e, n0 - e, 0, 0, s->main, ev);
+    if (s->profile)
+    {
+        if (! profile_on_launch) hipEventRecord(pe.second, s->main);
+        s->events[st.which].push_back(pe);
+    }
     MH_HIP_TRY(be);
-    if (! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
+    if (! alone && ! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
     return MH_OK;
 }
 
 // order the main stream after everything queued on the side stream (before a download / status read / return to the host)
 static int slab_join(mh_slab* s)
 {
-    if (s->lo < 0 && s->hi < 0) return MH_OK;
+    if (! has_neighbours(s)) return MH_OK;
     MH_HIP_TRY(hipEventRecord(s->join, s->side));
     MH_HIP_TRY(hipStreamWaitEvent(s->main, s->join, 0));
     return MH_OK;
 }
 
-static int slab_one_step(mh_slab* s, double dt)
+// stage `i` (0 or 1) of a step: RK1 = one stage + field swap; RK2: u1 = advance(u0); u = u0 * 0.5 + advance(u1) * 0.5 in place over u0
+static StageArgs stage_args(const mh_slab* s, int i, double dt)
 {
-    if (s->rk_order == 1)
-    {
-        if (int rc = slab_stage(s, s->field[0], nullptr, s->field[1], dt, 1.0, 0)) return rc;
-        std::swap(s->field[0], s->field[1]);
-        return MH_OK;
-    }
-    if (int rc = slab_stage(s, s->field[0], nullptr, s->field[1], dt, 1.0, 0)) return rc;
-    return slab_stage(s, s->field[1], s->field[0], s->field[0], dt, 0.5, 1);
+    StageArgs st;
+    if (i == 0) { st.in = s->field[0]; st.base = nullptr; st.out = s->field[1]; st.w = 1.0; }
+    else        { st.in = s->field[1]; st.base = s->field[0]; st.out = s->field[0]; st.w = 0.5; }
+    st.dt = dt; st.which = i;
+    return st;
 }
 
-extern "C" {
-
-int mh_comm_unique_id(void* id128)
+static int group_one_step(mh_slab** g, int n, double dt)
 {
-    RcclApi* a = rccl();
-    if (! a) { set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
-    ncclUniqueId id;
-    MH_RCCL_TRY(a->GetUniqueId(&id));
-    std::memcpy(id128, &id, sizeof id);
+    const int nstages = g[0]->rk_order;
+    StageArgs st[64];
+    for (int i = 0; i < nstages; ++i)
+    {
+        for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); st[r] = stage_args(g[r], i, dt); if (int rc = stage_begin(g[r], st[r])) return rc; }
+        for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); if (int rc = stage_finish(g[r], st[r])) return rc; }
+    }
+    if (nstages == 1) for (int r = 0; r < n; ++r) std::swap(g[r]->field[0], g[r]->field[1]);
     return MH_OK;
 }
 
-int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
-                   const void* comm_id128, int self_exchange, int device_id)
+static int slab_one_step(mh_slab* s, double dt) { return group_one_step(&s, 1, dt); }
+
+static int check_group(mh_slab** g, int n)
 {
-    if (! out || ! global) return MH_E_INVALID;
-    if (global->rank != 2 && global->rank != 3) { set_error("mh_slab: rank must be 2 or 3"); return MH_E_INVALID; }
+    if (! g || n < 1 || n > 64) { set_error("mh_slab group: need 1..64 slabs"); return MH_E_INVALID; }
+    for (int r = 0; r < n; ++r)
+        if (! g[r] || g[r]->world != n || g[r]->rank != r || g[r]->rk_order != g[0]->rk_order || g[r]->kind != g[0]->kind
+            || (n > 1 && g[r]->backend != EXCHANGE_LOOPBACK))
+        { set_error("mh_slab group: slab %d is not member %d of a loopback group of %d", r, r, n); return MH_E_INVALID; }
+    return MH_OK;
+}
+
+// everything of mh_slab_create but the exchange backend's connection
+static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc* global, const mh_cloud_desc* cglobal,
+                              const double* rv, const double* qv, int rk_order, int rank, int world, int self_exchange, int device_id, int backend)
+{
+    if (! out) return MH_E_INVALID;
     if (rank < 0 || rank >= world) { set_error("mh_slab: rank %d of %d", rank, world); return MH_E_INVALID; }
     if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return MH_E_INVALID; }
-    const bool periodic = global->bc_lo0 == MH_BC_PERIODIC;
-    if (periodic != (global->bc_hi0 == MH_BC_PERIODIC)) { set_error("periodic axis-0 bc must be set on both sides"); return MH_E_INVALID; }
+    bool periodic = false;
+    int nrows_global = 0;
+    if (kind == SLAB_EULER)
+    {
+        if (! global) return MH_E_INVALID;
+        if (global->rank != 2 && global->rank != 3) { set_error("mh_slab: rank must be 2 or 3"); return MH_E_INVALID; }
+        periodic = global->bc_lo0 == MH_BC_PERIODIC;
+        if (periodic != (global->bc_hi0 == MH_BC_PERIODIC)) { set_error("periodic axis-0 bc must be set on both sides"); return MH_E_INVALID; }
+        nrows_global = global->n[0];
+    }
+    else
+    {
+        if (! cglobal || ! rv || ! qv) return MH_E_INVALID;
+        if (cglobal->nr != cglobal->nr_global || cglobal->row_offset != 0) { set_error("mh_slab cloud: pass the description of the WHOLE grid (nr == nr_global, row_offset 0)"); return MH_E_INVALID; }
+        if (cglobal->nr < 2 || cglobal->nq < 3 || !(cglobal->gamma > 1.0)) { set_error("mh_slab cloud: need nr >= 2, nq >= 3, gamma > 1"); return MH_E_INVALID; }
+        nrows_global = cglobal->nr_global;
+    }
     MH_HIP_TRY(hipSetDevice(device_id));
     mh_slab* s = new mh_slab();
+    s->kind = kind;
     s->device = device_id; s->rank = rank; s->world = world; s->rk_order = rk_order;
     size_t a, b;
-    mh_partition_rows((size_t) global->n[0], (size_t) world, (size_t) rank, &a, &b);
+    mh_partition_rows((size_t) nrows_global, (size_t) world, (size_t) rank, &a, &b);
     s->row0 = (int) a; s->row1 = (int) b; s->n0 = s->row1 - s->row0;
-    s->n1 = global->rank == 3 ? global->n[1] * global->n[2] : global->n[1];      // row pitch: cells per axis-0 row (plane in 3-D)
     const bool wrap = periodic && (world > 1 || self_exchange);
     s->lo = rank > 0 ? rank - 1 : (wrap ? world - 1 : -1);
     s->hi = rank < world - 1 ? rank + 1 : (wrap ? 0 : -1);
-    s->desc = *global;
-    s->desc.n[0] = s->n0;
-    s->desc.bc_lo0 = s->lo >= 0 ? MH_BC_EXTERNAL : global->bc_lo0;
-    s->desc.bc_hi0 = s->hi >= 0 ? MH_BC_EXTERNAL : global->bc_hi0;
-    // Edge strips: the rows whose results are sent. In 2-D exactly the two ghost layers' worth (rows 0,1 and n0-2,n0-1): the edge
-    // launch sits on the stage's critical chain (exchange(k-1) -> edge(k) -> exchange(k)) while it shares the SIMDs with the interior
-    // launch, so its latency - rows per wave - is what matters: 8-row strips took 35 us per stage at 512 x 4096 per rank and made the
-    // side chain, not the interior, set the step time (rocprofv3 kernel trace, scripts/slab_trace.py); 2-row strips take ~15 us.
-    const int edge = global->rank == 2 ? 2 : 8;
-    s->edge_desc = s->desc;
-    s->edge_desc.chunk_rows = edge;
-    s->edge_rows = (s->lo >= 0 || s->hi >= 0) ? edge : 0;
+    s->backend = has_neighbours(s) ? backend : EXCHANGE_NONE;
+    int edge = 2;
+    if (kind == SLAB_EULER)
+    {
+        s->n1 = global->rank == 3 ? global->n[1] * global->n[2] : global->n[1];      // row pitch: cells per axis-0 row (plane in 3-D)
+        s->desc = *global;
+        s->desc.n[0] = s->n0;
+        s->desc.bc_lo0 = s->lo >= 0 ? MH_BC_EXTERNAL : global->bc_lo0;
+        s->desc.bc_hi0 = s->hi >= 0 ? MH_BC_EXTERNAL : global->bc_hi0;
+        // Edge strips: the rows whose results are sent. In 2-D exactly the two ghost layers' worth (rows 0,1 and n0-2,n0-1): the edge
+        // launch sits on the stage's critical chain (exchange(k-1) -> edge(k) -> exchange(k)) while it shares the SIMDs with the interior
+        // launch, so its latency - rows per wave - is what matters: 8-row strips took 35 us per stage at 512 x 4096 per rank and made the
+        // side chain, not the interior, set the step time (rocprofv3 kernel trace, scripts/slab_trace.py); 2-row strips take ~15 us.
+        edge = global->rank == 2 ? 2 : 8;
+        s->edge_desc = s->desc;
+        s->edge_desc.chunk_rows = edge;
+        s->edge_desc.tail_rows = -1;
+    }
+    else
+    {
+        s->n1 = cglobal->nq;
+        s->cloud = *cglobal;
+        s->cloud.nr = s->n0;
+        s->cloud.row_offset = s->row0;
+        s->cloud.bc_lo0 = s->lo >= 0 ? MH_BC_EXTERNAL : MH_BC_INFLOW;
+        s->cloud.bc_hi0 = s->hi >= 0 ? MH_BC_EXTERNAL : MH_BC_OUTFLOW;
+        s->cloud_edge = s->cloud;
+        s->cloud_edge.chunk_rows = edge;
+        s->cloud_edge.tail_rows = -1;
+    }
+    s->edge_rows = has_neighbours(s) ? edge : 0;
     if (2 * s->edge_rows > s->n0) s->edge_rows = s->n0 / 2;
     s->stagger = 4;          // measured at 512 / 1024 / 2048 rows per rank (scripts/slab_ab.py): 4 stages per period is ~1 us per step better than 2
-    if (const char* v = getenv("MH_SLAB_STAGGER")) s->stagger = atoi(v);          // measurement switches
-    if (global->rank != 2 || s->edge_rows != 2 || s->stagger < 2 || s->n0 < 4 * s->stagger + 4) s->stagger = 0;
-    if (s->edge_rows > 0 && global->rank == 2 && global->chunk_rows == 0)
+    if (const char* v = getenv("MH_SLAB_STAGGER")) s->stagger = atoi(v);          // measurement switches, read once per slab
+    if (kind != SLAB_EULER || global->rank != 2 || s->edge_rows != 2 || s->stagger < 2 || s->n0 < 4 * s->stagger + 4) s->stagger = 0;
+    if (s->edge_rows > 0 && kind == SLAB_EULER && global->rank == 2 && global->chunk_rows == 0)
     {
         // The interior launch alone should fill one residency round of 2048 waves and no more (a handful of waves in a second
         // round run alone, see euler2d.hip's default). The concurrent edge launch is NOT counted: it has priority, squeezes in at
@@ -300,17 +426,18 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     }
     if (const char* v = getenv("MH_SLAB_EVENT_ON_LAUNCH")) s->event_on_launch = atoi(v) != 0;
     if (const char* v = getenv("MH_SLAB_TEST_DELAY")) s->test_delay = atoi(v);
-    if ((s->lo >= 0 || s->hi >= 0) && s->n0 < 4) { delete s; set_error("slab of %d rows is thinner than two ghost layers", s->n0); return MH_E_INVALID; }
+    if (has_neighbours(s) && s->n0 < 4) { const int thin = s->n0; delete s; set_error("slab of %d rows is thinner than two ghost layers", thin); return MH_E_INVALID; }
 
     auto cleanup = [&] () { mh_slab_destroy(s); };
     if (hipStreamCreateWithFlags(&s->main, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess ||            // followed by the RCCL send of those rows: system-scope release
+        hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess ||            // followed by the send of those rows: system-scope release
         // ev_interior is consumed by the edge launches of this device only: device-scope release
         hipEventCreateWithFlags(&s->ev_interior, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
     { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
-    const size_t doubles = mh_euler_cart_field_doubles(&s->desc);
+    const size_t doubles = (size_t) 5 * (s->n0 + 4) * s->n1;
     for (auto& f : s->field)
     {
         if (hipMalloc((void**) &f, doubles * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab: hipMalloc failed"); return MH_E_NOMEM; }
@@ -319,20 +446,120 @@ int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order
     if (hipMalloc((void**) &s->status, 2 * sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     hipMemsetAsync(s->status, 0, 2 * sizeof(int32_t), s->main);
     if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
-
-    if (s->lo >= 0 || s->hi >= 0)
+    if (kind == SLAB_CLOUD)
     {
-        RcclApi* api = rccl();
-        if (! api) { cleanup(); set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
-        if (! comm_id128) { cleanup(); set_error("mh_slab: neighbours exist but no RCCL unique id was given"); return MH_E_INVALID; }
-        ncclUniqueId id;
-        std::memcpy(&id, comm_id128, sizeof id);
-        ncclResult_t r = api->CommInitRank(&s->comm, world, id, rank);
-        if (r != ncclSuccess) { cleanup(); return rccl_fail(r, "ncclCommInitRank"); }
+        std::vector<double> geom(mh_cloud_geometry_doubles(cglobal));
+        if (int rc = mh_cloud_pack_geometry(cglobal, rv, qv, geom.data())) { cleanup(); return rc; }
+        if (hipMalloc((void**) &s->geom, geom.size() * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**) &s->inflow, (size_t) 5 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab cloud: hipMalloc failed"); return MH_E_NOMEM; }
+        if (hipMemcpy(s->geom, geom.data(), geom.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(s->inflow, 0, (size_t) 5 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab cloud: geometry upload failed"); return MH_E_HIP; }
     }
     hipStreamSynchronize(s->main);
     *out = s;
     return MH_OK;
+}
+
+static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* global, const mh_cloud_desc* cglobal, const double* rv,
+                        const double* qv, int rk_order, int world, int device_id)
+{
+    if (! slabs || world < 1 || world > 64) { set_error("mh_slab group: need 1..64 slabs"); return MH_E_INVALID; }
+    for (int r = 0; r < world; ++r) slabs[r] = nullptr;
+    for (int r = 0; r < world; ++r)
+        if (int rc = slab_create_common(&slabs[r], kind, global, cglobal, rv, qv, rk_order, r, world, 0, device_id, EXCHANGE_LOOPBACK))
+        {
+            for (int q = 0; q < r; ++q) { mh_slab_destroy(slabs[q]); slabs[q] = nullptr; }
+            return rc;
+        }
+    for (int r = 0; r < world; ++r)
+    {
+        slabs[r]->peer_lo = slabs[r]->lo >= 0 ? slabs[slabs[r]->lo] : nullptr;
+        slabs[r]->peer_hi = slabs[r]->hi >= 0 ? slabs[slabs[r]->hi] : nullptr;
+    }
+    return MH_OK;
+}
+
+static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
+{
+    MH_HIP_TRY(hipSetDevice(s->device));
+    const size_t ncell = (size_t) s->n0 * s->n1;
+    MH_HIP_TRY(hipMemcpyAsync(s->staging, u_aos_slab_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, s->main));
+    MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
+    // physical ghost rows (cloud: none stored - inflow / zero-gradient rows are formed inside the kernel)
+    if (s->kind == SLAB_EULER) MH_HIP_TRY(fill_ghost_rows_launch(s->field[0], 5, s->n0, (size_t) s->n1, s->desc.bc_lo0, s->desc.bc_hi0, s->main));
+    return MH_OK;
+}
+
+// both dependency chains start from "everything done"
+static int slab_reset_chains(mh_slab* s)
+{
+    MH_HIP_TRY(hipSetDevice(s->device));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    s->phase = 0;
+    MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
+    MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
+    return MH_OK;
+}
+
+extern "C" {
+
+int mh_comm_unique_id(void* id128)
+{
+    RcclApi* a = rccl();
+    if (! a) { set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
+    ncclUniqueId id;
+    MH_RCCL_TRY(a->GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return MH_OK;
+}
+
+int mh_slab_connect(mh_slab* s, const void* comm_id128)
+{
+    if (! s) return MH_E_INVALID;
+    if (! has_neighbours(s) || s->comm) return MH_OK;
+    if (s->backend != EXCHANGE_RCCL) { set_error("mh_slab_connect: not an RCCL slab"); return slab_fail(s, MH_E_STATE); }
+    RcclApi* api = rccl();
+    if (! api) { set_error("librccl.so.1 could not be loaded"); return slab_fail(s, MH_E_STATE); }
+    if (! comm_id128) { set_error("mh_slab: neighbours exist but no RCCL unique id was given"); return slab_fail(s, MH_E_INVALID); }
+    MH_HIP_TRY(hipSetDevice(s->device));
+    ncclUniqueId id;
+    std::memcpy(&id, comm_id128, sizeof id);
+    ncclResult_t r = api->CommInitRank(&s->comm, s->world, id, s->rank);
+    if (r != ncclSuccess) return slab_fail(s, rccl_fail(r, "ncclCommInitRank"));
+    return MH_OK;
+}
+
+int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
+                   const void* comm_id128, int self_exchange, int device_id)
+{
+    mh_slab* s = nullptr;
+    if (int rc = slab_create_common(&s, SLAB_EULER, global, nullptr, nullptr, nullptr, rk_order, rank, world, self_exchange, device_id, EXCHANGE_RCCL)) return rc;
+    // comm_id128 == NULL with neighbours: the caller connects later (mh_slab_connect), after every rank has agreed that creation succeeded
+    if (comm_id128) if (int rc = mh_slab_connect(s, comm_id128)) { mh_slab_destroy(s); return rc; }
+    *out = s;
+    return MH_OK;
+}
+
+int mh_slab_cloud_create(mh_slab** out, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                         int rk_order, int rank, int world, const void* comm_id128, int device_id)
+{
+    mh_slab* s = nullptr;
+    if (int rc = slab_create_common(&s, SLAB_CLOUD, nullptr, global, r_vertices_host, q_vertices_host, rk_order, rank, world, 0, device_id, EXCHANGE_RCCL)) return rc;
+    if (comm_id128) if (int rc = mh_slab_connect(s, comm_id128)) { mh_slab_destroy(s); return rc; }
+    *out = s;
+    return MH_OK;
+}
+
+int mh_slab_group_create(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, int device_id)
+{
+    return group_create(slabs, SLAB_EULER, global, nullptr, nullptr, nullptr, rk_order, world, device_id);
+}
+
+int mh_slab_cloud_group_create(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                               int rk_order, int world, int device_id)
+{
+    return group_create(slabs, SLAB_CLOUD, nullptr, global, r_vertices_host, q_vertices_host, rk_order, world, device_id);
 }
 
 void mh_slab_destroy(mh_slab* s)
@@ -347,8 +574,11 @@ void mh_slab_destroy(mh_slab* s)
     for (auto& f : s->field) if (f) hipFree(f);
     if (s->staging) hipFree(s->staging);
     if (s->status) hipFree(s->status);
+    if (s->geom) hipFree(s->geom);
+    if (s->inflow) hipFree(s->inflow);
     if (s->ev_edge) hipEventDestroy(s->ev_edge);
     if (s->ev_interior) hipEventDestroy(s->ev_interior);
+    if (s->ev_copied) hipEventDestroy(s->ev_copied);
     if (s->join) hipEventDestroy(s->join);
     if (s->main) hipStreamDestroy(s->main);
     if (s->side) hipStreamDestroy(s->side);
@@ -366,17 +596,24 @@ int mh_slab_rows(const mh_slab* s, int* row0, int* row1)
 int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
 {
     if (! s || ! u_aos_slab_host) return MH_E_INVALID;
-    MH_HIP_TRY(hipSetDevice(s->device));
-    const size_t ncell = (size_t) s->n0 * s->n1;
-    MH_HIP_TRY(hipMemcpyAsync(s->staging, u_aos_slab_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, s->main));
-    MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
-    MH_HIP_TRY(fill_ghost_rows_launch(s->field[0], 5, s->n0, (size_t) s->n1, s->desc.bc_lo0, s->desc.bc_hi0, s->main));
-    if (int rc = slab_exchange(s, s->field[0], s->main)) return slab_fail(s, rc);
-    MH_HIP_TRY(hipStreamSynchronize(s->main));
-    MH_HIP_TRY(hipStreamSynchronize(s->side));
-    s->phase = 0;
-    MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));      // both dependency chains start from "everything done"
-    MH_HIP_TRY(hipEventRecord(s->ev_edge, s->side));
+    if (s->backend == EXCHANGE_LOOPBACK) { set_error("mh_slab_upload: member of a loopback group (use mh_slab_group_upload)"); return slab_fail(s, MH_E_STATE); }
+    if (int rc = slab_upload_rows(s, u_aos_slab_host)) return slab_fail(s, rc);
+    if (int rc = slab_exchange(s, s->field[0], s->main, true)) return slab_fail(s, rc);
+    if (int rc = slab_reset_chains(s)) return slab_fail(s, rc);
+    return MH_OK;
+}
+
+int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
+{
+    if (int rc = check_group(g, n)) return rc;
+    if (! u_aos_global_host) return MH_E_INVALID;
+    for (int r = 0; r < n; ++r)
+        if (int rc = slab_upload_rows(g[r], u_aos_global_host + (size_t) g[r]->row0 * g[r]->n1 * 5)) return slab_fail(g[r], rc);
+    for (int r = 0; r < n; ++r) MH_HIP_TRY(hipStreamSynchronize(g[r]->main));
+    for (int r = 0; r < n; ++r)
+        if (int rc = slab_exchange(g[r], g[r]->field[0], g[r]->main, true)) return slab_fail(g[r], rc);
+    for (int r = 0; r < n; ++r)
+        if (int rc = slab_reset_chains(g[r])) return slab_fail(g[r], rc);
     return MH_OK;
 }
 
@@ -391,14 +628,38 @@ int mh_slab_download(mh_slab* s, double* u_aos_slab_host)
     return MH_OK;
 }
 
+int mh_slab_group_download(mh_slab** g, int n, double* u_aos_global_host)
+{
+    if (int rc = check_group(g, n)) return rc;
+    if (! u_aos_global_host) return MH_E_INVALID;
+    for (int r = 0; r < n; ++r)
+        if (int rc = mh_slab_download(g[r], u_aos_global_host + (size_t) g[r]->row0 * g[r]->n1 * 5)) return rc;
+    return MH_OK;
+}
+
+int mh_slab_set_inflow(mh_slab* s, const double* inflow_prims_aos_host)
+{
+    if (! s || s->kind != SLAB_CLOUD || ! inflow_prims_aos_host) { set_error("mh_slab_set_inflow: not a cloud slab"); return MH_E_STATE; }
+    MH_HIP_TRY(hipSetDevice(s->device));
+    const size_t nq = (size_t) s->n1;
+    std::vector<double> soa(5 * nq);
+    for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_prims_aos_host[5 * j + q];
+    // after the stages already queued (they read the previous row); the staging vector is consumed before return
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    MH_HIP_TRY(hipMemcpy(s->inflow, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MH_OK;
+}
+
 int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
 {
     if (! s) return MH_E_INVALID;
+    if (s->backend == EXCHANGE_LOOPBACK) { set_error("mh_slab_step: member of a loopback group (use mh_slab_group_step)"); return slab_fail(s, MH_E_STATE); }
     MH_HIP_TRY(hipSetDevice(s->device));
     // RCCL point-to-point inside a stream capture crashes this stack (RCCL 2.26 / HIP 7.0: segfault in
     // hipStreamEndCapture, also through torch), so only the neighbour-less step is replayed from a graph; with
     // neighbours the step is issued eagerly from this loop (about ten HIP/RCCL calls per stage, no host language).
-    if (use_graph && s->rk_order == 2 && ! s->profile && s->lo < 0 && s->hi < 0)
+    if (use_graph && s->rk_order == 2 && ! s->profile && ! has_neighbours(s) && s->kind == SLAB_EULER)
     {
         if (! s->exec || s->graph_dt != dt)
         {
@@ -424,6 +685,15 @@ int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
     return MH_OK;
 }
 
+int mh_slab_group_step(mh_slab** g, int n, double dt, int nsteps)
+{
+    if (int rc = check_group(g, n)) return rc;
+    for (int k = 0; k < nsteps; ++k)
+        if (int rc = group_one_step(g, n, dt)) return slab_fail(g[0], rc);
+    for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); if (int rc = slab_join(g[r])) return slab_fail(g[r], rc); }
+    return MH_OK;
+}
+
 int mh_slab_synchronize(mh_slab* s)
 {
     if (! s) return MH_E_INVALID;
@@ -433,15 +703,28 @@ int mh_slab_synchronize(mh_slab* s)
     return MH_OK;
 }
 
-int mh_slab_status_word(mh_slab* s, int32_t* status)
+int mh_slab_status(mh_slab* s, mh_step_result* result)
 {
-    if (! s || ! status) return MH_E_INVALID;
+    if (! s || ! result) return MH_E_INVALID;
     MH_HIP_TRY(hipSetDevice(s->device));
-    int32_t h[2] = {0, 0};
+    uint32_t h[2] = {0, 0};
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
     MH_HIP_TRY(hipMemcpyAsync(h, s->status, sizeof h, hipMemcpyDeviceToHost, s->main));
     MH_HIP_TRY(hipMemsetAsync(s->status, 0, sizeof h, s->main));
     MH_HIP_TRY(hipStreamSynchronize(s->main));
-    *status = h[0];
+    result->status = (int32_t) h[0];
+    result->reserved = 0;
+    // device word: 0xFFFFFFFF - local flat index (status_device.hpp); here: flat index in the GLOBAL host array
+    result->first_bad_index = h[1] ? (uint64_t) (0xFFFFFFFFu - h[1]) + (uint64_t) s->row0 * (uint64_t) s->n1 : UINT64_MAX;
+    return MH_OK;
+}
+
+int mh_slab_status_word(mh_slab* s, int32_t* status)
+{
+    if (! status) return MH_E_INVALID;
+    mh_step_result r;
+    if (int rc = mh_slab_status(s, &r)) return rc;
+    *status = r.status;
     return MH_OK;
 }
 

@@ -11,7 +11,8 @@ from . import _lib as L
 
 class EulerCartSolver:
     def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
-                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict"):
+                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None):
+        """tail = (rows, chunk_rows) forces the graded tail of the stage launch (None: the library's default on large grids)"""
         self.lib = L.load_library()
         self.shape = tuple(int(n) for n in shape)
         rank = len(self.shape)
@@ -29,6 +30,8 @@ class EulerCartSolver:
         d.bc_hi0 = bcs[bc_hi0 or bc]
         d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
         d.chunk_rows = chunk_rows
+        if tail is not None:
+            d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
         self.desc = d
         self.rk_order = rk_order
         self.ctx = C.c_void_p()
@@ -134,7 +137,7 @@ class CloudSolver:
     cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
 
     def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0,
-                 arith="strict"):
+                 arith="strict", tail=None):
         self.lib = L.load_library()
         self.rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
         self.qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
@@ -142,6 +145,8 @@ class CloudSolver:
         d = L.CloudDesc(nr=self.nr, nq=self.nq, nr_global=self.nr, row_offset=0, gamma=gamma, plm_theta=plm_theta,
                         temperature_floor=temperature_floor, bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW,
                         arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith], chunk_rows=chunk_rows)
+        if tail is not None:
+            d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
         self.ctx = C.c_void_p()
         L.check(self.lib.mh_create(C.byref(self.ctx), device))
         L.check(self.lib.mh_cloud_configure(self.ctx, C.byref(d), self.rv.ctypes.data_as(C.c_void_p),

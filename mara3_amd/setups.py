@@ -37,6 +37,21 @@ def wave_ic(shape, gamma, seed=0):
     return u
 
 
+def smooth_wave_ic(shape, gamma, row_range=None):
+    """SURVEY.md §8d's second initial condition: rho = 1 + 0.2 sin(2 pi x) sin(2 pi y), p = rho^gamma, v = (0.5, 0.25), periodic.
+    No quiescent regions: every face sees a genuine Riemann problem. row_range=(a,b) builds only rows [a,b) of axis 0."""
+    a, b = row_range if row_range is not None else (0, shape[0])
+    x = ((np.arange(a, b) + 0.5) / shape[0])[:, None]
+    y = ((np.arange(shape[1]) + 0.5) / shape[1])[None, :]
+    d = 1.0 + 0.2 * np.sin(2 * np.pi * x) * np.sin(2 * np.pi * y)
+    u = np.zeros((b - a, shape[1], 5))
+    u[..., 0] = d
+    u[..., 1] = d * 0.5
+    u[..., 2] = d * 0.25
+    u[..., 4] = 0.5 * d * (0.5 ** 2 + 0.25 ** 2) + d ** gamma / (gamma - 1.0)
+    return u
+
+
 def baseline_dt(n, cfl=0.3, vmax=6.0):
     """Fixed step of the primary config: dt = 0.3*dx/6."""
     return cfl * (1.0 / n) / vmax

@@ -356,37 +356,51 @@ class SlabCloudStepper(SlabEulerStepper):
     def fill_ghosts_physical_only(self, f):
         pass        # inflow / zero-gradient rows are formed inside the kernel from the nozzle row / the last real row
 
+def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=0, arith="strict"):
+    """mh_euler_cart_desc of a WHOLE uniform-cartesian grid (the form mh_slab_create / mh_slab_group_create take)"""
+    rank_ = len(global_shape)
+    d = L.EulerCartDesc()
+    d.rank = rank_
+    for a in range(3):
+        d.n[a] = global_shape[a] if a < rank_ else 1
+        d.dl[a] = dl[a] if a < rank_ else 1.0
+    d.gamma, d.plm_theta = gamma, plm_theta
+    d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
+    phys = L.BC_PERIODIC if bc == "periodic" else L.BC_OUTFLOW
+    d.bc_lo0 = d.bc_hi0 = d.bc_transverse = phys
+    d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
+    d.chunk_rows = chunk_rows
+    return d
+
+
 class NativeSlabStepper:
     """The native (C++/HIP/RCCL) slab stepper of libmara_hip.so: same cut, ghost layout and message pattern as
     SlabEulerStepper, but the exchange is RCCL called from the library and the whole step is one HIP graph.
     `comm_id` is the 128-byte RCCL unique id every rank must share (see `native_comm_id`)."""
 
     def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
-                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict"):
+                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict", handle=None):
+        """comm_id=None on a rank with neighbours defers the RCCL communicator to connect() (ncclCommInitRank is collective: the host
+        first makes sure every rank got this far). handle: wrap a slab created elsewhere (a member of NativeSlabGroup)."""
         import numpy as np
         self.np = np
         self.lib = L.load_library()
-        rank_ = len(global_shape)
-        d = L.EulerCartDesc()
-        d.rank = rank_
-        for a in range(3):
-            d.n[a] = global_shape[a] if a < rank_ else 1
-            d.dl[a] = dl[a] if a < rank_ else 1.0
-        d.gamma, d.plm_theta = gamma, plm_theta
-        d.riemann = {"hlle": L.RIEMANN_HLLE, "hllc": L.RIEMANN_HLLC}[riemann]
-        phys = L.BC_PERIODIC if bc == "periodic" else L.BC_OUTFLOW
-        d.bc_lo0 = d.bc_hi0 = d.bc_transverse = phys
-        d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
-        d.chunk_rows = chunk_rows
-        self.handle = C.c_void_p()
-        idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
-        L.check(self.lib.mh_slab_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf,
-                                        1 if self_exchange else 0, device))
+        if handle is not None:
+            self.handle = handle
+        else:
+            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
+            self.handle = C.c_void_p()
+            idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
+            L.check(self.lib.mh_slab_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf,
+                                            1 if self_exchange else 0, device))
         a, b = C.c_int(), C.c_int()
         L.check(self.lib.mh_slab_rows(self.handle, C.byref(a), C.byref(b)))
         self.row0, self.row1 = a.value, b.value
         self.n0, self.n1 = self.row1 - self.row0, global_shape[1]
         self.slab_shape = (self.n0,) + tuple(global_shape[1:]) + (NQ,)
+
+    def connect(self, comm_id):
+        L.check(self.lib.mh_slab_connect(self.handle, C.create_string_buffer(bytes(comm_id), 128)))
 
     def load_slab(self, u_aos_slab):
         u = self.np.ascontiguousarray(u_aos_slab, dtype=self.np.float64)
@@ -408,6 +422,12 @@ class NativeSlabStepper:
         s = C.c_int32()
         L.check(self.lib.mh_slab_status_word(self.handle, C.byref(s)))
         return s.value
+
+    def status_result(self):
+        """(status bits, flat index in the GLOBAL host array of the first failing cell or None); clears the device word"""
+        r = L.StepResult()
+        L.check(self.lib.mh_slab_status(self.handle, C.byref(r)))
+        return r.status, (None if r.status == 0 else int(r.first_bad_index))
 
     def profile(self, on=True):
         L.check(self.lib.mh_slab_profile_enable(self.handle, 1 if on else 0))
@@ -444,3 +464,89 @@ def native_comm_id(rank, world, device=None):
     t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device if device is not None else "cpu")
     dist.broadcast(t, src=0)
     return bytes(t.cpu().tolist())
+
+
+class NativeSlabGroup:
+    """All `world` slabs of a decomposition as objects of ONE process on one GPU, exchanging ghost rows through the native stepper's
+    LOOPBACK backend (stream-ordered device-to-device copies under the event protocol of the RCCL ranks; include/mara_hip.h,
+    mh_slab_group_*). Euler (2-D, 3-D) with global_shape / dl, or the `cloud` grid with r_vertices / q_vertices."""
+
+    def __init__(self, global_shape=None, dl=None, gamma=5.0 / 3, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow", world=2,
+                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8):
+        import numpy as np
+        self.np = np
+        self.lib = L.load_library()
+        self.world = world
+        self.handles = (C.c_void_p * world)()
+        self.cloud = r_vertices is not None
+        if self.cloud:
+            rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
+            qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
+            nr, nq = len(rv) - 1, len(qv) - 1
+            d = L.CloudDesc(nr=nr, nq=nq, nr_global=nr, row_offset=0, gamma=gamma, plm_theta=plm_theta, temperature_floor=temperature_floor,
+                            bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith],
+                            chunk_rows=chunk_rows)
+            L.check(self.lib.mh_slab_cloud_group_create(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
+                                                        rk_order, world, device))
+            self.global_shape = (nr, nq)
+        else:
+            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
+            L.check(self.lib.mh_slab_group_create(self.handles, C.byref(d), rk_order, world, device))
+            self.global_shape = tuple(global_shape)
+        self.rows = []
+        for r in range(world):
+            a, b = C.c_int(), C.c_int()
+            L.check(self.lib.mh_slab_rows(C.c_void_p(self.handles[r]), C.byref(a), C.byref(b)))
+            self.rows.append((a.value, b.value))
+
+    def upload(self, u_aos_global):
+        u = self.np.ascontiguousarray(u_aos_global, dtype=self.np.float64)
+        assert u.shape == self.global_shape + (NQ,), (u.shape, self.global_shape)
+        L.check(self.lib.mh_slab_group_upload(self.handles, self.world, u.ctypes.data_as(C.c_void_p)))
+
+    def download(self):
+        u = self.np.empty(self.global_shape + (NQ,))
+        L.check(self.lib.mh_slab_group_download(self.handles, self.world, u.ctypes.data_as(C.c_void_p)))
+        return u
+
+    def set_inflow(self, inflow_prims):
+        p = self.np.ascontiguousarray(inflow_prims, dtype=self.np.float64)
+        assert p.shape == (self.global_shape[1], NQ)
+        for r in range(self.world):
+            L.check(self.lib.mh_slab_set_inflow(C.c_void_p(self.handles[r]), p.ctypes.data_as(C.c_void_p)))
+
+    def step(self, dt, nsteps=1):
+        L.check(self.lib.mh_slab_group_step(self.handles, self.world, dt, nsteps))
+
+    def synchronize(self):
+        for r in range(self.world):
+            L.check(self.lib.mh_slab_synchronize(C.c_void_p(self.handles[r])))
+
+    def status(self):
+        """(OR of the members' status bits, smallest global flat index of a failing cell or None)"""
+        bits, first = 0, None
+        for r in range(self.world):
+            res = L.StepResult()
+            L.check(self.lib.mh_slab_status(C.c_void_p(self.handles[r]), C.byref(res)))
+            bits |= res.status
+            if res.status:
+                first = int(res.first_bad_index) if first is None else min(first, int(res.first_bad_index))
+        return bits, first
+
+    def member_host(self, r):
+        a, b = self.rows[r]
+        u = self.np.empty((b - a,) + self.global_shape[1:] + (NQ,))
+        L.check(self.lib.mh_slab_download(C.c_void_p(self.handles[r]), u.ctypes.data_as(C.c_void_p)))
+        return u
+
+    def close(self):
+        for r in range(self.world):
+            if self.handles[r]:
+                self.lib.mh_slab_destroy(C.c_void_p(self.handles[r]))
+                self.handles[r] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -321,18 +321,17 @@ def test_sedov_newtonian_bit_exact_vs_reference(eng):
         assert bits_equal(got, g["u_%d" % n]), n
 
 
-@pytest.mark.parametrize("tail", ["24,4", "7,2", "50,8"])
+@pytest.mark.parametrize("tail", [(24, 4), (7, 2), (50, 8)])
 @pytest.mark.parametrize("case", [c for c in STEP_CASES if "plm" in c])
-def test_euler2d_graded_tail_is_bit_exact(eng, case, tail, monkeypatch):
+def test_euler2d_graded_tail_is_bit_exact(eng, case, tail):
     """The graded tail of the stage launch (the last rows go to short waves placed at the end of every XCD's share, euler2d.hip) only
-    re-orders and re-sizes the work: with MH_E2D_TAIL forcing it on the small golden grids the result stays bit-identical to the
+    re-orders and re-sizes the work: with the descriptor's tail_rows forcing it on the small golden grids the result stays bit-identical to the
     reference, for tails that are and are not multiples of their chunk and of the grid."""
-    monkeypatch.setenv("MH_E2D_TAIL", tail)
     g = golden(case)
     bc = "periodic" if int(g["bc"]) == 1 else "outflow"
     for riemann_ok in ("hlle",):
         for ns in g["nsteps"]:
-            s = eng.EulerCartSolver(g["u0"].shape[:2], g["dl"], float(g["gamma"]), float(g["theta"]), riemann_ok, int(g["rk"]), bc)
+            s = eng.EulerCartSolver(g["u0"].shape[:2], g["dl"], float(g["gamma"]), float(g["theta"]), riemann_ok, int(g["rk"]), bc, tail=tail)
             s.upload(g["u0"])
             s.step(float(g["dt"]), int(ns))
             got = s.download()

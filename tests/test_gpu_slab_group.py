@@ -1,0 +1,212 @@
+"""The NATIVE multi-rank slab stepper (mara3_amd/csrc/slab.hip: mh_slab_*) executed for real on ONE GPU.
+
+RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the ranks of a decomposition are created as objects of one
+process and exchange their ghost rows through the stepper's LOOPBACK backend: stream-ordered device-to-device copies under the very
+event protocol the RCCL ranks use. Everything else is the code `bench.py --gpus N` runs on N GPUs: the nd::partition_shape cut
+(src/core_ndarray.hpp:820-836; src/app_parallel.hpp:76-103 is the evaluator the slabs replace), ranks with lo != hi, ranks with one
+physical and one external side, uneven cuts, 2-row edge strips, staggered edges, edge / interior streams, RK1 and RK2.
+
+Requirement: per-cell arithmetic does not depend on the partition, so the union of the slabs is BIT-IDENTICAL to
+the single-domain run - and, where a reference vector exists, to the reference."""
+import numpy as np
+import pytest
+from conftest import golden, bits_equal
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import mara3_amd
+    from mara3_amd import engine
+    assert mara3_amd.load_library().mh_device_count() >= 1
+    return engine
+
+
+def run_group(shape, dl, gamma, theta, riemann, rk, bc, world, u0, dt, nsteps, arith="strict", chunk_rows=0, pieces=None):
+    from mara3_amd.slab import NativeSlabGroup
+    g = NativeSlabGroup(shape, dl, gamma, theta, riemann, rk, bc, world=world, arith=arith, chunk_rows=chunk_rows)
+    g.upload(u0)
+    for n in (pieces or [nsteps]):
+        g.step(dt, n)
+    g.synchronize()
+    out = g.download()
+    status = g.status()
+    rows = list(g.rows)
+    g.close()
+    return out, status, rows
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("case", ["euler2d_wave33x70_plm12_rk2_outflow", "euler2d_blast128_plm15_rk2", "euler2d_wave48x40_plm15_rk2_periodic",
+                                  "euler2d_blast64_plm20_rk1", "euler2d_blast64_pcm_rk1"])
+def test_group_equals_reference_golden(eng, case, world):
+    """2, 3 and 8 native slabs against the REFERENCE's vectors (strict arithmetic, HLLE): 33 rows over 8 ranks gives slabs of 4 and 5
+    rows (interior launch empty or one row), 128 over 3 an uneven cut; outflow (rank 0 has no lo, the last rank no hi) and periodic
+    (every rank has both; world 2: lo == hi)."""
+    g = golden(case)
+    u0 = g["u0"]
+    bc = "periodic" if int(g["bc"]) == 1 else "outflow"
+    done, pieces = 0, []
+    for ns in sorted(int(n) for n in g["nsteps"]):
+        pieces.append(ns - done)
+        done = ns
+    theta = float(g["theta"])
+    got, status, rows = run_group(u0.shape[:2], g["dl"], float(g["gamma"]), theta, "hlle", int(g["rk"]), bc, world, u0, float(g["dt"]), done, pieces=pieces)
+    assert status == (0, None)
+    assert rows[0][0] == 0 and rows[-1][1] == u0.shape[0] and all(rows[r][1] == rows[r + 1][0] for r in range(world - 1))
+    assert bits_equal(got, g["u_%d" % done]), (case, world, np.abs(got - g["u_%d" % done]).max())
+
+
+@pytest.mark.parametrize("bc", ["outflow", "periodic"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("riemann,arith,rk", [("hllc", "fast", 2), ("hlle", "strict", 2), ("hllc", "strict", 1)])
+def test_group_equals_single_domain_with_staggered_edges(eng, world, bc, riemann, arith, rk):
+    """Slabs thick enough for the staggered edge schedule (>= 20 rows per rank: 4-stage period, edges of 2, 4, 6, 8 rows), an uneven
+    cut (250 rows), step counts that end in the middle of a period and a download in between."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    shape, gamma = (250, 300), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=21)
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, riemann, rk, bc, arith=arith)
+    ref.upload(u0)
+    grp = NativeSlabGroup(shape, dl, gamma, 1.5, riemann, rk, bc, world=world, arith=arith)
+    grp.upload(u0)
+    for nsteps in (1, 2, 3, 1, 5):
+        ref.step(5e-4, nsteps)
+        grp.step(5e-4, nsteps)
+        grp.synchronize()
+        assert bits_equal(grp.download(), ref.download()), (world, bc, nsteps)
+    assert grp.status() == (0, None)
+    grp.close()
+
+
+@pytest.mark.parametrize("on_launch", [1, 0])
+@pytest.mark.parametrize("delay", [1, 2, 3])
+@pytest.mark.parametrize("stagger", [0, 4])
+def test_group_dependencies_hold_under_shifted_timing(eng, delay, stagger, on_launch, monkeypatch):
+    """Three slabs (outflow: a rank with only a hi neighbour, one with both, one with only a lo neighbour) with a ~150 us sleeping wave
+    queued in front of every edge launch (1), every interior launch (2) or both (3): the events alone must order the two chains of every
+    rank AND the copies between ranks. With and without staggered edges, events carried by the launches or recorded behind them."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    monkeypatch.setenv("MH_SLAB_TEST_DELAY", str(delay))
+    monkeypatch.setenv("MH_SLAB_STAGGER", str(stagger))
+    monkeypatch.setenv("MH_SLAB_EVENT_ON_LAUNCH", str(on_launch))
+    shape, gamma = (192, 260), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=22)
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, "outflow", arith="fast")
+    ref.upload(u0)
+    ref.step(5e-4, 7)
+    grp = NativeSlabGroup(shape, dl, gamma, 1.5, "hllc", 2, "outflow", world=3, arith="fast")
+    grp.upload(u0)
+    grp.step(5e-4, 7)
+    grp.synchronize()
+    assert bits_equal(grp.download(), ref.download())
+    grp.close()
+
+
+def test_group_baseline_cut_4096_over_8(eng):
+    """The BASELINE cut itself: 4096^2 over 8 ranks (512 x 4096 cells per rank, the staggered schedule and the one-residency-round
+    chunk heuristic active), PLM + HLLC RK2 FAST as bench.py runs it, 6 steps, bit-identical to the one-domain run; per-rank bit
+    fingerprints as bench.py's partition_check forms them."""
+    import torch
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup, slab_fingerprint, partition_rows
+    n, gamma = 4096, 5.0 / 3
+    dl = (1.0 / n, 1.0 / n)
+    dt = setups.baseline_dt(n)
+    u0 = setups.blast_ic((n, n), gamma)
+    ref = eng.EulerCartSolver((n, n), dl, gamma, 1.5, "hllc", 2, "outflow", arith="fast")
+    ref.upload(u0)
+    ref.step(dt, 6)
+    whole = ref.download()
+    ref.close()
+    grp = NativeSlabGroup((n, n), dl, gamma, 1.5, "hllc", 2, "outflow", world=8, arith="fast")
+    grp.upload(u0)
+    grp.step(dt, 6)
+    grp.synchronize()
+    assert grp.status() == (0, None)
+    for r in range(8):
+        a, b = partition_rows(n, 8, r)
+        assert (a, b) == grp.rows[r] == (512 * r, 512 * (r + 1))
+        mine = grp.member_host(r)
+        assert slab_fingerprint(torch.from_numpy(mine)) == slab_fingerprint(torch.from_numpy(whole[a:b])), r
+        assert bits_equal(mine, whole[a:b]), r
+    grp.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["euler3d_blast24_plm15_rk2", "euler3d_wave20x12x16_plm15_rk2_periodic"])
+def test_group_3d_axis0_slabs_equal_reference_golden(eng, case, world):
+    g = golden(case)
+    u0 = g["u0"]
+    bc = "periodic" if int(g["bc"]) == 1 else "outflow"
+    last = max(int(n) for n in g["nsteps"])
+    got, status, rows = run_group(u0.shape[:3], g["dl"], float(g["gamma"]), float(g["theta"]), "hlle", int(g["rk"]), bc, world, u0, float(g["dt"]), last)
+    assert status == (0, None)
+    assert bits_equal(got, g["u_%d" % last]), (case, world)
+
+
+def test_group_reports_first_failing_cell_in_global_index(eng):
+    """Error contract: the status comes back as {bits, first failing flat cell index} - here a negative density planted in
+    rank 2's share; the index is in the order of the GLOBAL host array."""
+    from mara3_amd import setups
+    from mara3_amd import _lib as L
+    from mara3_amd.slab import NativeSlabGroup
+    shape, gamma = (96, 130), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=23)
+    u0[70, 45, 0] = -1.0
+    grp = NativeSlabGroup(shape, dl, gamma, 1.5, "hllc", 2, "outflow", world=4, arith="fast")
+    grp.upload(u0)
+    grp.step(1e-4, 1)
+    bits, first = grp.status()
+    assert bits != 0
+    # the poisoned cell fails first in row-major order among everything it contaminates except its own stencil rows above it
+    assert first is not None and 68 * shape[1] <= first <= 70 * shape[1] + 45
+    assert grp.status() == (0, None)          # reading clears
+    grp.close()
+
+
+CLOUD_GROUP_CASES = ["cloud_nr70_plm_rk2", "cloud_nr32_plm_rk2", "cloud_nr32_plm_rk1", "cloud_nr24_pcm_rk1", "cloud_nr20x2dec_plm_rk2"]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("case", CLOUD_GROUP_CASES)
+def test_cloud_group_equals_reference_golden(eng, case, world):
+    """BASELINE config 4's decomposition in the NATIVE stepper: radial slabs of the `cloud` grid (CloudProblem::advance,
+    src/subprog_cloud.cpp:511-584, under evaluate_on<N>, :527-581), nozzle row per step at the step-start time, rank 0 with the inflow
+    boundary, the last rank with the zero-gradient one, two-row exchange. Bit-identical to the REFERENCE's single-domain vectors."""
+    from mara3_amd.slab import NativeSlabGroup
+    g = golden(case)
+    theta = float(g["theta"]) if int(g["method"]) == 2 else -1.0
+    grp = NativeSlabGroup(r_vertices=g["rv"], q_vertices=g["qv"], gamma=4.0 / 3, plm_theta=theta, rk_order=int(g["rk"]), world=world,
+                          temperature_floor=float(g["tfloor"]))
+    grp.upload(g["u0"])
+    for n in range(int(g["nsteps"])):
+        grp.set_inflow(g["inflow"][n])
+        grp.step(float(g["dt"]), 1)
+    grp.synchronize()
+    got = grp.download()
+    assert grp.status() == (0, None)
+    assert bits_equal(got, g["un"]), (case, world, np.abs(got - g["un"]).max())
+    grp.close()
+
+
+def test_cloud_group_fast_arith_equals_single_domain(eng):
+    from mara3_amd.slab import NativeSlabGroup
+    g = golden("cloud_nr70_plm_rk2")
+    one = eng.CloudSolver(g["rv"], g["qv"], 2, 1.2, float(g["tfloor"]), arith="fast")
+    one.upload(g["u0"])
+    grp = NativeSlabGroup(r_vertices=g["rv"], q_vertices=g["qv"], gamma=4.0 / 3, plm_theta=1.2, rk_order=2, world=4,
+                          temperature_floor=float(g["tfloor"]), arith="fast")
+    grp.upload(g["u0"])
+    for n in range(int(g["nsteps"])):
+        one.set_inflow(g["inflow"][n]); one.step(float(g["dt"]), 1)
+        grp.set_inflow(g["inflow"][n]); grp.step(float(g["dt"]), 1)
+    grp.synchronize()
+    assert bits_equal(grp.download(), one.download())
+    grp.close()
