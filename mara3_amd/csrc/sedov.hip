@@ -90,7 +90,11 @@ void sedov_stage_kernel(const double* __restrict__ u0, double* __restrict__ u1, 
         const double s0 = Src[q] * dv[i];
         u1[(size_t) q * n + i] = u0[(size_t) q * n + i] + (l0 + s0) * dt;
     }
-    if (bad && status) atomicOr(status, bad);
+    if (bad && status)          // {bits, first failing zone}: include/mara_hip.h, mh_step_result
+    {
+        atomicOr(status, bad);
+        atomicMax(reinterpret_cast<unsigned int*>(status) + 1, 0xFFFFFFFFu - (unsigned int) i);
+    }
 }
 
 // SedovProblem::make_diagnostic_fields and the indices of compute_time_series_data (src/subprog_sedov.cpp:252-308; the shock locator is

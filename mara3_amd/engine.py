@@ -9,7 +9,27 @@ import numpy as np
 from . import _lib as L
 
 
-class EulerCartSolver:
+class _StatusMixin:
+    """Error contract of the context API (include/mara_hip.h: mh_step_result, mh_status, mh_step_checked)."""
+
+    def status_result(self):
+        """(status bits, flat index of the first failing cell in host order, or None); clears the device word"""
+        r = L.StepResult()
+        L.check(self.lib.mh_status(self.ctx, C.byref(r)), self.ctx)
+        return r.status, (None if r.status == 0 else int(r.first_bad_index))
+
+    def step_checked(self, dt):
+        """One full time step as a transaction: returns (0, None) and commits, or (bits, first failing cell) and leaves the previous
+        solution in place (the reference's callers retry from the OLD solution, src/subprog_binary.cpp:285-292)."""
+        r = L.StepResult()
+        rc = self.lib.mh_step_checked(self.ctx, dt, C.byref(r))
+        if rc == -5:          # MH_E_PHYSICS
+            return r.status, int(r.first_bad_index)
+        L.check(rc, self.ctx)
+        return 0, None
+
+
+class EulerCartSolver(_StatusMixin):
     def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
                  bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None):
         """tail = (rows, chunk_rows) forces the graded tail of the stage launch (None: the library's default on large grids)"""
@@ -80,7 +100,7 @@ class EulerCartSolver:
         return ms.value, n.value
 
 
-class SedovSolver:
+class SedovSolver(_StatusMixin):
     """Host mirror of SedovProblem<mara::euler> (src/subprog_sedov.cpp): vertices + volume-integrated conserved state."""
 
     def __init__(self, vertices, gamma=4.0 / 3, device=0, system="euler"):
@@ -132,7 +152,7 @@ class SedovSolver:
             pass
 
 
-class CloudSolver:
+class CloudSolver(_StatusMixin):
     """Host mirror of CloudProblem's (solution_t, advance, next_solution) (src/subprog_cloud.cpp): vertices,
     cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
 

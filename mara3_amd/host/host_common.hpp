@@ -25,13 +25,28 @@ template<typename F> double time_ms(F&& f)
     return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
 }
 
-// negative density etc. cannot throw on the device: map the status word to the reference's exception
-inline void throw_on_status(mh_ctx* ctx)
+// A device stage cannot throw: it leaves status bits and the first failing cell (mh_step_result, include/mara_hip.h). Any bit ends the
+// run here with the exception the reference would have thrown for it - mara::srhd::recover_primitive's std::invalid_argument and its
+// four texts (src/physics_srhd.hpp:430-449) for the relativistic system; for mara::euler, whose recover_primitive never throws
+// upstream, a std::runtime_error that names what the kernel saw.
+inline void throw_on_status(mh_ctx* ctx, int system = MH_SYSTEM_EULER)
 {
-    int32_t status = 0;
-    check(mh_status_word(ctx, &status), ctx, "mh_status_word");
-    if (status & MH_STATUS_NEG_DENSITY) throw std::runtime_error("negative density in updated state");
-    if (status & MH_STATUS_NAN) throw std::runtime_error("nan in updated state");
+    mh_step_result r;
+    check(mh_status(ctx, &r), ctx, "mh_status");
+    if (r.status == 0) return;
+    const std::string where = " (first failing cell: flat index " + std::to_string((unsigned long long) r.first_bad_index) + ", device status 0x" + std::to_string(r.status) + ")";
+    if (system == MH_SYSTEM_SRHD)
+    {
+        const std::string head = "mara::srhd::recover_primitive failure: ";
+        if (r.status & MH_STATUS_C2P_FAILED)   throw std::invalid_argument(head + "root finder not converging" + where);
+        if (r.status & MH_STATUS_NEG_DENSITY)  throw std::invalid_argument(head + "negative density" + where);
+        if (r.status & MH_STATUS_NEG_PRESSURE) throw std::invalid_argument(head + "negative pressure" + where);
+        throw std::invalid_argument(head + "nan W" + where);
+    }
+    if (r.status & MH_STATUS_NEG_DENSITY)  throw std::runtime_error("negative density in updated state" + where);
+    if (r.status & MH_STATUS_NEG_PRESSURE) throw std::runtime_error("negative pressure in recovered primitive state" + where);
+    if (r.status & MH_STATUS_NAN)          throw std::runtime_error("nan in updated state" + where);
+    throw std::runtime_error("device status word not clean" + where);
 }
 
 // <outdir>/<name>: [int64 rank][int64 shape...][int64 nq][f64 time][int64 iteration][f64 vertices (1-D only)...][f64 data...]

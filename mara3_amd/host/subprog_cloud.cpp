@@ -85,27 +85,26 @@ public:
         }
         cfg.pretty_print(stdout, "config");
 
-        model::cloud_and_envelop envelop;
-        envelop.inner_radius = cfg.get_double("inner_radius");
-        envelop.cloud_index = cfg.get_double("density_index");
-        model::power_law_atmosphere atmosphere;
-        atmosphere.r0 = cfg.get_double("inner_radius");
-        atmosphere.rc = cfg.get_double("cloud_cutoff");
-        atmosphere.n1 = cfg.get_double("density_index");
-        atmosphere.n2 = cfg.get_double("density_index2");
-        atmosphere = atmosphere.with_total_mass(cfg.get_double("cloud_mass") * solar_mass_cgs);
-        model::jet_nozzle jet;
-        jet.r0 = cfg.get_double("inner_radius");
-        jet.Ej = cfg.get_double("jet_total_energy");
-        jet.tj = cfg.get_double("jet_duration");
-        jet.as = cfg.get_double("jet_structure_exp");
-        jet.qj = cfg.get_double("jet_opening_angle");
-        jet.G0 = cfg.get_double("jet_gamma_beta");
+        model::EjectaParams ejecta;
+        ejecta.cloud_slope = cfg.get_double("density_index");
+        model::HaloParams halo;
+        halo.reference_radius = cfg.get_double("inner_radius");
+        halo.break_radius = cfg.get_double("cloud_cutoff");
+        halo.inner_slope = cfg.get_double("density_index");
+        halo.outer_slope = cfg.get_double("density_index2");
+        halo = model::halo_scaled_to_mass(halo, cfg.get_double("cloud_mass") * solar_mass_cgs);
+        model::EngineParams engine;
+        engine.base_radius = cfg.get_double("inner_radius");
+        engine.energy = cfg.get_double("jet_total_energy");
+        engine.duration = cfg.get_double("jet_duration");
+        engine.angular_exponent = cfg.get_double("jet_structure_exp");
+        engine.opening_angle = cfg.get_double("jet_opening_angle");
+        engine.four_velocity0 = cfg.get_double("jet_gamma_beta");
 
         // reference units (:319-332): length = r0, mass = total atmosphere mass, time = r0 / c
-        const double ref_length = atmosphere.r0;
-        const double ref_mass = atmosphere.total_mass();
-        const double ref_time = atmosphere.r0 / light_speed_cgs;
+        const double ref_length = halo.reference_radius;
+        const double ref_mass = model::halo_mass(halo);
+        const double ref_time = halo.reference_radius / light_speed_cgs;
         const double ref_density = ref_mass / std::pow(ref_length, 3);
 
         // grid (:645-651): r = 10^linspace(0, decades, int(decades*nr)+1), theta = linspace(0, pi, nr+1)
@@ -124,8 +123,9 @@ public:
         {
             const double rc = (rv[i] + rv[i + 1]) * 0.5;
             const double r_cm = rc * ref_length;
-            const double density = envelop.density_at(r_cm, jet_delay_time) / ref_density;
-            const double gamma_beta = envelop.gamma_beta_at(r_cm, jet_delay_time);
+            const model::EjectaState shell = model::ejecta_at(ejecta, r_cm, jet_delay_time);
+            const double density = shell.density / ref_density;
+            const double gamma_beta = shell.four_velocity;
             const double P[5] = {density, gamma_beta, 0.0, 0.0, density * 1e-6};
             double U[5];
             to_conserved_density(P, U);
@@ -259,8 +259,8 @@ public:
             for (int j = 0; j < nq; ++j)
             {
                 const double q = (qv[j] + qv[j + 1]) * 0.5;
-                inflow[5 * j + 0] = jet.density_at_base() / ref_density;
-                inflow[5 * j + 1] = jet.gamma_beta(q, t_seconds) + jet.gamma_beta(M_PI - q, t_seconds);
+                inflow[5 * j + 0] = model::engine_base_density(engine) / ref_density;
+                inflow[5 * j + 1] = model::engine_four_velocity(engine, q, t_seconds) + model::engine_four_velocity(engine, M_PI - q, t_seconds);
             }
             if (iteration == 0) inflow_first = inflow;
             const double ms = host::time_ms([&] {
@@ -278,9 +278,7 @@ public:
             time += dt;
             iteration += 1;
             run_tasks();
-            int32_t status = 0;
-            host::check(mh_status_word(ctx, &status), ctx, "mh_status_word");
-            if (status) throw std::invalid_argument("mara::srhd::recover_primitive failure (device status word " + std::to_string(status) + ")");
+            host::throw_on_status(ctx, MH_SYSTEM_SRHD);          // the reference throws out of the failing step (physics_srhd.hpp:430-449)
             if (verbose) std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
         };
         while (time < tfinal && (max_steps == 0 || iteration < max_steps)) advance(true);

@@ -244,14 +244,14 @@ public:
             time += dt;
             iteration += 1;
             run_tasks();
+            // the reference throws out of the failing step (recover_primitive, physics_srhd.hpp:430-449): every bit, every step
+            host::throw_on_status(ctx, newtonian ? MH_SYSTEM_EULER : MH_SYSTEM_SRHD);
             if (verbose && iteration % 100 == 0)
             {
-                host::throw_on_status(ctx);
                 std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, count / ms);   // counts vertices, like the reference (:592)
             }
         };
         while (time < tfinal) advance(true);
-        host::throw_on_status(ctx);
         host::check(mh_download(ctx, u.data(), nz), ctx, "mh_download");
         host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nz)}, 5, time, iteration, v, u);
         // upstream's closing `run_tasks_on_next(state)` (:644): one more step whose only visible effect is a task that falls due on it;

@@ -63,6 +63,19 @@ def test_sedov_subprogram_option_errors(tmp_path):
     assert out.returncode == 1 and "wrong data type" in out.stdout
 
 
+def test_sedov_subprogram_ends_on_a_device_status_bit(tmp_path):
+    """Where the reference throws out of the failing step (mara::srhd::recover_primitive, src/physics_srhd.hpp:430-449: negative pressure)
+    the device leaves a status bit; the host must end the run on ANY bit with the reference's exception text, not carry on and exit 0.
+    A negative explosion pressure makes the very first recover_primitive fail. (With newtonian=1 nothing ends the run upstream either:
+    mara::euler::recover_primitive never throws, src/physics_euler.hpp:555-575.)"""
+    out = subprocess.run([EXE, "sedov", "nr=64", "tfinal=0.05", "explosion_pressure=-1.0", "cpi=0", "tsi=0", "dfi=0"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0, out.stdout[-500:]
+    assert "mara::srhd::recover_primitive failure" in out.stdout
+    assert "first failing cell" in out.stdout
+    assert not os.path.exists(os.path.join(tmp_path, "data", "final.bin"))
+
+
 def test_euler2d_subprogram_matches_reference(tmp_path):
     g = golden("euler2d_blast64_plm15_rk2")
     dt = float(g["dt"])
