@@ -289,6 +289,44 @@ int  mh_slab_profile_enable(mh_slab* slab, int on);
 int  mh_slab_profile_read(mh_slab* slab, double avg_ms[2], int nlaunches[2], int* bulk_rows);
 
 /* ------------------------------------------------------------------------ */
+/* Block stepper (one process per GPU): the 3-D Euler step under a 3-axis    */
+/* block decomposition (BASELINE config 5: 1024^3 as (2,2,2) blocks on 8     */
+/* GPUs) with the ghost exchange on all three axes as RCCL send/recv.        */
+/* Blocks per axis: mara::propose_block_decomposition<3>(world)              */
+/* (src/app_parallel.hpp:119-131); extents: nd::divvy as applied by          */
+/* create_access_pattern_array (:148-179): block b of B on an axis of N      */
+/* cells owns [b N / B, (b + 1) N / B); rank = (c0 B1 + c1) B2 + c2.         */
+/* Per stage and cut side one message: axis 0 two contiguous planes straight */
+/* out of the field (2 * 5 * plane doubles), axes 1 / 2 two rows / columns   */
+/* of every plane packed to [n0][5][2][n2] / [n0][5][n1][2]; all in one RCCL */
+/* group on a side stream while the interior updates on the main stream.     */
+/* ------------------------------------------------------------------------ */
+typedef struct mh_block mh_block;
+/* `global`: the WHOLE grid (rank 3; bc_lo0 / bc_hi0 / bc_transverse = the physical boundary conditions). comm_id128 as for mh_slab_create
+ * (NULL with neighbours: connect later with mh_block_connect, once every rank has agreed that creation succeeded). */
+int  mh_block_create(mh_block** block, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int device_id);
+int  mh_block_connect(mh_block* block, const void* comm_id128);
+void mh_block_destroy(mh_block* block);
+/* blocks per axis, this block's coordinates, first global cell and cell count per axis (any pointer may be NULL) */
+int  mh_block_extent(const mh_block* block, int blocks_per_axis[3], int coords[3], int start[3], int count[3]);
+/* neighbour ranks {axis0 lo, hi, axis1 lo, hi, axis2 lo, hi} (-1: physical boundary) and the message size per axis in doubles */
+int  mh_block_neighbours(const mh_block* block, int ranks[6], size_t message_doubles[3]);
+int  mh_block_upload(mh_block* block, const double* u_aos_block_host);       /* host AoS [n0][n1][n2][5] of this block's cells */
+int  mh_block_download(mh_block* block, double* u_aos_block_host);
+int  mh_block_step(mh_block* block, double dt, int nsteps);
+int  mh_block_synchronize(mh_block* block);
+/* global_n = {N0, N1, N2}: first_bad_index in the GLOBAL host array; NULL: within the block */
+int  mh_block_status(mh_block* block, mh_step_result* result, const int global_n[3]);
+/* HIP-event timing of the INTERIOR launches: reads (and clears) the averages of the launches since the last call, then sets the switch */
+int  mh_block_profile(mh_block* block, int enable, double avg_ms[2], int nlaunches[2], long* interior_cells);
+/* LOOPBACK group (see mh_slab_group_create): all `world` blocks as objects of one process on one GPU, receives as device-to-device
+ * copies under the same event protocol; the group calls take the GLOBAL host array [N0][N1][N2][5]. */
+int  mh_block_group_create(mh_block** blocks, const mh_euler_cart_desc* global, int rk_order, int world, int device_id);
+int  mh_block_group_upload(mh_block** blocks, int world, const double* u_aos_global_host);
+int  mh_block_group_download(mh_block** blocks, int world, double* u_aos_global_host);
+int  mh_block_group_step(mh_block** blocks, int world, double dt, int nsteps);
+
+/* ------------------------------------------------------------------------ */
 /* Per-function device entry points (parity tests call these through the ABI) */
 /* inputs/outputs are DEVICE arrays of n items, AoS rows of 5 (or 3 / 1)      */
 /* ------------------------------------------------------------------------ */
@@ -326,6 +364,10 @@ int mh_iso2d_riemann_n(size_t n, const double* Pl, const double* Pr, const doubl
 void mh_partition_rows(size_t count, size_t nparts, size_t part, size_t* start, size_t* final_);
 /* mara::propose_block_decomposition<Rank>, src/app_parallel.hpp:119-131 */
 int  mh_propose_block_decomposition(int rank, unsigned long nblocks, unsigned long* blocks_per_axis);
+/* mara::create_access_pattern_array, src/app_parallel.hpp:148-179, for propose_block_decomposition<3>(world): blocks per axis, the
+ * coordinates of block `rank` (row-major position in the array of access patterns), its first cell and cell count per axis
+ * (nd::divvy: block b of B owns [b N / B, (b + 1) N / B)). Host only. MH_E_INVALID where the reference throws "too many blocks". */
+int  mh_block_layout(const int global_n[3], int world, int rank, int blocks_per_axis[3], int coords[3], int start[3], int count[3]);
 
 /* Kepler two-body model, host side (src/model_two_body.hpp). Bodies are (mass, x, y, vx, vy).
  * mh_two_body_state = mara::compute_two_body_state(full_orbital_elements_t, t) :209-268 (Newton solve for the

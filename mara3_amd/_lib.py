@@ -150,6 +150,21 @@ SYMBOLS = [
     ("mh_slab_field_ptr", _vp, [_vp, _i]),
     ("mh_slab_profile_enable", _i, [_vp, _i]),
     ("mh_slab_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i), C.POINTER(_i)]),
+    ("mh_block_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i]),
+    ("mh_block_connect", _i, [_vp, _vp]),
+    ("mh_block_destroy", None, [_vp]),
+    ("mh_block_extent", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("mh_block_neighbours", _i, [_vp, C.POINTER(_i), C.POINTER(_sz)]),
+    ("mh_block_upload", _i, [_vp, _vp]),
+    ("mh_block_download", _i, [_vp, _vp]),
+    ("mh_block_step", _i, [_vp, _d, _i]),
+    ("mh_block_synchronize", _i, [_vp]),
+    ("mh_block_status", _i, [_vp, C.POINTER(StepResult), C.POINTER(_i)]),
+    ("mh_block_profile", _i, [_vp, _i, C.POINTER(_d), C.POINTER(_i), C.POINTER(C.c_long)]),
+    ("mh_block_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
+    ("mh_block_group_upload", _i, [C.POINTER(_vp), _i, _vp]),
+    ("mh_block_group_download", _i, [C.POINTER(_vp), _i, _vp]),
+    ("mh_block_group_step", _i, [C.POINTER(_vp), _i, _d, _i]),
     ("mh_plm_gradient_n", _i, [_sz, _dp, _dp, _dp, _d, _dp, _i, _vp]),
     ("mh_euler_recover_primitive_n", _i, [_sz, _dp, _d, _d, _dp, _i, _vp]),
     ("mh_euler_to_conserved_n", _i, [_sz, _dp, _d, _dp, _i, _vp]),
@@ -167,6 +182,7 @@ SYMBOLS = [
     ("mh_iso2d_riemann_n", _i, [_sz, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _vp, _vp]),
     ("mh_partition_rows", None, [_sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("mh_propose_block_decomposition", _i, [_i, C.c_ulong, C.POINTER(C.c_ulong)]),
+    ("mh_block_layout", _i, [C.POINTER(_i), _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("mh_two_body_state", _i, [_vp, _d, _vp]),
     ("mh_orbital_elements_from_state", _i, [_vp, _d, _vp]),
     ("mh_orbital_elements_diff", None, [_vp, _vp, _vp]),

@@ -888,6 +888,27 @@ int mh_propose_block_decomposition(int rank, unsigned long nblocks, unsigned lon
     return MH_OK;
 }
 
+// mara::create_access_pattern_array (src/app_parallel.hpp:148-179) for the blocks of propose_block_decomposition<3>(world): block
+// (c0, c1, c2) = the row-major position `rank` in the array of access patterns; extents per axis by nd::divvy
+int mh_block_layout(const int global_n[3], int world, int rank, int blocks_per_axis[3], int coords[3], int start[3], int count[3])
+{
+    if (! global_n || world < 1 || rank < 0 || rank >= world) { set_error("mh_block_layout: rank %d of %d", rank, world); return MH_E_INVALID; }
+    unsigned long B[3];
+    if (int rc = mh_propose_block_decomposition(3, (unsigned long) world, B)) return rc;
+    const int c[3] = {rank / (int) (B[1] * B[2]), (rank / (int) B[2]) % (int) B[1], rank % (int) B[2]};
+    for (int a = 0; a < 3; ++a)
+    {
+        size_t s0, s1;
+        mh_partition_rows((size_t) global_n[a], (size_t) B[a], (size_t) c[a], &s0, &s1);
+        if (s1 <= s0) { set_error("too many blocks for global domain size"); return MH_E_INVALID; }      // the reference's std::logic_error (:160-163)
+        if (blocks_per_axis) blocks_per_axis[a] = (int) B[a];
+        if (coords) coords[a] = c[a];
+        if (start) start[a] = (int) s0;
+        if (count) count[a] = (int) (s1 - s0);
+    }
+    return MH_OK;
+}
+
 // ---- device utilities -------------------------------------------------------
 int mh_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 int mh_malloc(void** ptr, size_t bytes) { MH_HIP_TRY(hipMalloc(ptr, bytes)); return MH_OK; }

@@ -38,6 +38,7 @@ static constexpr int W3 = 64;                  // lanes
 static constexpr int H3 = 2;                   // halo
 static constexpr int STRIP3 = W3 - 2 * H3;     // 60 output columns per wave
 static constexpr int ROWS3 = 8;                // axis-1 rows per workgroup (= waves)
+static constexpr int MAX_BOXES = 8;
 
 struct Stage3dParams
 {
@@ -45,12 +46,16 @@ struct Stage3dParams
     const double* u_base;
     double*       u_out;
     int32_t*      status;
-    long   plane_stride;     // n1*n2: doubles between variables of one axis-0 plane
-    long   row_stride;       // 5*n1*n2: doubles between consecutive axis-0 planes
-    int    n0, n1, n2;
-    int    row_begin, row_end, chunk_rows;
-    int    ntiles1, nstrips, nchunks;
-    int    bc_lo0, bc_hi0, bc_t;
+    long   plane_stride;     // (n1 + 2 g1) * (n2 + 2 g2): doubles between variables of one axis-0 plane
+    long   row_stride;       // 5 * plane_stride: doubles between consecutive axis-0 planes
+    long   pitch2;           // n2 + 2 g2: doubles between consecutive axis-1 rows of a plane
+    int    n0, n1, n2;       // cells of this field (without ghosts)
+    int    g1, g2;           // stored ghost layers on axes 1 and 2 (0, or 2 for a block of a 3-axis decomposition)
+    int    chunk_rows;
+    int    nboxes;           // the launch covers up to MAX_BOXES boxes of (axis-0 rows) x (axis-1 tiles) x (axis-2 strips)
+    Euler3dBox box[MAX_BOXES];
+    int    first_block[MAX_BOXES + 1];       // workgroups [first_block[k], first_block[k + 1]) work on box k
+    int    bc_lo0, bc_hi0, bc_lo1, bc_hi1, bc_lo2, bc_hi2;
     double gamma, theta, cx, cy, cz, weight;
 };
 
@@ -71,10 +76,14 @@ __device__ inline double dpp3_right(double x)
 __device__ inline State5 dpp3_left(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp3_left(s[q]); return r; }
 __device__ inline State5 dpp3_right(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp3_right(s[q]); return r; }
 
-__device__ inline int fold_index(int j, int n, int bc)
+// Transverse index with the boundary condition of its side folded in: outflow clamps to the edge cell, periodic wraps, and an
+// EXTERNAL side (a cut of the block decomposition) keeps the index, which then addresses the stored ghost cells [-2, -1] / [n, n + 1]
+// that the neighbour's face filled. Lanes far outside (unused halo lanes of the last strip) are clamped into the stored range.
+__device__ inline int fold_index(int j, int n, int bc_lo, int bc_hi)
 {
-    if (bc == 1) j = j < 0 ? j + n : (j >= n ? j - n : j);
-    return min(max(j, 0), n - 1);
+    if (j < 0)  j = bc_lo == MH_BC_EXTERNAL ? j : (bc_lo == MH_BC_PERIODIC ? j + n : 0);
+    if (j >= n) j = bc_hi == MH_BC_EXTERNAL ? j : (bc_hi == MH_BC_PERIODIC ? j - n : n - 1);
+    return min(max(j, bc_lo == MH_BC_EXTERNAL ? -H3 : 0), bc_hi == MH_BC_EXTERNAL ? n - 1 + H3 : n - 1);
 }
 
 // LDS exchange buffer: primitives of one axis-0 plane for the tile's rows and two rows on either side, double-buffered by
@@ -132,31 +141,38 @@ void euler3d_stage_kernel(Stage3dParams p)
         const int per_xcd = gridDim.x >> 3;
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);
     }
-    const int strip = b % p.nstrips;
-    const int t1 = (b / p.nstrips) % p.ntiles1;
-    const int chunk = b / (p.nstrips * p.ntiles1);
+    // which box of the launch (a single box for a whole-field stage; the boundary shell of a block is several)
+    int bk = 0;
+    while (bk + 1 < p.nboxes && b >= p.first_block[bk + 1]) ++bk;
+    const Euler3dBox bx = p.box[bk];
+    const int lb = b - p.first_block[bk];
+    const int box_strips = bx.s1 - bx.s0, box_tiles = bx.t1 - bx.t0;
+    const int strip = bx.s0 + lb % box_strips;
+    const int t1 = bx.t0 + (lb / box_strips) % box_tiles;
+    const int chunk = lb / (box_strips * box_tiles);
     const int lane = threadIdx.x & 63;
     const int row = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // wave index = tile row (uniform -> scalar registers)
-    const int r0 = p.row_begin + chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, p.row_end);
+    const int r0 = bx.r0 + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, bx.r1);
 
     const int j = t1 * ROWS3 + row;                         // axis-1 index of this wave's row (may exceed n1 - 1 in the last tile)
-    const int jc = fold_index(j, p.n1, p.bc_t);
+    const int jc = fold_index(j, p.n1, p.bc_lo1, p.bc_hi1);
     const int col = strip * STRIP3 - H3 + lane;
-    const int kc = fold_index(col, p.n2, p.bc_t);
+    const int kc = fold_index(col, p.n2, p.bc_lo2, p.bc_hi2);
     const bool writes = lane >= H3 && lane < W3 - H3 && col < p.n2 && j < p.n1;
 
     const long row_stride = p.row_stride, plane = p.plane_stride;
     auto row_off = [row_stride] (int r) { return (long) (r + H3) * row_stride; };
-    const unsigned c0 = (unsigned) (((long) jc * p.n2 + kc) * 8);
-    const unsigned cw = (unsigned) (writes ? ((long) j * p.n2 + col) * 8 : 0);
+    auto cell_bytes = [&p] (int jj, int kk) { return (unsigned) (((long) (jj + p.g1) * p.pitch2 + (kk + p.g2)) * 8); };
+    const unsigned c0 = cell_bytes(jc, kc);
+    const unsigned cw = writes ? cell_bytes(j, col) : 0u;
 
     // Rows just outside the tile (two on either side with PLM, one without): the first four waves each fetch one of them
     // per plane and publish its primitives, so that this duty is spread instead of loading the tile's edge waves.
     //   wave 0: row -2   wave 1: row -1   wave 2: row ROWS3   wave 3: row ROWS3 + 1
     const int eoff = row == 0 ? -2 : (row == 1 ? -1 : (row == 2 ? ROWS3 : ROWS3 + 1));
     const bool helper = row < 4 && (PLM || row == 1 || row == 2);
-    const unsigned ce = (unsigned) (((long) fold_index(t1 * ROWS3 + eoff, p.n1, p.bc_t) * p.n2 + kc) * 8);
+    const unsigned ce = cell_bytes(fold_index(t1 * ROWS3 + eoff, p.n1, p.bc_lo1, p.bc_hi1), kc);
     const int eslot = eoff + H3;
 
     const double theta = p.theta;
@@ -191,7 +207,7 @@ void euler3d_stage_kernel(Stage3dParams p)
     // error contract as in euler2d.hip: kind + flat cell index (r * n1 + j) * n2 + col behind wave-wide votes
     StatusAcc acc;
     const uint32_t cellu = (uint32_t) j * (uint32_t) p.n2 + (uint32_t) col, planeu = (uint32_t) p.n1 * (uint32_t) p.n2;
-    if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))
+    if (__any(writes && (!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0))))      // (halo lanes may hold never-used corner ghosts: they do not vote)
     {
         if (writes && !(P[0][4] >= 0.0)) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) r0 * planeu + cellu);
         if (writes && !(P[1][4] >= 0.0) && r0 + 1 < p.n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r0 + 1) * planeu + cellu);
@@ -216,7 +232,7 @@ void euler3d_stage_kernel(Stage3dParams p)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(Uin, gl);
-        const bool bad_pressure = !(P[K2][4] >= 0.0);
+        const bool bad_pressure = writes && !(P[K2][4] >= 0.0);
         lds_put(tile.U[row][K2], lane, Uin);
         Uin = Unext;
         if constexpr (PLM)
@@ -283,7 +299,7 @@ void euler3d_stage_kernel(Stage3dParams p)
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
-        const bool bad_density = !(Un[0] > 0.0);
+        const bool bad_density = writes && !(Un[0] > 0.0);
         if (__any(bad_pressure || bad_density))
         {
             if (writes && bad_pressure && r + 2 < p.n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r + 2) * planeu + cellu);
@@ -317,9 +333,8 @@ void euler3d_stage_kernel(Stage3dParams p)
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
-static hipError_t launch3(const Stage3dParams& p, hipStream_t stream)
+static hipError_t launch3(const Stage3dParams& p, int nblocks, hipStream_t stream)
 {
-    const int nblocks = p.nstrips * p.ntiles1 * p.nchunks;
     auto kernel = euler3d_stage_kernel<A, RIEMANN, PLM, COMBINE>;
     // 120 KB of LDS per workgroup: dynamic + opt-in, once per DEVICE (a process may hold contexts on several)
     static std::atomic<uint64_t> attr_set_on(0);
@@ -336,47 +351,82 @@ static hipError_t launch3(const Stage3dParams& p, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
-                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
+void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips)
 {
+    *ntiles1 = (d->n[1] + ROWS3 - 1) / ROWS3;
+    *nstrips = (d->n[2] + STRIP3 - 1) / STRIP3;
+}
+
+hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3dLayout& lay, const Euler3dBox* boxes, int nboxes,
+                                      const double* u_in, const double* u_base, double* u_out, double dt, double weight,
+                                      int32_t* status, hipStream_t stream)
+{
+    if (nboxes < 0 || nboxes > MAX_BOXES) return hipErrorInvalidValue;
     Stage3dParams p;
     p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.status = status;
     p.n0 = d->n[0]; p.n1 = d->n[1]; p.n2 = d->n[2];
-    p.plane_stride = (long) p.n1 * p.n2;
-    p.row_stride = 5L * p.n1 * p.n2;
-    p.row_begin = row_begin; p.row_end = row_end;
+    p.g1 = lay.g1; p.g2 = lay.g2;
+    p.pitch2 = p.n2 + 2 * p.g2;
+    p.plane_stride = (long) (p.n1 + 2 * p.g1) * p.pitch2;
+    p.row_stride = 5L * p.plane_stride;
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
-    p.ntiles1 = (p.n1 + ROWS3 - 1) / ROWS3;
-    p.nstrips = (p.n2 + STRIP3 - 1) / STRIP3;
-    p.nchunks = (row_end - row_begin + p.chunk_rows - 1) / p.chunk_rows;
-    p.bc_lo0 = d->bc_lo0; p.bc_hi0 = d->bc_hi0; p.bc_t = d->bc_transverse;
+    int ntiles1, nstrips;
+    euler3d_tiling(d, &ntiles1, &nstrips);
+    int nblocks = 0;
+    p.nboxes = 0;
+    for (int k = 0; k < nboxes; ++k)
+    {
+        const Euler3dBox& bx = boxes[k];
+        if (bx.r0 < 0 || bx.r1 > p.n0 || bx.t0 < 0 || bx.t1 > ntiles1 || bx.s0 < 0 || bx.s1 > nstrips) return hipErrorInvalidValue;
+        if (bx.r1 <= bx.r0 || bx.t1 <= bx.t0 || bx.s1 <= bx.s0) continue;          // empty box
+        const int nchunks = (bx.r1 - bx.r0 + p.chunk_rows - 1) / p.chunk_rows;
+        p.box[p.nboxes] = bx;
+        p.first_block[p.nboxes] = nblocks;
+        nblocks += nchunks * (bx.t1 - bx.t0) * (bx.s1 - bx.s0);
+        ++p.nboxes;
+    }
+    for (int k = p.nboxes; k <= MAX_BOXES; ++k) p.first_block[k] = nblocks;
+    p.bc_lo0 = d->bc_lo0; p.bc_hi0 = d->bc_hi0;
+    p.bc_lo1 = lay.bc_lo1; p.bc_hi1 = lay.bc_hi1; p.bc_lo2 = lay.bc_lo2; p.bc_hi2 = lay.bc_hi2;
     p.gamma = d->gamma; p.theta = d->plm_theta;
     p.cx = dt / d->dl[0]; p.cy = dt / d->dl[1]; p.cz = dt / d->dl[2];
     p.weight = weight;
-    if (p.nchunks <= 0) return hipSuccess;
+    if (nblocks <= 0) return hipSuccess;
 
     const bool plm = d->plm_theta >= 0.0, combine = weight != 1.0;
     const int key = (d->arith == MH_ARITH_FAST ? 8 : 0) | (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
     switch (key)
     {
-        case 0:  return launch3<StrictArith, 0, false, false>(p, stream);
-        case 1:  return launch3<StrictArith, 0, false, true >(p, stream);
-        case 2:  return launch3<StrictArith, 0, true,  false>(p, stream);
-        case 3:  return launch3<StrictArith, 0, true,  true >(p, stream);
-        case 4:  return launch3<StrictArith, 1, false, false>(p, stream);
-        case 5:  return launch3<StrictArith, 1, false, true >(p, stream);
-        case 6:  return launch3<StrictArith, 1, true,  false>(p, stream);
-        case 7:  return launch3<StrictArith, 1, true,  true >(p, stream);
-        case 8:  return launch3<FastArith, 0, false, false>(p, stream);
-        case 9:  return launch3<FastArith, 0, false, true >(p, stream);
-        case 10: return launch3<FastArith, 0, true,  false>(p, stream);
-        case 11: return launch3<FastArith, 0, true,  true >(p, stream);
-        case 12: return launch3<FastArith, 1, false, false>(p, stream);
-        case 13: return launch3<FastArith, 1, false, true >(p, stream);
-        case 14: return launch3<FastArith, 1, true,  false>(p, stream);
-        case 15: return launch3<FastArith, 1, true,  true >(p, stream);
+        case 0:  return launch3<StrictArith, 0, false, false>(p, nblocks, stream);
+        case 1:  return launch3<StrictArith, 0, false, true >(p, nblocks, stream);
+        case 2:  return launch3<StrictArith, 0, true,  false>(p, nblocks, stream);
+        case 3:  return launch3<StrictArith, 0, true,  true >(p, nblocks, stream);
+        case 4:  return launch3<StrictArith, 1, false, false>(p, nblocks, stream);
+        case 5:  return launch3<StrictArith, 1, false, true >(p, nblocks, stream);
+        case 6:  return launch3<StrictArith, 1, true,  false>(p, nblocks, stream);
+        case 7:  return launch3<StrictArith, 1, true,  true >(p, nblocks, stream);
+        case 8:  return launch3<FastArith, 0, false, false>(p, nblocks, stream);
+        case 9:  return launch3<FastArith, 0, false, true >(p, nblocks, stream);
+        case 10: return launch3<FastArith, 0, true,  false>(p, nblocks, stream);
+        case 11: return launch3<FastArith, 0, true,  true >(p, nblocks, stream);
+        case 12: return launch3<FastArith, 1, false, false>(p, nblocks, stream);
+        case 13: return launch3<FastArith, 1, false, true >(p, nblocks, stream);
+        case 14: return launch3<FastArith, 1, true,  false>(p, nblocks, stream);
+        case 15: return launch3<FastArith, 1, true,  true >(p, nblocks, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// whole transverse extent, rows [row_begin, row_end): the single-device / axis-0-slab form (no stored transverse ghosts)
+hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
+                                double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream)
+{
+    Euler3dLayout lay;
+    lay.bc_lo1 = lay.bc_hi1 = lay.bc_lo2 = lay.bc_hi2 = d->bc_transverse;
+    int ntiles1, nstrips;
+    euler3d_tiling(d, &ntiles1, &nstrips);
+    const Euler3dBox all = {row_begin, row_end, 0, ntiles1, 0, nstrips};
+    return euler3d_stage_launch_boxes(d, lay, &all, 1, u_in, u_base, u_out, dt, weight, status, stream);
 }
 
 } // namespace mh

@@ -22,10 +22,26 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
 hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
 
+// 3-D stage on a field WITH stored transverse ghost layers (a block of a 3-axis decomposition), over a list of boxes.
+// Layout: plane_stride = (n1 + 2 g1) * (n2 + 2 g2); cell (i, j, k), variable q at ((i + 2) * 5 + q) * plane_stride + (j + g1) * (n2 + 2 g2) + (k + g2).
+// Each transverse side has its own boundary kind; MH_BC_EXTERNAL sides read the stored ghost cells.
+struct Euler3dLayout { int g1 = 0, g2 = 0; int bc_lo1 = 0, bc_hi1 = 0, bc_lo2 = 0, bc_hi2 = 0; };
+// rows [r0, r1) of axis 0 x tiles [t0, t1) of 8 axis-1 rows x strips [s0, s1) of 60 axis-2 columns (the kernel's work items)
+struct Euler3dBox { int r0, r1, t0, t1, s0, s1; };
+void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips);
+hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3dLayout& lay, const Euler3dBox* boxes, int nboxes,
+                                      const double* u_in, const double* u_base, double* u_out, double dt, double weight,
+                                      int32_t* status, hipStream_t stream);
+
 hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream);
 hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, size_t row_pitch, hipStream_t stream);
 hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStream_t stream);
 hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, size_t row_pitch, hipStream_t stream);
+
+// padded block fields (Euler3dLayout): host AoS [n0][n1][n2][5] <-> device, and one transverse face <-> a message buffer [n0][5][len1][len2]
+hipError_t block_transpose_launch(bool to_soa, const double* src, double* dst, int n0, int n1, int n2, int g1, int g2, hipStream_t stream);
+hipError_t block_face_launch(bool pack, double* field, double* buf, int n0, int j0, int len1, int k0, int len2,
+                             int n1, int n2, int g1, int g2, hipStream_t stream);
 
 hipError_t sedov_stage_launch(int system, const double* u0, double* u1, const double* dv, const double* da, const double* rc,
                               int n, double gamma, double dt, int32_t* status, hipStream_t stream);

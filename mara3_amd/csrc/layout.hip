@@ -59,6 +59,43 @@ void stream_copy_kernel(const double* __restrict__ src, double* __restrict__ dst
         dst[i] = src[i];
 }
 
+// ---- fields with stored transverse ghost layers (blocks of a 3-axis decomposition, launch.hpp: Euler3dLayout) --------------------
+// host AoS [n0][n1][n2][5] <-> padded device field; one thread per cell
+template<bool TO_SOA>
+__global__ __launch_bounds__(256)
+void block_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst, int n0, int n1, int n2, int g1, int g2)
+{
+    const size_t ncell = (size_t) n0 * n1 * n2, pitch2 = (size_t) n2 + 2 * g2, plane = (size_t) (n1 + 2 * g1) * pitch2;
+    for (size_t c = (size_t) blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (size_t) gridDim.x * blockDim.x)
+    {
+        const size_t k = c % n2, j = (c / n2) % n1, i = c / ((size_t) n1 * n2);
+        const size_t base = (i + HALO) * 5 * plane + (j + g1) * pitch2 + (k + g2);
+        for (int q = 0; q < 5; ++q)
+        {
+            if (TO_SOA) dst[base + q * plane] = src[c * 5 + q];
+            else        dst[c * 5 + q] = src[base + q * plane];
+        }
+    }
+}
+
+// One transverse face of a padded field <-> a contiguous message buffer [n0][5][len1][len2]: cells (i, j0 + jj, k0 + kk) of the
+// interior planes i in [0, n0). PACK gathers the two edge layers that a neighbour needs, UNPACK scatters what it sent into the
+// ghost layers (j0 or k0 = -2 / n). An axis-2 face is 2 doubles per row (16-byte pieces): latency, not bandwidth, and small.
+template<bool PACK>
+__global__ __launch_bounds__(256)
+void block_face_kernel(double* __restrict__ field, double* __restrict__ buf, int n0, int j0, int len1, int k0, int len2,
+                       long pitch2, long plane, int g1, int g2)
+{
+    const size_t total = (size_t) n0 * 5 * len1 * len2;
+    for (size_t m = (size_t) blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (size_t) gridDim.x * blockDim.x)
+    {
+        const size_t kk = m % len2, jj = (m / len2) % len1, iq = m / ((size_t) len1 * len2);      // iq = i * 5 + q
+        const size_t f = (iq + (size_t) HALO * 5) * plane + (size_t) (j0 + (long) jj + g1) * pitch2 + (size_t) (k0 + (long) kk + g2);
+        if (PACK) buf[m] = field[f];
+        else      field[f] = buf[m];
+    }
+}
+
 static int grid_for(size_t n)
 {
     size_t b = (n + 255) / 256;
@@ -78,6 +115,25 @@ hipError_t soa_to_aos_launch(const double* soa, double* aos, int nq, int n0, siz
     const size_t ncell = (size_t) n0 * row_pitch;
     hipLaunchKernelGGL(transpose_kernel<false>, dim3(grid_for(ncell)), dim3(256), 0, stream,
                        soa, aos, nq, ncell, row_pitch);
+    return hipGetLastError();
+}
+
+hipError_t block_transpose_launch(bool to_soa, const double* src, double* dst, int n0, int n1, int n2, int g1, int g2, hipStream_t stream)
+{
+    const size_t ncell = (size_t) n0 * n1 * n2;
+    if (to_soa) hipLaunchKernelGGL(block_transpose_kernel<true>, dim3(grid_for(ncell)), dim3(256), 0, stream, src, dst, n0, n1, n2, g1, g2);
+    else        hipLaunchKernelGGL(block_transpose_kernel<false>, dim3(grid_for(ncell)), dim3(256), 0, stream, src, dst, n0, n1, n2, g1, g2);
+    return hipGetLastError();
+}
+
+hipError_t block_face_launch(bool pack, double* field, double* buf, int n0, int j0, int len1, int k0, int len2,
+                             int n1, int n2, int g1, int g2, hipStream_t stream)
+{
+    const size_t total = (size_t) n0 * 5 * len1 * len2;
+    if (total == 0) return hipSuccess;
+    const long pitch2 = n2 + 2 * g2, plane = (long) (n1 + 2 * g1) * pitch2;
+    if (pack) hipLaunchKernelGGL(block_face_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, field, buf, n0, j0, len1, k0, len2, pitch2, plane, g1, g2);
+    else      hipLaunchKernelGGL(block_face_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, field, buf, n0, j0, len1, k0, len2, pitch2, plane, g1, g2);
     return hipGetLastError();
 }
 

@@ -23,29 +23,16 @@
 // loaded), so the library has no link-time dependency on it and single-GPU hosts never touch it.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "launch.hpp"
+#include "rccl_api.hpp"
 
 namespace mh {
 
-struct RcclApi
-{
-    void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-
-static RcclApi* rccl()
+RcclApi* rccl()
 {
     static RcclApi api;
     static bool tried = false;
@@ -79,13 +66,12 @@ static RcclApi* rccl()
     return api.handle ? &api : nullptr;
 }
 
-static int rccl_fail(ncclResult_t r, const char* what)
+int rccl_fail(ncclResult_t r, const char* what)
 {
     RcclApi* a = rccl();
     set_error("RCCL error %d (%s) in %s", (int) r, a && a->GetErrorString ? a->GetErrorString(r) : "?", what);
     return MH_E_HIP;
 }
-#define MH_RCCL_TRY(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return rccl_fail(_r, #call); } while (0)
 
 } // namespace mh
 

@@ -55,3 +55,26 @@ def test_partition_and_block_decomposition_bit_exact(lib):
     # evaluate_on<8> on 4097 rows
     lib.mh_partition_rows(4097, 8, 7, C.byref(a), C.byref(b))
     assert (a.value, b.value) == (3584, 4097)
+
+
+def test_block_layout_matches_reference_access_patterns(lib):
+    """mh_block_layout = create_access_pattern_array over propose_block_decomposition<3> (src/app_parallel.hpp:119-179): blocks per axis
+    and per-axis extents against the tables produced by the reference's own headers, for every rank; too many blocks is refused where the
+    reference throws std::logic_error."""
+    from mara3_amd.block import block_layout
+    import mara3_amd
+    g = golden("decomposition")
+    shape = (4096, 1000, 640)
+    for world in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16):
+        B = tuple(int(x) for x in g["decomp_rank3"][world - 1])
+        seen = set()
+        for rank in range(world):
+            Bg, c, s, k = block_layout(shape, world, rank)
+            assert Bg == B and c == (rank // (B[1] * B[2]), (rank // B[2]) % B[1], rank % B[2])
+            for a, N in enumerate(shape):
+                table = g["blocks_%d_%d" % (N, B[a])]
+                assert (s[a], s[a] + k[a]) == tuple(int(x) for x in table[c[a]]), (world, rank, a)
+            seen.add(c)
+        assert len(seen) == world
+    with pytest.raises(mara3_amd.MaraHipError, match="too many blocks"):
+        block_layout((7, 7, 7), 1024, 0)          # (8, 8, 16) blocks of a 7^3 grid
