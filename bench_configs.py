@@ -154,11 +154,115 @@ def cloud_cpu_baseline():
             "sample": "%d RK2 steps of the %dx%d golden case (tests/golden/cloud_nr32_plm_rk2.npz), oracle/mara_oracle_srhd.c, 1 thread" % (reps, len(rv) - 1, len(qv) - 1)}
 
 
+def blast_block(global_shape, start, count, gamma, radius=0.1, p_in=10.0, p_out=0.1):
+    """setups.blast_ic restricted to the cells [start, start + count) of the global grid (a block's own initial condition)"""
+    import numpy as np
+    axes = [(np.arange(s, s + k) + 0.5) / N for s, k, N in zip(start, count, global_shape)]
+    X = np.meshgrid(*axes, indexing="ij", sparse=True)
+    r2 = sum((x - 0.5) ** 2 for x in X)
+    u = np.zeros(tuple(count) + (5,))
+    u[..., 0] = 1.0
+    u[..., 4] = np.where(r2 < radius * radius, p_in, p_out) / (gamma - 1.0)
+    return u
+
+
+def run_c5_blocks(args):
+    """BASELINE config 5 as configured: the 3-D blast under the (B0, B1, B2) block decomposition of propose_block_decomposition<3>(N),
+    n^3 cells PER RANK (weak scaling: 1024^3 on 8 GPUs at n = 512), ghost exchange on every cut side. One process per GPU under
+    torch.distributed.run (RCCL), or --loopback-blocks N: the N blocks as objects of this process on one GPU (rehearsal)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mara3_amd import setups
+    from mara3_amd.block import NativeBlock, NativeBlockGroup, block_layout
+    from mara3_amd.slab import native_comm_id
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    nblocks = args.loopback_blocks or world
+    n = args.grid or 512
+    gamma = 5.0 / 3
+    B = block_layout((n, n, n), nblocks, 0)[0]
+    shape = tuple(n * b for b in B)
+    dl = tuple(1.0 / max(shape) for _ in shape)          # cubic cells; the domain is [0, N_a / max N] per axis
+    dt = setups.baseline_dt(max(shape))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    res = {}
+    for arith in ("fast", "strict"):
+        if args.loopback_blocks:
+            st = NativeBlockGroup(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", world=nblocks, device=local_rank, arith=arith)
+            st.upload(blast_block(shape, (0, 0, 0), shape, gamma))
+            probe = st.members[nblocks // 2]
+        else:
+            st = NativeBlock(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", rank=rank, world=world, comm_id=None, device=local_rank, arith=arith)
+            if world > 1:
+                ok = torch.tensor([1], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                st.connect(native_comm_id(rank, world, device="cuda"))
+            st.upload(blast_block(shape, st.start, st.count, gamma))
+            probe = st
+        st.step(dt, args.warmup)
+        st.synchronize()
+        fence()
+        t0 = time.perf_counter()
+        st.step(dt, args.steps)
+        st.synchronize()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        probe.profile(True)
+        st.step(dt, 3)
+        st.synchronize()
+        (ms1, ms2), (nl1, nl2), cells = probe.profile(False)
+        status = st.status()[0]
+        ncell = shape[0] * shape[1] * shape[2]
+        avg_ms = 0.5 * (ms1 + ms2)
+        bytes_stage = cells * (80 + 120) / 2
+        res[arith] = {"value": ncell * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "status_word": status,
+                      "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None,
+                                   "kernel": "euler3d_stage_kernel<%s,%s,PLM> interior launch of one block (mean of both RK2 stages)" % (arith, args.riemann),
+                                   "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl1 + nl2,
+                                   "timing": "HIP events on the launch stream, 3 extra steps after the timed region"},
+                      "messages": {"neighbours": probe.neighbours, "doubles_per_axis": probe.message_doubles}}
+        st.close()
+    out = {
+        "metric": "zone-updates/sec (Mcells/s), 3D Euler blast %dx%dx%d PLM+%s RK2, (%d,%d,%d) blocks" % (shape + (args.riemann.upper(),) + tuple(B)),
+        "value": res["fast"]["value"], "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["fast"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "3D Euler blast (radius 0.1), %d^3 cells per block, (%d,%d,%d) blocks of propose_block_decomposition<3>(%d), PLM(theta=1.5)+%s, RK2, fixed dt=0.3*dx/6"
+                               % ((n,) + tuple(B) + (nblocks, args.riemann.upper())),
+                   "decomposition": ("REHEARSAL on one GPU: %d block objects exchanging through the loopback backend" % nblocks) if args.loopback_blocks
+                                    else "one block per GPU, ghost exchange on every cut side as one RCCL group per stage",
+                   "arith": "fast (headline of this line); strict beside it", "status_word": res["fast"]["status_word"]},
+        "roofline": res["fast"]["roofline"], "messages": res["fast"]["messages"], "arith_strict": res["strict"],
+    }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
 def run_c5(args):
     import numpy as np
     import mara3_amd
     from mara3_amd import setups
     from mara3_amd.engine import EulerCartSolver
+    if args.loopback_blocks or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return run_c5_blocks(args)
     n = args.grid or 512
     gamma = 5.0 / 3
     res = {}
@@ -208,7 +312,10 @@ def run_c5(args):
 def attach_traffic(out, key, ok):
     """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json), mean of the two stage kinds like `achieved`."""
     try:
+        from bench import csrc_fingerprint
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if t.get("csrc_sha16") != csrc_fingerprint():
+            ok = False          # recorded for other kernel sources: not reported
         if ok:
             val = 0.5 * (t[key + "_stage1_bytes_per_launch"] + t[key + "_stage2_bytes_per_launch"])
             out["roofline"]["traffic"] = val
@@ -227,12 +334,15 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--riemann", default="hlle", choices=["hlle", "hllc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loopback-blocks", type=int, default=0, help="c5: this many blocks (grid^3 cells each) as objects of one process on one GPU")
     args = ap.parse_args()
     import mara3_amd
     lib = mara3_amd.load_library()
     if lib.mh_device_count() < 1:
         raise SystemExit("bench_configs.py needs an MI355X; there is no CPU path")
     out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args)
+    if out is None:          # not rank 0 of a multi-process run
+        return
     out = attach_traffic(out, {"c3": "c3_binary_2048", "c4": "c4_cloud_4096", "c5": "c5_euler3d_384"}[args.config],
                          args.config == "c3" or (args.config == "c4" and (args.grid or 4096) == 4096) or (args.config == "c5" and args.grid == 384))
     print(json.dumps(out), flush=True)
