@@ -105,6 +105,7 @@ struct mh_slab
     mh_slab* peer_hi = nullptr;
     hipEvent_t ev_copied = nullptr;              // EXCHANGE_LOOPBACK: this slab's copies out of its peers' rows have completed
     double* cur_out = nullptr;                   // output field of the stage being issued (read by the peers' loopback copies)
+    bool skew_pending = false;                   // group member r >= 1: its first interior launch after an upload starts behind member r-1's
     hipGraphExec_t exec = nullptr;
     double graph_dt = 0.0;
     bool profile = false;
@@ -261,6 +262,14 @@ static int stage_finish(mh_slab* s, StageArgs& st)
     // neighbours the stop slot of the launch belongs to the stream-ordering event, so they are recorded around it.
     const bool profile_on_launch = s->profile && alone && launch_carries_events(s);
     if (! alone) if (int rc = slab_exchange(s, st.out, s->side, false)) return rc;
+    if (s->skew_pending)
+    {
+        // Band skew (loopback groups on ONE device): member r's first interior launch waits for member r-1's, so that from then on the
+        // bands run about one stage apart - a first-stage (issue-bound) launch of one band overlaps a second-stage (bandwidth-bound)
+        // launch of its neighbour instead of a launch of its own kind. The ghost exchange bounds the distance to one stage either way.
+        s->skew_pending = false;
+        if (s->peer_lo && s->peer_lo->rank < s->rank) MH_HIP_TRY(hipStreamWaitEvent(s->main, s->peer_lo->ev_interior, 0));
+    }
     LaunchEvents ev;
     const bool on_launch = ! alone && launch_carries_events(s) && s->event_on_launch;
     if (on_launch) ev.stop = s->ev_interior;
@@ -600,6 +609,9 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
         if (int rc = slab_exchange(g[r], g[r]->field[0], g[r]->main, true)) return slab_fail(g[r], rc);
     for (int r = 0; r < n; ++r)
         if (int rc = slab_reset_chains(g[r])) return slab_fail(g[r], rc);
+    int skew = 0;
+    if (const char* v = getenv("MH_SLAB_GROUP_SKEW")) skew = atoi(v);
+    for (int r = 1; r < n; ++r) g[r]->skew_pending = skew != 0;
     return MH_OK;
 }
 
