@@ -128,8 +128,10 @@ __device__ inline void store_row(double* row, long plane_stride, unsigned lane_b
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(b64_t, U[q]), rs, lane_bytes, (unsigned) (q * plane_stride * 8), 0);
 }
 
-// The work of one workgroup `b` of a stage launch of `nblocks` workgroups (the kernels below are thin wrappers: a plain stage
-// launch, and the mixed launch that deals first-stage and second-stage work items of two row bands to neighbouring workgroups).
+// The work of one workgroup `b` of a stage launch of `nblocks` workgroups (the kernel below is a thin wrapper). Kept separate from the
+// kernel because a "mixed" launch was measured that dealt first-stage and second-stage work items of two row bands to neighbouring
+// workgroups of ONE grid, hoping that the issue-bound and the bandwidth-bound kind would overlap on every CU: 0.730 against 0.737 ms per
+// 4096^2 step (FAST, HLLC), slower for every other variant (profiles/r02/mixed_launch_probe.jsonl) - not kept.
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
 __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const int nblocks)
 {
@@ -342,32 +344,6 @@ void euler2d_stage_kernel(Stage2dParams p)
     stage_body<A, RIEMANN, PLM, COMBINE>(p, (int) blockIdx.x, (int) gridDim.x);
 }
 
-// Mixed launch: first-stage work items (m.first: issue-bound) and second-stage work items (m.second: bandwidth-bound, it streams a
-// third field) of two DISJOINT row bands in one grid, dealt alternately within every XCD's share of the workgroups, so that each CU
-// holds waves of both kinds at any time and the two pipes overlap instead of taking turns launch by launch. Each kind keeps its own
-// XCD-aware work-item order and graded tail: slot s of an XCD's share is the v-th workgroup of its kind there, i.e. workgroup
-// v * 8 + xcd of that kind's own (virtual) launch.
-struct MixedParams { Stage2dParams first, second; int nblocks_first, nblocks_second; };
-
-template<class A, int RIEMANN, bool PLM>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, 2)
-void euler2d_mixed_kernel(MixedParams m)
-{
-    const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-    const long ma = (m.nblocks_first + 7) >> 3, mb = (m.nblocks_second + 7) >> 3, mt = ma + mb;
-    const long before = (long) s * ma / mt, upto = (long) (s + 1) * ma / mt;        // first-stage workgroups among slots [0, s) / [0, s]
-    if (upto > before)
-    {
-        const int b = (int) before * 8 + xcd;
-        if (b < m.nblocks_first) stage_body<A, RIEMANN, PLM, false>(m.first, b, m.nblocks_first);
-    }
-    else
-    {
-        const int b = (int) (s - before) * 8 + xcd;
-        if (b < m.nblocks_second) stage_body<A, RIEMANN, PLM, true>(m.second, b, m.nblocks_second);
-    }
-}
-
 // The slab stepper orders its two streams with events. An event recorded by hipEventRecord is a separate marker packet behind
 // the kernel; handed to the launch itself (hipExtLaunchKernel's stopEvent) it rides on the dispatch packet's own completion signal,
 // one packet less on the chain between consecutive stages. With a start event too the pair brackets exactly the kernel (profiling
@@ -495,40 +471,6 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
         case 13: return launch<FastArith, 1, false, true >(p, stream, ev);
         case 14: return launch<FastArith, 1, true,  false>(p, stream, ev);
         case 15: return launch<FastArith, 1, true,  true >(p, stream, ev);
-    }
-    return hipErrorInvalidValue;
-}
-
-template<class A, int RIEMANN, bool PLM>
-static hipError_t launch_mixed(const MixedParams& m, hipStream_t stream, const LaunchEvents& ev)
-{
-    const int slots = (m.nblocks_first + 7) / 8 + (m.nblocks_second + 7) / 8;
-    if (ev.stop) hipExtLaunchKernelGGL((euler2d_mixed_kernel<A, RIEMANN, PLM>), dim3(slots * 8), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, ev.start, ev.stop, 0, m);
-    else         hipLaunchKernelGGL((euler2d_mixed_kernel<A, RIEMANN, PLM>), dim3(slots * 8), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, m);
-    return hipGetLastError();
-}
-
-hipError_t euler2d_mixed_launch(const mh_euler_cart_desc* d, double dt,
-                                const double* in1, double* out1, int a0, int a1,
-                                const double* in2, const double* base2, double* out2, double weight2, int b0, int b1,
-                                int32_t* status, hipStream_t stream, LaunchEvents ev)
-{
-    MixedParams m;
-    m.nblocks_first = build_params(m.first, d, in1, nullptr, out1, dt, 1.0, a0, a1, 0, 0, status);
-    m.nblocks_second = build_params(m.second, d, in2, base2, out2, dt, weight2, b0, b1, 0, 0, status);
-    // one of the two empty: a plain launch of the other
-    if (m.nblocks_second <= 0) return euler2d_stage_launch2(d, in1, nullptr, out1, dt, 1.0, a0, a1, 0, 0, status, stream, ev);
-    if (m.nblocks_first <= 0)  return euler2d_stage_launch2(d, in2, base2, out2, dt, weight2, b0, b1, 0, 0, status, stream, ev);
-    switch (variant_key(d, false) >> 1)
-    {
-        case 0: return launch_mixed<StrictArith, 0, false>(m, stream, ev);
-        case 1: return launch_mixed<StrictArith, 0, true >(m, stream, ev);
-        case 2: return launch_mixed<StrictArith, 1, false>(m, stream, ev);
-        case 3: return launch_mixed<StrictArith, 1, true >(m, stream, ev);
-        case 4: return launch_mixed<FastArith, 0, false>(m, stream, ev);
-        case 5: return launch_mixed<FastArith, 0, true >(m, stream, ev);
-        case 6: return launch_mixed<FastArith, 1, false>(m, stream, ev);
-        case 7: return launch_mixed<FastArith, 1, true >(m, stream, ev);
     }
     return hipErrorInvalidValue;
 }
