@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmara_hip.so")
+# MARA_HIP_LIBRARY: another build of the same library (A/B measurements of kernel variants on one box)
+_LIB_PATH = os.environ.get("MARA_HIP_LIBRARY") or os.path.join(_HERE, "libmara_hip.so")
 
 # enums of include/mara_hip.h
 OK = 0

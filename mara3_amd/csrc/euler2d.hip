@@ -243,7 +243,7 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         if constexpr (A::recompute_conserved) U[K1] = load_row(in + row_off(rp), p.plane_stride, jc8);      // row r+1 was converted a row ago
         else                                  Unext = load_row(in + row_off(rp), p.plane_stride, jc8);
         State5 Ubase;
-        if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);
+        if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);      // (requesting it a row earlier: no faster, measured)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(U[K2], gl);

@@ -196,8 +196,11 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     const double abar = 0.5 * (al + ar);
     const double ppvrs = __builtin_fma(-0.5 * (ur - ul), dbar * abar, 0.5 * (pl + pr));
     const double pstar = __builtin_fmax(0.0, ppvrs);
-    const double ql = pstar <= pl ? 1.0 : sqrt_fast(__builtin_fma(g.gfac, pstar * rcp_nr(pl) - 1.0, 1.0));
-    const double qr = pstar <= pr ? 1.0 : sqrt_fast(__builtin_fma(g.gfac, pstar * rcp_nr(pr) - 1.0, 1.0));
+    // q_K = sqrt(1 + gfac (p* / p_K - 1)) = sqrt(x / p_K) = x rsqrt(x p_K), x = p_K + gfac (p* - p_K): one inverse root and no reciprocal
+    // (the reciprocal + square root form cost 2.5 % of the smooth-wave step, where one side of nearly every face takes this branch)
+    const double xl = __builtin_fma(g.gfac, pstar - pl, pl), xr = __builtin_fma(g.gfac, pstar - pr, pr);
+    const double ql = pstar <= pl ? 1.0 : xl * rsqrt_fast(xl * pl);
+    const double qr = pstar <= pr ? 1.0 : xr * rsqrt_fast(xr * pr);
     const double sl = __builtin_fma(-al, ql, ul);
     const double sr = __builtin_fma(ar, qr, ur);
     const double ml = dl * (sl - ul);       // mass flux relative to the left wave
