@@ -362,7 +362,8 @@ static int check_cloud(const mh_cloud_desc* d)
 
 size_t mh_cloud_geometry_doubles(const mh_cloud_desc* d)
 {
-    return d ? (size_t) (d->nr_global + 1) + d->nq + (d->nq + 1) + d->nq : 0;
+    // rv | dmu | sinq | cotq | per-row factors [nr_global][8] | per-column factors [nq][8]   (the last two: MH_ARITH_FAST only)
+    return d ? (size_t) (d->nr_global + 1) + d->nq + (d->nq + 1) + d->nq + (size_t) 8 * d->nr_global + (size_t) 8 * d->nq : 0;
 }
 
 int mh_cloud_pack_geometry(const mh_cloud_desc* d, const double* rv, const double* qv, double* out)
@@ -379,6 +380,22 @@ int mh_cloud_pack_geometry(const mh_cloud_desc* d, const double* rv, const doubl
         cotq[j] = std::tan(M_PI_2 - (qv[j] + qv[j + 1]) * 0.5);
     }
     for (int j = 0; j <= d->nq; ++j) sinq[j] = std::sin((qv[j] + qv[j]) * 0.5);
+    // MH_ARITH_FAST: the products the strict kernel forms per cell and stage in the reference's order (src/subprog_cloud.cpp:260-290)
+    // factorise into a per-row and a per-column part; the fast kernel multiplies the two (not bit-exact, far inside its tolerance):
+    //   dv = d3 (dmu 2 pi / 3), 1 / dv, -dAr = -(r_i r_i) (dmu 2 pi), -dAq = -(r_c dr) (sin q_j 2 pi)
+    double* rowf = cotq + d->nq;
+    double* colf = rowf + (size_t) 8 * d->nr_global;
+    for (int i = 0; i < d->nr_global; ++i)
+    {
+        const double r0 = rv[i], r1 = rv[i + 1], d3 = r1 * r1 * r1 - r0 * r0 * r0, rc = (r0 + r1) * 0.5;
+        const double row[8] = {r0 * r0, r1 * r1, d3, 1.0 / d3, rc * (r1 - r0), rc, 1.0 / rc, 0.0};
+        for (int k = 0; k < 8; ++k) rowf[(size_t) 8 * i + k] = row[k];
+    }
+    for (int j = 0; j < d->nq; ++j)
+    {
+        const double col[8] = {dmu[j] * 2 * M_PI, dmu[j] * 2 * M_PI / 3.0, 1.0 / (dmu[j] * 2 * M_PI / 3.0), sinq[j] * 2 * M_PI, sinq[j + 1] * 2 * M_PI, cotq[j], 0.0, 0.0};
+        for (int k = 0; k < 8; ++k) colf[(size_t) 8 * j + k] = col[k];
+    }
     return MH_OK;
 }
 

@@ -46,6 +46,8 @@ struct CloudParams
     const double* dmu;         // [nq]   -cos q_{j+1} - -cos q_j
     const double* sinq;        // [nq+1] sin q_j
     const double* cotq;        // [nq]   tan(pi/2 - theta_c)
+    const double* rowf;        // [nr_global][8] per-row factors    (MH_ARITH_FAST; mh_cloud_pack_geometry)
+    const double* colf;        // [nq][8]        per-column factors
     const double* inflow;      // [5][nq] primitives of the inner ghost row
     int32_t*      status;
     long   plane_stride, row_stride;
@@ -97,6 +99,27 @@ __device__ inline RowGeom row_geometry(const double* rv, int i)
 
 struct ColGeom { double dmu, sin_lo, sin_hi, cot; };
 
+// everything one cell's update needs from the grid, per row of the march
+struct CellGeom { double dv, inv_dv, nAr_lo, nAr_hi, nAq_lo, nAq_hi, rc, inv_rc; };
+
+// the five variables of one stored row through a buffer resource: wave-uniform row pointer (scalar registers), per-lane byte offset,
+// scalar plane offset - five buffer instructions and no vector address arithmetic (as euler2d.hip)
+using cb64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
+__device__ inline State5 cloud_load_row(const double* row, long plane, unsigned lane_bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, (int) (5 * plane * 8), 0x00020000);
+    State5 U;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * plane * 8), 0));
+    return U;
+}
+__device__ inline void cloud_store_row(double* row, long plane, unsigned lane_bytes, const State5& U)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int) (5 * plane * 8), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cb64_t, U[q]), rs, lane_bytes, (unsigned) (q * plane * 8), 0);
+}
+
 __device__ inline double cell_volume(const RowGeom& rg, const ColGeom& cg, const Recip& three)
 {
     return divide(rg.d3 * cg.dmu * 2 * M_PI, three);
@@ -138,29 +161,64 @@ void cloud_stage_kernel(CloudParams p)
     const Recip three = make_recip(3.0, 1.0);
     const double theta = p.theta, tfloor = p.tfloor;
     const ColGeom cg = {p.dmu[jc], p.sinq[jc], p.sinq[jc + 1], p.cotq[jc]};
+    // MH_ARITH_FAST: per-column factors of the host's table (dmu 2 pi, dmu 2 pi / 3, its inverse, sin q_j 2 pi, sin q_{j+1} 2 pi)
+    double col_ar = 0.0, col_dv = 0.0, col_inv_dv = 0.0, col_aq_lo = 0.0, col_aq_hi = 0.0;
+    if constexpr (S::table_geometry)
+    {
+        const double* cf = p.colf + 8L * jc;
+        col_ar = cf[0]; col_dv = cf[1]; col_inv_dv = cf[2]; col_aq_lo = cf[3]; col_aq_hi = cf[4];
+    }
+    // geometry of the cells of global row i: the reference's products in its order (strict), or per-row x per-column factors (fast)
+    auto cell_geometry = [&] (int i) -> CellGeom
+    {
+        CellGeom c;
+        if constexpr (S::table_geometry)
+        {
+            const double* rf = p.rowf + 8L * i;          // wave-uniform: scalar loads
+            c.dv = rf[2] * col_dv;
+            c.inv_dv = rf[3] * col_inv_dv;
+            c.nAr_lo = -(rf[0] * col_ar);
+            c.nAr_hi = -(rf[1] * col_ar);
+            c.nAq_lo = -(rf[4] * col_aq_lo);
+            c.nAq_hi = -(rf[4] * col_aq_hi);
+            c.rc = rf[5];
+            c.inv_rc = rf[6];
+        }
+        else
+        {
+            const RowGeom rg = row_geometry(p.rv, i);
+            c.dv = cell_volume(rg, cg, three);
+            c.inv_dv = 0.0;
+            c.nAr_lo = -(rg.rr_lo * cg.dmu * 2 * M_PI);
+            c.nAr_hi = -(rg.rr_hi * cg.dmu * 2 * M_PI);
+            c.nAq_lo = -(rg.rcdr * cg.sin_lo * 2 * M_PI);
+            c.nAq_hi = -(rg.rcdr * cg.sin_hi * 2 * M_PI);
+            c.rc = rg.rc;
+            c.inv_rc = 0.0;
+        }
+        return c;
+    };
 
     const long row_stride = p.row_stride, plane = p.plane_stride;
-    const double* in = p.u_in + jc;
+    const double* in = p.u_in;
     auto row_off = [row_stride] (int r) { return (long) (r + CHALO) * row_stride; };
+    const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
     StatusAcc acc;        // error contract (status_device.hpp): recover_primitive's status bits + the flat index r * n1 + col of the cell
 
     // the five conserved variables of a stored row (clamped to the stored range: rows -2 .. n0+1)
     auto load_raw = [&] (int r) -> State5
     {
         const int rr = min(max(r, -CHALO), p.n0 + CHALO - 1);
-        State5 U;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) U[q] = in[q * plane + row_off(rr)];
-        return U;
+        return cloud_load_row(in + row_off(rr), plane, jc8);
     };
     // primitive of a stored row (real row, or a ghost row received from the neighbouring slab) from its loaded variables
     auto prim_of_raw = [&] (int r, const State5& raw) -> State5
     {
-        const RowGeom rg = row_geometry(p.rv, p.row_offset + r);
+        const CellGeom c = cell_geometry(p.row_offset + r);
         double x[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) x[q] = raw[q];
-        S::to_density(x, cell_volume(rg, cg, three));
+        S::to_density(x, c.dv, c.inv_dv);
         State5 U, P;
 #pragma unroll
         for (int q = 0; q < 5; ++q) U[q] = x[q];
@@ -263,29 +321,21 @@ void cloud_stage_kernel(CloudParams p)
         if (pole_hi) Fy_hi = times_zero(Fy_lo);
 
         // ---- geometry, source terms, update
-        const RowGeom rg = row_geometry(p.rv, p.row_offset + r);
-        const double dv = cell_volume(rg, cg, three);
-        const double nAr_lo = -(rg.rr_lo * cg.dmu * 2 * M_PI);
-        const double nAr_hi = -(rg.rr_hi * cg.dmu * 2 * M_PI);
-        const double nAq_lo = -(rg.rcdr * cg.sin_lo * 2 * M_PI);
-        const double nAq_hi = -(rg.rcdr * cg.sin_hi * 2 * M_PI);
-        const State5 Src = S::source(P0, rg.rc, cg.cot, g);
+        const CellGeom c = cell_geometry(p.row_offset + r);
+        const State5 Src = S::source(P0, c.rc, c.inv_rc, cg.cot, g);
+        const State5 U0 = cloud_load_row(in + row_off(r), plane, jc8);       // the row's own conserved values once more (no register ring: three waves per SIMD)
+        State5 Ubase;
+        if constexpr (COMBINE) Ubase = cloud_load_row(p.u_base + row_off(r), plane, jc8);
 
         State5 Un;
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
-            const double u0 = in[q * plane + row_off(r)];
-            const double u1 = S::update(u0, Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], nAr_lo, nAr_hi, nAq_lo, nAq_hi, Src[q], dv, p.dt);
-            if constexpr (COMBINE) Un[q] = S::combine(p.u_base[jc + q * plane + row_off(r)], u1, p.weight);
+            const double u1 = S::update(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
+            if constexpr (COMBINE) Un[q] = S::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
         }
-        if (writes)
-        {
-            double* out = p.u_out + col;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) out[q * plane + row_off(r)] = Un[q];
-        }
+        if (writes) cloud_store_row(p.u_out + row_off(r), plane, col8, Un);
 
         P0 = P1; P1 = P2;
         if constexpr (PLM) G0 = G1;
@@ -307,6 +357,8 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     p.dmu = p.rv + d->nr_global + 1;
     p.sinq = p.dmu + d->nq;
     p.cotq = p.sinq + d->nq + 1;
+    p.rowf = p.cotq + d->nq;
+    p.colf = p.rowf + 8L * d->nr_global;
     p.inflow = inflow_dev;
     p.status = status;
     p.plane_stride = d->nq;

@@ -15,6 +15,10 @@ namespace srhd_fast {
 
 using srhd::Gamma;
 
+// The iteration starts from p = 0 like the reference's (src/physics_srhd.hpp:378) and that is part of the RESULT, not only of the cost:
+// in cold gas |f| < 1e-10 holds at the first test, so the accepted pressure is ONE Newton step from the start value. Starting from the
+// neighbouring cell's pressure instead (measured: it would save a step or two per cell) lands 1e-9 away in relative terms - closer to
+// the root, but outside the 1e-12 agreement with the reference that this arithmetic mode promises.
 __device__ inline int recover_primitive(const State5& U, const Gamma& g, double temperature_floor, State5& P)
 {
     const double gm = g.gamma;
@@ -72,9 +76,13 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     double W, rW;
     fast::sqrt_rsqrt(1.0 + uu, W, rW);
     const double H = __builtin_fma(P[4], g.hfac, P[0]);
-    const double rH = fast::rcp_nr(H);
     const double D = P[0] * W;
     const double p = P[4];
+    // 1 / H and 1 / (1 - vv c2) = H / (H - vv gamma p) from ONE reciprocal, that of H (H - vv gamma p)
+    const double vv = uu * rW * rW;                // uu / (1 + uu)
+    const double B = __builtin_fma(-vv, g.gamma * p, H);
+    const double rHB = fast::rcp_nr(H * B);
+    const double rH = B * rHB;
     const double Dh = H * W;                       // D h = rho W (H / rho)
     U[0] = D;
     U[1] = Dh * P[1];
@@ -88,10 +96,9 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     F[3] = AXIS == 2 ? __builtin_fma(v, U[3], p) : v * U[3];
     F[4] = v * (U[4] + p);
     const double c2 = g.gamma * p * rH;
-    const double vv = uu * rW * rW;                // uu / (1 + uu)
     const double v2 = v * v;
     const double k0 = fast::sqrt_fast(c2 * (1 - vv) * (1 - vv * c2 - v2 * (1 - c2)));
-    const double rden = fast::rcp_nr(1 - vv * c2);
+    const double rden = H * H * rHB;
     const double a = v * (1 - c2);
     lam_m = (a - k0) * rden;
     lam_p = (a + k0) * rden;
@@ -114,11 +121,11 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     return F;
 }
 
-__device__ inline State5 source_terms(const State5& P, double r, double cotq, const Gamma& g)
+// rr = 1 / r (the cloud kernel takes it from the host's per-row table)
+__device__ inline State5 source_terms_rinv(const State5& P, double rr, double cotq, const Gamma& g)
 {
     const double ur = P[1], uq = P[2], up = P[3], pg = P[4];
     const double H = __builtin_fma(P[4], g.hfac, P[0]);
-    const double rr = fast::rcp_nr(r);
     State5 S;
     S[0] = 0.0;
     S[1] = __builtin_fma(H, __builtin_fma(uq, uq, up * up), 2.0 * pg) * rr;
@@ -127,6 +134,7 @@ __device__ inline State5 source_terms(const State5& P, double r, double cotq, co
     S[4] = 0.0;
     return S;
 }
+__device__ inline State5 source_terms(const State5& P, double r, double cotq, const Gamma& g) { return source_terms_rinv(P, fast::rcp_nr(r), cotq, g); }
 
 } // namespace srhd_fast
 
@@ -134,11 +142,12 @@ __device__ inline State5 source_terms(const State5& P, double r, double cotq, co
 struct SrhdStrict
 {
     static constexpr int min_waves_per_simd = 2;      // 163-167 VGPRs: three waves fit anyway
-    static __device__ inline void to_density(double (&x)[5], double dv) { divide_group<5>(x, make_recip(dv, 1.0)); }
+    static constexpr bool table_geometry = false;     // geometry factors formed per cell in the reference's order
+    static __device__ inline void to_density(double (&x)[5], double dv, double) { divide_group<5>(x, make_recip(dv, 1.0)); }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
+    static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
     static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return plm_gradient(l, c, r, th); }
     template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd::riemann_hlle<AXIS>(Pl, Pr, g); }
-    static __device__ inline State5 source(const State5& P, double r, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
     // u0 + ((Fr_hi (-dAr_hi) - Fr_lo (-dAr_lo)) + (Fq_hi (-dAq_hi) - Fq_lo (-dAq_lo)) + S dv) dt     src/subprog_cloud.cpp:572-574
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
     {
@@ -153,11 +162,12 @@ struct SrhdStrict
 struct SrhdFast
 {
     static constexpr int min_waves_per_simd = 3;      // hold the allocation at 168 VGPRs
-    static __device__ inline void to_density(double (&x)[5], double dv) { const double r = fast::rcp_nr(dv); for (int q = 0; q < 5; ++q) x[q] *= r; }
+    static constexpr bool table_geometry = true;      // per-row x per-column factors from the host's tables (mh_cloud_pack_geometry)
+    static __device__ inline void to_density(double (&x)[5], double, double inv_dv) { for (int q = 0; q < 5; ++q) x[q] *= inv_dv; }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive(U, g, tf, P); }
+    static __device__ inline State5 source(const State5& P, double, double inv_r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms_rinv(P, inv_r, cot, g); }
     static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return fast::plm_gradient(l, c, r, th); }
     template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd_fast::riemann_hlle<AXIS>(Pl, Pr, g); }
-    static __device__ inline State5 source(const State5& P, double r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms(P, r, cot, g); }
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
     {
         const double lr = __builtin_fma(fxh, nArh, -fxl * nArl);
