@@ -474,6 +474,24 @@ int  mh_binary_get_solution(mh_binary* b, double* u_aos_host /* may be NULL */, 
  * from the old solution, subprog_binary.cpp:285-292). safe_mode_steps (may be NULL) counts the steps that needed it.
  * Returns MH_E_PHYSICS if the safe-mode retry fails too (the reference's exception then escapes). */
 int  mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps);
+/* Multi-GPU for uniform-depth trees: the mesh is cut into BANDS of whole rows of tree blocks - rank r of N owns block rows
+ * partition_shape(n / block_size, N)[r] (src/core_ndarray.hpp:820-836); the reference hands whole blocks to its thread pool
+ * (tree.map(fn, pool), src/core_tree.hpp:615-625) and blocks must stay whole because work_done_on is nonlinear in each block's sink
+ * sums (src/subprog_binary_scheme.cpp:356-365). Per stage one two-row ghost exchange with the periodic neighbours; per host
+ * synchronisation one sum of the 2 x 18 totals (max of the wavespeed, of the status words) over the ranks, then every rank does the
+ * same scalar bookkeeping. xv, yv, u_init_aos, buffer_rate describe the WHOLE mesh (a band keeps its rows); mh_binary_set_solution /
+ * get_solution take the whole-mesh host array as well and touch the band's rows [row0, row1) only. mh_binary_next is collective over the
+ * ranks. RCCL form (one process per GPU) and LOOPBACK group (all bands as objects of one process on one GPU, see mh_slab_group_create).
+ * Fields do not depend on the partition bit for bit while the binary is not live; the totals agree to the order of summation. */
+int  mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
+                           const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host, int rank, int world,
+                           const void* comm_id128);
+int  mh_binary_band_rows(const mh_binary* b, int* row0, int* row1);
+int  mh_binary_group_create(mh_binary** bands, int world, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
+                            const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host);
+int  mh_binary_group_set_solution(mh_binary** bands, int world, const double* u_aos_host, const mh_binary_state* state);
+int  mh_binary_group_get_solution(mh_binary** bands, int world, double* u_aos_host, mh_binary_state* state);
+int  mh_binary_group_next(mh_binary** bands, int world, int nsteps, int* safe_mode_steps);
 double mh_binary_last_dt(const mh_binary* b);
 const double* mh_binary_field_ptr(mh_binary* b);
 int  mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaunches);

@@ -202,6 +202,12 @@ SYMBOLS = [
     ("mh_binary_set_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
     ("mh_binary_get_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
     ("mh_binary_next", _i, [_vp, _i, C.POINTER(_i)]),
+    ("mh_binary_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    ("mh_binary_band_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("mh_binary_group_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
+    ("mh_binary_group_set_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),
+    ("mh_binary_group_get_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),
+    ("mh_binary_group_next", _i, [C.POINTER(_vp), _i, _i, C.POINTER(_i)]),
     ("mh_binary_last_dt", _d, [_vp]),
     ("mh_binary_field_ptr", _vp, [_vp]),
     ("mh_binary_profile", _i, [_vp, _i, C.POINTER(_d), C.POINTER(_i)]),

@@ -293,3 +293,74 @@ class BinaryTreeSolver(BinarySolver):
         u = np.empty((len(self.blocks), self.bs, self.bs, 3))
         L.check(self.lib.mh_binary_get_solution(self.handle, u.ctypes.data_as(C.c_void_p), None))
         return u
+
+
+class BinaryBandGroup:
+    """The uniform-depth mesh cut into `world` BANDS of whole rows of tree blocks, as objects of one process on one GPU exchanging ghost
+    rows through the LOOPBACK backend (include/mara_hip.h: mh_binary_group_*; the RCCL form is mh_binary_band_create, one process per
+    GPU). Same interface as BinarySolver where it applies; arrays are the WHOLE mesh [n][n][3]."""
+
+    def __init__(self, cfg, world=2, device=0, chunk_rows=0, arith="strict"):
+        self.lib = L.load_library()
+        self.cfg, self.world = cfg, world
+        self.n = grid_size(cfg)
+        self.xv = vertices(cfg)
+        self.yv = self.xv
+        self.u_init, self.buffer_rate, recommended_time_step = solver_data(cfg, self.xv, self.yv)
+        self.desc = make_desc(cfg, chunk_rows=chunk_rows, xv=self.xv, yv=self.yv, arith=arith)
+        run = L.BinaryRun()
+        run.rk_order = int(cfg["rk_order"])
+        run.fixed_dt = int(cfg["fixed_dt"])
+        run.no_accretion_force = int(cfg["no_accretion_force"])
+        run.cfl_number = float(cfg["cfl_number"])
+        run.recommended_time_step = float(recommended_time_step)
+        run.begin_live_binary = float(cfg["begin_live_binary"])
+        self.run = run
+        self.handles = (C.c_void_p * world)()
+        L.check(self.lib.mh_binary_group_create(self.handles, world, device, C.byref(self.desc), C.byref(run), self.xv.ctypes.data_as(C.c_void_p),
+                                                self.yv.ctypes.data_as(C.c_void_p), self.u_init.ctypes.data_as(C.c_void_p),
+                                                self.buffer_rate.ctypes.data_as(C.c_void_p)))
+        self.rows = []
+        for r in range(world):
+            a, b = C.c_int(), C.c_int()
+            L.check(self.lib.mh_binary_band_rows(C.c_void_p(self.handles[r]), C.byref(a), C.byref(b)))
+            self.rows.append((a.value, b.value))
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
+
+    def set_solution(self, u, state):
+        up = None if u is None else np.ascontiguousarray(u, dtype=np.float64).ctypes.data_as(C.c_void_p)
+        L.check(self.lib.mh_binary_group_set_solution(self.handles, self.world, up, C.byref(state)))
+
+    def state(self):
+        s = L.BinaryState()
+        L.check(self.lib.mh_binary_group_get_solution(self.handles, self.world, None, C.byref(s)))
+        return s
+
+    def solution(self):
+        u = np.empty((self.n, self.n, 3))
+        L.check(self.lib.mh_binary_group_get_solution(self.handles, self.world, u.ctypes.data_as(C.c_void_p), None))
+        return u
+
+    def next(self, nsteps=1):
+        safe = C.c_int(0)
+        L.check(self.lib.mh_binary_group_next(self.handles, self.world, int(nsteps), C.byref(safe)))
+        return safe.value
+
+    @property
+    def last_dt(self):
+        return self.lib.mh_binary_last_dt(C.c_void_p(self.handles[0]))
+
+    def close(self):
+        # member 0 owns the stream the others run on: destroy it last
+        for r in reversed(range(self.world)):
+            if self.handles[r]:
+                self.lib.mh_binary_destroy(C.c_void_p(self.handles[r]))
+                self.handles[r] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

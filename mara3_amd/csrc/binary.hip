@@ -61,7 +61,9 @@ struct BinaryStageParams
     const double* yv;
     double*       partials;   // [nwaves][NPART]
     int32_t*      status;
+    const double* xvg;        // x vertices of the WHOLE mesh (xv = xvg + row0: this band's)
     int    n, chunk_rows, nstrips, nchunks;
+    int    n0, row0, ext0;    // band of the mesh held by this field: rows [row0, row0 + n0); ext0: its ghost rows belong to other bands
     double theta, dt, weight;
     BinaryConsts c;
 };
@@ -130,9 +132,9 @@ void binary_stage_kernel(BinaryStageParams p)
     const int lane = threadIdx.x & 63;
     const int chunk = w / p.nstrips;
     const int strip = w - chunk * p.nstrips;
-    const int n = p.n;
+    const int n = p.n, n0 = p.n0;
     const int r0 = chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, n);
+    const int r1 = min(r0 + p.chunk_rows, n0);
 
     // column of this lane: `col` is the un-wrapped index (positions), `jc` the periodic image (data)
     const int col = strip * BSTRIP - BHALO + lane;
@@ -146,7 +148,8 @@ void binary_stage_kernel(BinaryStageParams p)
     const double yv_lo = p.yv[min(max(col, 0), n)];
     const double yc = (p.yv[jc] + p.yv[jc + 1]) * 0.5;
     const double dy = p.yv[jc + 1] - p.yv[jc];
-    auto xc_of = [&p, n] (int r) { const int rw = r < 0 ? r + n : (r >= n ? r - n : r); return (p.xv[rw] + p.xv[rw + 1]) * 0.5; };
+    // centre of the cell that the data of (possibly ghost) row r belongs to: the periodic image within the whole mesh
+    auto xc_of = [&p, n] (int r) { const int g = p.row0 + r; const int rw = g < 0 ? g + n : (g >= n ? g - n : g); return (p.xvg[rw] + p.xvg[rw + 1]) * 0.5; };
 
     const BinaryConsts& c = p.c;
     const typename A::Ctx k = A::make(c);
@@ -174,7 +177,7 @@ void binary_stage_kernel(BinaryStageParams p)
 #pragma unroll
         for (int q = 0; q < 3; ++q) Fx[0][q] = Fx[0][q] * dy;
     }
-    State3 Upre = load_row3(in + row_off(min(r0 + 3, n + 1)), n, jc8);
+    State3 Upre = load_row3(in + row_off(min(r0 + 3, n0 + 1)), n, jc8);
 
     double part[NPART];
 #pragma unroll
@@ -185,7 +188,7 @@ void binary_stage_kernel(BinaryStageParams p)
     auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
     {
         constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
-        const State3 Unext = load_row3(in + row_off(min(r + 4, n + 1)), n, jc8);
+        const State3 Unext = load_row3(in + row_off(min(r + 4, n0 + 1)), n, jc8);
         const State3 Uinit = load_row3(p.u_init + row_off(r), n, jc8);
         const double brate = load_row1(p.br + (long) r * n, n, jc8);
         State3 Ubase;
@@ -286,13 +289,16 @@ void binary_stage_kernel(BinaryStageParams p)
         }
         if (__any(!(sigma_new >= 0.0)))          // validate_u :726-752 (and NaN); a scalar branch never taken in a healthy run
         {
-            if (writes && !(sigma_new >= 0.0)) acc.note_value(sigma_new, MH_STATUS_NEG_DENSITY, (uint32_t) r * (uint32_t) n + (uint32_t) col);
+            if (writes && !(sigma_new >= 0.0)) acc.note_value(sigma_new, MH_STATUS_NEG_DENSITY, (uint32_t) (p.row0 + r) * (uint32_t) n + (uint32_t) col);
         }
         if (writes)
         {
             store_row3(p.u_out + row_off(r), n, col8, Un);
-            if (r < BHALO) store_row3(p.u_out + row_off(n + r), n, col8, Un);          // periodic ghost rows of the output
-            if (r >= n - BHALO) store_row3(p.u_out + row_off(r - n), n, col8, Un);
+            if (! p.ext0)          // the whole mesh in this field: periodic ghost rows of the output (a band's come from its neighbours)
+            {
+                if (r < BHALO) store_row3(p.u_out + row_off(n + r), n, col8, Un);
+                if (r >= n - BHALO) store_row3(p.u_out + row_off(r - n), n, col8, Un);
+            }
         }
         U[K0] = Upre;
         Upre = Unext;
@@ -324,7 +330,7 @@ struct BinarySinkParams
     const double* xv;
     const double* yv;
     double*       block_out;   // [nb * nb][NBLK]
-    int    n, bs, nb, qform;
+    int    n, bs, nb, qform;   // nb: tree blocks per row of blocks (= n / bs); xv points at this band's first vertex
     double dt;
     BinaryConsts c;
 };
@@ -453,11 +459,11 @@ void binary_reduce_kernel(const double* partials, int nwaves, const double* bloc
 
 // ---- maximum wavespeed ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int n, int qform, BinaryConsts c, unsigned long long* result)
+void binary_maxw_kernel(const double* u, const double* xv, const double* yv, int n0, int n, int qform, BinaryConsts c, unsigned long long* result)
 {
     const Recip rmach = make_recip(c.mach, 1.0);
     double m = 0.0;
-    const long total = (long) n * n;
+    const long total = (long) n0 * n;
     for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
     {
         const int i = (int) (idx / n), j = (int) (idx - (long) i * n);
@@ -505,34 +511,38 @@ BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]
     return c;
 }
 
-static int binary_chunk_rows(const mh_binary_desc* d, int nstrips)
+static int binary_chunk_rows(const mh_binary_desc* d, int nstrips, int rows)
 {
     if (d->chunk_rows > 0) return d->chunk_rows;
     const long chunks_max = 2048 / nstrips > 0 ? 2048 / nstrips : 1;     // one residency round at 2 waves / SIMD
-    const long c = (d->n + chunks_max - 1) / chunks_max;
+    const long c = (rows + chunks_max - 1) / chunks_max;
     return (int) (c > 96 ? 32 : (c < 4 ? 4 : c));
 }
 
-size_t binary_scratch_doubles(const mh_binary_desc* d)
+size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band)
 {
+    const int rows = band ? band->n0 : d->n;
     const int nstrips = (d->n + BSTRIP - 1) / BSTRIP;
-    const int chunk = binary_chunk_rows(d, nstrips);
-    const long nwaves = (long) nstrips * ((d->n + chunk - 1) / chunk);
+    const int chunk = binary_chunk_rows(d, nstrips, rows);
+    const long nwaves = (long) nstrips * ((rows + chunk - 1) / chunk);
     const long nb = d->n / d->block_size;
-    return (size_t) (nwaves * NPART + nb * nb * NBLK);
+    return (size_t) (nwaves * NPART + (long) (rows / d->block_size) * nb * NBLK);
 }
 
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream)
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band)
 {
+    // xv: the x vertices of the WHOLE mesh; a band (rows [row0, row0 + n0), a multiple of the block size) sees its own slice of them
+    const int n0 = band ? band->n0 : d->n, row0 = band ? band->row0 : 0;
     BinaryStageParams p;
-    p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.u_init = u_init; p.br = br; p.xv = xv; p.yv = yv;
+    p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.u_init = u_init; p.br = br; p.xv = xv + row0; p.xvg = xv; p.yv = yv;
     p.status = status;
     p.n = d->n;
+    p.n0 = n0; p.row0 = row0; p.ext0 = band ? band->ext0 : 0;
     p.nstrips = (d->n + BSTRIP - 1) / BSTRIP;
-    p.chunk_rows = binary_chunk_rows(d, p.nstrips);
-    p.nchunks = (d->n + p.chunk_rows - 1) / p.chunk_rows;
+    p.chunk_rows = binary_chunk_rows(d, p.nstrips, n0);
+    p.nchunks = (n0 + p.chunk_rows - 1) / p.chunk_rows;
     p.theta = theta;
     p.dt = dt;
     p.weight = weight;
@@ -558,27 +568,29 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     if (e != hipSuccess) return e;
 
     BinarySinkParams s;
-    s.u_in = u_in; s.xv = xv; s.yv = yv;
+    s.u_in = u_in; s.xv = xv + row0; s.yv = yv;
     s.block_out = scratch + (long) nwaves * NPART;
     s.n = d->n; s.bs = d->block_size; s.nb = d->n / d->block_size; s.qform = d->angmom_form;
     s.dt = dt;
     s.c = p.c;
-    hipLaunchKernelGGL(binary_sink_kernel, dim3(s.nb * s.nb), dim3(256), 0, stream, s);
+    const int tree_blocks = (n0 / d->block_size) * s.nb;          // the band's rows of tree blocks x blocks per row
+    hipLaunchKernelGGL(binary_sink_kernel, dim3(tree_blocks), dim3(256), 0, stream, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.partials, nwaves, s.block_out, s.nb * s.nb, totals);
+    hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.partials, nwaves, s.block_out, tree_blocks, totals);
     return hipGetLastError();
 }
 
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
-                              double* result, hipStream_t stream)
+                              double* result, hipStream_t stream, const BinaryBand* band)
 {
     hipError_t e = hipMemsetAsync(result, 0, sizeof(double), stream);
     if (e != hipSuccess) return e;
     const BinaryConsts c = binary_make_consts(d, bodies);
-    const long total = (long) d->n * d->n;
+    const int n0 = band ? band->n0 : d->n, row0 = band ? band->row0 : 0;
+    const long total = (long) n0 * d->n;
     const int nblocks = (int) ((total + 256 * 4 - 1) / (256 * 4) < 2048 ? (total + 256 * 4 - 1) / (256 * 4) : 2048);
-    hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv, yv, d->n, (int) d->angmom_form, c, reinterpret_cast<unsigned long long*>(result));
+    hipLaunchKernelGGL(binary_maxw_kernel, dim3(nblocks), dim3(256), 0, stream, u, xv + row0, yv, n0, d->n, (int) d->angmom_form, c, reinterpret_cast<unsigned long long*>(result));
     return hipGetLastError();
 }
 

@@ -7,21 +7,31 @@
 // implicitly after every array expression; here the field never leaves the device and the host only sees ~300 bytes
 // per step. The step is transactional: stage outputs go to alternate buffers and the solution pointer is swapped
 // only after the status word came back clean, because the reference's safe-mode retry restarts from the OLD solution.
+//
+// Multi-GPU (uniform-depth trees): the mesh is cut into BANDS of whole rows of tree blocks, rank r of N owning block rows
+// partition_shape(n / block_size, N)[r] (the reference distributes whole blocks over its thread pool, tree.map(fn, pool)
+// src/core_tree.hpp:615-625; blocks stay whole because work_done_on is nonlinear in each block's sink sums, scheme.cpp:356-365).
+// Per stage: the stage launch over the band, one two-row ghost exchange with the (periodic) neighbours, and per host
+// synchronisation one sum of the 2 x 18 totals (+ max of the wavespeed, + the status words) over the ranks, after which every
+// rank does the same scalar bookkeeping on the same numbers. Backends as the slab stepper: RCCL (one process per GPU: send/recv
+// and three small all-reduces) or LOOPBACK (the bands as objects of one process sharing one stream: copies and a host sum).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
 #include <vector>
 #include "launch.hpp"
+#include "rccl_api.hpp"
 #include "binary_host.hpp"
+#include "binary_device.hpp"
 
 namespace mh {
 
-size_t binary_scratch_doubles(const mh_binary_desc* d);
+size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band);
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream);
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band);
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
-                              double* result, hipStream_t stream);
+                              double* result, hipStream_t stream, const BinaryBand* band);
 
 // graded trees (binary_tree.hip)
 struct TreeGeom { const int32_t* topo; const int32_t* level; const double* edges; int nb, bs; };
@@ -93,7 +103,18 @@ struct mh_binary
     int32_t* level_dev = nullptr;
     double* edges_dev = nullptr;
     std::vector<double> host_staging;
+    // band decomposition (see the header comment): rows [row0, row0 + n0) of the mesh; world == 1: the whole mesh
+    int rank = 0, world = 1, row0 = 0, n0 = 0;
+    int backend = 0;                                 // 0 none, 1 RCCL, 2 loopback
+    mh_binary* peer_lo = nullptr;
+    mh_binary* peer_hi = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owns_stream = true;                         // loopback members run on the first member's stream
+    double* reduced_dev = nullptr;                   // RCCL: the small block summed over the ranks (out of place: the local one stays local)
 };
+
+enum { BAND_NONE = 0, BAND_RCCL = 1, BAND_LOOPBACK = 2 };
+static BinaryBand band_of(const mh_binary* b) { return BinaryBand{b->n0, b->row0, b->world > 1 ? 1 : 0}; }
 
 static double* totals_dev(mh_binary* b, int stage) { return b->dev_small + stage * MH_BINARY_NTOTALS; }
 static double* maxw_dev(mh_binary* b) { return b->dev_small + 2 * MH_BINARY_NTOTALS; }
@@ -117,8 +138,11 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
         MH_HIP_TRY(binary_tree_stage_launch(&b->desc, b->geom, b->work, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
                                             totals_dev(b, slot), b->status, b->stream));
     else
+    {
+        const BinaryBand band = band_of(b);
         MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
-                                       totals_dev(b, slot), b->scratch, b->status, b->stream));
+                                       totals_dev(b, slot), b->scratch, b->status, b->stream, &band));
+    }
     if (b->profile)
     {
         MH_HIP_TRY(hipEventRecord(e1, b->stream));
@@ -132,42 +156,128 @@ static bool same_point(const mh_binary_state& a, const mh_binary_state& c)
     return a.time == c.time && memcmp(&a.orbital_elements, &c.orbital_elements, sizeof(mh_full_orbital_elements)) == 0;
 }
 
-// one attempt at a full step from (u[0], state); on success the new solution is in u[0] and *out
-static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch_maxw, mh_binary_state* out, bool* failed)
+// A TEAM is what advances together: one solver (world 1, or one RCCL rank of several processes), or all the band objects of a
+// loopback group. Every member holds the same scalar state; phase by phase the members are driven in lockstep.
+struct Team { mh_binary** m; int n; };
+static int check_binary_group(mh_binary** g, int n);
+
+// two ghost rows per side of field u[k] of every member, from its periodic neighbours (after the stage launches that wrote them)
+static int team_exchange(const Team& t, int k)
+{
+    for (int r = 0; r < t.n; ++r)
+    {
+        mh_binary* b = t.m[r];
+        if (b->world == 1) continue;
+        const size_t n = (size_t) b->desc.n, blk = 2 * 3 * n;          // two rows, three variables: contiguous
+        double* f = b->u[k];
+        if (b->backend == BAND_LOOPBACK)
+        {
+            // members share one stream: every stage launch of the team is already queued in front of these copies
+            const double* lo = b->peer_lo->u[k] + (size_t) b->peer_lo->n0 * 3 * n;          // the low neighbour's last two rows
+            const double* hi = b->peer_hi->u[k] + blk;                                        // the high neighbour's first two rows
+            MH_HIP_TRY(hipMemcpyAsync(f, lo, blk * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+            MH_HIP_TRY(hipMemcpyAsync(f + (size_t) (b->n0 + 2) * 3 * n, hi, blk * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+        }
+        else
+        {
+            RcclApi* api = rccl();
+            if (! api || ! b->comm) { set_error("binary bands: RCCL communicator missing"); return MH_E_STATE; }
+            const int lo = (b->rank + b->world - 1) % b->world, hi = (b->rank + 1) % b->world;
+            MH_RCCL_TRY(api->GroupStart());
+            MH_RCCL_TRY(api->Send(f + blk, blk, ncclDouble, lo, b->comm, b->stream));                                   // rows 0, 1
+            MH_RCCL_TRY(api->Send(f + (size_t) b->n0 * 3 * n, blk, ncclDouble, hi, b->comm, b->stream));                // rows n0 - 2, n0 - 1
+            MH_RCCL_TRY(api->Recv(f + (size_t) (b->n0 + 2) * 3 * n, blk, ncclDouble, hi, b->comm, b->stream));          // order as slab.hip (lo == hi at world 2)
+            MH_RCCL_TRY(api->Recv(f, blk, ncclDouble, lo, b->comm, b->stream));
+            MH_RCCL_TRY(api->GroupEnd());
+        }
+    }
+    return MH_OK;
+}
+
+// bring the small block (2 x 18 totals, maximum wavespeed, status words) to the host of every member - summed / maximised over the bands
+static int team_fetch(const Team& t)
+{
+    for (int r = 0; r < t.n; ++r)
+    {
+        mh_binary* b = t.m[r];
+        const double* src = b->dev_small;
+        if (b->world > 1 && b->backend == BAND_RCCL)
+        {
+            RcclApi* api = rccl();
+            if (! api || ! b->comm) { set_error("binary bands: RCCL communicator missing"); return MH_E_STATE; }
+            const size_t nt = 2 * MH_BINARY_NTOTALS;
+            MH_RCCL_TRY(api->AllReduce(b->dev_small, b->reduced_dev, nt, ncclDouble, ncclSum, b->comm, b->stream));
+            MH_RCCL_TRY(api->AllReduce(b->dev_small + nt, b->reduced_dev + nt, 1, ncclUint64, ncclMax, b->comm, b->stream));     // wavespeeds are > 0: bit order = value order
+            MH_RCCL_TRY(api->AllReduce(b->dev_small + nt + 1, b->reduced_dev + nt + 1, 2, ncclUint32, ncclMax, b->comm, b->stream));   // largest status word / earliest cell of any rank
+            src = b->reduced_dev;
+        }
+        MH_HIP_TRY(hipMemcpyAsync(b->mirror, src, sizeof(HostMirror), hipMemcpyDeviceToHost, b->stream));
+    }
+    for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipStreamSynchronize(t.m[r]->stream));
+    if (t.n > 1)
+    {
+        // loopback: the members' blocks are summed here, in band order
+        HostMirror sum = *t.m[0]->mirror;
+        for (int r = 1; r < t.n; ++r)
+        {
+            const HostMirror& o = *t.m[r]->mirror;
+            for (int s2 = 0; s2 < 2; ++s2) for (int k = 0; k < MH_BINARY_NTOTALS; ++k) sum.totals[s2][k] = sum.totals[s2][k] + o.totals[s2][k];
+            if (o.maxw > sum.maxw) sum.maxw = o.maxw;
+            sum.status[0] |= o.status[0];
+            if ((uint32_t) o.status[1] > (uint32_t) sum.status[1]) sum.status[1] = o.status[1];
+        }
+        for (int r = 0; r < t.n; ++r) *t.m[r]->mirror = sum;
+    }
+    return MH_OK;
+}
+
+static int team_maxw(const Team& t, int k, const mh_two_body_t& B)
+{
+    for (int r = 0; r < t.n; ++r)
+    {
+        mh_binary* b = t.m[r];
+        if (b->tree) MH_HIP_TRY(binary_tree_min_dt_launch(&b->desc, b->geom, b->u[k], B.body1, maxw_dev(b), b->stream));
+        else { const BinaryBand band = band_of(b); MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[k], B.body1, maxw_dev(b), b->stream, &band)); }
+    }
+    return MH_OK;
+}
+
+// one attempt at a full step from (u[0], state); on success the new solution is in u[2] of every member and *out
+static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetch_maxw, mh_binary_state* out, bool* failed)
 {
     static_assert(sizeof(mh_two_body_t) == 10 * sizeof(double), "bodies are passed as double[10]");
+    mh_binary* b = t.m[0];                     // scalars: identical on every member
     const mh_binary_state S0 = b->state;
     const double theta = safe_mode ? 0.0 : b->desc.plm_theta;
     const bool naf = b->run.no_accretion_force != 0;
     *failed = false;
     mh_two_body_t B1, B2;
     if (int rc = binary_bodies(S0.orbital_elements, S0.time, &B1)) return rc;
-    MH_HIP_TRY(hipMemsetAsync(b->status, 0, 2 * sizeof(int32_t), b->stream));
+    for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipMemsetAsync(t.m[r]->status, 0, 2 * sizeof(int32_t), t.m[r]->stream));
 
-    auto fetch = [b] () -> int
+    auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot) -> int
     {
-        // totals, maximum wavespeed and the status words are one device block laid out like HostMirror: one copy per synchronisation
-        MH_HIP_TRY(hipMemcpyAsync(b->mirror, b->dev_small, sizeof(HostMirror), hipMemcpyDeviceToHost, b->stream));
-        MH_HIP_TRY(hipStreamSynchronize(b->stream));
-        return MH_OK;
+        for (int r = 0; r < t.n; ++r)
+            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot)) return rc;
+        return team_exchange(t, outk);
     };
 
     if (b->run.rk_order == 1)
     {
-        if (int rc = launch_stage(b, b->u[0], nullptr, b->u[2], B1, dt, 1.0, theta, 0)) return rc;
-        if (int rc = fetch()) return rc;
+        if (int rc = stage(0, -1, 2, B1, dt, 1.0, theta, 0)) return rc;
+        if (int rc = team_fetch(t)) return rc;
         if (b->mirror->status[0]) { *failed = true; return MH_OK; }
         if (binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, out) != MH_OK) { *failed = true; return MH_OK; }
         return MH_OK;
     }
 
-    if (int rc = launch_stage(b, b->u[0], nullptr, b->u[1], B1, dt, 1.0, theta, 0)) return rc;
+    if (int rc = stage(0, -1, 1, B1, dt, 1.0, theta, 0)) return rc;
     mh_binary_state S1;
     const bool live = S0.time > b->run.begin_live_binary;
     if (live)
     {
         // the elements the second stage is evaluated with depend on the first stage's totals
-        if (int rc = fetch()) return rc;
+        if (int rc = team_fetch(t)) return rc;
         if (b->mirror->status[0]) { *failed = true; return MH_OK; }
         if (binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
         if (int rc = binary_bodies(S1.orbital_elements, S1.time, &B2)) return rc;
@@ -176,7 +286,7 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
     {
         if (int rc = binary_bodies(S0.orbital_elements, S0.time + dt, &B2)) return rc;   // elements + (...) * 0 = elements
     }
-    if (int rc = launch_stage(b, b->u[1], b->u[0], b->u[2], B2, dt, 0.5, theta, 1)) return rc;
+    if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1)) return rc;
 
     // look ahead: the next step's maximum wavespeed, evaluated on the step result while the totals travel
     mh_binary_state ahead = S0;
@@ -187,12 +297,11 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
         mh_two_body_t Bn;
         if (binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK)
         {
-            if (b->tree) MH_HIP_TRY(binary_tree_min_dt_launch(&b->desc, b->geom, b->u[2], Bn.body1, maxw_dev(b), b->stream));
-            else         MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[2], Bn.body1, maxw_dev(b), b->stream));
+            if (int rc = team_maxw(t, 2, Bn)) return rc;
             launched_ahead = true;
         }
     }
-    if (int rc = fetch()) return rc;
+    if (int rc = team_fetch(t)) return rc;
     if (b->mirror->status[0]) { *failed = true; return MH_OK; }
     if (! live && binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
     mh_two_body_t B2s;
@@ -209,9 +318,59 @@ static int binary_attempt(mh_binary* b, double dt, bool safe_mode, bool prefetch
     binary_combine_scalars(S0, S2, out);
     if (launched_ahead)
     {
-        b->maxw_ready = true;
-        b->maxw_value = b->mirror->maxw;
-        b->maxw_for = ahead;
+        for (int r = 0; r < t.n; ++r)
+        {
+            t.m[r]->maxw_ready = true;
+            t.m[r]->maxw_value = b->mirror->maxw;
+            t.m[r]->maxw_for = ahead;
+        }
+    }
+    return MH_OK;
+}
+
+// nsteps x next_solution for a team (subprog_binary.cpp:258-293)
+static int team_next(const Team& t, int nsteps, int* safe_mode_steps)
+{
+    mh_binary* b = t.m[0];
+    if (safe_mode_steps) *safe_mode_steps = 0;
+    for (int s = 0; s < nsteps; ++s)
+    {
+        // dt: subprog_binary.cpp:281-283
+        double dt = b->run.recommended_time_step;
+        if (! b->run.fixed_dt)
+        {
+            double maxw;
+            if (b->maxw_ready && same_point(b->maxw_for, b->state)) maxw = b->maxw_value;
+            else
+            {
+                mh_two_body_t B;
+                if (int rc = binary_bodies(b->state.orbital_elements, b->state.time, &B)) return rc;
+                if (int rc = team_maxw(t, 0, B)) return rc;
+                if (int rc = team_fetch(t)) return rc;
+                maxw = b->mirror->maxw;
+            }
+            // uniform grid: the reduction returns the largest wavespeed; graded tree: already min over blocks of spacing / wavespeed
+            dt = b->tree ? b->run.cfl_number * maxw : b->run.cfl_number * (b->h / maxw);
+        }
+        for (int r = 0; r < t.n; ++r) t.m[r]->maxw_ready = false;
+        mh_binary_state next;
+        bool failed = false;
+        if (int rc = binary_attempt(t, dt, false, s + 1 < nsteps, &next, &failed)) return rc;
+        if (failed)
+        {
+            if (safe_mode_steps) ++*safe_mode_steps;
+            dt = dt * 0.1;
+            for (int r = 0; r < t.n; ++r) t.m[r]->maxw_ready = false;
+            if (int rc = binary_attempt(t, dt, true, false, &next, &failed)) return rc;
+            if (failed) { set_error("negative density in updated state"); return MH_E_PHYSICS; }
+        }
+        for (int r = 0; r < t.n; ++r)
+        {
+            mh_binary* m = t.m[r];
+            double* tmp = m->u[0]; m->u[0] = m->u[2]; m->u[2] = tmp;      // commit
+            m->state = next;
+            m->last_dt = dt;
+        }
     }
     return MH_OK;
 }
@@ -236,7 +395,7 @@ size_t mh_binary_field_doubles(const mh_binary_desc* d)
 size_t mh_binary_scratch_doubles(const mh_binary_desc* d)
 {
     if (check_binary_desc(d) != MH_OK) return 0;
-    return binary_scratch_doubles(d);
+    return binary_scratch_doubles(d, nullptr);
 }
 
 int mh_binary_stage(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base, double* u_out,
@@ -246,7 +405,7 @@ int mh_binary_stage(const mh_binary_desc* d, const double* xv, const double* yv,
     if (int rc = check_binary_desc(d)) return rc;
     if (! xv || ! yv || ! u_in || ! u_out || ! u_init || ! br || ! bodies || ! totals || ! scratch || u_in == u_out) { set_error("binary stage: null or aliased argument"); return MH_E_INVALID; }
     if (w != 1.0 && ! u_base) { set_error("binary stage: combine needs u_base"); return MH_E_INVALID; }
-    MH_HIP_TRY(binary_stage_launch(d, xv, yv, u_in, u_base, u_out, u_init, br, bodies, dt, w, d->plm_theta, totals, scratch, status, (hipStream_t) stream));
+    MH_HIP_TRY(binary_stage_launch(d, xv, yv, u_in, u_base, u_out, u_init, br, bodies, dt, w, d->plm_theta, totals, scratch, status, (hipStream_t) stream, nullptr));
     return MH_OK;
 }
 
@@ -255,50 +414,119 @@ int mh_binary_max_wavespeed(const mh_binary_desc* d, const double* xv, const dou
 {
     if (int rc = check_binary_desc(d)) return rc;
     if (! xv || ! yv || ! u || ! bodies || ! result) { set_error("binary max_wavespeed: null argument"); return MH_E_INVALID; }
-    MH_HIP_TRY(binary_maxw_launch(d, xv, yv, u, bodies, result, (hipStream_t) stream));
+    MH_HIP_TRY(binary_maxw_launch(d, xv, yv, u, bodies, result, (hipStream_t) stream, nullptr));
+    return MH_OK;
+}
+
+// u_init_aos / br: the WHOLE mesh ([n][n][3], [n][n]); a band keeps its rows. shared_stream: loopback members run on one stream.
+static int binary_create_common(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
+                                const double* u_init_aos, const double* br, int rank, int world, int backend, hipStream_t shared_stream)
+{
+    if (! out || ! run || ! xv || ! yv || ! u_init_aos || ! br) { set_error("binary create: null argument"); return MH_E_INVALID; }
+    if (int rc = check_binary_desc(d)) return rc;
+    if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
+    const int block_rows = d->n / d->block_size;
+    if (rank < 0 || rank >= world || world > block_rows) { set_error("binary bands: rank %d of %d over %d rows of tree blocks", rank, world, block_rows); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(device));
+    mh_binary* b = new mh_binary();
+    b->device = device;
+    b->desc = *d;
+    b->run = *run;
+    b->rank = rank; b->world = world;
+    b->backend = world > 1 ? backend : BAND_NONE;
+    size_t ba, bb;
+    mh_partition_rows((size_t) block_rows, (size_t) world, (size_t) rank, &ba, &bb);          // whole rows of tree blocks, nd::partition_shape's formula
+    b->row0 = (int) ba * d->block_size;
+    b->n0 = (int) (bb - ba) * d->block_size;
+    const size_t n = d->n, n0 = (size_t) b->n0;
+    int depth = 0;
+    while ((d->block_size << depth) < d->n) ++depth;
+    b->h = 2.0 * d->domain_radius / d->block_size / (1 << depth);
+    b->field_doubles = (size_t) 3 * (n0 + 4) * n;
+    const BinaryBand band = band_of(b);
+    auto fail = [&] (hipError_t e, const char* what) { mh_binary_destroy(b); return hip_fail(e, what); };
+#define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
+    if (shared_stream) { b->stream = shared_stream; b->owns_stream = false; }
+    else B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->br, n0 * n * sizeof(double)));
+    B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
+    B_TRY(hipMalloc(&b->scratch, binary_scratch_doubles(d, &band) * sizeof(double)));
+    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
+    B_TRY(hipMemsetAsync(b->dev_small, 0, sizeof(HostMirror), b->stream));
+    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
+    if (b->backend == BAND_RCCL) B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
+    B_TRY(hipMalloc(&b->staging, n0 * n * 3 * sizeof(double)));
+    B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
+    B_TRY(hipMemcpyAsync(b->xv, xv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->yv, yv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->br, br + (size_t) b->row0 * n, n0 * n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(hipMemcpyAsync(b->staging, u_init_aos + (size_t) b->row0 * n * 3, n0 * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    B_TRY(aos_to_soa_launch(b->staging, b->u_init, 3, b->n0, n, b->stream));
+    // ghost rows of the initial field are never read (the buffer term is cell-local); the whole mesh keeps its periodic images anyway
+    if (world == 1) B_TRY(fill_ghost_rows_launch(b->u_init, 3, d->n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+    B_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    B_TRY(hipStreamSynchronize(b->stream));
+#undef B_TRY
+    memset(&b->state, 0, sizeof(b->state));
+    *out = b;
     return MH_OK;
 }
 
 int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
                      const double* u_init_aos, const double* br)
 {
-    if (! out || ! run || ! xv || ! yv || ! u_init_aos || ! br) { set_error("binary create: null argument"); return MH_E_INVALID; }
-    if (int rc = check_binary_desc(d)) return rc;
-    if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
-    MH_HIP_TRY(hipSetDevice(device));
-    mh_binary* b = new mh_binary();
-    b->device = device;
-    b->desc = *d;
-    b->run = *run;
-    const size_t n = d->n;
-    int depth = 0;
-    while ((d->block_size << depth) < d->n) ++depth;
-    b->h = 2.0 * d->domain_radius / d->block_size / (1 << depth);
-    b->field_doubles = mh_binary_field_doubles(d);
-    auto fail = [&] (hipError_t e, const char* what) { mh_binary_destroy(b); return hip_fail(e, what); };
-#define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
-    B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
-    B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
-    B_TRY(hipMalloc(&b->br, n * n * sizeof(double)));
-    B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
-    B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
-    B_TRY(hipMalloc(&b->scratch, binary_scratch_doubles(d) * sizeof(double)));
-    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
-    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
-    B_TRY(hipMalloc(&b->staging, n * n * 3 * sizeof(double)));
-    B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
-    B_TRY(hipMemcpyAsync(b->xv, xv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    B_TRY(hipMemcpyAsync(b->yv, yv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    B_TRY(hipMemcpyAsync(b->br, br, n * n * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    B_TRY(hipMemcpyAsync(b->staging, u_init_aos, n * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    B_TRY(aos_to_soa_launch(b->staging, b->u_init, 3, d->n, n, b->stream));
-    B_TRY(fill_ghost_rows_launch(b->u_init, 3, d->n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
-    B_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-    B_TRY(hipStreamSynchronize(b->stream));
-#undef B_TRY
-    memset(&b->state, 0, sizeof(b->state));
+    return binary_create_common(out, device, d, run, xv, yv, u_init_aos, br, 0, 1, BAND_NONE, nullptr);
+}
+
+int mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
+                          const double* u_init_aos, const double* br, int rank, int world, const void* comm_id128)
+{
+    mh_binary* b = nullptr;
+    if (int rc = binary_create_common(&b, device, d, run, xv, yv, u_init_aos, br, rank, world, BAND_RCCL, nullptr)) return rc;
+    if (world > 1)
+    {
+        RcclApi* api = rccl();
+        if (! api || ! comm_id128) { mh_binary_destroy(b); set_error("binary bands: RCCL not available or no unique id given"); return MH_E_STATE; }
+        ncclUniqueId id;
+        memcpy(&id, comm_id128, sizeof id);
+        ncclResult_t r = api->CommInitRank(&b->comm, world, id, rank);
+        if (r != ncclSuccess) { mh_binary_destroy(b); return rccl_fail(r, "ncclCommInitRank"); }
+    }
     *out = b;
+    return MH_OK;
+}
+
+int mh_binary_group_create(mh_binary** bands, int world, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv,
+                           const double* yv, const double* u_init_aos, const double* br)
+{
+    if (! bands || world < 1 || world > 64) { set_error("binary group: need 1..64 bands"); return MH_E_INVALID; }
+    for (int r = 0; r < world; ++r) bands[r] = nullptr;
+    for (int r = 0; r < world; ++r)
+        if (int rc = binary_create_common(&bands[r], device, d, run, xv, yv, u_init_aos, br, r, world, BAND_LOOPBACK, r == 0 ? nullptr : bands[0]->stream))
+        {
+            for (int q = r - 1; q >= 0; --q) { mh_binary_destroy(bands[q]); bands[q] = nullptr; }
+            return rc;
+        }
+    for (int r = 0; r < world; ++r)
+    {
+        bands[r]->peer_lo = bands[(r + world - 1) % world];
+        bands[r]->peer_hi = bands[(r + 1) % world];
+    }
+    // the ghost rows of the initial solution
+    const Team t = {bands, world};
+    if (int rc = team_exchange(t, 0)) return rc;
+    MH_HIP_TRY(hipStreamSynchronize(bands[0]->stream));
+    return MH_OK;
+}
+
+int mh_binary_band_rows(const mh_binary* b, int* row0, int* row1)
+{
+    if (! b) return MH_E_INVALID;
+    if (row0) *row0 = b->row0;
+    if (row1) *row1 = b->row0 + b->n0;
     return MH_OK;
 }
 
@@ -368,7 +596,9 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
     (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals);
     if (b->mirror) (void) hipHostFree(b->mirror);
-    if (b->stream) (void) hipStreamDestroy(b->stream);
+    (void) hipFree(b->reduced_dev);
+    if (b->comm && rccl()) rccl()->CommDestroy(b->comm);
+    if (b->stream && b->owns_stream) (void) hipStreamDestroy(b->stream);
     delete b;
 }
 
@@ -384,17 +614,41 @@ int mh_binary_set_solution(mh_binary* b, const double* u_aos, const mh_binary_st
     }
     else if (u_aos)
     {
-        MH_HIP_TRY(hipMemcpyAsync(b->staging, u_aos, n * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        MH_HIP_TRY(aos_to_soa_launch(b->staging, b->u[0], 3, b->desc.n, n, b->stream));
-        MH_HIP_TRY(fill_ghost_rows_launch(b->u[0], 3, b->desc.n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+        // u_aos is the WHOLE mesh [n][n][3]; a band takes its rows (its ghost rows: mh_binary_group_set_solution / the RCCL exchange below)
+        const size_t n0 = (size_t) b->n0;
+        MH_HIP_TRY(hipMemcpyAsync(b->staging, u_aos + (size_t) b->row0 * n * 3, n0 * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        MH_HIP_TRY(aos_to_soa_launch(b->staging, b->u[0], 3, b->n0, n, b->stream));
+        if (b->world == 1) MH_HIP_TRY(fill_ghost_rows_launch(b->u[0], 3, b->desc.n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
     }
     else
     {
         MH_HIP_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
+    if (b->world > 1 && b->backend == BAND_RCCL)
+    {
+        const Team t = {&b, 1};
+        if (int rc = team_exchange(t, 0)) return rc;          // collective: every rank sets its solution
+    }
     MH_HIP_TRY(hipStreamSynchronize(b->stream));
     b->state = *state;
     b->maxw_ready = false;
+    return MH_OK;
+}
+
+int mh_binary_group_set_solution(mh_binary** g, int n, const double* u_aos, const mh_binary_state* state)
+{
+    if (int rc = check_binary_group(g, n)) return rc;
+    for (int r = 0; r < n; ++r) if (int rc = mh_binary_set_solution(g[r], u_aos, state)) return rc;
+    const Team t = {g, n};
+    if (int rc = team_exchange(t, 0)) return rc;
+    MH_HIP_TRY(hipStreamSynchronize(g[0]->stream));
+    return MH_OK;
+}
+
+int mh_binary_group_get_solution(mh_binary** g, int n, double* u_aos, mh_binary_state* state)
+{
+    if (int rc = check_binary_group(g, n)) return rc;
+    for (int r = 0; r < n; ++r) if (int rc = mh_binary_get_solution(g[r], u_aos, r == 0 ? state : nullptr)) return rc;
     return MH_OK;
 }
 
@@ -414,9 +668,10 @@ int mh_binary_get_solution(mh_binary* b, double* u_aos, mh_binary_state* state)
     }
     else if (u_aos)
     {
-        const size_t n = b->desc.n;
-        MH_HIP_TRY(soa_to_aos_launch(b->u[0], b->staging, 3, b->desc.n, n, b->stream));
-        MH_HIP_TRY(hipMemcpyAsync(u_aos, b->staging, n * n * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        // into the WHOLE-mesh host array: a band writes its own rows only
+        const size_t n = b->desc.n, n0 = (size_t) b->n0;
+        MH_HIP_TRY(soa_to_aos_launch(b->u[0], b->staging, 3, b->n0, n, b->stream));
+        MH_HIP_TRY(hipMemcpyAsync(u_aos + (size_t) b->row0 * n * 3, b->staging, n0 * n * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         MH_HIP_TRY(hipStreamSynchronize(b->stream));
     }
     if (state) *state = b->state;
@@ -426,46 +681,28 @@ int mh_binary_get_solution(mh_binary* b, double* u_aos, mh_binary_state* state)
 int mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps)
 {
     if (! b || nsteps < 0) { set_error("binary next: bad argument"); return MH_E_INVALID; }
+    if (b->backend == BAND_LOOPBACK) { set_error("binary next: member of a loopback group (use mh_binary_group_next)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
-    if (safe_mode_steps) *safe_mode_steps = 0;
-    for (int s = 0; s < nsteps; ++s)
-    {
-        // dt: subprog_binary.cpp:281-283
-        double dt = b->run.recommended_time_step;
-        if (! b->run.fixed_dt)
-        {
-            double maxw;
-            if (b->maxw_ready && same_point(b->maxw_for, b->state)) maxw = b->maxw_value;
-            else
-            {
-                mh_two_body_t B;
-                if (int rc = binary_bodies(b->state.orbital_elements, b->state.time, &B)) return rc;
-                if (b->tree) MH_HIP_TRY(binary_tree_min_dt_launch(&b->desc, b->geom, b->u[0], B.body1, maxw_dev(b), b->stream));
-                else         MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[0], B.body1, maxw_dev(b), b->stream));
-                MH_HIP_TRY(hipMemcpyAsync(&b->mirror->maxw, maxw_dev(b), sizeof(double), hipMemcpyDeviceToHost, b->stream));
-                MH_HIP_TRY(hipStreamSynchronize(b->stream));
-                maxw = b->mirror->maxw;
-            }
-            // uniform grid: the reduction returns the largest wavespeed; graded tree: already min over blocks of spacing / wavespeed
-            dt = b->tree ? b->run.cfl_number * maxw : b->run.cfl_number * (b->h / maxw);
-        }
-        b->maxw_ready = false;
-        mh_binary_state next;
-        bool failed = false;
-        if (int rc = binary_attempt(b, dt, false, s + 1 < nsteps, &next, &failed)) return rc;
-        if (failed)
-        {
-            if (safe_mode_steps) ++*safe_mode_steps;
-            dt = dt * 0.1;
-            b->maxw_ready = false;
-            if (int rc = binary_attempt(b, dt, true, false, &next, &failed)) return rc;
-            if (failed) { set_error("negative density in updated state"); return MH_E_PHYSICS; }
-        }
-        double* t = b->u[0]; b->u[0] = b->u[2]; b->u[2] = t;      // commit
-        b->state = next;
-        b->last_dt = dt;
-    }
+    const Team t = {&b, 1};
+    return team_next(t, nsteps, safe_mode_steps);
+}
+
+static int check_binary_group(mh_binary** g, int n)
+{
+    if (! g || n < 1 || n > 64) { set_error("binary group: need 1..64 bands"); return MH_E_INVALID; }
+    for (int r = 0; r < n; ++r)
+        if (! g[r] || g[r]->world != n || g[r]->rank != r || (n > 1 && g[r]->backend != BAND_LOOPBACK))
+        { set_error("binary group: band %d is not member %d of a loopback group of %d", r, r, n); return MH_E_INVALID; }
     return MH_OK;
+}
+
+int mh_binary_group_next(mh_binary** g, int n, int nsteps, int* safe_mode_steps)
+{
+    if (int rc = check_binary_group(g, n)) return rc;
+    if (nsteps < 0) { set_error("binary next: bad argument"); return MH_E_INVALID; }
+    MH_HIP_TRY(hipSetDevice(g[0]->device));
+    const Team t = {g, n};
+    return team_next(t, nsteps, safe_mode_steps);
 }
 
 double mh_binary_last_dt(const mh_binary* b) { return b ? b->last_dt : 0.0; }
@@ -499,6 +736,7 @@ int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaun
 int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_momentum)
 {
     if (! b) { set_error("binary disk_totals: null solver"); return MH_E_INVALID; }
+    if (b->world > 1) { set_error("binary disk_totals: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* partial = b->u[2];
@@ -516,6 +754,7 @@ int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_
 int mh_binary_diagnostic_fields(mh_binary* b, double* sigma, double* radial_velocity, double* phi_velocity)
 {
     if (! b) { set_error("binary diagnostic_fields: null solver"); return MH_E_INVALID; }
+    if (b->world > 1) { set_error("binary diagnostic_fields: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* fields = b->u[1];

@@ -12,6 +12,10 @@ namespace mh {
 
 using iso2d::State3;
 
+// A band of the uniform-depth mesh held by one device field: rows [row0, row0 + n0) of the n x n cells (whole rows of tree blocks);
+// ext0: the ghost rows of the field belong to other bands (filled by the exchange) instead of being the periodic image of its own rows
+struct BinaryBand { int n0, row0, ext0; };
+
 struct BinaryConsts
 {
     double h;                 // grid spacing 2 R / block_size / 2^level of the grid or block being processed

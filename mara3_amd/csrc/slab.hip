@@ -54,9 +54,10 @@ RcclApi* rccl()
             MH_SYM(GroupEnd, "ncclGroupEnd");
             MH_SYM(Send, "ncclSend");
             MH_SYM(Recv, "ncclRecv");
+            MH_SYM(AllReduce, "ncclAllReduce");
             MH_SYM(GetErrorString, "ncclGetErrorString");
 #undef MH_SYM
-            if (! (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv))
+            if (! (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv && api.AllReduce))
             {
                 dlclose(api.handle);
                 api.handle = nullptr;
