@@ -29,9 +29,67 @@ def oracle():
     return mara_oracle
 
 
+def run_c3_bands(args):
+    """BASELINE config 3 over N GPUs: the 2048^2 mesh as N bands of whole rows of tree blocks (strong scaling), one process per GPU under
+    torch.distributed.run (RCCL), or --loopback-bands N: the bands as objects of this process on one GPU (rehearsal)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mara3_amd import binary
+    from mara3_amd.slab import native_comm_id
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
+    n = binary.grid_size(cfg)
+    nbands = args.loopback_bands or world
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    res = {}
+    for arith in ("fast", "strict"):
+        if args.loopback_bands:
+            s = binary.BinaryBandGroup(cfg, world=nbands, device=local_rank, arith=arith)
+        else:
+            s = binary.BinaryBand(cfg, rank, world, native_comm_id(rank, world, device="cuda"), device=local_rank, arith=arith)
+        s.next(args.warmup)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        safe = s.next(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res[arith] = {"value": n * n * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "safe_mode_steps": safe}
+        s.close()
+    out = {
+        "metric": "zone-updates/sec (Mcells/s), subprog_binary 2048^2 (depth=5 block_size=64), PLM+HLLE+viscosity RK2, %d bands" % nbands,
+        "value": res["fast"]["value"], "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["fast"]["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "binary depth=5 block_size=64 focus_factor=1e9 fixed_dt=1 rk_order=2 plm_theta=1.8, other run_config defaults",
+                   "decomposition": ("REHEARSAL on one GPU: %d band objects exchanging through the loopback backend" % nbands) if args.loopback_bands
+                                    else "one band of whole rows of tree blocks per GPU, 2-row RCCL halo per stage, all-reduce of 2 x 18 totals per step"},
+        "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+        "arith_strict": res["strict"],
+    }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
 def run_c3(args):
     import numpy as np
     from mara3_amd import binary
+    if args.loopback_bands or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return run_c3_bands(args)
     cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
     n = binary.grid_size(cfg)
     fast = c3_run(args, binary, cfg, n, "fast")
@@ -334,6 +392,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--riemann", default="hlle", choices=["hlle", "hllc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loopback-bands", type=int, default=0, help="c3: the mesh as this many bands (objects of one process on one GPU)")
     ap.add_argument("--loopback-blocks", type=int, default=0, help="c5: this many blocks (grid^3 cells each) as objects of one process on one GPU")
     args = ap.parse_args()
     import mara3_amd

@@ -364,3 +364,37 @@ class BinaryBandGroup:
             self.close()
         except Exception:
             pass
+
+
+class BinaryBand(BinarySolver):
+    """ONE band of the mesh in this process (RCCL backend: one process per GPU; `comm_id` = the 128-byte unique id every rank shares,
+    mara3_amd.slab.native_comm_id). next() is collective over the ranks; solution() returns the whole-mesh array with this band's rows
+    filled in (rows [row0, row1))."""
+
+    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict"):
+        self.lib = L.load_library()
+        self.cfg = cfg
+        self.n = grid_size(cfg)
+        self.xv = vertices(cfg)
+        self.yv = self.xv
+        self.u_init, self.buffer_rate, recommended_time_step = solver_data(cfg, self.xv, self.yv)
+        self.desc = make_desc(cfg, chunk_rows=chunk_rows, xv=self.xv, yv=self.yv, arith=arith)
+        run = L.BinaryRun()
+        run.rk_order = int(cfg["rk_order"])
+        run.fixed_dt = int(cfg["fixed_dt"])
+        run.no_accretion_force = int(cfg["no_accretion_force"])
+        run.cfl_number = float(cfg["cfl_number"])
+        run.recommended_time_step = float(recommended_time_step)
+        run.begin_live_binary = float(cfg["begin_live_binary"])
+        self.run = run
+        self.handle = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
+        L.check(self.lib.mh_binary_band_create(C.byref(self.handle), device, C.byref(self.desc), C.byref(run), self.xv.ctypes.data_as(C.c_void_p),
+                                               self.yv.ctypes.data_as(C.c_void_p), self.u_init.ctypes.data_as(C.c_void_p),
+                                               self.buffer_rate.ctypes.data_as(C.c_void_p), rank, world, idbuf))
+        a, b = C.c_int(), C.c_int()
+        L.check(self.lib.mh_binary_band_rows(self.handle, C.byref(a), C.byref(b)))
+        self.row0, self.row1 = a.value, b.value
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
