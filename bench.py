@@ -164,6 +164,9 @@ def main():
                     help="native: C++ slab stepper of libmara_hip.so (RCCL called from the library); torch: Python stepper over torch.distributed")
     ap.add_argument("--single-arith", action="store_true", help="headline leg only: no other variants (legs), no extra configs")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of K steps of the headline leg (the first one is `value`)")
+    ap.add_argument("--precondition", type=int, default=60,
+                    help="steps run on the freshly loaded grid BEFORE the initial condition is loaded again and the W warm-up steps start: the first ~25 "
+                         "launches after an idle period run up to 25 %% slower while the power management settles (kernel trace, DESIGN.md §6); 0 = off")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -281,7 +284,15 @@ def main():
             prime(arith, riemann)
         st = make_stepper(arith, riemann, bc)
         native = not isinstance(st, SlabEulerStepper)
-        st.load_slab(initial_state(workload, st.row0, st.row1))
+        ic = initial_state(workload, st.row0, st.row1)
+        st.load_slab(ic)
+        if args.precondition > 0:
+            # clock settling, not part of the workload: the run restarts from the initial condition afterwards
+            st.step(dt, args.precondition)
+            if native:
+                st.synchronize()
+            st.load_slab(ic)
+        del ic
         st.step(dt, args.warmup)
         if native:
             st.synchronize()
@@ -355,6 +366,8 @@ def main():
             final = torch.from_numpy(st.slab_host()) if native else st.u[2:2 + st.n0].permute(0, 2, 1).contiguous().cpu()
         if native:
             st.close()
+        res["preconditioning"] = ("%d steps on the loaded grid, then the initial condition is loaded again (clock settling; not part of the workload)" % args.precondition
+                                  if args.precondition > 0 else "none")
         return res, final, args.warmup + nblocks * args.steps + nprof
 
     def partition_check(arith, riemann, u_mine, nsteps_total):
@@ -410,9 +423,10 @@ def main():
             l1 = float(s.item()) / (n * n * 5)
         del u_other
         other_riemann = "hlle" if args.riemann == "hllc" else "hllc"
-        more = [("strict", other_riemann, "blast"), ("fast", other_riemann, "blast")]
-        if n % 2 == 0:
-            more += [(primary, args.riemann, "smooth_wave"), ("strict", "hlle", "smooth_wave")]
+        # the further variants are one-GPU measurements: a multi-GPU run stays short (each leg would set up its own communicator)
+        more = []
+        if not decomposed:
+            more = [("strict", other_riemann, "blast"), ("fast", other_riemann, "blast"), (primary, args.riemann, "smooth_wave"), ("strict", "hlle", "smooth_wave")]
         for (a, r, w) in more:
             legs["%s_%s_%s" % (a, r, w)] = run_leg(a, r, w)[0]
         for key, leg in legs.items():
@@ -434,7 +448,8 @@ def main():
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
-                       "timed_region": "HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage"},
+                       "timed_region": "HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage",
+                       "preconditioning": res["preconditioning"]},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
         if "repeat_blocks" in res:

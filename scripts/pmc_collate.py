@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Collate the rocprofv3 passes of scripts/profile_r2.sh (gpurun_out/prof_r2) into the committed evidence:
+   profiles/r02/kernels_<part>.md     per kernel: avg duration (kernel trace), HBM bytes per launch from PMC (2*FETCH_SIZE + WRITE_SIZE, KB;
+                                      FETCH_SIZE tallies 64 B per 128-B request on gfx950, re-calibrated on mh::stream_copy_kernel in the same
+                                      script), VALU instructions and utilisation, fp64 FLOP/s from the SQ_INSTS_VALU_*_F64 counters
+   profiles/pmc_traffic.json          bytes per launch keyed as bench.py reads them, stamped with the hash of the kernel sources"""
+import csv, glob, json, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_fingerprint
+OUT = os.path.join(ROOT, "gpurun_out", "prof_r2")
+DST = os.path.join(ROOT, "profiles", "r02")
+os.makedirs(DST, exist_ok=True)
+
+
+def counters(tag, kind):
+    acc, dur = collections.defaultdict(list), collections.defaultdict(list)
+    for f in glob.glob(os.path.join(OUT, "%s_%s" % (tag, kind), "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "mh::" not in k:
+                continue
+            short = k.split("(")[0].replace("void mh::", "").replace("mh::", "")
+            acc[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            dur[short].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: sum(v) / len(v) for k, v in dur.items()}
+
+
+def trace(tag):
+    out = {}
+    for f in glob.glob(os.path.join(OUT, tag + "_trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Name"]
+            if "mh::" in k:
+                out[k.split("(")[0].replace("void mh::", "").replace("mh::", "")] = (float(r["AverageNs"]), int(r["Calls"]))
+    return out
+
+
+def calibration():
+    f, _ = counters("calib", "fetch")
+    w, _ = counters("calib", "write")
+    known = 5 * 4096 * 4096 * 8
+    return known / (f[("stream_copy_kernel", "FETCH_SIZE")] * 1024), known / (w[("stream_copy_kernel", "WRITE_SIZE")] * 1024)
+
+
+def table(tags, part):
+    ffac, wfac = calibration()
+    lines = ["# rocprofv3 summary, round 2 (%s), one MI355X" % part, "",
+             "Source: `scripts/profile_r2.sh %s` (one rocprofv3 pass per counter group; program directly after `--`), collated by `scripts/pmc_collate.py`." % part,
+             "Calibration on `mh::stream_copy_kernel` (671 088 640 B read and written, 8 B per lane): bytes / (FETCH_SIZE KB x 1024) = %.3f, bytes / (WRITE_SIZE KB x 1024) = %.3f"
+             % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
+             "| run | kernel | avg us (kernel trace) | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
+             "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    traffic = {}
+    for tag in tags:
+        tr = trace(tag)
+        fe, _ = counters(tag, "fetch")
+        wr, _ = counters(tag, "write")
+        sq, _ = counters(tag, "sq")
+        fl, fdur = counters(tag, "flop")
+        for k in sorted(tr):
+            if not any(x in k for x in ("stage_kernel", "update_kernel", "flux_kernel", "gradient_kernel", "sink_kernel")):
+                continue
+            avg, calls = tr[k]
+            hbm = None
+            if (k, "FETCH_SIZE") in fe and (k, "WRITE_SIZE") in wr:
+                hbm = (round(ffac) * fe[(k, "FETCH_SIZE")] + round(wfac) * wr[(k, "WRITE_SIZE")]) * 1024
+                traffic[(tag, k)] = hbm
+            valu = sq.get((k, "SQ_INSTS_VALU"))
+            busy = wait = None
+            if (k, "SQ_ACTIVE_INST_VALU") in sq and sq.get((k, "SQ_BUSY_CYCLES")):
+                busy = sq[(k, "SQ_ACTIVE_INST_VALU")] * 4 / (sq[(k, "SQ_BUSY_CYCLES")] * 32)          # quad-cycles per SIMD over 32 SIMDs per shader engine
+                wait = sq[(k, "SQ_WAIT_INST_ANY")] / sq[(k, "SQ_WAVE_CYCLES")]
+            tf = None
+            if (k, "SQ_INSTS_VALU_FMA_F64") in fl:
+                flops = 64 * (fl[(k, "SQ_INSTS_VALU_ADD_F64")] + fl[(k, "SQ_INSTS_VALU_MUL_F64")] + 2 * fl[(k, "SQ_INSTS_VALU_FMA_F64")] + fl[(k, "SQ_INSTS_VALU_TRANS_F64")])
+                tf = flops / (avg * 1e-9) / 1e12
+            fmt = lambda x, f: "" if x is None else f % x
+            lines.append("| %s | `%s` | %.1f | %d | %s | %s | %s | %s | %s | %s |" % (tag, k, avg / 1e3, calls, fmt(hbm and hbm / 1e6, "%.1f"), fmt(valu, "%.3g"),
+                         fmt(busy, "%.2f"), fmt(wait, "%.2f"), fmt(tf, "%.1f"), fmt(tf and tf / 78.6, "%.2f")))
+    lines += ["", "VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32): the counter ticks in quad-cycles per SIMD, SQ_BUSY_CYCLES per shader engine of 32 SIMDs.",
+              "wait-on-instr = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES. fp64 FLOP/s = 64 x (ADD + MUL + 2 FMA + TRANS of SQ_INSTS_VALU_*_F64) / avg duration."]
+    open(os.path.join(DST, "kernels_%s.md" % part), "w").write("\n".join(lines) + "\n")
+    return traffic
+
+
+if __name__ == "__main__":
+    part = sys.argv[1] if len(sys.argv) > 1 else "headline"
+    if part == "headline":
+        tr = table(["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"], "headline")
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        out = {"csrc_sha16": csrc_fingerprint(),
+               "_comment": "HBM bytes per launch of the RK2 stage kernels at 4096^2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 20 "
+                           "--warmup 3 --single-arith`, scripts/profile_r2.sh): 2 x FETCH_SIZE + WRITE_SIZE, calibrated on mh::stream_copy_kernel in the same script "
+                           "(profiles/r02/kernels_headline.md). Keyed by the hash of mara3_amd/csrc/*.hip|*.hpp: bench.py reports `traffic` only for the sources "
+                           "these numbers were measured on."}
+        for (tag, k), v in tr.items():
+            arith, riemann = tag.split("_")
+            stage = "stage2" if k.endswith("true>") else "stage1"
+            out["%s_%s_%s_bytes_per_launch" % (stage, arith, riemann)] = v
+        json.dump(out, open(path, "w"), indent=1)
+        print(json.dumps(out, indent=1)[:1500])
+    else:
+        tr = table(["c3", "c4", "c4s", "c5"], "configs")
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        t = json.load(open(path))
+        for (tag, k), v in tr.items():
+            t["%s:%s" % (tag, k)] = v
+        json.dump(t, open(path, "w"), indent=1)
+    print(open(os.path.join(DST, "kernels_%s.md" % part)).read())
