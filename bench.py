@@ -165,8 +165,8 @@ def main():
     ap.add_argument("--single-arith", action="store_true", help="headline leg only: no other variants (legs), no extra configs")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of K steps of the headline leg (the first one is `value`)")
     ap.add_argument("--precondition", type=int, default=60,
-                    help="steps run on the freshly loaded grid BEFORE the initial condition is loaded again and the W warm-up steps start: the first ~25 "
-                         "launches after an idle period run up to 25 %% slower while the power management settles (kernel trace, DESIGN.md §6); 0 = off")
+                    help="steps of a scratch grid run right BEFORE the W warm-up steps: the first ~25 launches after an idle period (building and "
+                         "uploading the initial condition) run up to 25 %% slower while the clocks settle (kernel trace, DESIGN.md §6); 0 = off")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -284,15 +284,17 @@ def main():
             prime(arith, riemann)
         st = make_stepper(arith, riemann, bc)
         native = not isinstance(st, SlabEulerStepper)
-        ic = initial_state(workload, st.row0, st.row1)
-        st.load_slab(ic)
+        st.load_slab(initial_state(workload, st.row0, st.row1))
         if args.precondition > 0:
-            # clock settling, not part of the workload: the run restarts from the initial condition afterwards
-            st.step(dt, args.precondition)
-            if native:
-                st.synchronize()
-            st.load_slab(ic)
-        del ic
+            # Clock settling, not part of the workload: building and uploading the initial condition leaves the GPU idle for a few hundred
+            # ms, and the first ~25 stage launches after an idle period run up to 25 % slower (kernel trace). A scratch grid of
+            # this rank's size is stepped right before the W warm-up steps of the real one.
+            rows = max(64, min(n, st.row1 - st.row0))
+            scratch = NativeSlabStepper((rows, n), dl, gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith)
+            scratch.load_slab(setups.blast_ic((rows, n), gamma))
+            scratch.step(dt, args.precondition)
+            scratch.synchronize()
+            scratch.close()
         st.step(dt, args.warmup)
         if native:
             st.synchronize()
@@ -366,8 +368,8 @@ def main():
             final = torch.from_numpy(st.slab_host()) if native else st.u[2:2 + st.n0].permute(0, 2, 1).contiguous().cpu()
         if native:
             st.close()
-        res["preconditioning"] = ("%d steps on the loaded grid, then the initial condition is loaded again (clock settling; not part of the workload)" % args.precondition
-                                  if args.precondition > 0 else "none")
+        res["preconditioning"] = ("%d steps of a scratch grid of the same size right before the warm-up steps (clock settling after the idle upload phase; not part of "
+                                  "the workload)" % args.precondition if args.precondition > 0 else "none")
         return res, final, args.warmup + nblocks * args.steps + nprof
 
     def partition_check(arith, riemann, u_mine, nsteps_total):
