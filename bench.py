@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6 # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
 BYTES_STAGE1 = 2 * 5 * 8       # read U, write U1                      
 BYTES_STAGE2 = 3 * 5 * 8       # read U1, read U0, write U (in place)
 BYTES_STEP = BYTES_STAGE1 + BYTES_STAGE2   # 200 B per zone-update
@@ -348,6 +349,13 @@ def main():
                 r["traffic_note"] = "no rocprofv3 PMC record for this kernel build / workload (profiles/pmc_traffic.json is keyed by the kernel sources' hash)"
             else:
                 r["traffic_note"] = "recorded: rocprofv3 PMC passes of these kernel sources (profiles/pmc_traffic.json), not measured in this run"
+                # the other roofline of this kernel: fp64 issue. FLOP per launch and VALU-busy are the recorded SQ counters of the same passes
+                # (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES), the duration is this run's.
+                rec = recorded_traffic(traffic_key.replace("_bytes_per_launch", "_fp64"))
+                if rec and avg > 0:
+                    tf = rec["fp64_flops_per_launch"] / (avg * 1e-3) / 1e12
+                    r["fp64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                                 "valu_busy": rec["valu_busy"], "note": "recorded counters (20-step blast), this run's duration"}
             return r
 
         res = {

@@ -367,18 +367,36 @@ def run_c5(args):
     return out
 
 
-def attach_traffic(out, key, ok):
-    """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json), mean of the two stage kinds like `achieved`."""
+def attach_traffic(out, config):
+    """From the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, keyed by the hash of the kernel sources; reported only while it
+    matches): HBM bytes per launch of the stage kernels (mean of the two RK2 stage kinds, like `achieved`) and the OTHER roofline of these
+    kernels - fp64 issue: FLOP per launch from SQ_INSTS_VALU_*_F64 over this run's average launch duration, against the 78.6 TF vector peak,
+    with the recorded VALU-busy fraction. The configs' stage kernels are issue-bound (VALU-busy 0.65-0.98), so `bound` says so."""
     try:
         from bench import csrc_fingerprint
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if t.get("csrc_sha16") != csrc_fingerprint():
-            ok = False          # recorded for other kernel sources: not reported
-        if ok:
-            val = 0.5 * (t[key + "_stage1_bytes_per_launch"] + t[key + "_stage2_bytes_per_launch"])
-            out["roofline"]["traffic"] = val
-            if "arith_strict" in out and "roofline" in out["arith_strict"]:
-                out["arith_strict"]["roofline"]["traffic"] = val
+            return out
+        names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),
+                 "c4": ("c4", "cloud_stage_kernel<Srhd%s, true, false>", "cloud_stage_kernel<Srhd%s, true, true>"),
+                 "c5": ("c5", "euler3d_stage_kernel<%sArith, 0, true, false>", "euler3d_stage_kernel<%sArith, 0, true, true>")}[config]
+        for mode, roof in (("Fast", out.get("roofline")), ("Strict", (out.get("arith_strict") or {}).get("roofline"))):
+            if not roof or not roof.get("avg_launch_ms"):
+                continue
+            tag = "c4s" if (config == "c4" and mode == "Strict") else names[0]
+            keys = ["%s:%s" % (tag, n % mode) for n in names[1:]]
+            if config == "c5":
+                continue          # recorded at 384^3, the bench runs 512^3: not comparable per launch
+            if all(k in t for k in keys):
+                roof["traffic"] = 0.5 * (t[keys[0]] + t[keys[1]])
+            fk = [k + ":fp64" for k in keys]
+            if all(k in t for k in fk):
+                flops = 0.5 * (t[fk[0]]["fp64_flops_per_launch"] + t[fk[1]]["fp64_flops_per_launch"])
+                tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
+                roof["fp64"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                "valu_busy": 0.5 * (t[fk[0]]["valu_busy"] + t[fk[1]]["valu_busy"]),
+                                "note": "recorded SQ counters (profiles/r02/kernels_configs.md), this run's duration"}
+                roof["bound_measured"] = "fp64 issue (VALU-busy %.2f); the HBM figure above is the contract's roofline" % roof["fp64"]["valu_busy"]
     except Exception:
         pass
     return out
@@ -402,8 +420,8 @@ def main():
     out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args)
     if out is None:          # not rank 0 of a multi-process run
         return
-    out = attach_traffic(out, {"c3": "c3_binary_2048", "c4": "c4_cloud_4096", "c5": "c5_euler3d_384"}[args.config],
-                         args.config == "c3" or (args.config == "c4" and (args.grid or 4096) == 4096) or (args.config == "c5" and args.grid == 384))
+    if not (args.loopback_bands or args.loopback_blocks or args.grid):
+        out = attach_traffic(out, args.config)
     print(json.dumps(out), flush=True)
 
 

@@ -51,7 +51,7 @@ def table(tags, part):
              % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
              "| run | kernel | avg us (kernel trace) | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
-    traffic = {}
+    traffic, extra = {}, {}
     for tag in tags:
         tr = trace(tag)
         fe, _ = counters(tag, "fetch")
@@ -75,19 +75,20 @@ def table(tags, part):
             if (k, "SQ_INSTS_VALU_FMA_F64") in fl:
                 flops = 64 * (fl[(k, "SQ_INSTS_VALU_ADD_F64")] + fl[(k, "SQ_INSTS_VALU_MUL_F64")] + 2 * fl[(k, "SQ_INSTS_VALU_FMA_F64")] + fl[(k, "SQ_INSTS_VALU_TRANS_F64")])
                 tf = flops / (avg * 1e-9) / 1e12
+                extra[(tag, k)] = {"fp64_flops_per_launch": flops, "valu_busy": busy, "valu_instructions_per_launch": valu}
             fmt = lambda x, f: "" if x is None else f % x
             lines.append("| %s | `%s` | %.1f | %d | %s | %s | %s | %s | %s | %s |" % (tag, k, avg / 1e3, calls, fmt(hbm and hbm / 1e6, "%.1f"), fmt(valu, "%.3g"),
                          fmt(busy, "%.2f"), fmt(wait, "%.2f"), fmt(tf, "%.1f"), fmt(tf and tf / 78.6, "%.2f")))
     lines += ["", "VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32): the counter ticks in quad-cycles per SIMD, SQ_BUSY_CYCLES per shader engine of 32 SIMDs.",
               "wait-on-instr = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES. fp64 FLOP/s = 64 x (ADD + MUL + 2 FMA + TRANS of SQ_INSTS_VALU_*_F64) / avg duration."]
     open(os.path.join(DST, "kernels_%s.md" % part), "w").write("\n".join(lines) + "\n")
-    return traffic
+    return traffic, extra
 
 
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "headline"
     if part == "headline":
-        tr = table(["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"], "headline")
+        tr, ex = table(["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"], "headline")
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         out = {"csrc_sha16": csrc_fingerprint(),
                "_comment": "HBM bytes per launch of the RK2 stage kernels at 4096^2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 20 "
@@ -98,13 +99,17 @@ if __name__ == "__main__":
             arith, riemann = tag.split("_")
             stage = "stage2" if k.endswith("true>") else "stage1"
             out["%s_%s_%s_bytes_per_launch" % (stage, arith, riemann)] = v
+            if (tag, k) in ex:
+                out["%s_%s_%s_fp64" % (stage, arith, riemann)] = ex[(tag, k)]
         json.dump(out, open(path, "w"), indent=1)
         print(json.dumps(out, indent=1)[:1500])
     else:
-        tr = table(["c3", "c4", "c4s", "c5"], "configs")
+        tr, ex = table(["c3", "c4", "c4s", "c5"], "configs")
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         t = json.load(open(path))
         for (tag, k), v in tr.items():
             t["%s:%s" % (tag, k)] = v
+        for (tag, k), v in ex.items():
+            t["%s:%s:fp64" % (tag, k)] = v
         json.dump(t, open(path, "w"), indent=1)
     print(open(os.path.join(DST, "kernels_%s.md" % part)).read())
