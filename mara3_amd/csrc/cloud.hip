@@ -305,10 +305,19 @@ void cloud_stage_kernel(CloudParams p)
         if constexpr (PLM)
         {
             const State5 Graw = S::plm(dpp_left(P0), P0, dpp_right(P0), theta);
-            const State5 Gl = dpp_left(Graw), Gr = dpp_right(Graw);
             State5 Gy;
+            if constexpr (S::exact_zero_products)
+            {
+                // pole cells: the neighbour's slope times zero (extend_zeros, :563) - NaN and the sign of zero propagate as upstream
+                const State5 Gl = dpp_left(Graw), Gr = dpp_right(Graw);
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Gy[q] = pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]);
+                for (int q = 0; q < 5; ++q) Gy[q] = pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]);
+            }
+            else
+            {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) Gy[q] = (pole_lo || pole_hi) ? 0.0 : Graw[q];          // the value of that product
+            }
             const State5 SL = dpp_left(face_plus(P0, Gy));
             Fy_lo = S::template hlle<1>(SL, face_minus(P0, Gy), g);
         }
@@ -317,8 +326,16 @@ void cloud_stage_kernel(CloudParams p)
             Fy_lo = S::template hlle<1>(dpp_left(P0), P0, g);
         }
         Fy_hi = dpp_right(Fy_lo);
-        if (pole_lo) Fy_lo = times_zero(Fy_hi);
-        if (pole_hi) Fy_hi = times_zero(Fy_lo);
+        if constexpr (S::exact_zero_products)
+        {
+            if (pole_lo) Fy_lo = times_zero(Fy_hi);
+            if (pole_hi) Fy_hi = times_zero(Fy_lo);
+        }
+        else
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { Fy_lo[q] = pole_lo ? 0.0 : Fy_lo[q]; Fy_hi[q] = pole_hi ? 0.0 : Fy_hi[q]; }
+        }
 
         // ---- geometry, source terms, update
         const CellGeom c = cell_geometry(p.row_offset + r);

@@ -73,8 +73,9 @@ template<int AXIS>
 __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, State5& F, double& lam_m, double& lam_p)
 {
     const double uu = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
-    double W, rW;
-    fast::sqrt_rsqrt(1.0 + uu, W, rW);
+    const double x1 = 1.0 + uu;
+    const double rW = fast::rsqrt_fast(x1);
+    const double W = x1 * rW;                      // sqrt(x) = x rsqrt(x), to an ulp or two (x >= 1 here)
     const double H = __builtin_fma(P[4], g.hfac, P[0]);
     const double D = P[0] * W;
     const double p = P[4];
@@ -143,6 +144,7 @@ struct SrhdStrict
 {
     static constexpr int min_waves_per_simd = 2;      // 163-167 VGPRs: three waves fit anyway
     static constexpr bool table_geometry = false;     // geometry factors formed per cell in the reference's order
+    static constexpr bool exact_zero_products = true; // pole slopes / fluxes as (neighbour's value) * 0, like extend_zeros: NaN and -0 propagate
     static __device__ inline void to_density(double (&x)[5], double dv, double) { divide_group<5>(x, make_recip(dv, 1.0)); }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
     static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
@@ -163,6 +165,7 @@ struct SrhdFast
 {
     static constexpr int min_waves_per_simd = 3;      // hold the allocation at 168 VGPRs
     static constexpr bool table_geometry = true;      // per-row x per-column factors from the host's tables (mh_cloud_pack_geometry)
+    static constexpr bool exact_zero_products = false;// pole slopes / fluxes are plain zeros
     static __device__ inline void to_density(double (&x)[5], double, double inv_dv) { for (int q = 0; q < 5; ++q) x[q] *= inv_dv; }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive(U, g, tf, P); }
     static __device__ inline State5 source(const State5& P, double, double inv_r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms_rinv(P, inv_r, cot, g); }
