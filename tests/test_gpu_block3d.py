@@ -122,3 +122,35 @@ def test_config5_per_rank_share_as_eight_blocks_of_256(eng):
     assert grp.status() == (0, None)
     assert bits_equal(grp.download(), want)
     grp.close()
+
+
+@pytest.mark.timeout(1200)
+def test_config5_as_configured_per_gpu_share_512_as_eight_blocks(eng):
+    """The (2,2,2) decomposition at HALF the configured linear size - 512^3 as 8 blocks of 256^3, each with a real shell / interior split and
+    21 MB-class faces scaled by 1/4 - on one GPU, 2 steps, FAST PLM + HLLE RK2: bit-identical to the undivided 512^3 run (one rank's share
+    of the 1024^3 case), status clean, mass conserved to rounding. (1024^3 itself is 43 GB per field copy: it needs the 8 GPUs.)"""
+    from mara3_amd import setups
+    from mara3_amd.block import NativeBlockGroup
+    n, gamma = 512, 5.0 / 3
+    dl = (1.0 / n,) * 3
+    u0 = setups.blast_ic((n, n, n), gamma)
+    dt = setups.baseline_dt(n)
+    ref = eng.EulerCartSolver((n, n, n), dl, gamma, 1.5, "hlle", 2, "outflow", arith="fast")
+    ref.upload(u0)
+    ref.step(dt, 2)
+    want = ref.download()
+    assert ref.status() == 0
+    ref.close()
+    grp = NativeBlockGroup((n, n, n), dl, gamma, 1.5, "hlle", 2, "outflow", world=8, arith="fast")
+    assert all(m.count == (256, 256, 256) for m in grp.members)
+    assert grp.members[0].message_doubles == (2 * 5 * 260 * 260, 256 * 5 * 2 * 256, 256 * 5 * 256 * 2)
+    grp.upload(u0)
+    mass0 = float(u0[..., 0].sum())
+    del u0
+    grp.step(dt, 2)
+    grp.synchronize()
+    assert grp.status() == (0, None)
+    got = grp.download()
+    grp.close()
+    assert bits_equal(got, want)
+    assert abs(float(got[..., 0].sum()) - mass0) <= 1e-12 * mass0

@@ -210,3 +210,50 @@ def test_cloud_group_fast_arith_equals_single_domain(eng):
     grp.synchronize()
     assert bits_equal(grp.download(), one.download())
     grp.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_cloud_config4_as_configured_4096_over_4_slabs(eng, arith):
+    """BASELINE config 4 as stated - `cloud` at 4096^2 (nr = 4096, one decade), RK2, PLM theta = 1.2, 4 radial slabs with the two-row halo -
+    on one GPU through the loopback backend, against the single-domain run: 3 steps with a time-dependent nozzle row, bit-identical, status
+    clean. (The state is a synthetic admissible SRHD flow on the sub-program's grid; the sub-program's own initial condition lives in the
+    compiled host, tests/test_gpu_host_subprograms.py.)"""
+    from mara3_amd.slab import NativeSlabGroup
+    nr = 4096
+    rv = 10.0 ** np.linspace(0.0, 1.0, nr + 1)
+    qv = np.linspace(0.0, np.pi, nr + 1)
+    rc, qc = 0.5 * (rv[1:] + rv[:-1]), 0.5 * (qv[1:] + qv[:-1])
+    gamma = 4.0 / 3
+    rho = rc[:, None] ** -2.0 * (1.0 + 0.3 * np.cos(3 * qc)[None, :])
+    ur = 0.4 * np.exp(-((rc[:, None] - 3.0) / 1.5) ** 2) * (1.0 + 0.5 * np.cos(qc)[None, :] ** 2)
+    uq = 0.05 * np.sin(2 * qc)[None, :] * np.ones_like(rho)
+    pre = 1e-3 * rho
+    W = np.sqrt(1.0 + ur ** 2 + uq ** 2)
+    h = 1.0 + pre / rho * (gamma / (gamma - 1.0))
+    D = rho * W
+    dv = (rv[1:] ** 3 - rv[:-1] ** 3)[:, None] * (-np.cos(qv[1:]) + np.cos(qv[:-1]))[None, :] * 2 * np.pi / 3.0
+    u0 = np.zeros((nr, nr, 5))
+    u0[..., 0] = D * dv
+    u0[..., 1] = D * h * ur * dv
+    u0[..., 2] = D * h * uq * dv
+    u0[..., 4] = (D * h * W - pre - D) * dv
+    dt = 0.4 * (rv[1] - rv[0])
+    def nozzle(step):
+        row = np.zeros((nr, 5))
+        row[:, 0] = 1.0
+        row[:, 1] = 0.6 * np.exp(-0.5 * (qc / 0.3) ** 2) * np.exp(-0.1 * step) + 0.6 * np.exp(-0.5 * ((np.pi - qc) / 0.3) ** 2) * np.exp(-0.1 * step)
+        row[:, 4] = 1e-3
+        return row
+    one = eng.CloudSolver(rv, qv, 2, 1.2, 1e-8, arith=arith)
+    one.upload(u0)
+    grp = NativeSlabGroup(r_vertices=rv, q_vertices=qv, gamma=gamma, plm_theta=1.2, rk_order=2, world=4, temperature_floor=1e-8, arith=arith)
+    assert grp.rows == [(1024 * r, 1024 * (r + 1)) for r in range(4)]
+    grp.upload(u0)
+    for step in range(3):
+        one.set_inflow(nozzle(step)); one.step(dt, 1)
+        grp.set_inflow(nozzle(step)); grp.step(dt, 1)
+    grp.synchronize()
+    assert one.status() == 0 and grp.status() == (0, None)
+    assert bits_equal(grp.download(), one.download())
+    grp.close(); one.close()
