@@ -368,3 +368,36 @@ def test_cloud_full_size_equatorial_symmetry(tmp_path):
     scale[2] = scale[1]                                        # the polar momentum is measured against the radial one
     err = np.abs(u - mirror).reshape(-1, 5).max(axis=0)
     assert np.all(err <= 1e-9 * scale), err / scale
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="needs the HDF5 tools of the image")
+def test_output_files_hold_what_the_reference_tools_read(tmp_path):
+    """Format pin from the CONSUMER side: no reference-written file can be produced here, but the reference ships the
+    readers of its files - tools/plot_cloud.py and tools/plot_binary.py. Every dataset, group and compound member those scripts access must
+    exist, with that nesting, in the files `mara_hip` writes:
+      tools/plot_cloud.py:18-25, :77-102, :134-136     diagnostics.NNNN.h5 of `cloud`: top-level datasets
+      tools/plot_binary.py:99-106, :143-149             diagnostics.NNNN.h5 of `binary`: groups vertices | sigma | radial_velocity | phi_velocity / <block>
+      tools/plot_binary.py:222-256, :331-350, :386-438  chkpt.NNNN.h5 of `binary`: compound /time_series (members by name) and /run_config items."""
+    out = run(["cloud", "nr=32", "num_decades=1", "rk_order=2", "max_steps=3", "cpi=0", "dfi=1e-9", "outdir=c"], str(tmp_path))
+    assert "diagnostics" in out
+    hdr = subprocess.run([H5DUMP, "-H", os.path.join(tmp_path, "c", "diagnostics.0001.h5")], check=True, capture_output=True, text=True).stdout
+    top_level = hdr.split("\n")
+    for name in ("time", "radial_vertices", "polar_vertices", "mass_density", "gas_pressure", "radial_gamma_beta", "radial_energy_flow",
+                 "solid_angle_at_theta", "shock_midpoint_radius", "shock_pressure_radius", "shock_luminosity_radius"):
+        assert any(line.startswith('   DATASET "%s"' % name) for line in top_level), name          # depth 1: h5f['<name>']
+    out = run(["binary", "depth=2", "block_size=16", "focus_factor=1e9", "max_iterations=3", "tfinal=100.0", "cpi=1e-9", "dfi=1e-9", "tsi=1e-9", "outdir=b"], str(tmp_path))
+    hdr = subprocess.run([H5DUMP, "-H", os.path.join(tmp_path, "b", "diagnostics.0001.h5")], check=True, capture_output=True, text=True).stdout
+    for group in ("vertices", "sigma", "radial_velocity", "phi_velocity"):
+        assert '   GROUP "%s"' % group in hdr, group
+        body = hdr[hdr.index('   GROUP "%s"' % group):]
+        assert '      DATASET "' in body[:body.index("\n   }")], group                               # one dataset per block inside the group
+    hdr = subprocess.run([H5DUMP, "-H", os.path.join(tmp_path, "b", "chkpt.0001.h5")], check=True, capture_output=True, text=True).stdout
+    ts = hdr[hdr.index('DATASET "time_series"'):]
+    ts = ts[:ts.index("DATASPACE")]
+    for member in ("time", "disk_mass", "mass_ejected", "mass_accreted_on", "disk_angular_momentum", "angular_momentum_ejected", "integrated_torque_on",
+                   "angular_momentum_accreted_on", "work_done_on", "orbital_elements_acc", "orbital_elements_grav", "orbital_elements",
+                   "position_of_mass1", "position_of_mass2", "elements", "separation", "eccentricity", "total_mass", "pomega", "tau", "cm_position_x"):
+        assert '"%s"' % member in ts, member
+    rc = hdr[hdr.index('GROUP "run_config"'):]
+    for item in ("mass_ratio", "eccentricity", "disk_mass", "begin_live_binary"):
+        assert 'DATASET "%s"' % item in rc, item
