@@ -62,14 +62,18 @@ def host_cores():
     return min(cores, int(os.environ.get("MARA_BENCH_CPU_THREADS", "64")))
 
 
+KERNEL_SOURCES = ("euler2d.hip", "euler3d.hip", "cloud.hip", "binary.hip", "euler_device.hpp", "euler_device_fast.hpp", "srhd_device.hpp",
+                  "srhd_device_fast.hpp", "iso2d_device.hpp", "binary_device.hpp", "status_device.hpp")
+
+
 def csrc_fingerprint():
-    """sha256 (16 hex digits) over the kernel sources: PMC traffic recorded for other sources is not reported (see `traffic`)."""
+    """sha256 (16 hex digits) over the sources of the measured stage kernels and their device headers: PMC numbers recorded for other
+    sources are not reported (see `traffic`). Host-side files of the library (steppers, API) do not enter."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mara3_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -304,7 +304,8 @@ int  mh_slab_profile_read(mh_slab* slab, double avg_ms[2], int nlaunches[2], int
 typedef struct mh_block mh_block;
 /* `global`: the WHOLE grid (rank 3; bc_lo0 / bc_hi0 / bc_transverse = the physical boundary conditions). comm_id128 as for mh_slab_create
  * (NULL with neighbours: connect later with mh_block_connect, once every rank has agreed that creation succeeded). */
-int  mh_block_create(mh_block** block, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int device_id);
+int  mh_block_create(mh_block** block, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int self_exchange,
+                     int device_id);          /* self_exchange != 0 with world == 1: periodic axes wrap through RCCL send/recv to self (exercises the exchange on one GPU) */
 int  mh_block_connect(mh_block* block, const void* comm_id128);
 void mh_block_destroy(mh_block* block);
 /* blocks per axis, this block's coordinates, first global cell and cell count per axis (any pointer may be NULL) */
@@ -485,7 +486,7 @@ int  mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps);
  * Fields do not depend on the partition bit for bit while the binary is not live; the totals agree to the order of summation. */
 int  mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
                            const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host, int rank, int world,
-                           const void* comm_id128);
+                           const void* comm_id128, int self_exchange /* world == 1: the RCCL halo and all-reduces, to self */);
 int  mh_binary_band_rows(const mh_binary* b, int* row0, int* row1);
 int  mh_binary_group_create(mh_binary** bands, int world, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
                             const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host);

@@ -151,7 +151,7 @@ SYMBOLS = [
     ("mh_slab_field_ptr", _vp, [_vp, _i]),
     ("mh_slab_profile_enable", _i, [_vp, _i]),
     ("mh_slab_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i), C.POINTER(_i)]),
-    ("mh_block_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i]),
+    ("mh_block_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i, _i]),
     ("mh_block_connect", _i, [_vp, _vp]),
     ("mh_block_destroy", None, [_vp]),
     ("mh_block_extent", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
@@ -202,7 +202,7 @@ SYMBOLS = [
     ("mh_binary_set_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
     ("mh_binary_get_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
     ("mh_binary_next", _i, [_vp, _i, C.POINTER(_i)]),
-    ("mh_binary_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    ("mh_binary_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp, _i, _i, _vp, _i]),
     ("mh_binary_band_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     ("mh_binary_group_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
     ("mh_binary_group_set_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),

@@ -371,7 +371,7 @@ class BinaryBand(BinarySolver):
     mara3_amd.slab.native_comm_id). next() is collective over the ranks; solution() returns the whole-mesh array with this band's rows
     filled in (rows [row0, row1))."""
 
-    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict"):
+    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict", self_exchange=False):
         self.lib = L.load_library()
         self.cfg = cfg
         self.n = grid_size(cfg)
@@ -391,7 +391,7 @@ class BinaryBand(BinarySolver):
         idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
         L.check(self.lib.mh_binary_band_create(C.byref(self.handle), device, C.byref(self.desc), C.byref(run), self.xv.ctypes.data_as(C.c_void_p),
                                                self.yv.ctypes.data_as(C.c_void_p), self.u_init.ctypes.data_as(C.c_void_p),
-                                               self.buffer_rate.ctypes.data_as(C.c_void_p), rank, world, idbuf))
+                                               self.buffer_rate.ctypes.data_as(C.c_void_p), rank, world, idbuf, 1 if self_exchange else 0))
         a, b = C.c_int(), C.c_int()
         L.check(self.lib.mh_binary_band_rows(self.handle, C.byref(a), C.byref(b)))
         self.row0, self.row1 = a.value, b.value

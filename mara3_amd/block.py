@@ -20,7 +20,7 @@ class NativeBlock:
     """One rank's block (RCCL backend; `comm_id` as for NativeSlabStepper), or a wrapped member of a NativeBlockGroup."""
 
     def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow", rank=0, world=1, comm_id=None,
-                 device=0, chunk_rows=0, arith="strict", handle=None):
+                 device=0, chunk_rows=0, arith="strict", handle=None, self_exchange=False):
         self.lib = L.load_library()
         self.global_shape = tuple(int(n) for n in global_shape)
         if handle is not None:
@@ -29,7 +29,7 @@ class NativeBlock:
             d = euler_cart_desc(self.global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
             self.handle = C.c_void_p()
             idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
-            L.check(self.lib.mh_block_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf, device))
+            L.check(self.lib.mh_block_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf, 1 if self_exchange else 0, device))
         B, c, s, k = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
         L.check(self.lib.mh_block_extent(self.handle, B, c, s, k))
         self.blocks, self.coords, self.start, self.count = tuple(B), tuple(c), tuple(s), tuple(k)

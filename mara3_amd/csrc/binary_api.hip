@@ -105,6 +105,7 @@ struct mh_binary
     std::vector<double> host_staging;
     // band decomposition (see the header comment): rows [row0, row0 + n0) of the mesh; world == 1: the whole mesh
     int rank = 0, world = 1, row0 = 0, n0 = 0;
+    bool banded = false;                             // ghost rows come from an exchange (world > 1, or the RCCL path to self at world 1)
     int backend = 0;                                 // 0 none, 1 RCCL, 2 loopback
     mh_binary* peer_lo = nullptr;
     mh_binary* peer_hi = nullptr;
@@ -114,7 +115,7 @@ struct mh_binary
 };
 
 enum { BAND_NONE = 0, BAND_RCCL = 1, BAND_LOOPBACK = 2 };
-static BinaryBand band_of(const mh_binary* b) { return BinaryBand{b->n0, b->row0, b->world > 1 ? 1 : 0}; }
+static BinaryBand band_of(const mh_binary* b) { return BinaryBand{b->n0, b->row0, b->banded ? 1 : 0}; }
 
 static double* totals_dev(mh_binary* b, int stage) { return b->dev_small + stage * MH_BINARY_NTOTALS; }
 static double* maxw_dev(mh_binary* b) { return b->dev_small + 2 * MH_BINARY_NTOTALS; }
@@ -167,7 +168,7 @@ static int team_exchange(const Team& t, int k)
     for (int r = 0; r < t.n; ++r)
     {
         mh_binary* b = t.m[r];
-        if (b->world == 1) continue;
+        if (! b->banded) continue;
         const size_t n = (size_t) b->desc.n, blk = 2 * 3 * n;          // two rows, three variables: contiguous
         double* f = b->u[k];
         if (b->backend == BAND_LOOPBACK)
@@ -201,7 +202,7 @@ static int team_fetch(const Team& t)
     {
         mh_binary* b = t.m[r];
         const double* src = b->dev_small;
-        if (b->world > 1 && b->backend == BAND_RCCL)
+        if (b->banded && b->backend == BAND_RCCL)
         {
             RcclApi* api = rccl();
             if (! api || ! b->comm) { set_error("binary bands: RCCL communicator missing"); return MH_E_STATE; }
@@ -420,7 +421,7 @@ int mh_binary_max_wavespeed(const mh_binary_desc* d, const double* xv, const dou
 
 // u_init_aos / br: the WHOLE mesh ([n][n][3], [n][n]); a band keeps its rows. shared_stream: loopback members run on one stream.
 static int binary_create_common(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
-                                const double* u_init_aos, const double* br, int rank, int world, int backend, hipStream_t shared_stream)
+                                const double* u_init_aos, const double* br, int rank, int world, int backend, hipStream_t shared_stream, bool self_exchange = false)
 {
     if (! out || ! run || ! xv || ! yv || ! u_init_aos || ! br) { set_error("binary create: null argument"); return MH_E_INVALID; }
     if (int rc = check_binary_desc(d)) return rc;
@@ -433,7 +434,8 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     b->desc = *d;
     b->run = *run;
     b->rank = rank; b->world = world;
-    b->backend = world > 1 ? backend : BAND_NONE;
+    b->banded = world > 1 || self_exchange;
+    b->backend = b->banded ? backend : BAND_NONE;
     size_t ba, bb;
     mh_partition_rows((size_t) block_rows, (size_t) world, (size_t) rank, &ba, &bb);          // whole rows of tree blocks, nd::partition_shape's formula
     b->row0 = (int) ba * d->block_size;
@@ -466,7 +468,7 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     B_TRY(hipMemcpyAsync(b->staging, u_init_aos + (size_t) b->row0 * n * 3, n0 * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
     B_TRY(aos_to_soa_launch(b->staging, b->u_init, 3, b->n0, n, b->stream));
     // ghost rows of the initial field are never read (the buffer term is cell-local); the whole mesh keeps its periodic images anyway
-    if (world == 1) B_TRY(fill_ghost_rows_launch(b->u_init, 3, d->n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+    if (! b->banded) B_TRY(fill_ghost_rows_launch(b->u_init, 3, d->n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
     B_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     B_TRY(hipStreamSynchronize(b->stream));
 #undef B_TRY
@@ -482,11 +484,11 @@ int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const
 }
 
 int mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
-                          const double* u_init_aos, const double* br, int rank, int world, const void* comm_id128)
+                          const double* u_init_aos, const double* br, int rank, int world, const void* comm_id128, int self_exchange)
 {
     mh_binary* b = nullptr;
-    if (int rc = binary_create_common(&b, device, d, run, xv, yv, u_init_aos, br, rank, world, BAND_RCCL, nullptr)) return rc;
-    if (world > 1)
+    if (int rc = binary_create_common(&b, device, d, run, xv, yv, u_init_aos, br, rank, world, BAND_RCCL, nullptr, world == 1 && self_exchange)) return rc;
+    if (b->banded)
     {
         RcclApi* api = rccl();
         if (! api || ! comm_id128) { mh_binary_destroy(b); set_error("binary bands: RCCL not available or no unique id given"); return MH_E_STATE; }
@@ -618,13 +620,13 @@ int mh_binary_set_solution(mh_binary* b, const double* u_aos, const mh_binary_st
         const size_t n0 = (size_t) b->n0;
         MH_HIP_TRY(hipMemcpyAsync(b->staging, u_aos + (size_t) b->row0 * n * 3, n0 * n * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
         MH_HIP_TRY(aos_to_soa_launch(b->staging, b->u[0], 3, b->n0, n, b->stream));
-        if (b->world == 1) MH_HIP_TRY(fill_ghost_rows_launch(b->u[0], 3, b->desc.n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
+        if (! b->banded) MH_HIP_TRY(fill_ghost_rows_launch(b->u[0], 3, b->desc.n, n, MH_BC_PERIODIC, MH_BC_PERIODIC, b->stream));
     }
     else
     {
         MH_HIP_TRY(hipMemcpyAsync(b->u[0], b->u_init, b->field_doubles * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
-    if (b->world > 1 && b->backend == BAND_RCCL)
+    if (b->banded && b->backend == BAND_RCCL)
     {
         const Team t = {&b, 1};
         if (int rc = team_exchange(t, 0)) return rc;          // collective: every rank sets its solution
@@ -736,7 +738,7 @@ int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaun
 int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_momentum)
 {
     if (! b) { set_error("binary disk_totals: null solver"); return MH_E_INVALID; }
-    if (b->world > 1) { set_error("binary disk_totals: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
+    if (b->banded) { set_error("binary disk_totals: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* partial = b->u[2];
@@ -754,7 +756,7 @@ int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_
 int mh_binary_diagnostic_fields(mh_binary* b, double* sigma, double* radial_velocity, double* phi_velocity)
 {
     if (! b) { set_error("binary diagnostic_fields: null solver"); return MH_E_INVALID; }
-    if (b->world > 1) { set_error("binary diagnostic_fields: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
+    if (b->banded) { set_error("binary diagnostic_fields: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* fields = b->u[1];

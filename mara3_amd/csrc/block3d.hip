@@ -230,7 +230,8 @@ static void shell_range(int cells, int unit, bool cut_lo, bool cut_hi, int min_l
     *lo = l; *hi = h;
 }
 
-static int block_create_common(mh_block** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world, int device_id, int backend)
+static int block_create_common(mh_block** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world, int device_id, int backend,
+                               bool self_exchange = false)
 {
     if (! out || ! global) return MH_E_INVALID;
     if (global->rank != 3) { set_error("mh_block: a 3-D grid is required"); return MH_E_INVALID; }
@@ -249,8 +250,9 @@ static int block_create_common(mh_block** out, const mh_euler_cart_desc* global,
     {
         const bool periodic = a == 0 ? periodic0 : periodic_t;
         int cl[3] = {b->c[0], b->c[1], b->c[2]}, ch[3] = {b->c[0], b->c[1], b->c[2]};
-        cl[a] = b->c[a] > 0 ? b->c[a] - 1 : (periodic && b->B[a] > 1 ? b->B[a] - 1 : -1);
-        ch[a] = b->c[a] < b->B[a] - 1 ? b->c[a] + 1 : (periodic && b->B[a] > 1 ? 0 : -1);
+        const bool wrap = periodic && (b->B[a] > 1 || self_exchange);          // self_exchange: a periodic axis of ONE block wraps through the exchange, to itself
+        cl[a] = b->c[a] > 0 ? b->c[a] - 1 : (wrap ? b->B[a] - 1 : -1);
+        ch[a] = b->c[a] < b->B[a] - 1 ? b->c[a] + 1 : (wrap ? 0 : -1);
         b->nbr[a][0] = cl[a] < 0 ? -1 : (cl[0] * b->B[1] + cl[1]) * b->B[2] + cl[2];
         b->nbr[a][1] = ch[a] < 0 ? -1 : (ch[0] * b->B[1] + ch[1]) * b->B[2] + ch[2];
         any = any || b->nbr[a][0] >= 0 || b->nbr[a][1] >= 0;
@@ -364,10 +366,11 @@ int mh_block_connect(mh_block* b, const void* comm_id128)
     return MH_OK;
 }
 
-int mh_block_create(mh_block** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int device_id)
+int mh_block_create(mh_block** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int self_exchange,
+                    int device_id)
 {
     mh_block* b = nullptr;
-    if (int rc = block_create_common(&b, global, rk_order, rank, world, device_id, BLOCK_EXCHANGE_RCCL)) return rc;
+    if (int rc = block_create_common(&b, global, rk_order, rank, world, device_id, BLOCK_EXCHANGE_RCCL, world == 1 && self_exchange != 0)) return rc;
     if (comm_id128) if (int rc = mh_block_connect(b, comm_id128)) { mh_block_destroy(b); return rc; }
     *out = b;
     return MH_OK;

@@ -183,3 +183,46 @@ def test_native_slab_dependencies_hold_under_shifted_timing(delay, stagger, on_l
     st.synchronize()
     assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64))
     st.close()
+
+
+@pytest.mark.parametrize("shape", [(40, 24, 70), (16, 16, 130)])
+def test_native_block_rccl_exchange_to_self_on_all_three_axes(shape):
+    """The block stepper's RCCL path (mara3_amd/csrc/block3d.hip: six ncclSend / ncclRecv in one group, packed axis-1 / axis-2 faces,
+    shell / interior streams) on one GPU: one block of a periodic domain whose wrap-around goes through the exchange, to itself, on ALL
+    THREE axes - the message order that pairs a rank with the same neighbour on both sides of an axis. Bit-identical to the kernel's own
+    periodic handling."""
+    import numpy as np
+    from mara3_amd import setups
+    from mara3_amd.slab import native_comm_id
+    from mara3_amd.block import NativeBlock
+    from mara3_amd.engine import EulerCartSolver
+    gamma = 1.4
+    dl = tuple(1.0 / n for n in shape)
+    u0 = setups.wave_ic(shape, gamma, seed=13)
+    ref = EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, "periodic", arith="fast")
+    ref.upload(u0); ref.step(1e-3, 5)
+    blk = NativeBlock(shape, dl, gamma, 1.5, "hllc", 2, "periodic", rank=0, world=1, comm_id=native_comm_id(0, 1), arith="fast", self_exchange=True)
+    assert blk.neighbours == (0, 0, 0, 0, 0, 0)
+    blk.upload(u0); blk.step(1e-3, 5); blk.synchronize()
+    assert blk.status()[0] == 0
+    assert np.array_equal(blk.download().view(np.uint64), ref.download().view(np.uint64))
+    blk.close()
+
+
+def test_binary_band_rccl_halo_and_allreduce_to_self():
+    """`binary` over bands, RCCL backend, on one GPU: a single band whose periodic ghost rows travel through ncclSend / ncclRecv to self and
+    whose totals, wavespeed and status go through the three ncclAllReduce calls (over one rank: the identity) - field AND scalars
+    bit-identical to the whole-mesh solver, CFL time step included."""
+    import numpy as np
+    from mara3_amd import binary
+    from mara3_amd.slab import native_comm_id
+    cfg = binary.config(depth=2, block_size=16)
+    one = binary.BinarySolver(cfg)
+    band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), self_exchange=True)
+    assert (band.row0, band.row1) == (0, 64)
+    for nsteps in (1, 3):
+        assert one.next(nsteps) == 0 and band.next(nsteps) == 0
+        assert band.last_dt == one.last_dt
+        assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
+        assert binary.state_as_dict(band.state()) == binary.state_as_dict(one.state())
+    one.close(); band.close()
