@@ -272,6 +272,12 @@ int  mh_slab_set_inflow(mh_slab* slab, const double* inflow_prims_aos_host);
 int  mh_slab_group_create(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, int device_id);
 int  mh_slab_cloud_group_create(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
                                 int rk_order, int world, int device_id);
+/* The same groups with member r on device_ids[r]: ONE process (one host thread) driving several GPUs - what the reference's thread slabs
+ * (mara::evaluate_on<N>, src/app_parallel.hpp:75-103) become when a slab is a device; "receives" are peer copies. With all ids equal this is
+ * the group above (the form that is tested on a one-GPU box); distinct devices have not been exercised there. */
+int  mh_slab_group_create_on(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, const int* device_ids);
+int  mh_slab_cloud_group_create_on(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                                   int rk_order, int world, const int* device_ids);
 int  mh_slab_group_upload(mh_slab** slabs, int world, const double* u_aos_global_host);
 int  mh_slab_group_download(mh_slab** slabs, int world, double* u_aos_global_host);
 int  mh_slab_group_step(mh_slab** slabs, int world, double dt, int nsteps);

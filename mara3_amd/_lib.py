@@ -137,6 +137,8 @@ SYMBOLS = [
     ("mh_slab_set_inflow", _i, [_vp, _vp]),
     ("mh_slab_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
     ("mh_slab_cloud_group_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i]),
+    ("mh_slab_group_create_on", _i, [C.POINTER(_vp), _descp, _i, _i, C.POINTER(_i)]),
+    ("mh_slab_cloud_group_create_on", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, C.POINTER(_i)]),
     ("mh_slab_group_upload", _i, [C.POINTER(_vp), _i, _vp]),
     ("mh_slab_group_download", _i, [C.POINTER(_vp), _i, _vp]),
     ("mh_slab_group_step", _i, [C.POINTER(_vp), _i, _d, _i]),

@@ -456,13 +456,16 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     return MH_OK;
 }
 
+// device_ids == nullptr: every member on device_id. Otherwise member r lives on device_ids[r]: ONE process, one host thread, several
+// GPUs - what the reference's evaluate_on<N> thread slabs become when the slabs are devices. The "receives" are then peer copies
+// (peer access is enabled between neighbouring members' devices); events order streams of different devices as they do on one.
 static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* global, const mh_cloud_desc* cglobal, const double* rv,
-                        const double* qv, int rk_order, int world, int device_id)
+                        const double* qv, int rk_order, int world, int device_id, const int* device_ids)
 {
     if (! slabs || world < 1 || world > 64) { set_error("mh_slab group: need 1..64 slabs"); return MH_E_INVALID; }
     for (int r = 0; r < world; ++r) slabs[r] = nullptr;
     for (int r = 0; r < world; ++r)
-        if (int rc = slab_create_common(&slabs[r], kind, global, cglobal, rv, qv, rk_order, r, world, 0, device_id, EXCHANGE_LOOPBACK))
+        if (int rc = slab_create_common(&slabs[r], kind, global, cglobal, rv, qv, rk_order, r, world, 0, device_ids ? device_ids[r] : device_id, EXCHANGE_LOOPBACK))
         {
             for (int q = 0; q < r; ++q) { mh_slab_destroy(slabs[q]); slabs[q] = nullptr; }
             return rc;
@@ -471,6 +474,14 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
     {
         slabs[r]->peer_lo = slabs[r]->lo >= 0 ? slabs[slabs[r]->lo] : nullptr;
         slabs[r]->peer_hi = slabs[r]->hi >= 0 ? slabs[slabs[r]->hi] : nullptr;
+        for (mh_slab* p : {slabs[r]->peer_lo, slabs[r]->peer_hi})
+            if (p && p->device != slabs[r]->device)
+            {
+                MH_HIP_TRY(hipSetDevice(slabs[r]->device));
+                const hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_fail(e, "hipDeviceEnablePeerAccess");
+                (void) hipGetLastError();
+            }
     }
     return MH_OK;
 }
@@ -549,13 +560,26 @@ int mh_slab_cloud_create(mh_slab** out, const mh_cloud_desc* global, const doubl
 
 int mh_slab_group_create(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, int device_id)
 {
-    return group_create(slabs, SLAB_EULER, global, nullptr, nullptr, nullptr, rk_order, world, device_id);
+    return group_create(slabs, SLAB_EULER, global, nullptr, nullptr, nullptr, rk_order, world, device_id, nullptr);
+}
+
+int mh_slab_group_create_on(mh_slab** slabs, const mh_euler_cart_desc* global, int rk_order, int world, const int* device_ids)
+{
+    if (! device_ids) return MH_E_INVALID;
+    return group_create(slabs, SLAB_EULER, global, nullptr, nullptr, nullptr, rk_order, world, 0, device_ids);
 }
 
 int mh_slab_cloud_group_create(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
                                int rk_order, int world, int device_id)
 {
-    return group_create(slabs, SLAB_CLOUD, nullptr, global, r_vertices_host, q_vertices_host, rk_order, world, device_id);
+    return group_create(slabs, SLAB_CLOUD, nullptr, global, r_vertices_host, q_vertices_host, rk_order, world, device_id, nullptr);
+}
+
+int mh_slab_cloud_group_create_on(mh_slab** slabs, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
+                                  int rk_order, int world, const int* device_ids)
+{
+    if (! device_ids) return MH_E_INVALID;
+    return group_create(slabs, SLAB_CLOUD, nullptr, global, r_vertices_host, q_vertices_host, rk_order, world, 0, device_ids);
 }
 
 void mh_slab_destroy(mh_slab* s)
@@ -605,9 +629,12 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
     if (! u_aos_global_host) return MH_E_INVALID;
     for (int r = 0; r < n; ++r)
         if (int rc = slab_upload_rows(g[r], u_aos_global_host + (size_t) g[r]->row0 * g[r]->n1 * 5)) return slab_fail(g[r], rc);
-    for (int r = 0; r < n; ++r) MH_HIP_TRY(hipStreamSynchronize(g[r]->main));
+    for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); MH_HIP_TRY(hipStreamSynchronize(g[r]->main)); }
     for (int r = 0; r < n; ++r)
+    {
+        MH_HIP_TRY(hipSetDevice(g[r]->device));
         if (int rc = slab_exchange(g[r], g[r]->field[0], g[r]->main, true)) return slab_fail(g[r], rc);
+    }
     for (int r = 0; r < n; ++r)
         if (int rc = slab_reset_chains(g[r])) return slab_fail(g[r], rc);
     int skew = 0;

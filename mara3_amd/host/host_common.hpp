@@ -29,10 +29,8 @@ template<typename F> double time_ms(F&& f)
 // run here with the exception the reference would have thrown for it - mara::srhd::recover_primitive's std::invalid_argument and its
 // four texts (src/physics_srhd.hpp:430-449) for the relativistic system; for mara::euler, whose recover_primitive never throws
 // upstream, a std::runtime_error that names what the kernel saw.
-inline void throw_on_status(mh_ctx* ctx, int system = MH_SYSTEM_EULER)
+inline void throw_on_result(const mh_step_result& r, int system = MH_SYSTEM_EULER)
 {
-    mh_step_result r;
-    check(mh_status(ctx, &r), ctx, "mh_status");
     if (r.status == 0) return;
     const std::string where = " (first failing cell: flat index " + std::to_string((unsigned long long) r.first_bad_index) + ", device status 0x" + std::to_string(r.status) + ")";
     if (system == MH_SYSTEM_SRHD)
@@ -47,6 +45,13 @@ inline void throw_on_status(mh_ctx* ctx, int system = MH_SYSTEM_EULER)
     if (r.status & MH_STATUS_NEG_PRESSURE) throw std::runtime_error("negative pressure in recovered primitive state" + where);
     if (r.status & MH_STATUS_NAN)          throw std::runtime_error("nan in updated state" + where);
     throw std::runtime_error("device status word not clean" + where);
+}
+
+inline void throw_on_status(mh_ctx* ctx, int system = MH_SYSTEM_EULER)
+{
+    mh_step_result r;
+    check(mh_status(ctx, &r), ctx, "mh_status");
+    throw_on_result(r, system);
 }
 
 // <outdir>/<name>: [int64 rank][int64 shape...][int64 nq][f64 time][int64 iteration][f64 vertices (1-D only)...][f64 data...]

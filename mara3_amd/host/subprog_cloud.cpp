@@ -51,7 +51,9 @@ mara::config_t config_template()
     .item("profile", 0)              // print the average stage-kernel time from HIP events at the end; not a reference option
     .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
     .item("write_inflow", 0)         // also dump the nozzle row of the first step (tests)
-    .item("device", 0);
+    .item("device", 0)
+    .item("gpus", 1);                // radial slabs over this many GPUs of the node, ONE process (the reference's `evaluate_on<N>` thread slabs,
+                                     // :527-581, with a device per slab); more slabs than visible devices share them round-robin. Not a reference option
 }
 
 // conserved density of a primitive state, mara::srhd::primitive_t::to_conserved_density (src/physics_srhd.hpp:213-227);
@@ -150,7 +152,32 @@ public:
         mh_ctx* ctx = nullptr;
         host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
         host::check(mh_cloud_configure(ctx, &d, rv.data(), qv.data(), cfg.get_int("rk_order")), ctx, "mh_cloud_configure");
-        host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+        // gpus > 1: the step runs on a group of radial slabs (BASELINE config 4: slab decomposition + two-row halo per stage), member r on
+        // device r of the node; the context above then only serves make_diagnostic_fields when that task is due
+        const int gpus = int(cfg.get_int("gpus"));
+        if (gpus < 1 || gpus > 64) throw std::invalid_argument("gpus must be 1..64");
+        std::vector<mh_slab*> slabs(gpus > 1 ? gpus : 0, nullptr);
+        if (gpus > 1)
+        {
+            const int visible = mh_device_count();
+            std::vector<int> ids(gpus);
+            for (int r = 0; r < gpus; ++r) ids[r] = r % (visible > 0 ? visible : 1);
+            if (visible < gpus) std::printf("gpus=%d on %d visible device(s): slabs share devices round-robin\n", gpus, visible);
+            if (mh_slab_cloud_group_create_on(slabs.data(), &d, rv.data(), qv.data(), int(cfg.get_int("rk_order")), gpus, ids.data()) != MH_OK)
+                throw std::runtime_error(std::string("mh_slab_cloud_group_create_on: ") + mh_last_error(nullptr));
+        }
+        auto group_check = [] (int rc, const char* what) { if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(nullptr)); };
+        auto upload_solution = [&] ()
+        {
+            if (gpus > 1) group_check(mh_slab_group_upload(slabs.data(), gpus, u.data()), "mh_slab_group_upload");
+            else          host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+        };
+        auto download_solution = [&] ()
+        {
+            if (gpus > 1) group_check(mh_slab_group_download(slabs.data(), gpus, u.data()), "mh_slab_group_download");
+            else          host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
+        };
+        upload_solution();
 
         const double dt = (rv[1] - rv[0]) / 1.0 * cfg.get_double("cfl_number");
         const double tfinal = cfg.get_double("tfinal");
@@ -179,7 +206,7 @@ public:
             std::vector<hsize_t> shape;
             u = sol.read_cells("conserved", 5, shape);
             if (shape.size() != 2 || shape[0] != hsize_t(nr) || shape[1] != hsize_t(nq)) throw std::invalid_argument("cloud: the restart file holds a different grid");
-            host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+            upload_solution();
             schedule = h5io::read_schedule(file.open_group("schedule"));
             for (const char* task : {"write_checkpoint", "write_diagnostics", "write_time_series"})
                 if (! schedule.tasks.count(task)) schedule.create_and_mark_as_due(task);
@@ -194,7 +221,7 @@ public:
         auto write_checkpoint = [&] ()
         {
             // write_checkpoint :758-767, write_solution :590-597
-            host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
+            download_solution();
             const std::string path = path_of("chkpt", schedule.at("write_checkpoint").num_times_performed);
             {
                 auto file = h5io::Node::create_file(path);
@@ -213,6 +240,11 @@ public:
         {
             // write_diagnostics :769-799: make_diagnostic_fields (:334-433) is evaluated on the device, the file gets its results
             std::vector<double> fields(std::size_t(5) * nr * nq), columns(std::size_t(15) * nq);
+            if (gpus > 1)          // gather the slabs into the context (one device) for the diagnostic fields: only when the task is due
+            {
+                download_solution();
+                host::check(mh_upload(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_upload");
+            }
             host::check(mh_cloud_diagnostics(ctx, units, fields.data(), columns.data()), ctx, "mh_cloud_diagnostics");
             const std::string path = path_of("diagnostics", schedule.at("write_diagnostics").num_times_performed);
             {
@@ -264,9 +296,18 @@ public:
             }
             if (iteration == 0) inflow_first = inflow;
             const double ms = host::time_ms([&] {
-                host::check(mh_cloud_set_inflow(ctx, inflow.data()), ctx, "mh_cloud_set_inflow");
-                host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
-                host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+                if (gpus > 1)
+                {
+                    for (mh_slab* sl : slabs) group_check(mh_slab_set_inflow(sl, inflow.data()), "mh_slab_set_inflow");
+                    group_check(mh_slab_group_step(slabs.data(), gpus, dt, 1), "mh_slab_group_step");
+                    for (mh_slab* sl : slabs) group_check(mh_slab_synchronize(sl), "mh_slab_synchronize");
+                }
+                else
+                {
+                    host::check(mh_cloud_set_inflow(ctx, inflow.data()), ctx, "mh_cloud_set_inflow");
+                    host::check(mh_step(ctx, dt, 1), ctx, "mh_step");
+                    host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+                }
             });
             if (tasks_on)
             {
@@ -278,7 +319,20 @@ public:
             time += dt;
             iteration += 1;
             run_tasks();
-            host::throw_on_status(ctx, MH_SYSTEM_SRHD);          // the reference throws out of the failing step (physics_srhd.hpp:430-449)
+            // the reference throws out of the failing step (physics_srhd.hpp:430-449)
+            if (gpus > 1)
+            {
+                mh_step_result worst = {0, 0, UINT64_MAX};
+                for (mh_slab* sl : slabs)
+                {
+                    mh_step_result r;
+                    group_check(mh_slab_status(sl, &r), "mh_slab_status");
+                    worst.status |= r.status;
+                    if (r.status && r.first_bad_index < worst.first_bad_index) worst.first_bad_index = r.first_bad_index;
+                }
+                host::throw_on_result(worst, MH_SYSTEM_SRHD);
+            }
+            else host::throw_on_status(ctx, MH_SYSTEM_SRHD);
             if (verbose) std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
         };
         while (time < tfinal && (max_steps == 0 || iteration < max_steps)) advance(true);
@@ -289,7 +343,7 @@ public:
             host::check(mh_profile_read(ctx, &avg_ms, &launches), ctx, "mh_profile_read");
             std::printf("profile: stage kernel avg %.6f ms over %d launches\n", avg_ms, launches);
         }
-        host::check(mh_download(ctx, u.data(), std::size_t(nr) * nq), ctx, "mh_download");
+        download_solution();
         std::vector<double> vertices(rv);
         vertices.insert(vertices.end(), qv.begin(), qv.end());
         host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nr), long(nq)}, 5, time, iteration, vertices, u);
@@ -298,6 +352,7 @@ public:
         // upstream's closing `run_tasks_on_next(state)` (:935): one more step whose only visible effect is a task that falls due on it.
         // final.bin above is the state the loop ended with; a run cut short by max_steps (not upstream) ends there.
         if (max_steps == 0 && tasks_on) advance(false);
+        for (mh_slab* sl : slabs) mh_slab_destroy(sl);
         mh_destroy(ctx);
         return 0;
     }

@@ -30,7 +30,8 @@ mara::config_t config_template()
     .item("ambient_pressure", 0.1)
     .item("write_final", 1)
     .item("steps_per_call", 10)       // time steps per mh_step call (the reference steps one at a time; state stays on the device either way)
-    .item("device", 0);
+    .item("device", 0)
+    .item("gpus", 1);                 // axis-0 slabs over this many GPUs of the node, one process (not a reference option)
 }
 
 class subprog_euler2d : public mara::sub_program_t
@@ -66,10 +67,28 @@ public:
         d.bc_lo0 = d.bc_hi0 = d.bc_transverse = MH_BC_OUTFLOW;
         d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
 
+        // gpus > 1: axis-0 slabs (nd::partition_shape, the cut of the reference's evaluate_on<N> thread slabs) on a group of devices driven
+        // by this one process, two-row halo per stage; more slabs than visible devices share them round-robin
+        const int gpus = int(cfg.get_int("gpus"));
+        if (gpus < 1 || gpus > 64) throw std::invalid_argument("gpus must be 1..64");
+        auto group_check = [] (int rc, const char* what) { if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(nullptr)); };
         mh_ctx* ctx = nullptr;
-        host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
-        host::check(mh_euler_cart_configure(ctx, &d, cfg.get_int("rk_order")), ctx, "mh_euler_cart_configure");
-        host::check(mh_upload(ctx, u.data(), std::size_t(n) * n), ctx, "mh_upload");
+        std::vector<mh_slab*> slabs(gpus > 1 ? gpus : 0, nullptr);
+        if (gpus > 1)
+        {
+            const int visible = mh_device_count();
+            std::vector<int> ids(gpus);
+            for (int r = 0; r < gpus; ++r) ids[r] = r % (visible > 0 ? visible : 1);
+            if (visible < gpus) std::printf("gpus=%d on %d visible device(s): slabs share devices round-robin\n", gpus, visible);
+            group_check(mh_slab_group_create_on(slabs.data(), &d, int(cfg.get_int("rk_order")), gpus, ids.data()), "mh_slab_group_create_on");
+            group_check(mh_slab_group_upload(slabs.data(), gpus, u.data()), "mh_slab_group_upload");
+        }
+        else
+        {
+            host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
+            host::check(mh_euler_cart_configure(ctx, &d, cfg.get_int("rk_order")), ctx, "mh_euler_cart_configure");
+            host::check(mh_upload(ctx, u.data(), std::size_t(n) * n), ctx, "mh_upload");
+        }
 
         const double dt = cfg.get_double("cfl_number") * dx / 6.0;
         const double tfinal = cfg.get_double("tfinal");
@@ -82,19 +101,41 @@ public:
             int todo = 0;
             for (double t = time; t < tfinal && todo < batch; t += dt) ++todo;
             const double ms = host::time_ms([&] {
-                host::check(mh_step(ctx, dt, todo), ctx, "mh_step");
-                host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+                if (gpus > 1)
+                {
+                    group_check(mh_slab_group_step(slabs.data(), gpus, dt, todo), "mh_slab_group_step");
+                    for (mh_slab* sl : slabs) group_check(mh_slab_synchronize(sl), "mh_slab_synchronize");
+                }
+                else
+                {
+                    host::check(mh_step(ctx, dt, todo), ctx, "mh_step");
+                    host::check(mh_synchronize(ctx), ctx, "mh_synchronize");
+                }
             });
             for (int s = 0; s < todo; ++s) time += dt;
             iteration += todo;
-            host::throw_on_status(ctx);
+            if (gpus > 1)
+            {
+                mh_step_result worst = {0, 0, UINT64_MAX};
+                for (mh_slab* sl : slabs)
+                {
+                    mh_step_result r;
+                    group_check(mh_slab_status(sl, &r), "mh_slab_status");
+                    worst.status |= r.status;
+                    if (r.status && r.first_bad_index < worst.first_bad_index) worst.first_bad_index = r.first_bad_index;
+                }
+                host::throw_on_result(worst);
+            }
+            else host::throw_on_status(ctx);
             std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(n) * n * todo / ms);
         }
         if (cfg.get_int("write_final"))
         {
-            host::check(mh_download(ctx, u.data(), std::size_t(n) * n), ctx, "mh_download");
+            if (gpus > 1) group_check(mh_slab_group_download(slabs.data(), gpus, u.data()), "mh_slab_group_download");
+            else          host::check(mh_download(ctx, u.data(), std::size_t(n) * n), ctx, "mh_download");
             host::dump_state(cfg.get_string("outdir"), "final.bin", {long(n), long(n)}, 5, time, iteration, {}, u);
         }
+        for (mh_slab* sl : slabs) mh_slab_destroy(sl);
         mh_destroy(ctx);
         return 0;
     }

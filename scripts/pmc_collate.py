@@ -93,7 +93,7 @@ if __name__ == "__main__":
         out = {"csrc_sha16": csrc_fingerprint(),
                "_comment": "HBM bytes per launch of the RK2 stage kernels at 4096^2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 20 "
                            "--warmup 3 --single-arith`, scripts/profile_r2.sh): 2 x FETCH_SIZE + WRITE_SIZE, calibrated on mh::stream_copy_kernel in the same script "
-                           "(profiles/r02/kernels_headline.md). Keyed by the hash of mara3_amd/csrc/*.hip|*.hpp: bench.py reports `traffic` only for the sources "
+                           "(profiles/r02/kernels_headline.md). Keyed by the hash of the stage kernels' sources and device headers (bench.py: KERNEL_SOURCES): bench.py reports `traffic` only for the sources "
                            "these numbers were measured on."}
         for (tag, k), v in tr.items():
             arith, riemann = tag.split("_")

@@ -104,6 +104,28 @@ def test_cloud_subprogram_matches_reference(tmp_path, case, args):
     assert "kzps=" in stdout
 
 
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_cloud_subprogram_over_radial_slabs_matches_reference(tmp_path, gpus):
+    """BASELINE config 4's decomposition through the sub-program itself: `mara_hip cloud gpus=N` steps N radial slabs (one process, slab r on
+    device r; on a one-GPU box the slabs share the device) with the two-row halo per stage, and must land on the reference-composed run bit
+    for bit, like gpus=1 - including a diagnostics task, which gathers the slabs."""
+    g = golden("cloud_nr70_plm_rk2")
+    stdout = run(["cloud", "tfinal=1e9", "write_inflow=1", "nr=70", "num_decades=1", "rk_order=2", "max_steps=2", "gpus=%d" % gpus, "dfi=1e-9"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert d["iteration"] == int(g["nsteps"])
+    assert bits_equal(d["data"], g["un"]), np.abs(d["data"] - g["un"]).max()
+    assert "share devices round-robin" in stdout and "write diagnostics" in stdout
+
+
+def test_euler2d_subprogram_over_slabs_matches_reference(tmp_path):
+    g = golden("euler2d_blast64_plm15_rk2")
+    dt = float(g["dt"])
+    run(["euler2d", "n=64", "tfinal=%r" % float(9.5 * dt), "riemann=hlle", "plm_theta=1.5", "rk_order=2", "steps_per_call=3", "gpus=3"], str(tmp_path))
+    d = read_dump(os.path.join(tmp_path, "data", "final.bin"))
+    assert d["iteration"] == 10
+    assert bits_equal(d["data"], g["u_10"])
+
+
 @pytest.mark.parametrize("case", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d3_b8_axisym", "binary_d2_b16_q", "binary_d2_b16_live"])
 def test_binary_subprogram_matches_reference(tmp_path, case):
     """The whole host path of `mara_hip binary`: set-up with the host libm (bit-exact vertices), dt choice, RK steps,
