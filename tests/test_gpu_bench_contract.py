@@ -28,3 +28,25 @@ def test_bench_json_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mcells/s" and c["sample"]
     assert d["config"]["status_word"] == 0
+    # round 2: the pinned variant, the smooth wave and the other configs are in the driver-run line too, each with its own rooflines
+    legs = d["legs"]
+    for key in ("strict_hllc_blast", "strict_hlle_blast", "fast_hlle_blast", "fast_hllc_smooth_wave", "strict_hlle_smooth_wave"):
+        assert key in legs and legs[key]["value"] > 0 and legs[key]["status_word"] == 0
+        assert 0.0 < legs[key]["roofline"]["frac"] < 1.0 and 0.0 < legs[key]["roofline_stage1"]["frac"] < 1.0
+    assert len(d["repeat_blocks"]["ms_per_step"]) == 4
+    assert any(k.startswith("l1_fast_vs_strict_after_") and d[k] <= 1e-12 for k in d)
+    for cfg in ("c3", "c4", "c5"):
+        assert d["extra_configs"][cfg].get("value", 0) > 0, d["extra_configs"][cfg]
+    if r["traffic"] is not None:
+        assert r["fp64"]["peak"] == 78.6 and 0.0 < r["fp64"]["frac"] < 1.0 and 0.0 < r["fp64"]["valu_busy"] <= 1.0
+
+
+def test_bench_loopback_rehearsal_of_the_multi_gpu_path():
+    """`bench.py --loopback-slabs 4`: the N > 1 code path of the bench (decomposed stepper, timing, per-rank fingerprints, partition check
+    against a one-GPU run) on one GPU through the native stepper's loopback backend."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--loopback-slabs", "4", "--single-arith", "--no-cpu-baseline",
+                          "--blocks", "2"], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["slabs_bit_identical_to_one_gpu_run"] is True
+    assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["status_word"] == 0
