@@ -154,3 +154,26 @@ def test_config5_as_configured_per_gpu_share_512_as_eight_blocks(eng):
     grp.close()
     assert bits_equal(got, want)
     assert abs(float(got[..., 0].sum()) - mass0) <= 1e-12 * mass0
+
+
+def test_blocks_long_run_stays_bit_identical(eng):
+    """120 steps of (2,2,3) blocks of a periodic 40 x 36 x 66 grid (uneven axis-2 extents 22, 22, 22 -> strips of one partial tile): the
+    shell / interior chains and the six-message exchange over many stages."""
+    from mara3_amd import setups
+    from mara3_amd.block import NativeBlockGroup
+    shape, gamma = (40, 36, 66), 1.4
+    dl = tuple(1.0 / n for n in shape)
+    u0 = setups.wave_ic(shape, gamma, seed=52)
+    dt = 0.2 * min(dl) / 2.0
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hlle", 2, "periodic", arith="strict")
+    ref.upload(u0)
+    grp = NativeBlockGroup(shape, dl, gamma, 1.5, "hlle", 2, "periodic", world=12, arith="strict")
+    assert grp.members[0].blocks == (2, 2, 3)
+    grp.upload(u0)
+    for _ in range(4):
+        ref.step(dt, 30)
+        grp.step(dt, 30)
+    grp.synchronize()
+    assert grp.status() == (0, None)
+    assert bits_equal(grp.download(), ref.download())
+    grp.close()

@@ -257,3 +257,27 @@ def test_cloud_config4_as_configured_4096_over_4_slabs(eng, arith):
     assert one.status() == 0 and grp.status() == (0, None)
     assert bits_equal(grp.download(), one.download())
     grp.close(); one.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,shape", [(8, (1000, 600)), (5, (333, 1030))])
+def test_group_long_run_stays_bit_identical(eng, world, shape):
+    """300 steps (600 stages, 75 stagger periods) of an uneven cut: an ordering hole between the two chains of a rank, or between ranks,
+    that only opens now and then would show up here as a single differing bit."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    gamma = 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=51)
+    dt = 0.2 * min(dl) / 2.0
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, "periodic", arith="fast")
+    ref.upload(u0)
+    grp = NativeSlabGroup(shape, dl, gamma, 1.5, "hllc", 2, "periodic", world=world, arith="fast")
+    grp.upload(u0)
+    for _ in range(6):
+        ref.step(dt, 50)
+        grp.step(dt, 50)
+    grp.synchronize()
+    assert grp.status() == (0, None) and ref.status() == 0
+    assert bits_equal(grp.download(), ref.download())
+    grp.close()
