@@ -178,14 +178,14 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
 
     const double gamma = p.gamma, theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(gamma);
+    const typename A::Limiter lim = A::limiter(theta);
 
     // ---- register window: three slots used as rings (index = row mod 3 relative to the chunk start), so that the
     // row loop, unrolled by three, needs no register-to-register rotation at all.
     //   U[k]: conserved of rows r, r+1, r+2        P[k]: primitives of rows r, r+1, r+2
     //   G[k]: axis-0 slope of rows r, r+1          Fx[k]: axis-0 flux through faces r-1/2, r+1/2
-    //   D[k]: (FAST) theta * (P of row r+1 - P of row r), the limiter's one-sided difference across face r+1/2
+    //   D[k]: (FAST) P of row r+1 - P of row r, the limiter's one-sided difference across face r+1/2
     State5 U[3], P[3], G[3], Fx[3], D[3];
-    const double half_over_theta = 0.5 / theta;
     {
         const State5 Pa = A::c2p(load_row(in + row_off(r0 - 2), p.plane_stride, jc8), gl);
         const State5 Pb = A::c2p(load_row(in + row_off(r0 - 1), p.plane_stride, jc8), gl);
@@ -199,17 +199,17 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         if constexpr (A::recompute_conserved) U[0] = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
         if constexpr (PLM && A::shared_differences)
         {
-            const State5 Dab = A::scaled_difference(Pa, Pb, theta), Db0 = A::scaled_difference(Pb, P[0], theta);
-            D[0] = A::scaled_difference(P[0], P[1], theta);
-            const State5 Gb = A::plm_from_differences(Dab, Db0, half_over_theta);
-            G[0] = A::plm_from_differences(Db0, D[0], half_over_theta);
-            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
+            const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
+            D[0] = A::difference(P[0], P[1]);
+            const State5 Gb = A::plm_from_differences(Dab, Db0, lim);
+            G[0] = A::plm_from_differences(Db0, D[0], lim);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb, lim), A::minus(P[0], G[0], lim), gl);
         }
         else if constexpr (PLM)
         {
-            const State5 Gb = A::plm(Pa, Pb, P[0], theta);
-            G[0] = A::plm(Pb, P[0], P[1], theta);
-            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
+            const State5 Gb = A::plm(Pa, Pb, P[0], lim);
+            G[0] = A::plm(Pb, P[0], P[1], lim);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb, lim), A::minus(P[0], G[0], lim), gl);
         }
         else
         {
@@ -252,14 +252,14 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         const bool bad_pressure = !(P[K2][4] >= 0.0);
         if constexpr (PLM && A::shared_differences)
         {
-            D[K1] = A::scaled_difference(P[K1], P[K2], theta);
-            G[K1] = A::plm_from_differences(D[K0], D[K1], half_over_theta);
-            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
+            D[K1] = A::difference(P[K1], P[K2]);
+            G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
         }
         else if constexpr (PLM)
         {
-            G[K1] = A::plm(P[K0], P[K1], P[K2], theta);
-            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
+            G[K1] = A::plm(P[K0], P[K1], P[K2], lim);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
         }
         else
         {
@@ -270,16 +270,16 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM && A::shared_differences)
         {
-            const State5 Dr = A::scaled_difference(P[K0], from_right(P[K0]), theta);
-            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, half_over_theta);
-            const State5 SL = from_left(A::plus(P[K0], Gy));
-            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy), gl);
+            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
+            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
+            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
         }
         else if constexpr (PLM)
         {
-            const State5 Gy = A::plm(from_left(P[K0]), P[K0], from_right(P[K0]), theta);
-            const State5 SL = from_left(A::plus(P[K0], Gy));       // left neighbour's right-going face state
-            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy), gl);
+            const State5 Gy = A::plm(from_left(P[K0]), P[K0], from_right(P[K0]), lim);
+            const State5 SL = from_left(A::plus(P[K0], Gy, lim));       // left neighbour's right-going face state
+            Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
         }
         else
         {

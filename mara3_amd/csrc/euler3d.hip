@@ -177,6 +177,7 @@ void euler3d_stage_kernel(Stage3dParams p)
 
     const double theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(p.gamma);
+    const typename A::Limiter lim = A::limiter(theta);
     const double* in = p.u_in;
 
     // ---- register window along axis 0: three slots used as rings (index = plane mod 3 relative to the chunk start)
@@ -194,9 +195,9 @@ void euler3d_stage_kernel(Stage3dParams p)
         P[1] = A::c2p(Ub, gl);
         if constexpr (PLM)
         {
-            const State5 Gb = A::plm(Pa, Pb, P[0], theta);
-            G[0] = A::plm(Pb, P[0], P[1], theta);
-            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb), A::minus(P[0], G[0]), gl);
+            const State5 Gb = A::plm(Pa, Pb, P[0], lim);
+            G[0] = A::plm(Pb, P[0], P[1], lim);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb, lim), A::minus(P[0], G[0], lim), gl);
         }
         else
         {
@@ -237,8 +238,8 @@ void euler3d_stage_kernel(Stage3dParams p)
         Uin = Unext;
         if constexpr (PLM)
         {
-            G[K1] = A::plm(P[K0], P[K1], P[K2], theta);
-            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0]), A::minus(P[K1], G[K1]), gl);
+            G[K1] = A::plm(P[K0], P[K1], P[K2], lim);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
         }
         else
         {
@@ -249,9 +250,9 @@ void euler3d_stage_kernel(Stage3dParams p)
         State5 Fz_lo, Fz_hi;
         if constexpr (PLM)
         {
-            const State5 Gz = A::plm(dpp3_left(P[K0]), P[K0], dpp3_right(P[K0]), theta);
-            const State5 SL = dpp3_left(A::plus(P[K0], Gz));
-            Fz_lo = A::template flux<RIEMANN, 2>(SL, A::minus(P[K0], Gz), gl);
+            const State5 Gz = A::plm(dpp3_left(P[K0]), P[K0], dpp3_right(P[K0]), lim);
+            const State5 SL = dpp3_left(A::plus(P[K0], Gz, lim));
+            Fz_lo = A::template flux<RIEMANN, 2>(SL, A::minus(P[K0], Gz, lim), gl);
         }
         else
         {
@@ -272,14 +273,14 @@ void euler3d_stage_kernel(Stage3dParams p)
             const State5 Pm1 = lds_get(tile.P[pb][row + H3 - 1], lane), Pp1 = lds_get(tile.P[pb][row + H3 + 1], lane);
             if constexpr (PLM)
             {
-                const State5 Gy = A::plm(Pm1, P[K0], Pp1, theta);
+                const State5 Gy = A::plm(Pm1, P[K0], Pp1, lim);
                 {
                     const State5 Pm2 = lds_get(tile.P[pb][row + H3 - 2], lane);
-                    Fy_lo = A::template flux<RIEMANN, 1>(A::plus(Pm1, A::plm(Pm2, Pm1, P[K0], theta)), A::minus(P[K0], Gy), gl);
+                    Fy_lo = A::template flux<RIEMANN, 1>(A::plus(Pm1, A::plm(Pm2, Pm1, P[K0], lim), lim), A::minus(P[K0], Gy, lim), gl);
                 }
                 {
                     const State5 Pp2 = lds_get(tile.P[pb][row + H3 + 2], lane);
-                    Fy_hi = A::template flux<RIEMANN, 1>(A::plus(P[K0], Gy), A::minus(Pp1, A::plm(P[K0], Pp1, Pp2, theta)), gl);
+                    Fy_hi = A::template flux<RIEMANN, 1>(A::plus(P[K0], Gy, lim), A::minus(Pp1, A::plm(P[K0], Pp1, Pp2, lim), lim), gl);
                 }
             }
             else

@@ -6,9 +6,11 @@
 //   * x / d  ->  x * r with r = v_rcp_f64(d) + one third-order step (0.5 ulp measured), one r per denominator,
 //   * inverse roots via v_rsq_f64 + one third-order step (< 1 ulp); sqrt(x) = x * rsqrt(x) + one correction,
 //   * the literal 0.0 / 1.0 normal-vector products removed (exact for finite data),
-//   * the limiter as max(0, min(a, b, c)) + min(0, max(a, b, c)) (identical to the sign-product form for finite arguments except for
-//     the sign of an exact zero), its one-sided differences formed once per face where the kernel can share them,
-//   * HLLC with wave speeds from the primitives, the conserved state and flux of the sampled side only, region choice by selects.
+//   * the limiter from min / max alone (minmod_between: identical to the sign-product form for finite arguments except for the sign of
+//     an exact zero), on UNSCALED one-sided differences formed once per face where the kernel can share them (theta rides in the
+//     face-state FMA),
+//   * HLLC with wave speeds from the primitives, the conserved state and flux of the sampled side only, the star flux as a blend
+//     F_K + c (S* U_K - F_K + p* D) with c = 0 outside the star region instead of selects on the results.
 // Less than half the executed instructions of the strict path; see DESIGN.md §5.2 / §6 for the measured difference.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -51,17 +53,23 @@ __device__ inline double sqrt_fast(double x)
     return g;
 }
 
-// minmod(a, b, c) = max(0, min(a, b, c)) + min(0, max(a, b, c)): the common-sign smallest magnitude, else 0.
-// Same value as 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min(|a|,|b|,|c|) for finite arguments (the sign of an exact
-// zero may differ); 7 fp64 instructions and no integer sign logic.
+// minmod(a, b, c) with b BETWEEN a and c in sign (b is a positive multiple of a + c): the common-sign smallest magnitude, else 0, as
+//     max(min(b, max(min(a, c), 0)), min(max(a, c), 0))
+// - both positive: min(b, min(a, c)); both negative: max(b, max(a, c)); mixed: 0. Same value as the reference's
+// 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min(|a|,|b|,|c|) for finite arguments (the sign of an exact zero may differ); 6 fp64
+// instructions, no selects and no integer sign logic.
+__device__ inline double minmod_between(double a, double b, double c)
+{
+    const double lo = __builtin_fmin(a, c), hi = __builtin_fmax(a, c);
+    return __builtin_fmax(__builtin_fmin(b, __builtin_fmax(lo, 0.0)), __builtin_fmin(hi, 0.0));
+}
+
 __device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
 {
     const double a = (y0 - yl) * theta;
     const double b = (yr - yl) * 0.5;
     const double c = (yr - y0) * theta;
-    const double lo = __builtin_fmin(__builtin_fmin(a, b), c);
-    const double hi = __builtin_fmax(__builtin_fmax(a, b), c);
-    return __builtin_fmax(0.0, lo) + __builtin_fmin(0.0, hi);
+    return minmod_between(a, b, c);
 }
 
 __device__ inline State5 plm_gradient(const State5& l, const State5& c, const State5& r, double theta)
@@ -199,8 +207,9 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     // q_K = sqrt(1 + gfac (p* / p_K - 1)) = sqrt(x / p_K) = x rsqrt(x p_K), x = p_K + gfac (p* - p_K): one inverse root and no reciprocal
     // (the reciprocal + square root form cost 2.5 % of the smooth-wave step, where one side of nearly every face takes this branch)
     const double xl = __builtin_fma(g.gfac, pstar - pl, pl), xr = __builtin_fma(g.gfac, pstar - pr, pr);
-    const double ql = pstar <= pl ? 1.0 : xl * rsqrt_fast(xl * pl);
-    const double qr = pstar <= pr ? 1.0 : xr * rsqrt_fast(xr * pr);
+    // x <= p_K exactly when p* <= p_K, where the root is <= 1: fmax picks the 1 (and turns the NaN of p_K == 0 into it)
+    const double ql = __builtin_fmax(xl * rsqrt_fast(xl * pl), 1.0);
+    const double qr = __builtin_fmax(xr * rsqrt_fast(xr * pr), 1.0);
     const double sl = __builtin_fma(-al, ql, ul);
     const double sr = __builtin_fma(ar, qr, ur);
     const double ml = dl * (sl - ul);       // mass flux relative to the left wave
@@ -221,13 +230,16 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     State5 U, Fk, F;
     conserved_and_flux<AXIS>(Pk, g, U, Fk);
     const double rinv = rcp_nr(sk - sstar);
-    const double sp = sk * __builtin_fma(mk, sstar - Pk[1 + AXIS], Pk[4]);
+    // F = F_K + c (S* U_K - F_K + p* D), c = S_K / (S_K - S*) in the star region and 0 outside it: the same F*_K (subtract F_K from
+    // eq. 10.41 over the common denominator) as a blend, two instructions per component and no selects on the five results
+    const double pk_star = __builtin_fma(mk, sstar - Pk[1 + AXIS], Pk[4]);
+    const double c = star ? sk * rinv : 0.0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = sstar * __builtin_fma(sk, U[q], -Fk[q]);
-    F[1 + AXIS] += sp;
-    F[4] = __builtin_fma(sp, sstar, F[4]);
+    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(sstar, U[q], -Fk[q]);
+    F[1 + AXIS] += pk_star;
+    F[4] = __builtin_fma(pk_star, sstar, F[4]);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = star ? F[q] * rinv : Fk[q];
+    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(c, F[q], Fk[q]);
     return F;
 }
 
@@ -243,9 +255,11 @@ struct StrictArith
     using Gamma = GammaLaw;
     static __device__ inline Gamma gamma_law(double gamma) { return make_gamma_law(gamma); }
     static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return recover_primitive(U, g.gamma, 0.0); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double theta) { return plm_gradient(l, c, r, theta); }
-    static __device__ inline State5 plus(const State5& P, const State5& G) { return face_plus(P, G); }
-    static __device__ inline State5 minus(const State5& P, const State5& G) { return face_minus(P, G); }
+    struct Limiter { double theta; };
+    static __device__ inline Limiter limiter(double theta) { return Limiter{theta}; }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return plm_gradient(l, c, r, lim.theta); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter&) { return face_plus(P, G); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter&) { return face_minus(P, G); }
     template<int RIEMANN, int AXIS>
     static __device__ inline State5 flux(const State5& Pl, const State5& Pr, const Gamma& g) { return riemann<RIEMANN, AXIS>(Pl, Pr, g); }
     // u - ((Fxhi - Fxlo)*cx + (Fyhi - Fylo)*cy)
@@ -276,51 +290,57 @@ struct FastArith
 #define MH_FAST_MIN_WAVES_STAGE1 2          // 3 (168 VGPRs, ~40 spills) was measured: no faster, DESIGN.md §6
 #endif
     static constexpr int min_waves_first_stage = MH_FAST_MIN_WAVES_STAGE1;
-    // The limiter's one-sided differences theta (y_{i+1} - y_i) belong to a FACE: each is formed once and used by the two cells it
-    // separates (carried in the register ring along the marching axis, passed by DPP across lanes); the central difference is
-    // their sum times 1 / (2 theta). 4 instead of 6 fp64 instructions per variable and axis in front of the min/max.
+    // The limiter's one-sided differences y_{i+1} - y_i belong to a FACE: each is formed once and used by the two cells it separates
+    // (carried in the register ring along the marching axis, passed by DPP across lanes). The limiter works on them UNSCALED:
+    //     minmod(theta dl, (dl + dr) / 2, theta dr) = theta minmod(dl, (dl + dr) / (2 theta), dr),
+    // and the factor theta / 2 of the half-cell extrapolation rides in the FMA that forms the face state. 1 + 2 + 6 fp64 instructions
+    // per variable and axis (the difference, the central term, the limiter) where the three-value form takes 13.
     static constexpr bool shared_differences = true;
     // The 2-D stage kernel converts a loaded row to primitives once and keeps only those; the conserved state the update starts
     // from is formed again from the primitives (8 instructions, equal to the stored one to rounding) instead of being carried through
     // the register window: no register-to-register moves in the row loop and 20 VGPRs fewer.
     static constexpr bool recompute_conserved = true;
     static __device__ inline State5 p2c(const State5& P, const fast::GammaLawFast& g) { return fast::to_conserved(P, g); }
-    static __device__ inline State5 scaled_difference(const State5& P, const State5& Pnext, double theta)
+    struct Limiter
+    {
+        double central;      // 1 / (2 theta): weight of dl + dr in the limiter's central argument
+        double half_theta;   // theta / 2: (slope in limiter units) -> (half-cell extrapolation)
+    };
+    static __device__ inline Limiter limiter(double theta) { return Limiter{0.5 / theta, 0.5 * theta}; }
+    static __device__ inline State5 difference(const State5& P, const State5& Pnext)
     {
         State5 D;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) D[q] = (Pnext[q] - P[q]) * theta;
+        for (int q = 0; q < 5; ++q) D[q] = Pnext[q] - P[q];
         return D;
     }
-    static __device__ inline State5 plm_from_differences(const State5& Dl, const State5& Dr, double half_over_theta)
+    // the limited slope in units of theta (see shared_differences): plus / minus below scale it
+    static __device__ inline State5 plm_from_differences(const State5& Dl, const State5& Dr, const Limiter& lim)
     {
         State5 G;
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
-        {
-            const double a = Dl[q], c = Dr[q], b = (a + c) * half_over_theta;
-            const double lo = __builtin_fmin(__builtin_fmin(a, b), c);
-            const double hi = __builtin_fmax(__builtin_fmax(a, b), c);
-            G[q] = __builtin_fmax(0.0, lo) + __builtin_fmin(0.0, hi);
-        }
+        for (int q = 0; q < 5; ++q) G[q] = fast::minmod_between(Dl[q], (Dl[q] + Dr[q]) * lim.central, Dr[q]);
         return G;
     }
     using Gamma = fast::GammaLawFast;
     static __device__ inline Gamma gamma_law(double gamma) { return fast::make_gamma_law(gamma); }
     static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return fast::recover_primitive(U, g, 0.0); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double theta) { return fast::plm_gradient(l, c, r, theta); }
-    static __device__ inline State5 plus(const State5& P, const State5& G)
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim)
+    {
+        return plm_from_differences(difference(l, c), difference(c, r), lim);
+    }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim)
     {
         State5 S;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], 0.5, P[q]);
+        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], lim.half_theta, P[q]);
         return S;
     }
-    static __device__ inline State5 minus(const State5& P, const State5& G)
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim)
     {
         State5 S;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], -0.5, P[q]);
+        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], -lim.half_theta, P[q]);
         return S;
     }
     template<int RIEMANN, int AXIS>
