@@ -35,10 +35,10 @@ hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const d
 
 // graded trees (binary_tree.hip)
 struct TreeGeom { const int32_t* topo; const int32_t* level; const double* edges; int nb, bs; };
-struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals; };
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals, *tile_maxw; };
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                                    double theta, double* totals, int32_t* status, hipStream_t stream);
+                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result);
 hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g, const double* u, const double bodies[10], double* result, hipStream_t stream);
 
 // diagnostics (binary_diag.hip)
@@ -98,7 +98,7 @@ struct mh_binary
     // graded tree (mh_binary_tree_create): block-major fields [nb][3][bs][bs], neighbour table, per-stage work arrays
     bool tree = false;
     TreeGeom geom = {nullptr, nullptr, nullptr, 0, 0};
-    TreeBuffers work = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    TreeBuffers work = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t* topo_dev = nullptr;
     int32_t* level_dev = nullptr;
     double* edges_dev = nullptr;
@@ -125,8 +125,9 @@ static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_bod
     return mh_two_body_state(&E, t, B);
 }
 
+// Bnext (graded trees only): the stage also leaves the time-step bound of the state it writes, evaluated with these bodies, in maxw_dev
 static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, double* u_out, const mh_two_body_t& B, double dt,
-                        double weight, double theta, int slot)
+                        double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->profile)
@@ -137,7 +138,7 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     }
     if (b->tree)
         MH_HIP_TRY(binary_tree_stage_launch(&b->desc, b->geom, b->work, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
-                                            totals_dev(b, slot), b->status, b->stream));
+                                            totals_dev(b, slot), b->status, b->stream, Bnext ? Bnext->body1 : nullptr, maxw_dev(b)));
     else
     {
         const BinaryBand band = band_of(b);
@@ -256,10 +257,10 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
     if (int rc = binary_bodies(S0.orbital_elements, S0.time, &B1)) return rc;
     for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipMemsetAsync(t.m[r]->status, 0, 2 * sizeof(int32_t), t.m[r]->stream));
 
-    auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot) -> int
+    auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot, const mh_two_body_t* Bnext = nullptr) -> int
     {
         for (int r = 0; r < t.n; ++r)
-            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot)) return rc;
+            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot, Bnext)) return rc;
         return team_exchange(t, outk);
     };
 
@@ -287,21 +288,19 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
     {
         if (int rc = binary_bodies(S0.orbital_elements, S0.time + dt, &B2)) return rc;   // elements + (...) * 0 = elements
     }
-    if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1)) return rc;
-
-    // look ahead: the next step's maximum wavespeed, evaluated on the step result while the totals travel
+    // look ahead: the next step's maximum wavespeed, evaluated on the step result while the totals travel - on a graded tree by
+    // the second stage's own last workgroup, on the uniform mesh by a launch behind it
     mh_binary_state ahead = S0;
     bool launched_ahead = false;
+    mh_two_body_t Bn;
     if (prefetch_maxw && ! live && ! b->run.fixed_dt)
     {
         ahead.time = S0.time * 0.5 + ((S0.time + dt) + dt) * 0.5;
-        mh_two_body_t Bn;
-        if (binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK)
-        {
-            if (int rc = team_maxw(t, 2, Bn)) return rc;
-            launched_ahead = true;
-        }
+        launched_ahead = binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK;
     }
+    if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1, launched_ahead && b->tree ? &Bn : nullptr)) return rc;
+    if (launched_ahead && ! b->tree)
+        if (int rc = team_maxw(t, 2, Bn)) return rc;
     if (int rc = team_fetch(t)) return rc;
     if (b->mirror->status[0]) { *failed = true; return MH_OK; }
     if (! live && binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
@@ -568,6 +567,7 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     B_TRY(hipMalloc(&b->work.fy, (size_t) nb * 3 * (bs + 1) * bs * sizeof(double)));
     B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * ((bs * bs + 255) / 256) * 16 * sizeof(double)));      // [nb][tiles of 256 cells][16 partial sums]
     B_TRY(hipMalloc(&b->work.block_vals, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
+    B_TRY(hipMalloc(&b->work.tile_maxw, (size_t) nb * ((bs * bs + 255) / 256) * sizeof(double)));
     B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
     b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
@@ -596,7 +596,7 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
     (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->staging);      // status lives inside dev_small
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
-    (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals);
+    (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals); (void) hipFree(b->work.tile_maxw);
     if (b->mirror) (void) hipHostFree(b->mirror);
     (void) hipFree(b->reduced_dev);
     if (b->comm && rccl()) rccl()->CommDestroy(b->comm);

@@ -1,9 +1,9 @@
 // `binary` on a GRADED block tree for gfx950 (the sub-program's default mesh).
 //
 // Leaf blocks of bs x bs cells at different levels. One evaluation of binary::advance_u (src/subprog_binary_scheme.cpp:790-904)
-// runs as four kernels over the blocks, each stage of the reference's tree pipeline being one of them:
-//   tree_c2p_kernel      p0      = recover_primitive(u)                                            :802
-//   tree_grad_kernel     gx, gy  = plm_gradient(p0 extended by one guard zone) / spacing(level)     :794-811
+// runs as three kernels over the blocks and a one-workgroup reduction:
+//   tree_prim_grad_kernel  p0    = recover_primitive(u)                                            :802
+//                        gx, gy  = plm_gradient(p0 extended by one guard zone) / spacing(level)     :794-811
 //   tree_flux_kernel     fhat_x, fhat_y on every face of every block, guard values of p0, gx, gy     :472-516
 //   tree_update_kernel   flux correction at refinement jumps (:614-700), sources, update, totals     :568-587, :345-411
 // Guard zones follow mara::get_cell_block (mesh_tree_operators.hpp:223-258): a neighbour of the same level is copied, a coarser
@@ -44,11 +44,13 @@ __device__ inline State3 load3(const double* F, int bs, int b, int i, int j)
     return s;
 }
 
-// value of a cell-centred field at (i, j) of block b, where ONE of i, j may be -1 or bs: the guard zone of get_cell_block
-__device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i, int j)
+// value of a cell-centred quantity at (i, j) of block b, where ONE of i, j may be -1 or bs: the guard zone of get_cell_block.
+// leaf(block, i, j) gives the quantity at an interior cell of a block (a load, or a recomputation)
+template<class Leaf>
+__device__ inline State3 fetch_with(const TreeGeom& g, int b, int i, int j, Leaf leaf)
 {
     const int bs = g.bs;
-    if (i >= 0 && i < bs && j >= 0 && j < bs) return load3(F, bs, b, i, j);
+    if (i >= 0 && i < bs && j >= 0 && j < bs) return leaf(b, i, j);
     const int side = i < 0 ? 0 : (i >= bs ? 1 : (j < 0 ? 2 : 3));
     const int axis = side >> 1;                    // 0: the neighbour lies along x
     const bool upper = side & 1;
@@ -58,14 +60,14 @@ __device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i,
     if (kind == NB_SAME)
     {
         const int n = upper ? 0 : bs - 1;
-        return axis == 0 ? load3(F, bs, t[1], n, a) : load3(F, bs, t[1], a, n);
+        return axis == 0 ? leaf(t[1], n, a) : leaf(t[1], a, n);
     }
     if (kind == NB_COARSER)
     {
         // refine_cells: the fine guard cell takes the value of the coarse cell it lies in
         const int n = upper ? 0 : bs - 1;
         const int tc = t[2] * (bs / 2) + a / 2;
-        return axis == 0 ? load3(F, bs, t[1], n, tc) : load3(F, bs, t[1], tc, n);
+        return axis == 0 ? leaf(t[1], n, tc) : leaf(t[1], tc, n);
     }
     // finer: coarsen_cells of the 2 x 2 fine cells under the guard cell: average along x, then along y
     const int fa = 2 * a;                          // first of the two fine tangential indices in the combined (2 bs) edge
@@ -75,54 +77,58 @@ __device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i,
     State3 r;
     if (axis == 0)
     {
-        const State3 c00 = load3(F, bs, fb, n0, ta), c10 = load3(F, bs, fb, n0 + 1, ta), c01 = load3(F, bs, fb, n0, ta + 1), c11 = load3(F, bs, fb, n0 + 1, ta + 1);
+        const State3 c00 = leaf(fb, n0, ta), c10 = leaf(fb, n0 + 1, ta), c01 = leaf(fb, n0, ta + 1), c11 = leaf(fb, n0 + 1, ta + 1);
 #pragma unroll
         for (int q = 0; q < 3; ++q) r[q] = ((c00[q] + c10[q]) / 2 + (c01[q] + c11[q]) / 2) / 2;
     }
     else
     {
-        const State3 c00 = load3(F, bs, fb, ta, n0), c10 = load3(F, bs, fb, ta + 1, n0), c01 = load3(F, bs, fb, ta, n0 + 1), c11 = load3(F, bs, fb, ta + 1, n0 + 1);
+        const State3 c00 = leaf(fb, ta, n0), c10 = leaf(fb, ta + 1, n0), c01 = leaf(fb, ta, n0 + 1), c11 = leaf(fb, ta + 1, n0 + 1);
 #pragma unroll
         for (int q = 0; q < 3; ++q) r[q] = ((c00[q] + c10[q]) / 2 + (c01[q] + c11[q]) / 2) / 2;
     }
     return r;
 }
 
-__device__ inline double spacing_of(const BinaryConsts& c, int level) { return c.h0 / (1 << level); }     // spacing_at_root / 2^level :793-799
-
-template<class A, bool QFORM>
-__global__ __launch_bounds__(256)
-void tree_c2p_kernel(const double* u, double* prim, const double* edges, int nb, int bs)
+__device__ inline State3 fetch(const double* F, const TreeGeom& g, int b, int i, int j)
 {
-    const long total = (long) nb * bs * bs;
-    for (long idx = (long) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
-    {
-        const int b = (int) (idx / (bs * bs)), c = (int) (idx - (long) b * bs * bs);
-        const int i = c / bs, j = c - i * bs;
-        const double* xv = edges + (long) b * 2 * (bs + 1);
-        const double* yv = xv + bs + 1;
-        const State3 P = A::template c2p<QFORM>(load3(u, bs, b, i, j), (xv[i] + xv[i + 1]) * 0.5, (yv[j] + yv[j + 1]) * 0.5);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) prim[cell_index(bs, b, q, i, j)] = P[q];
-    }
+    const int bs = g.bs;
+    return fetch_with(g, b, i, j, [F, bs] (int bb, int ii, int jj) { return load3(F, bs, bb, ii, jj); });
 }
 
-template<class A>
+__device__ inline double spacing_of(const BinaryConsts& c, int level) { return c.h0 / (1 << level); }     // spacing_at_root / 2^level :793-799
+
+// Primitives and slopes in one launch: a cell's primitives are stored (the flux and update kernels read them), those of its four
+// neighbours are recovered again from the conserved field - same function, same inputs, same bits as the stored ones - so that the
+// slopes need no earlier pass over the tree.
+template<class A, bool QFORM>
 __global__ __launch_bounds__(256)
-void tree_grad_kernel(const double* prim, double* gx, double* gy, TreeGeom g, BinaryConsts c, double theta)
+void tree_prim_grad_kernel(const double* u, double* prim, double* gx, double* gy, TreeGeom g, BinaryConsts c, double theta)
 {
     const int b = blockIdx.x, bs = g.bs;
     BinaryConsts cb = c;
     cb.h = spacing_of(c, g.level[b]);
     const typename A::Ctx k = A::make(cb);
-    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < bs * bs; idx += 256 * gridDim.y)      // grid = (blocks, tiles of 256 cells)
+    const double* edges = g.edges;
+    auto prim_of = [u, edges, bs] (int bb, int ii, int jj)
+    {
+        const double* xv = edges + (long) bb * 2 * (bs + 1);
+        const double* yv = xv + bs + 1;
+        return A::template c2p<QFORM>(load3(u, bs, bb, ii, jj), (xv[ii] + xv[ii + 1]) * 0.5, (yv[jj] + yv[jj + 1]) * 0.5);
+    };
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < bs * bs; idx += 256 * gridDim.y)
     {
         const int i = idx / bs, j = idx - i * bs;
-        const State3 P0 = load3(prim, bs, b, i, j);
-        const State3 Gx = A::plm_per_length(fetch(prim, g, b, i - 1, j), P0, fetch(prim, g, b, i + 1, j), theta, k);
-        const State3 Gy = A::plm_per_length(fetch(prim, g, b, i, j - 1), P0, fetch(prim, g, b, i, j + 1), theta, k);
+        const State3 P0 = prim_of(b, i, j);
+        const State3 Gx = A::plm_per_length(fetch_with(g, b, i - 1, j, prim_of), P0, fetch_with(g, b, i + 1, j, prim_of), theta, k);
+        const State3 Gy = A::plm_per_length(fetch_with(g, b, i, j - 1, prim_of), P0, fetch_with(g, b, i, j + 1, prim_of), theta, k);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { gx[cell_index(bs, b, q, i, j)] = Gx[q]; gy[cell_index(bs, b, q, i, j)] = Gy[q]; }
+        for (int q = 0; q < 3; ++q)
+        {
+            prim[cell_index(bs, b, q, i, j)] = P0[q];
+            gx[cell_index(bs, b, q, i, j)] = Gx[q];
+            gy[cell_index(bs, b, q, i, j)] = Gy[q];
+        }
     }
 }
 
@@ -202,12 +208,14 @@ __device__ inline double corrected_fy(const double* fy, const TreeGeom& g, int b
 
 static constexpr int NTREE_SUMS = 16;      // per block: mass_acc[2], L_acc[2], torque[2], px_acc[2], py_acc[2], fx[2], fy[2], mass_ej, L_ej
 
-template<class A, bool COMBINE, bool QFORM>
+template<class A, bool COMBINE, bool QFORM, bool MAXW>
 __global__ __launch_bounds__(256)
 void tree_update_kernel(const double* u_in, const double* u_base, double* u_out, const double* u_init, const double* br, const double* prim,
-                        const double* fx, const double* fy, TreeGeom g, BinaryConsts c, double dt, double weight, double* block_out, int32_t* status)
+                        const double* fx, const double* fy, TreeGeom g, BinaryConsts c, BinaryConsts c_next, double dt, double weight, double* block_out,
+                        double* tile_maxw, int32_t* status)
 {
     const int b = blockIdx.x, bs = g.bs;
+    double wmax = 0.0;        // MAXW: as tree_maxw_kernel, on the state this launch writes, with the bodies of the next step's start
     const double* xv = g.edges + (long) b * 2 * (bs + 1);
     const double* yv = xv + bs + 1;
     double acc[NTREE_SUMS];
@@ -281,6 +289,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
         acc[15] = acc[15] + (QFORM ? s_buffer[2] : (xc * s_buffer[2] - yc * s_buffer[1])) * dA;
 
         double l[3];
+        State3 unew;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             l[q] = ((corrected_fx(fx, g, b, q, i + 1, j) - corrected_fx(fx, g, b, q, i, j)) + (corrected_fy(fy, g, b, q, i, j + 1) - corrected_fy(fy, g, b, q, i, j))) * dt;
@@ -294,22 +303,37 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
             double un = u1;
             if constexpr (COMBINE) un = u_base[cell_index(bs, b, q, i, j)] * (1.0 - weight) + u1 * weight;
             u_out[cell_index(bs, b, q, i, j)] = un;
+            unew[q] = un;
+        }
+        if constexpr (MAXW)
+        {
+            State3 Pn;
+            if constexpr (QFORM) iso2d::recover_primitive_angmom(unew, xc, yc, Pn);
+            else                 iso2d::recover_primitive(unew, Pn);
+            const double w = iso2d::max_wavespeed(Pn, binary_cs2(c_next, make_recip(c_next.mach, 1.0), xc, yc));
+            wmax = (wmax < w) ? w : wmax;
         }
     }
     __shared__ double red[NTREE_SUMS][256];
 #pragma unroll
     for (int k = 0; k < NTREE_SUMS; ++k) red[k][threadIdx.x] = acc[k];
+    __shared__ double wred[256];
+    if constexpr (MAXW) wred[threadIdx.x] = wmax;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1)
     {
         if ((int) threadIdx.x < off)
+        {
             for (int k = 0; k < NTREE_SUMS; ++k) red[k][threadIdx.x] = red[k][threadIdx.x] + red[k][threadIdx.x + off];
+            if constexpr (MAXW) wred[threadIdx.x] = wred[threadIdx.x] < wred[threadIdx.x + off] ? wred[threadIdx.x + off] : wred[threadIdx.x];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0)
     {
         double* out = block_out + ((long) b * gridDim.y + blockIdx.y) * NTREE_SUMS;       // raw partial sums of this tile; signs and work: tree_totals_kernel
         for (int k = 0; k < NTREE_SUMS; ++k) out[k] = red[k][0];
+        if constexpr (MAXW) tile_maxw[(long) b * gridDim.y + blockIdx.y] = wred[0];        // largest wavespeed of the tile's new state
     }
     sacc.commit(status);
 }
@@ -321,7 +345,8 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
 // entry adds them in block order, the loads of eight blocks issued together - a plain loop is a chain of dependent load latencies
 // (13 us for 64 blocks, 100 us with the tile sums inside it).
 __global__ __launch_bounds__(1024)
-void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c, int qform, double* block_vals, double* totals)
+void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c, int qform, double* block_vals, double* totals,
+                        const double* tile_maxw, const int32_t* level, double* maxw_result)
 {
     auto block_sum = [&] (int b, int k)
     {
@@ -345,8 +370,32 @@ void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c
         }
         block_vals[idx] = val;
     }
+    // after a step's final stage: the next step's time-step bound, min over blocks of spacing / max over the block's tiles
+    // (maximum_timestep :1107-1126; max and min are order-independent, so this equals tree_maxw_kernel's result on the same state)
+    __shared__ double dred[1024];
+    if (tile_maxw)
+    {
+        double dtmin = __longlong_as_double(0x7ff0000000000000LL);
+        for (int b = threadIdx.x; b < nb; b += blockDim.x)
+        {
+            double m = 0.0;
+            for (int tile = 0; tile < tiles; ++tile) { const double w = tile_maxw[(long) b * tiles + tile]; m = (m < w) ? w : m; }
+            const double dtb = spacing_of(c, level[b]) / m;
+            dtmin = dtb < dtmin ? dtb : dtmin;
+        }
+        dred[threadIdx.x] = dtmin;
+    }
     __threadfence_block();
     __syncthreads();
+    if (tile_maxw)
+    {
+        for (int off = 512; off > 0; off >>= 1)
+        {
+            if ((int) threadIdx.x < off) dred[threadIdx.x] = dred[threadIdx.x + off] < dred[threadIdx.x] ? dred[threadIdx.x + off] : dred[threadIdx.x];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *maxw_result = dred[0];
+    }
     const int t = threadIdx.x;
     if (t >= MH_BINARY_NTOTALS) return;
     double s = 0.0;
@@ -402,31 +451,36 @@ __global__ void tree_set_inf_kernel(double* x) { *x = __longlong_as_double(0x7ff
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
 BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]);
 
-struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals; };
+struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals, *tile_maxw; };
 
+// bodies_next != nullptr: the stage also leaves min over blocks of spacing / largest wavespeed of the state it writes, evaluated with
+// those bodies, in *maxw_result (what binary_tree_min_dt_launch computes in two launches of its own)
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                                    double theta, double* totals, int32_t* status, hipStream_t stream)
+                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result)
 {
     BinaryConsts c = binary_make_consts(d, bodies);
-    const dim3 blk(256), grid(g.nb);
-    const long cells = (long) g.nb * g.bs * g.bs;
-    const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0, q = d->angmom_form != 0;
-    const dim3 cgrid((unsigned) ((cells + 255) / 256));
+    BinaryConsts cn = bodies_next ? binary_make_consts(d, bodies_next) : c;
+    const dim3 blk(256);
+    const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0, q = d->angmom_form != 0, maxw = bodies_next != nullptr;
     auto run = [&] (auto policy, auto qform)
     {
         using A = decltype(policy);
         constexpr bool Q = decltype(qform)::value;
-        hipLaunchKernelGGL((tree_c2p_kernel<A, Q>), cgrid, blk, 0, stream, u_in, w.prim, g.edges, g.nb, g.bs);
         const unsigned cell_tiles = (unsigned) ((g.bs * g.bs + 255) / 256), face_tiles = (unsigned) (((g.bs + 1) * g.bs + 255) / 256);
-        hipLaunchKernelGGL((tree_grad_kernel<A>), dim3(g.nb, cell_tiles), blk, 0, stream, w.prim, w.gx, w.gy, g, c, theta);
+        hipLaunchKernelGGL((tree_prim_grad_kernel<A, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, w.prim, w.gx, w.gy, g, c, theta);
         hipLaunchKernelGGL((tree_flux_kernel<A, Q>), dim3(g.nb, 2 * face_tiles), blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
-        if (combine) hipLaunchKernelGGL((tree_update_kernel<A, true, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
-        else         hipLaunchKernelGGL((tree_update_kernel<A, false, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, u_base, u_out, u_init, br, w.prim, w.fx, w.fy, g, c, dt, weight, w.block_out, status);
+        const dim3 ugrid(g.nb, cell_tiles);
+#define MH_TREE_UPDATE(COMBINE, MAXW) hipLaunchKernelGGL((tree_update_kernel<A, COMBINE, Q, MAXW>), ugrid, blk, 0, stream, u_in, u_base, u_out, u_init, br, \
+                                                         w.prim, w.fx, w.fy, g, c, cn, dt, weight, w.block_out, w.tile_maxw, status)
+        if (combine) { if (maxw) MH_TREE_UPDATE(true, true); else MH_TREE_UPDATE(true, false); }
+        else         { if (maxw) MH_TREE_UPDATE(false, true); else MH_TREE_UPDATE(false, false); }
+#undef MH_TREE_UPDATE
     };
     if (fast) { if (q) run(BinFast(), std::true_type()); else run(BinFast(), std::false_type()); }
     else      { if (q) run(BinStrict(), std::true_type()); else run(BinStrict(), std::false_type()); }
-    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(1024), 0, stream, w.block_out, g.nb, (g.bs * g.bs + 255) / 256, c, (int) q, w.block_vals, totals);
+    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(1024), 0, stream, w.block_out, g.nb, (g.bs * g.bs + 255) / 256, c, (int) q, w.block_vals, totals,
+                       maxw ? w.tile_maxw : nullptr, g.level, maxw_result);
     return hipGetLastError();
 }
 
