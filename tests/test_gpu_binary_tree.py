@@ -72,6 +72,28 @@ def test_next_solution_on_a_graded_tree(binary, name):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["binary_tree_d3_b8", "binary_tree_d4_b8_default_focus", "binary_tree_d3_b8_q"])
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_time_step_bound_folded_into_the_final_stage_equals_the_stand_alone_one(binary, name, arith):
+    """Within one call of several steps the next step's bound (min over blocks of spacing / largest wavespeed) comes out of the final
+    stage's own kernels, evaluated with the next step's bodies; step by step it comes from the two stand-alone kernels. max and min are
+    order-independent, so time steps and solutions must agree bit for bit."""
+    g = golden(name)
+    cfg, _ = cfg_of(binary, g)
+    a, b = make(binary, cfg, g, arith=arith), make(binary, cfg, g, arith=arith)
+    n = 7
+    assert a.next(n) == 0
+    dts = []
+    for _ in range(n):
+        assert b.next(1) == 0
+        dts.append(b.last_dt)
+    assert a.last_dt == dts[-1] and len(set(dts)) > 1                 # the bound moves from step to step, and the last one agrees
+    assert a.state().time == b.state().time and a.state().iteration == b.state().iteration == n
+    assert np.array_equal(a.solution(), b.solution())
+    a.close()
+    b.close()
+
+
 def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
     """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
     policy arithmetic, so the two must agree to the last bit."""
