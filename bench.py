@@ -140,6 +140,18 @@ def cpu_reference(gamma, theta):
             "sample": "%d RK2 steps at %dx%d PLM+HLLE, reference headers composed as in oracle/ref_drivers/euler_cart_ref.cpp" % (steps, n, n)}
 
 
+def compact(obj, drop=("timing", "traffic_note", "preconditioning", "peak", "unit", "bound", "kernel", "launches", "algorithmic_bytes_per_launch")):
+    """The legs and the embedded config lines repeat what the headline objects state once (units, peaks, how the events were taken): drop those
+    keys there and keep six significant digits, so that the ONE JSON line stays a few kilobytes."""
+    if isinstance(obj, dict):
+        return {k: compact(v, drop) for k, v in obj.items() if k not in drop and not (k == "note" and isinstance(v, str) and ("recorded counters" in v or v.startswith("per GPU, 200 B")))}
+    if isinstance(obj, list):
+        return [compact(v, drop) for v in obj]
+    if isinstance(obj, float):
+        return float("%.6g" % obj)
+    return obj
+
+
 def extra_configs():
     """BASELINE configs 3, 4, 5 on this GPU, each as a child process of bench_configs.py (its JSON line is embedded as is). Step counts per
     config: a child starts on a GPU that idled through its set-up, so the warm-up steps cover the clock ramp that the headline leg's scratch-grid
@@ -473,13 +485,15 @@ def main():
         if partition_ok is not None:
             out["slabs_bit_identical_to_one_gpu_run"] = bool(partition_ok)
         if legs:
-            out["legs"] = legs
+            out["legs"] = compact(legs)
+            out["legs_note"] = ("each leg: the same measurement as the headline's (graph replay, scratch-grid preconditioning, HIP events riding on 5 further steps; "
+                                "roofline = second RK2 stage, roofline_stage1 = first, both against 8000 GB/s and, as fp64, 78.6 TFLOP/s with the recorded counters)")
         if l1 is not None:
             out["l1_fast_vs_strict_after_%d_steps" % nsteps_primary] = l1
         if world == 1 and not args.loopback_slabs:
             torch.cuda.empty_cache()
             if not args.single_arith and not args.no_extra_configs and n == 4096:
-                out["extra_configs"] = extra_configs()
+                out["extra_configs"] = compact(extra_configs(), drop=("timing", "traffic_note", "higher_is_better", "vs_baseline", "dtype", "data", "n_gpus", "scaling"))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(n, gamma, args.theta, args.riemann)
                 ref = cpu_reference(gamma, args.theta)
