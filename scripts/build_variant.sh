@@ -10,7 +10,8 @@ cd $ROOT/mara3_amd/csrc
 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -Wno-unused-value $extra"
 objs=""
 for f in *.hip; do
-  /opt/rocm/bin/hipcc $HIPFLAGS -c $f -o $out/obj/${f%.hip}.o &
+  per_file=""; [ $f = euler3d_fast.hip ] && per_file="-mllvm -amdgpu-sched-strategy=max-ilp"      # as the Makefile
+  /opt/rocm/bin/hipcc $HIPFLAGS $per_file -c $f -o $out/obj/${f%.hip}.o &
   objs="$objs $out/obj/${f%.hip}.o"
 done
 for f in twobody binary_host; do
