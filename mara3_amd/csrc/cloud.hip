@@ -159,7 +159,8 @@ void cloud_stage_kernel(CloudParams p)
 
     const srhd::Gamma g = srhd::make_gamma(p.gamma);
     const Recip three = make_recip(3.0, 1.0);
-    const double theta = p.theta, tfloor = p.tfloor;
+    const double tfloor = p.tfloor;
+    const typename S::Limiter lim = S::limiter(p.theta);
     const ColGeom cg = {p.dmu[jc], p.sinq[jc], p.sinq[jc + 1], p.cotq[jc]};
     // MH_ARITH_FAST: per-column factors of the host's table (dmu 2 pi, dmu 2 pi / 3, its inverse, sin q_j 2 pi, sin q_{j+1} 2 pi)
     double col_ar = 0.0, col_dv = 0.0, col_inv_dv = 0.0, col_aq_lo = 0.0, col_aq_hi = 0.0;
@@ -167,6 +168,15 @@ void cloud_stage_kernel(CloudParams p)
     {
         const double* cf = p.colf + 8L * jc;
         col_ar = cf[0]; col_dv = cf[1]; col_inv_dv = cf[2]; col_aq_lo = cf[3]; col_aq_hi = cf[4];
+    }
+    // MH_ARITH_FAST at the poles (extend_zeros on the polar slopes and fluxes, :563 / :570): the pole lanes' own constants are zero - the face
+    // area of the pole face and the slope's weight in the face states - instead of selects on five slopes and ten fluxes per row
+    typename S::Limiter lim_polar = lim;
+    if constexpr (! S::exact_zero_products)
+    {
+        if (pole_lo) col_aq_lo = 0.0;
+        if (pole_hi) col_aq_hi = 0.0;
+        if (pole_lo || pole_hi) lim_polar.half_theta = 0.0;
     }
     // geometry of the cells of global row i: the reference's products in its order (strict), or per-row x per-column factors (fast)
     auto cell_geometry = [&] (int i) -> CellGeom
@@ -210,6 +220,25 @@ void cloud_stage_kernel(CloudParams p)
     {
         const int rr = min(max(r, -CHALO), p.n0 + CHALO - 1);
         return cloud_load_row(in + row_off(rr), plane, jc8);
+    };
+    // MH_ARITH_FAST: the conserved values of rows r, r+1, r+2 wait for their update in a per-wave LDS ring (no barrier: private to the
+    // wave) instead of being read a second time - that second read misses in L2 and made the launch's HBM traffic 1.6 x / 1.4 x algorithmic
+    __shared__ double own_rows[S::lds_row_ring ? CWAVES_PER_BLOCK : 1][3][5][CWAVE];
+    const int wave_in_block = (int) (threadIdx.x >> 6);
+    auto ring_put = [&] (int slot, const State5& raw)
+    {
+        if constexpr (S::lds_row_ring)
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) own_rows[wave_in_block][slot][q][lane] = raw[q];
+        }
+    };
+    auto ring_get = [&] (int slot) -> State5
+    {
+        State5 U;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) U[q] = own_rows[S::lds_row_ring ? wave_in_block : 0][slot][q][lane];
+        return U;
     };
     // primitive of a stored row (real row, or a ghost row received from the neighbouring slab) from its loaded variables
     auto prim_of_raw = [&] (int r, const State5& raw) -> State5
@@ -262,15 +291,18 @@ void cloud_stage_kernel(CloudParams p)
     {
         State5 dummy = {};
         const State5 Pb = prim_bc(r0 - 1, dummy);
-        P0 = prim_of_row(r0);
-        P1 = prim_bc(r0 + 1, P0);
+        const State5 raw0 = load_raw(r0), raw1 = load_raw(r0 + 1);
+        ring_put(0, raw0);
+        ring_put(1, raw1);
+        P0 = prim_of_raw(r0, raw0);
+        P1 = prim_bc_raw(r0 + 1, P0, raw1);
         if constexpr (PLM)
         {
-            G0 = S::plm(Pb, P0, P1, theta);
+            G0 = S::plm(Pb, P0, P1, lim);
             State5 Gb;
             if (r0 == 0 && phys_lo) Gb = times_zero(G0);                       // extend_zeros on G
-            else                    Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, theta);
-            Fx_lo = S::template hlle<0>(face_plus(Pb, Gb), face_minus(P0, G0), g);
+            else                    Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, lim);
+            Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
         }
         else
         {
@@ -281,19 +313,21 @@ void cloud_stage_kernel(CloudParams p)
     // software pipeline: row r+2 (needed now, for the primitives of the face after next) was requested one iteration ago;
     // row r+3 is requested at the top of the iteration
     State5 Uahead = load_raw(r0 + 2);
+    int slot = 0;                                       // ring slot of row r; row r + 2 goes to slot + 2 (mod 3)
     for (int r = r0; r < r1; ++r)
     {
         const State5 Unext = load_raw(r + 3);
 
         // ---- radial face r+1/2
         const State5 P2 = prim_bc_raw(r + 2, P1, Uahead);
+        ring_put(slot == 0 ? 2 : slot - 1, Uahead);
         Uahead = Unext;
         State5 G1, Fx_hi;
         if constexpr (PLM)
         {
             if (r + 1 == p.n0 && phys_hi) G1 = times_zero(G0);
-            else                          G1 = S::plm(P0, P1, P2, theta);
-            Fx_hi = S::template hlle<0>(face_plus(P0, G0), face_minus(P1, G1), g);
+            else                          G1 = S::plm(P0, P1, P2, lim);
+            Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
         }
         else
         {
@@ -304,7 +338,7 @@ void cloud_stage_kernel(CloudParams p)
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM)
         {
-            const State5 Graw = S::plm(dpp_left(P0), P0, dpp_right(P0), theta);
+            const State5 Graw = S::plm(dpp_left(P0), P0, dpp_right(P0), lim);
             State5 Gy;
             if constexpr (S::exact_zero_products)
             {
@@ -315,11 +349,10 @@ void cloud_stage_kernel(CloudParams p)
             }
             else
             {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) Gy[q] = (pole_lo || pole_hi) ? 0.0 : Graw[q];          // the value of that product
+                Gy = Graw;          // (a pole lane's lim_polar gives it no weight)
             }
-            const State5 SL = dpp_left(face_plus(P0, Gy));
-            Fy_lo = S::template hlle<1>(SL, face_minus(P0, Gy), g);
+            const State5 SL = dpp_left(S::plus(P0, Gy, lim_polar));
+            Fy_lo = S::template hlle<1>(SL, S::minus(P0, Gy, lim_polar), g);
         }
         else
         {
@@ -331,18 +364,28 @@ void cloud_stage_kernel(CloudParams p)
             if (pole_lo) Fy_lo = times_zero(Fy_hi);
             if (pole_hi) Fy_hi = times_zero(Fy_lo);
         }
-        else
-        {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { Fy_lo[q] = pole_lo ? 0.0 : Fy_lo[q]; Fy_hi[q] = pole_hi ? 0.0 : Fy_hi[q]; }
-        }
+        // (MH_ARITH_FAST: the pole faces' area factors are zero, see lim_polar above)
 
         // ---- geometry, source terms, update
+        // the row's own conserved values once more (no register ring: three waves per SIMD). FAST: requested as ONE group ahead of the
+        // geometry and source arithmetic - left to itself the scheduler, at the 168-register limit, may split the group into load - wait - use
+        // triples (measured: +12 % on the launch); any earlier - ahead of the polar Riemann problem - and 19 registers spill. STRICT (176-186
+        // registers, two waves per SIMD either way): the compiler's own placement is 3 % faster than this one.
+        State5 U0, Ubase;
+        auto load_own_row = [&] () __attribute__((always_inline))
+        {
+            if constexpr (S::lds_row_ring) U0 = ring_get(slot);
+            else                           U0 = cloud_load_row(in + row_off(r), plane, jc8);
+            if constexpr (COMBINE) Ubase = cloud_load_row(p.u_base + row_off(r), plane, jc8);
+        };
+        if constexpr (S::group_own_row_loads)
+        {
+            load_own_row();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const CellGeom c = cell_geometry(p.row_offset + r);
         const State5 Src = S::source(P0, c.rc, c.inv_rc, cg.cot, g);
-        const State5 U0 = cloud_load_row(in + row_off(r), plane, jc8);       // the row's own conserved values once more (no register ring: three waves per SIMD)
-        State5 Ubase;
-        if constexpr (COMBINE) Ubase = cloud_load_row(p.u_base + row_off(r), plane, jc8);
+        if constexpr (! S::group_own_row_loads) load_own_row();
 
         State5 Un;
 #pragma unroll
@@ -357,6 +400,7 @@ void cloud_stage_kernel(CloudParams p)
         P0 = P1; P1 = P2;
         if constexpr (PLM) G0 = G1;
         Fx_lo = Fx_hi;
+        slot = slot == 2 ? 0 : slot + 1;
     }
 
     acc.commit(p.status);

@@ -35,16 +35,18 @@ __device__ inline int recover_primitive(const State5& U, const Gamma& g, double 
         const double x = tau + D + p;
         const double rx = fast::rcp_nr(x);
         const double v2 = __builtin_fmin(SS * rx * rx, 1.0 - 1e-10);
-        const double W2 = fast::rcp_nr(1.0 - v2);
-        double W, rW;
-        fast::sqrt_rsqrt(W2, W, rW);
+        // W = 1 / sqrt(1 - v2) straight from the inverse root (the reference forms W2 = 1 / (1 - v2) and takes its root), 1 / W = (1 - v2) W
+        const double omv = 1.0 - v2;
+        const double W = fast::rsqrt_fast(omv);
+        const double rW = omv * W;
+        const double W2 = W * W;
         const double e = __builtin_fma(p, 1.0 - W2, __builtin_fma(D, 1.0 - W, tau)) * rD * rW;
         const double d = D * rW;
         const double h = 1.0 + e + p * W * rD;
-        const double cs2 = gm * p * fast::rcp_nr(d * h);
+        // f / g with g = v2 cs2 - 1, cs2 = gamma p / (d h):  f d h / (v2 gamma p - d h) - one reciprocal for the sound speed and the Newton step
         const double f = __builtin_fma(d * e, gm - 1.0, -p);
-        const double gg = __builtin_fma(v2, cs2, -1.0);
-        p = __builtin_fma(-f, fast::rcp_nr(gg), p);
+        const double dh = d * h;
+        p = __builtin_fma(-(f * dh), fast::rcp_nr(__builtin_fma(v2, gm * p, -dh)), p);
         if (fabs(f) < 1e-10)
         {
             W0 = W;
@@ -98,7 +100,9 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     F[4] = v * (U[4] + p);
     const double c2 = g.gamma * p * rH;
     const double v2 = v * v;
-    const double k0 = fast::sqrt_fast(c2 * (1 - vv) * (1 - vv * c2 - v2 * (1 - c2)));
+    // sqrt(x) = x rsqrt(x) without the correction step (an ulp or two: it only enters the signal speeds); x == 0 gives 0 * inf, which fmax turns into 0
+    const double k2 = c2 * (1 - vv) * (1 - vv * c2 - v2 * (1 - c2));
+    const double k0 = __builtin_fmax(k2 * fast::rsqrt_fast(k2), 0.0);
     const double rden = H * H * rHB;
     const double a = v * (1 - c2);
     lam_m = (a - k0) * rden;
@@ -145,10 +149,16 @@ struct SrhdStrict
     static constexpr int min_waves_per_simd = 2;      // 163-167 VGPRs: three waves fit anyway
     static constexpr bool table_geometry = false;     // geometry factors formed per cell in the reference's order
     static constexpr bool exact_zero_products = true; // pole slopes / fluxes as (neighbour's value) * 0, like extend_zeros: NaN and -0 propagate
+    static constexpr bool group_own_row_loads = false;// (cloud.hip: where the update's loads of the row's conserved values are requested)
+    static constexpr bool lds_row_ring = false;       // the row's conserved values are read again at the update
     static __device__ inline void to_density(double (&x)[5], double dv, double) { divide_group<5>(x, make_recip(dv, 1.0)); }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
     static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return plm_gradient(l, c, r, th); }
+    using Limiter = StrictArith::Limiter;
+    static __device__ inline Limiter limiter(double theta) { return StrictArith::limiter(theta); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return StrictArith::plm(l, c, r, lim); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return StrictArith::plus(P, G, lim); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return StrictArith::minus(P, G, lim); }
     template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd::riemann_hlle<AXIS>(Pl, Pr, g); }
     // u0 + ((Fr_hi (-dAr_hi) - Fr_lo (-dAr_lo)) + (Fq_hi (-dAq_hi) - Fq_lo (-dAq_lo)) + S dv) dt     src/subprog_cloud.cpp:572-574
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
@@ -165,11 +175,18 @@ struct SrhdFast
 {
     static constexpr int min_waves_per_simd = 3;      // hold the allocation at 168 VGPRs
     static constexpr bool table_geometry = true;      // per-row x per-column factors from the host's tables (mh_cloud_pack_geometry)
-    static constexpr bool exact_zero_products = false;// pole slopes / fluxes are plain zeros
+    static constexpr bool exact_zero_products = false;// pole slopes / fluxes are plain zeros (zero lane constants, cloud.hip: lim_polar)
+    static constexpr bool group_own_row_loads = true;
+    static constexpr bool lds_row_ring = true;        // ... or wait for it in a per-wave LDS ring
     static __device__ inline void to_density(double (&x)[5], double, double inv_dv) { for (int q = 0; q < 5; ++q) x[q] *= inv_dv; }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive(U, g, tf, P); }
     static __device__ inline State5 source(const State5& P, double, double inv_r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms_rinv(P, inv_r, cot, g); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, double th) { return fast::plm_gradient(l, c, r, th); }
+    // the limiter on unscaled differences, theta / 2 in the face-state FMA (euler_device_fast.hpp: FastArith)
+    using Limiter = FastArith::Limiter;
+    static __device__ inline Limiter limiter(double theta) { return FastArith::limiter(theta); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return FastArith::plm(l, c, r, lim); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return FastArith::plus(P, G, lim); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return FastArith::minus(P, G, lim); }
     template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd_fast::riemann_hlle<AXIS>(Pl, Pr, g); }
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
     {
