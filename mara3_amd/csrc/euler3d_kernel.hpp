@@ -226,7 +226,15 @@ void euler3d_stage_kernel(Stage3dParams p)
 
         // ---- axis 2 (lanes): this lane computes the flux through its LEFT face
         State5 Fz_lo, Fz_hi;
-        if constexpr (PLM)
+        if constexpr (PLM && A::shared_differences)
+        {
+            // the limiter's one-sided differences belong to a face: formed once, the left one comes from the left neighbour's lane
+            const State5 Dr = A::difference(P[K0], dpp3_right(P[K0]));
+            const State5 Gz = A::plm_from_differences(dpp3_left(Dr), Dr, lim);
+            const State5 SL = dpp3_left(A::plus(P[K0], Gz, lim));
+            Fz_lo = A::template flux<RIEMANN, 2>(SL, A::minus(P[K0], Gz, lim), gl);
+        }
+        else if constexpr (PLM)
         {
             const State5 Gz = A::plm(dpp3_left(P[K0]), P[K0], dpp3_right(P[K0]), lim);
             const State5 SL = dpp3_left(A::plus(P[K0], Gz, lim));
@@ -249,7 +257,21 @@ void euler3d_stage_kernel(Stage3dParams p)
         State5 Fy_lo, Fy_hi;
         {
             const State5 Pm1 = lds_get(tile.P[pb][row + H3 - 1], lane), Pp1 = lds_get(tile.P[pb][row + H3 + 1], lane);
-            if constexpr (PLM)
+            if constexpr (PLM && A::shared_differences)
+            {
+                // three slopes (this row's and its two neighbours') from four differences instead of six
+                const State5 Dm = A::difference(Pm1, P[K0]), Dp = A::difference(P[K0], Pp1);
+                const State5 Gy = A::plm_from_differences(Dm, Dp, lim);
+                {
+                    const State5 Pm2 = lds_get(tile.P[pb][row + H3 - 2], lane);
+                    Fy_lo = A::template flux<RIEMANN, 1>(A::plus(Pm1, A::plm_from_differences(A::difference(Pm2, Pm1), Dm, lim), lim), A::minus(P[K0], Gy, lim), gl);
+                }
+                {
+                    const State5 Pp2 = lds_get(tile.P[pb][row + H3 + 2], lane);
+                    Fy_hi = A::template flux<RIEMANN, 1>(A::plus(P[K0], Gy, lim), A::minus(Pp1, A::plm_from_differences(Dp, A::difference(Pp1, Pp2), lim), lim), gl);
+                }
+            }
+            else if constexpr (PLM)
             {
                 const State5 Gy = A::plm(Pm1, P[K0], Pp1, lim);
                 {

@@ -118,11 +118,10 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     const double ap = __builtin_fmax(0.0, __builtin_fmax(alp, arp));
     const double am = __builtin_fmin(0.0, __builtin_fmin(alm, arm));
     const double rden = fast::rcp_nr(ap - am);
-    const double apam = ap * am;
+    const double wl = ap * rden, wr = am * rden, wu = wl * am;       // the three weights divided once (euler_device_fast.hpp)
     State5 F;
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-        F[q] = __builtin_fma(-(Ul[q] - Ur[q]), apam, __builtin_fma(-Fr[q], am, Fl[q] * ap)) * rden;
+    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));
     return F;
 }
 
