@@ -180,6 +180,28 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
     const typename A::Gamma gl = A::gamma_law(gamma);
     const typename A::Limiter lim = A::limiter(theta);
 
+    // MH_ARITH_FAST keeps only primitives in the register window. The conserved values of rows r, r+1, r+2 wait for their update in a
+    // per-wave LDS ring (private to the wave: no barrier) - so that the update starts from the STORED state and the scheme conserves to
+    // rounding, as the reference does (re-forming the state from the primitives, A::p2c, cost an ulp of energy per cell and step)
+    constexpr bool lds_ring = A::recompute_conserved && A::lds_conserved_ring;
+    __shared__ double own_rows[lds_ring ? WAVES_PER_BLOCK : 1][3][5][WAVE];
+    const int wave_in_block = (int) (threadIdx.x >> 6);
+    auto ring_put = [&] (int slot, const State5& raw)
+    {
+        if constexpr (lds_ring)
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) own_rows[wave_in_block][slot][q][lane] = raw[q];
+        }
+    };
+    auto ring_get = [&] (int slot) -> State5
+    {
+        State5 Uq;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) Uq[q] = own_rows[lds_ring ? wave_in_block : 0][slot][q][lane];
+        return Uq;
+    };
+
     // ---- register window: three slots used as rings (index = row mod 3 relative to the chunk start), so that the
     // row loop, unrolled by three, needs no register-to-register rotation at all.
     //   U[k]: conserved of rows r, r+1, r+2        P[k]: primitives of rows r, r+1, r+2
@@ -194,6 +216,8 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         U[2] = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
         P[0] = A::c2p(U[0], gl);
         P[1] = A::c2p(U[1], gl);
+        ring_put(0, U[0]);
+        ring_put(1, U[1]);
         // (recompute_conserved: U[] is the ring of LOADED rows instead - slot (row - r0) mod 3 holds row r+2, r+3 or r+4 until its
         // conversion; rows r0, r0+1 are converted already and their slots take rows r0+3, r0+4)
         if constexpr (A::recompute_conserved) U[0] = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
@@ -247,6 +271,7 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(U[K2], gl);
+        ring_put(K2, U[K2]);
         // a negative (or NaN) pressure: the strict arithmetic turns it into NaN sound speeds that reach the density check below, the fast
         // arithmetic's guarded inverse root would not - so it is flagged where it appears (once per cell and stage)
         const bool bad_pressure = !(P[K2][4] >= 0.0);
@@ -289,7 +314,8 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
 
         // ---- conservative update (+ RK combine)
         State5 Un, Uc;
-        if constexpr (A::recompute_conserved) Uc = A::p2c(P[K0], gl);
+        if constexpr (lds_ring)                    Uc = ring_get(K0);
+        else if constexpr (A::recompute_conserved) Uc = A::p2c(P[K0], gl);
         else                                  Uc = U[K0];
 #pragma unroll
         for (int q = 0; q < 5; ++q)

@@ -249,6 +249,7 @@ struct StrictArith
     static constexpr int min_waves_first_stage = 2;
     static constexpr bool shared_differences = false;       // the reference's plm_gradient takes the three values, bit for bit
     static constexpr bool recompute_conserved = false;      // the update starts from the stored conserved state, bit for bit
+    static constexpr bool lds_conserved_ring = false;
     using Gamma = GammaLaw;
     static __device__ inline Gamma gamma_law(double gamma) { return make_gamma_law(gamma); }
     static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return recover_primitive(U, g.gamma, 0.0); }
@@ -293,10 +294,13 @@ struct FastArith
     // and the factor theta / 2 of the half-cell extrapolation rides in the FMA that forms the face state. 1 + 2 + 6 fp64 instructions
     // per variable and axis (the difference, the central term, the limiter) where the three-value form takes 13.
     static constexpr bool shared_differences = true;
-    // The 2-D stage kernel converts a loaded row to primitives once and keeps only those; the conserved state the update starts
-    // from is formed again from the primitives (8 instructions, equal to the stored one to rounding) instead of being carried through
-    // the register window: no register-to-register moves in the row loop and 20 VGPRs fewer.
+    // The 2-D stage kernel converts a loaded row to primitives once and keeps only those in its register window (no register-to-register
+    // moves in the row loop, 20 VGPRs fewer); the conserved values the update starts from wait in a per-wave LDS ring meanwhile
+    // (lds_conserved_ring; euler2d.hip). The first version re-formed them from the primitives instead (p2c, 8 instructions, equal to the
+    // stored ones to rounding): same speed, but an ulp of energy per cell and step - 2e-13 of the total after 8000 steps where the stored
+    // state conserves to 3e-16.
     static constexpr bool recompute_conserved = true;
+    static constexpr bool lds_conserved_ring = true;
     static __device__ inline State5 p2c(const State5& P, const fast::GammaLawFast& g) { return fast::to_conserved(P, g); }
     struct Limiter
     {
