@@ -218,7 +218,9 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     //   F*_K = (S* (S_K U_K - F_K) + S_K p* D) / (S_K - S*), D = (0, n, S*), p* = p_K + rho_K (S_K - u_K)(S* - u_K)   (Toro eq. 10.41-10.43),
     // algebraically F_K + S_K (U*_K - U_K) of eq. 10.38-10.39 with one division instead of three. Conditions in the reference's
     // order (physics_iso2d.hpp:576-583): 0 <= S_L, S_L <= 0 <= S*, S* <= 0 <= S_R, S_R <= 0.
-    const bool left = 0.0 <= sstar;
+    // (0 <= S_L comes first upstream: where the pressure-based estimates cross, S_R < 0 < S_L - strongly colliding flows at gamma near 1 -
+    // the face takes the left flux whatever the sign of S*; tests/test_gpu_toro.py, the isothermal-limit test, found this case)
+    const bool left = (0.0 <= sstar) | (0.0 <= sl);
     State5 Pk;
 #pragma unroll
     for (int q = 0; q < 5; ++q) Pk[q] = left ? Pl[q] : Pr[q];

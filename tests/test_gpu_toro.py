@@ -62,3 +62,22 @@ def test_same_profile_along_every_axis(engine, rank, axis):
     assert got[3] == (0, None) and got[4]
     for qa, qb in zip(want[:3], got[:3]):
         assert np.max(np.abs(qa - qb)) <= 1e-13 * np.max(np.abs(qa)), (rank, axis)
+
+
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_gamma_to_one_gives_the_reference_isothermal_hllc_on_the_device(engine, oracle, arith, axis):
+    """The second anchor of row a5 (tests/test_euler_hllc_isothermal_limit_cpu.py, here on the HIP path): for gamma -> 1 the Euler HLLC
+    solver must turn into the reference's isothermal HLLC (src/physics_iso2d.hpp:556-583, 610-687; restated in the oracle bit for bit
+    against reference-made vectors) in the mass and momentum components - same wave-speed estimates, contact speed and region choice."""
+    from test_euler_hllc_isothermal_limit_cpu import states
+    n, eps = 4000, 1e-9
+    gamma = 1.0 + eps
+    rho, v, cs2 = states(n, 11 + axis)
+    P3 = [np.stack([rho[k], v[k, :, 0], v[k, :, 1]], axis=1) for k in range(2)]
+    P5 = [np.stack([rho[k], v[k, :, 0], v[k, :, 1], np.zeros(n), rho[k] * cs2[k] / gamma], axis=1) for k in range(2)]
+    Fi, _, threw = oracle.iso2d_riemann(P3[0], P3[1], cs2[0], cs2[1], axis, oracle.RIEMANN_HLLC)
+    Fe = engine.euler_riemann(P5[0], P5[1], axis, gamma, "hllc", arith=arith)
+    ok = threw == 0
+    err = np.abs(Fe[ok][:, :3] - Fi[ok]).max(axis=0) / np.abs(Fi[ok]).max(axis=0)
+    assert np.all(err <= 1e-6), err
