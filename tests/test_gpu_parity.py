@@ -268,6 +268,42 @@ def test_fast_functions_within_a_few_ulp(eng):
             assert (np.abs(Ff - Fs) <= 1e-12 * scale).all(), (solver, axis, (np.abs(Ff - Fs) / scale).max())
 
 
+@pytest.mark.parametrize("gamma", [5.0 / 3, 1.4, 1.05])
+def test_fast_hllc_takes_the_branches_of_the_strict_solver_in_extreme_flows(eng, oracle, gamma):
+    """Every region of the HLLC solver, the degenerate ones included: supersonic to either side, strong rarefactions (p* clipped at 0) and
+    strongly colliding streams, where the pressure-based wave-speed estimates cross (S_R < 0 < S_L) and the reference's order of tests
+    (0 <= S_L first, physics_iso2d.hpp:576-583) decides. The branch-free FAST selection must land in the same region as the STRICT
+    solver (== the C restatement) everywhere."""
+    rng = np.random.default_rng(int(gamma * 1000))
+    n = 6000
+    rho = rng.uniform(0.05, 4.0, (2, n))
+    p = rng.uniform(0.02, 3.0, (2, n))
+    a = np.sqrt(gamma * p / rho)
+    mach = rng.uniform(-6.0, 6.0, (2, n))
+    mach[:, : n // 3] = np.abs(mach[:, : n // 3]) * np.array([[1.0], [-1.0]])          # a third collide head-on
+    mach[:, n // 3: n // 2] = np.abs(mach[:, n // 3: n // 2]) * np.array([[-1.0], [1.0]])  # a sixth separate
+    vt = rng.uniform(-1.0, 1.0, (2, n, 2))
+    for axis in range(3):
+        P = []
+        for k in range(2):
+            v = np.zeros((n, 3))
+            v[:, axis] = mach[k] * a[k]
+            v[:, (axis + 1) % 3] = vt[k, :, 0]
+            v[:, (axis + 2) % 3] = vt[k, :, 1]
+            P.append(np.concatenate([rho[k][:, None], v, p[k][:, None]], axis=1))
+        Fs = eng.euler_riemann(P[0], P[1], axis, gamma, "hllc", arith="strict")
+        Ff = eng.euler_riemann(P[0], P[1], axis, gamma, "hllc", arith="fast")
+        assert bits_equal(Fs, oracle.euler_riemann(P[0], P[1], axis, gamma, oracle.RIEMANN_HLLC))
+        scale = np.abs(Fs).max(axis=1, keepdims=True)
+        assert (np.abs(Ff - Fs) <= 1e-11 * scale).all(), (axis, (np.abs(Ff - Fs) / scale).max())
+    # the crossing case is in the sample: S_L > 0 > S_R by the estimates themselves
+    ul, ur = mach[0] * a[0], mach[1] * a[1]
+    pst = np.maximum(0.0, 0.5 * (p[0] + p[1]) - 0.5 * (ur - ul) * 0.5 * (rho[0] + rho[1]) * 0.5 * (a[0] + a[1]))
+    q = [np.where(pst <= p[k], 1.0, np.sqrt(1.0 + (gamma + 1) / (2 * gamma) * (pst / p[k] - 1.0))) for k in range(2)]
+    crossing = (ul - a[0] * q[0] > 0) & (ur + a[1] * q[1] < 0)
+    assert crossing.sum() > 50 and (pst == 0.0).sum() > 50
+
+
 @pytest.mark.parametrize("case", STEP_CASES)
 def test_fast_euler2d_steps_within_l1_tolerance(eng, case):
     g = golden(case)
