@@ -1,0 +1,53 @@
+"""Long runs against the reference ITSELF: the final states of the reference's own composition (oracle/ref_drivers over /root/reference/src,
+3 to 7 CPU-minutes each, scripts/make_long_reference_states.py) are too large to commit, so their SHA-256 is the fixture
+(tests/golden/long_runs_reference_hashes.json) and bit-identity of the STRICT device state is asserted through it - after 1500 steps of the 2-D
+blast, 2000 of the periodic wave, 250 of the 3-D blast, and 388 of `cloud` at 1024 x 512, where the reference then throws and so must we."""
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import numpy as np
+import pytest
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "long_runs_reference_hashes.json")))
+EXE = os.path.join(ROOT, "mara3_amd", "host", "mara_hip")
+
+
+@pytest.mark.parametrize("name", sorted(FIX["euler"]))
+def test_euler_long_run_is_bit_identical_to_the_reference_composition(name):
+    from mara3_amd import setups
+    from mara3_amd.engine import EulerCartSolver
+    c = FIX["euler"][name]
+    shape = tuple(c["shape"])
+    u0 = setups.blast_ic(shape, c["gamma"]) if c["ic"] == "blast" else setups.smooth_wave_ic(shape, c["gamma"])
+    states = {}
+    for arith in ("strict", "fast"):
+        s = EulerCartSolver(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "periodic" if c["bc"] else "outflow", arith=arith)
+        s.upload(u0)
+        s.step(c["dt"], c["nsteps"])
+        states[arith] = s.download()
+        assert s.status() == 0
+    assert hashlib.sha256(states["strict"].tobytes()).hexdigest() == c["sha256"]
+    # FAST against the (bit-identical) STRICT state: north_star's conserved-variable L1 bound, thousands of steps in
+    assert np.abs(states["fast"] - states["strict"]).mean() <= 1e-12 * np.abs(states["strict"]).mean()
+
+
+def test_cloud_long_run_is_bit_identical_and_ends_where_the_reference_throws(tmp_path):
+    c = FIX["cloud"]["nr512_rk2_plm12_388steps"]
+    p = subprocess.run([EXE, "cloud"] + c["args"] + ["cpi=0", "outdir=o", "arith=strict"], cwd=str(tmp_path), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-400:]
+    raw = open(os.path.join(str(tmp_path), "o", "final.bin"), "rb").read()
+    rank = struct.unpack_from("q", raw, 0)[0]
+    off = 8 + 8 * rank + 8 + 8 + 8
+    nv = struct.unpack_from("q", raw, off)[0]
+    u = np.frombuffer(raw, dtype=np.float64, offset=off + 8 + 8 * nv)
+    assert u.size == c["shape"][0] * c["shape"][1] * 5
+    assert hashlib.sha256(u.tobytes()).hexdigest() == c["sha256"]
+    # one step further the state's two cells with D <= 0 reach recover_primitive: the reference's exception, in both arithmetic modes
+    for arith in ("strict", "fast"):
+        q = subprocess.run([EXE, "cloud", "nr=512", "rk_order=2", "reconstruct_method=2", "max_steps=389", "cpi=0", "outdir=x", "arith=" + arith],
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=280)
+        assert q.returncode != 0 and c["then"] in (q.stdout + q.stderr) and q.stdout.count("kzps=") == 388
