@@ -51,3 +51,22 @@ def test_cloud_long_run_is_bit_identical_and_ends_where_the_reference_throws(tmp
         q = subprocess.run([EXE, "cloud", "nr=512", "rk_order=2", "reconstruct_method=2", "max_steps=389", "cpi=0", "outdir=x", "arith=" + arith],
                            cwd=str(tmp_path), capture_output=True, text=True, timeout=280)
         assert q.returncode != 0 and c["then"] in (q.stdout + q.stderr) and q.stdout.count("kzps=") == 388
+
+
+@pytest.mark.parametrize("name", sorted(FIX["sedov"]))
+def test_sedov_long_run_is_bit_identical_to_the_reference_composition(tmp_path, name):
+    """`mara_hip sedov` (both hydro systems of SedovProblem<HydroSystem>) through 5000 steps against oracle/_ref/sedov_ref's final state."""
+    from conftest import golden
+    c = FIX["sedov"][name]
+    v = golden("sedov_newtonian_nr256")["vertices"]
+    dt = 0.4 * (v[1] - v[0])
+    p = subprocess.run([EXE, "sedov"] + c["args"] + ["tfinal=%r" % float((c["nsteps"] - 0.5) * dt), "outdir=o", "cpi=0"], cwd=str(tmp_path), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-400:]
+    raw = open(os.path.join(str(tmp_path), "o", "final.bin"), "rb").read()
+    rank = struct.unpack_from("q", raw, 0)[0]
+    off = 8 + 8 * rank + 8 + 8
+    assert struct.unpack_from("q", raw, off)[0] == c["nsteps"]          # iteration
+    off += 8
+    nv = struct.unpack_from("q", raw, off)[0]
+    u = np.frombuffer(raw, dtype=np.float64, offset=off + 8 + 8 * nv)
+    assert hashlib.sha256(u.tobytes()).hexdigest() == c["sha256"]
