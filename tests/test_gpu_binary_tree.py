@@ -94,6 +94,23 @@ def test_time_step_bound_folded_into_the_final_stage_equals_the_stand_alone_one(
     b.close()
 
 
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_default_tree_through_200_steps_against_the_reference_composition(binary, arith):
+    """The sub-program's default mesh (64 blocks of 24^2 on levels 2-4) and options, 200 adaptive steps (0.29 orbits) in ONE call - so with
+    the time-step bound of every step but the first coming out of the final stage's own kernels - against binary_tree_ref's state
+    (23 CPU-seconds of the reference's tree machinery and leaf physics). Measured: 8e-15 of the field scale, the time to 2.5e-16."""
+    g = golden("binary_tree_default_200steps")
+    s = binary.BinaryTreeSolver(binary.config(), blocks=g["blocks"], edges=g["xv"], u_init=g["u_init"], buffer_rate=g["br"],
+                                recommended_time_step=g["stage_scalars"][1], arith=arith)
+    assert s.next(200) == 0
+    ok, rel = close(s.solution(), g["u_final"], rel=1e-12)
+    assert ok, rel
+    sc = g["scalars"]
+    assert abs(s.state().time - sc[0]) <= 1e-14 * sc[0] and s.state().iteration == int(sc[1]) == 200
+    assert abs(s.last_dt - sc[42 + 199]) <= 1e-13 * sc[42 + 199]
+    s.close()
+
+
 def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
     """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
     policy arithmetic, so the two must agree to the last bit."""
