@@ -225,6 +225,23 @@ def test_safe_mode_retry(mods, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_200_adaptive_steps_against_the_reference_composition(mods, arith):
+    """A uniform-depth tree fine enough to run without the safe mode (256^2: depth 4, block_size 16, domain_radius 8), 200 CFL-limited
+    steps in one call (look-ahead time-step bound, one host synchronisation per step) against binary_ref's state - 35 CPU-seconds of the
+    reference's leaf physics under the restated scheme glue (row a16 stays "partially pinned"). Host-side set-up from the configuration."""
+    lib, binary, engine, L = mods
+    g = golden("binary_d4_b16_r8_200steps")
+    s = binary.BinarySolver(binary.config(depth=4, block_size=16, domain_radius=8.0), arith=arith)
+    assert s.next(200) == 0
+    u, ref, sc = s.solution(), g["u_final"], g["scalars"]
+    scale = np.abs(ref).reshape(-1, 3).max(axis=0)
+    err = np.abs(u - ref).reshape(-1, 3).max(axis=0) / scale
+    assert np.all(err <= 1e-12), err
+    assert abs(s.state().time - sc[0]) <= 1e-14 * sc[0] and s.state().iteration == int(sc[1]) == 200
+    s.close()
+
+
 def test_full_size_point_symmetry_and_positivity(mods):
     """BASELINE config 3 at full size (2048^2 = 32 x 32 blocks of 64^2). An equal-mass circular binary and the disk model
     are symmetric under (x, y) -> (-x, -y) with (px, py) -> (-px, -py); the scheme preserves that up to rounding."""
