@@ -82,6 +82,49 @@ def test_fast_cloud_steps_within_tolerance_of_reference(eng, case):
     assert np.all(err <= 1e-12 * scale), err / scale
 
 
+@pytest.mark.parametrize("theta,rk", [(1.2, 1), (2.0, 1), (-1.0, 1)])      # (one stage: random data do not survive a second one)
+def test_fast_cloud_stage_on_random_extreme_states_lands_on_the_strict_result(eng, theta, rk):
+    """Uncorrelated random cells - Lorentz factors up to 30 in either radial direction, polar motion, pressures from 1e-6 rho to 30 rho,
+    densities over four decades - so that every face is an extreme Riemann problem, the limiter sees every sign pattern and the Newton
+    iteration of recover_primitive starts far from its root: the FAST kernel (leaner Newton step, unscaled limiter, zero pole constants,
+    conserved rows in LDS) must land on the STRICT kernel's update in all of them."""
+    rng = np.random.default_rng(int(1000 * abs(theta)) + rk)
+    nr, nq = 48, 130                                    # three strips of 60 columns, ragged; both poles
+    rv = np.logspace(0.0, 0.5, nr + 1)
+    qv = np.linspace(0.0, np.pi, nq + 1)
+    rho = 10.0 ** rng.uniform(-3.0, 1.0, (nr, nq))
+    P = np.zeros((nr, nq, 5))
+    P[..., 0] = rho
+    P[..., 1] = rng.uniform(-1.0, 1.0, (nr, nq)) * 10.0 ** rng.uniform(-2.0, 1.5, (nr, nq))      # radial gamma-beta
+    P[..., 2] = rng.uniform(-0.5, 0.5, (nr, nq))
+    P[..., 4] = rho * 10.0 ** rng.uniform(-6.0, 1.5, (nr, nq))
+    U = eng.srhd_to_conserved(P.reshape(-1, 5)).reshape(nr, nq, 5)
+    dmu = -np.cos(qv[1:]) - -np.cos(qv[:-1])
+    dv = ((rv[1:] ** 3 - rv[:-1] ** 3)[:, None] * dmu[None, :] * 2 * np.pi) / 3
+    u0 = U * dv[..., None]
+    inflow = P[0].copy()
+    dt = 0.05 * (rv[1] - rv[0])
+    out = {}
+    for arith in ("strict", "fast"):
+        s = eng.CloudSolver(rv, qv, rk, theta, 0.0, arith=arith)
+        s.upload(u0)
+        s.set_inflow(inflow)
+        s.step(dt, 1)
+        out[arith] = s.download()
+        st = s.status()
+        assert st == 0, st
+    a, b = out["strict"], out["fast"]
+    ok = np.isfinite(a).all(axis=-1) & np.isfinite(b).all(axis=-1)
+    assert ok.mean() > 0.99
+    scale = np.abs(a[ok]).mean(axis=0)
+    scale[1:4] = scale[1:4].max()
+    assert np.all(np.abs(a[ok] - b[ok]).mean(axis=0) <= 1e-12 * scale), np.abs(a[ok] - b[ok]).mean(axis=0) / scale
+    # no cell is off by more than the reach of one Newton step taken or not taken at the |f| < 1e-10 threshold
+    cell = np.abs(a[ok]).copy()
+    cell[:, 1:4] = np.abs(a[ok][:, 1:4]).max(axis=1, keepdims=True)
+    assert np.all(np.abs(a[ok] - b[ok]) <= 1e-8 * np.maximum(cell, scale[None, :] * 1e-6))
+
+
 def test_cloud_reports_c2p_failure_in_status_word(eng):
     g = golden("cloud_nr32_plm_rk1")
     u = g["u0"].copy()
