@@ -180,6 +180,45 @@ def test_fast_arithmetic_within_tolerance_of_reference(mods, name):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["binary_d2_b16", "binary_d1_b24_nu", "binary_d2_b16_q"])
+def test_fast_stage_on_random_extreme_states_lands_on_the_strict_result(mods, name):
+    """Uncorrelated random cells on the meshes of three reference cases (alpha and constant-nu viscosity, both conserved-variable forms):
+    surface densities over three decades, velocities to ten times the local sound speed in any direction. One forward-Euler stage, FAST
+    against STRICT, compared through the increments u1 - u0 (which carry the whole of the stage's arithmetic)."""
+    lib, binary, engine, L = mods
+    g = golden(name)
+    cfg, over = cfg_of(binary, g)
+    cfg["rk_order"], cfg["fixed_dt"] = 1, 1
+    n = g["u_init"].shape[0]
+    rng = np.random.default_rng(n)
+    sigma = 10.0 ** rng.uniform(-2.0, 1.0, (n, n))
+    xc = 0.5 * (g["xv"][1:] + g["xv"][:-1])
+    cs = np.sqrt(1.0 / np.sqrt(xc[:, None] ** 2 + xc[None, :] ** 2 + 0.01)) / float(cfg["mach_number"])
+    u0 = np.zeros((n, n, 3))
+    u0[..., 0] = sigma
+    u0[..., 1] = sigma * rng.uniform(-10.0, 10.0, (n, n)) * cs
+    u0[..., 2] = sigma * rng.uniform(-10.0, 10.0, (n, n)) * cs
+    if not int(cfg.get("conserve_linear_p", 1)):
+        # (Sigma, Sigma s_r, Sigma l_z) at the cell centres
+        px, py = u0[..., 1].copy(), u0[..., 2].copy()
+        X, Y = np.meshgrid(xc, xc, indexing="ij")
+        r = np.sqrt(X * X + Y * Y)
+        u0[..., 1] = (px * X + py * Y) / r
+        u0[..., 2] = X * py - Y * px
+    dt = 1e-3 * float(g["stage_scalars"][1])
+    out = {}
+    for arith in ("strict", "fast"):
+        s = binary.BinarySolver(cfg, xv=g["xv"], yv=g["yv"], u_init=u0, buffer_rate=g["br"], recommended_time_step=dt, arith=arith)
+        assert s.next(1) == 0
+        out[arith] = s.solution()
+        s.close()
+    da, db = out["strict"] - u0, out["fast"] - u0
+    scale = np.abs(da).reshape(-1, 3).mean(axis=0)
+    scale[1:] = scale[1:].max()
+    err = np.abs(da - db).reshape(-1, 3).mean(axis=0) / scale
+    assert np.all(err <= 1e-10), err
+
+
 def test_next_in_one_call_equals_step_by_step(mods):
     """The look-ahead wavespeed reduction must not change a single bit."""
     lib, binary, engine, L = mods
