@@ -149,7 +149,7 @@ struct SrhdStrict
     static constexpr bool table_geometry = false;     // geometry factors formed per cell in the reference's order
     static constexpr bool exact_zero_products = true; // pole slopes / fluxes as (neighbour's value) * 0, like extend_zeros: NaN and -0 propagate
     static constexpr bool group_own_row_loads = false;// (cloud.hip: where the update's loads of the row's conserved values are requested)
-    static constexpr bool lds_row_ring = false;       // the row's conserved values are read again at the update
+    static constexpr bool lds_row_ring = true;        // the row's conserved values wait for the update in a per-wave LDS ring
     static __device__ inline void to_density(double (&x)[5], double dv, double) { divide_group<5>(x, make_recip(dv, 1.0)); }
     static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
     static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
