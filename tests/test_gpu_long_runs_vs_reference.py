@@ -94,3 +94,43 @@ def test_decomposed_long_run_is_bit_identical_to_the_reference_composition(name,
     u = g.download()
     g.close()
     assert hashlib.sha256(np.ascontiguousarray(u).tobytes()).hexdigest() == c["sha256"]
+
+
+def test_baseline_config2_at_full_size_is_bit_identical_to_the_reference_composition():
+    """BASELINE config 2 as stated - 4096^2, PLM 1.5, RK2, the Sedov-type blast, 20 steps with the fixed dt of bench.py - in the variant that is
+    pinned to the reference (STRICT, HLLE): all 16 777 216 cells, through the hash of the state that 13 CPU-minutes of the reference's own
+    lazy-array composition leave behind. (FAST + HLLC, the variant bench.py times, within the north star's L1 of it.)"""
+    from mara3_amd import setups
+    from mara3_amd.engine import EulerCartSolver
+    c = FIX["fullsize"]["c2_4096x4096_20steps"]
+    shape = tuple(c["shape"])
+    u0 = setups.blast_ic(shape, c["gamma"])
+    assert c["dt"] == setups.baseline_dt(shape[0])
+    s = EulerCartSolver(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "outflow", arith="strict")
+    s.upload(u0)
+    s.step(c["dt"], c["nsteps"])
+    u = s.download()
+    assert s.status() == 0
+    s.close()
+    assert hashlib.sha256(u.tobytes()).hexdigest() == c["sha256"]
+    f = EulerCartSolver(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "outflow", arith="fast")
+    f.upload(u0)
+    f.step(c["dt"], c["nsteps"])
+    uf = f.download()
+    f.close()
+    assert np.abs(uf - u).mean() <= 1e-12 * np.abs(u).mean()
+
+
+def test_baseline_config4_at_full_size_is_bit_identical_to_the_reference_composition(tmp_path):
+    """BASELINE config 4 as stated - `cloud nr=4096 num_decades=1 rk_order=2 plm_theta=1.2`, 4096 x 4096 cells - through the compiled host,
+    3 RK2 steps, against the hash of the reference composition's state (oracle/_ref/cloud_ref, 220 CPU-seconds)."""
+    c = FIX["fullsize"]["c4_cloud_nr4096_3steps"]
+    p = subprocess.run([EXE, "cloud"] + c["args"] + ["cpi=0", "outdir=o", "arith=strict"], cwd=str(tmp_path), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-400:]
+    raw = open(os.path.join(str(tmp_path), "o", "final.bin"), "rb").read()
+    rank = struct.unpack_from("q", raw, 0)[0]
+    off = 8 + 8 * rank + 8 + 8 + 8
+    nv = struct.unpack_from("q", raw, off)[0]
+    u = np.frombuffer(raw, dtype=np.float64, offset=off + 8 + 8 * nv)
+    assert u.size == c["shape"][0] * c["shape"][1] * 5
+    assert hashlib.sha256(u.tobytes()).hexdigest() == c["sha256"]
