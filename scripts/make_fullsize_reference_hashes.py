@@ -1,6 +1,6 @@
 """Runs HERE (CPU, minutes): the reference's own composition at the BASELINE sizes - config 2 (4096^2, 20 RK2 steps), config 4 (`cloud`
 nr=4096, one decade: 4096 x 4096, 3 RK2 steps) and, memory permitting, config 5's per-GPU share - and prints the SHA-256 of the final states
-(0.7 - 5 GB each; nothing is kept). usage: make_fullsize_reference_hashes.py c2|c4|c5 [...]"""
+(0.7 - 5 GB each; nothing is kept). usage: make_fullsize_reference_hashes.py c2|c4|c5|c5full [...]"""
 import hashlib, json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,7 +36,9 @@ for what in sys.argv[1:]:
         if what == "c2":
             out[what] = euler((4096, 4096), 20, tmp)
         elif what == "c5":
-            out[what] = euler((256, 256, 256), 4, tmp)
+            out[what] = euler((384, 384, 384), 3, tmp)
+        elif what == "c5full":          # config 5's per-GPU share: 134 M cells, ~30 GB of lazy-array temporaries here
+            out[what] = euler((512, 512, 512), 1, tmp)
         elif what == "c4":
             subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "cloud_ref"), "4096", "1", "2", "2", "1.2", "3", os.path.join(tmp, "c")])
             out[what] = dict(args=["nr=4096", "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=3"], shape=[4096, 4096], sha256=sha_of_file(os.path.join(tmp, "c.un.f64")))

@@ -134,3 +134,24 @@ def test_baseline_config4_at_full_size_is_bit_identical_to_the_reference_composi
     u = np.frombuffer(raw, dtype=np.float64, offset=off + 8 + 8 * nv)
     assert u.size == c["shape"][0] * c["shape"][1] * 5
     assert hashlib.sha256(u.tobytes()).hexdigest() == c["sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(k for k in FIX["fullsize"] if k.startswith("c5_")))
+def test_baseline_config5_sizes_are_bit_identical_to_the_reference_composition(name):
+    """The 3-D Euler blast of BASELINE config 5 (PLM 1.5 + HLLE, RK2, fixed dt) at 384^3 and at the per-GPU share of the configured run, 512^3,
+    against the hash of the reference composition's state (12 to 25 CPU-minutes and 13 to 30 GB of its lazy arrays each)."""
+    from mara3_amd import setups
+    from mara3_amd.engine import EulerCartSolver
+    c = FIX["fullsize"][name]
+    shape = tuple(c["shape"])
+    assert c["dt"] == setups.baseline_dt(shape[0])
+    s = EulerCartSolver(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "outflow", arith="strict")
+    s.upload(setups.blast_ic(shape, c["gamma"]))
+    s.step(c["dt"], c["nsteps"])
+    u = s.download()
+    assert s.status() == 0
+    s.close()
+    h = hashlib.sha256()
+    for k in range(0, shape[0], 32):          # (in slabs: tobytes() of the whole 5 GB array would double the host footprint)
+        h.update(np.ascontiguousarray(u[k:k + 32]).tobytes())
+    assert h.hexdigest() == c["sha256"]
