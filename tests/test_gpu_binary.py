@@ -281,6 +281,25 @@ def test_200_adaptive_steps_against_the_reference_composition(mods, arith):
     s.close()
 
 
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_config3_at_full_size_against_a_digest_of_the_reference_composition(mods, arith):
+    """BASELINE config 3 as stated (2048^2 = 32 x 32 blocks of 64^2, defaults otherwise, CFL-limited dt), two RK2 steps, against binary_ref's
+    state (47 CPU-seconds). The state itself is 100 MB, so the fixture is a digest of it: the mean of every tree block, one cell of every
+    block, and the 48 x 48 cells around the binary (sinks, softened potentials). Tolerance as everywhere on this path: 1e-12 of the field
+    scale (device libm for exp / tanh / pow)."""
+    lib, binary, engine, L = mods
+    g = golden("binary_c3_fullsize_2steps_digest")
+    s = binary.BinarySolver(binary.config(depth=5, block_size=64), arith=arith)
+    assert s.next(2) == 0
+    u, scale, sc = s.solution(), g["scale"], g["scalars"]
+    n, bs = 2048, 64
+    assert np.all(np.abs(u.reshape(n // bs, bs, n // bs, bs, 3).mean(axis=(1, 3)) - g["block_means"]) <= 1e-12 * scale)
+    assert np.all(np.abs(u[31::64, 17::64] - g["samples"]) <= 1e-12 * scale)
+    assert np.all(np.abs(u[n // 2 - 24:n // 2 + 24, n // 2 - 24:n // 2 + 24] - g["centre"]) <= 1e-12 * scale)
+    assert abs(s.state().time - sc[0]) <= 1e-14 * sc[0] and s.state().iteration == int(sc[1]) == 2
+    s.close()
+
+
 def test_full_size_point_symmetry_and_positivity(mods):
     """BASELINE config 3 at full size (2048^2 = 32 x 32 blocks of 64^2). An equal-mass circular binary and the disk model
     are symmetric under (x, y) -> (-x, -y) with (px, py) -> (-px, -py); the scheme preserves that up to rounding."""
