@@ -16,13 +16,24 @@ FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "long_runs_reference_
 EXE = os.path.join(ROOT, "mara3_amd", "host", "mara_hip")
 
 
+def initial_state(c):
+    """The case's initial condition, made on THIS host. The smooth wave goes through numpy's sin and pow, whose last bit may depend on the
+    host CPU's vector extensions; the reference's hash belongs to the initial state of the container it was made in, so a host that forms a
+    different one cannot be held to it (skip, not fail). The blast has no transcendental in it."""
+    from mara3_amd import setups
+    shape = tuple(c["shape"])
+    u0 = setups.blast_ic(shape, c["gamma"]) if c["ic"] == "blast" else setups.smooth_wave_ic(shape, c["gamma"])
+    if "ic_sha256" in c and hashlib.sha256(np.ascontiguousarray(u0).tobytes()).hexdigest() != c["ic_sha256"]:
+        pytest.skip("this host's numpy forms a different initial state (last bits of sin / pow) than the one the reference run started from")
+    return u0
+
+
 @pytest.mark.parametrize("name", sorted(FIX["euler"]))
 def test_euler_long_run_is_bit_identical_to_the_reference_composition(name):
-    from mara3_amd import setups
     from mara3_amd.engine import EulerCartSolver
     c = FIX["euler"][name]
     shape = tuple(c["shape"])
-    u0 = setups.blast_ic(shape, c["gamma"]) if c["ic"] == "blast" else setups.smooth_wave_ic(shape, c["gamma"])
+    u0 = initial_state(c)
     states = {}
     for arith in ("strict", "fast"):
         s = EulerCartSolver(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "periodic" if c["bc"] else "outflow", arith=arith)
@@ -77,10 +88,9 @@ def test_sedov_long_run_is_bit_identical_to_the_reference_composition(tmp_path, 
 def test_decomposed_long_run_is_bit_identical_to_the_reference_composition(name, kind, world):
     """The multi-rank steppers (all ranks as loopback objects on this GPU: slabs with the staggered two-stream schedule, the (2,2,2) blocks
     with shell / interior launches and packed faces) through the same long runs, straight against the reference's hash."""
-    from mara3_amd import setups
     c = FIX["euler"][name]
     shape = tuple(c["shape"])
-    u0 = setups.blast_ic(shape, c["gamma"]) if c["ic"] == "blast" else setups.smooth_wave_ic(shape, c["gamma"])
+    u0 = initial_state(c)
     dl, bc = tuple(1.0 / n for n in shape), ("periodic" if c["bc"] else "outflow")
     if kind == "slabs":
         from mara3_amd.slab import NativeSlabGroup
