@@ -167,3 +167,21 @@ def test_baseline_config5_sizes_are_bit_identical_to_the_reference_composition(n
     for k in range(0, shape[0], 32):          # (in slabs: tobytes() of the whole 5 GB array would double the host footprint)
         h.update(np.ascontiguousarray(u[k:k + 32]).tobytes())
     assert h.hexdigest() == c["sha256"]
+
+
+def test_long_periodic_run_through_rccl_reaches_the_reference_hash():
+    """The same 2000 steps of the periodic wave with the ghost rows travelling through RCCL (one rank exchanging with itself: ncclSend / ncclRecv
+    on the exchange stream, staggered edges, events riding on the launches) - 4000 exchanges - against the reference's hash."""
+    from mara3_amd.slab import NativeSlabStepper, native_comm_id
+    c = FIX["euler"]["euler2d_wave384_plm15_rk2_periodic_2000steps"]
+    shape = tuple(c["shape"])
+    u0 = initial_state(c)
+    st = NativeSlabStepper(shape, tuple(1.0 / n for n in shape), c["gamma"], c["theta"], "hlle", 2, "periodic", rank=0, world=1,
+                           comm_id=native_comm_id(0, 1, device="cuda"), self_exchange=True, arith="strict")
+    st.load_slab(u0)
+    st.step(c["dt"], c["nsteps"])
+    st.synchronize()
+    u = st.slab_host()
+    assert st.status_result() == (0, None)
+    st.close()
+    assert hashlib.sha256(np.ascontiguousarray(u).tobytes()).hexdigest() == c["sha256"]
