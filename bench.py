@@ -192,7 +192,20 @@ def main():
     ap.add_argument("--loopback-slabs", type=int, default=0,
                     help="rehearsal on ONE GPU of the N > 1 code path: the grid as this many slab objects of the native stepper exchanging through its "
                          "loopback backend (RCCL refuses two ranks on one device), incl. the partition check against the one-domain run")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 from a plain command line: print the multi-rank child's command line and stop (nothing touches the GPU)")
+    ap.add_argument("--launch-timeout", type=int, default=900, help="wall-clock limit in seconds of the multi-rank child the supervisor starts")
+    ap.add_argument("--deadline", type=int, default=600,
+                    help="N > 1: seconds after which a rank that is still waiting (ncclCommInitRank, a barrier whose peers are gone) leaves with status 3")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process becomes the supervisor of N ranks (bench_launch.py) - before torch or HIP are loaded
+        import bench_launch
+        bench_launch.supervise(__file__, sys.argv[1:], args.gpus, timeout_s=args.launch_timeout, dry=args.dry_launch,
+                               retry_with=("--stepper", "torch") if args.stepper == "native" else None)
+    if args.dry_launch:
+        raise SystemExit("--dry-launch is for --gpus N > 1 without torch.distributed.run in front")
 
     import torch
     import torch.distributed as dist
@@ -201,34 +214,19 @@ def main():
     from mara3_amd.slab import SlabEulerStepper, NativeSlabStepper, NativeSlabGroup, native_comm_id, partition_rows
     from mara3_amd.slab import slab_fingerprint as slab_checksum
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.loopback_slabs and world != 1:
+    import bench_launch
+    if args.loopback_slabs and int(os.environ.get("WORLD_SIZE", "1")) != 1:
         raise SystemExit("--loopback-slabs is a one-GPU rehearsal")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    ranks = bench_launch.Ranks(args.gpus, args.deadline)      # device check, device selection, RCCL process group - under the watchdog at N > 1
+    world, rank, local_rank, watch = ranks.world, ranks.rank, ranks.local_rank, ranks.watch
     mara3_amd.load_library()           # fails loudly if the HIP library is missing
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n, gamma = args.n, 5.0 / 3
     dl = (1.0 / n, 1.0 / n)
     dt = setups.baseline_dt(n)
     nslabs = args.loopback_slabs if args.loopback_slabs else world
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
+    fence = ranks.fence
     state = {"stepper": args.stepper}
 
     class GroupAsStepper:
@@ -263,13 +261,9 @@ def main():
                                        comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
             except mara3_amd.MaraHipError as e:
                 err = e
-            ok = torch.tensor([0 if st is None else 1], device="cuda")
-            if world > 1:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must take the same path
-            if int(ok.item()) == 1:
+            if ranks.agree(st is not None):                       # every rank must take the same path
                 if world > 1:
-                    # an RCCL unique id is good for one communicator: a fresh one per stepper, broadcast from rank 0
-                    st.connect(native_comm_id(rank, world, device="cuda"))
+                    st.use_comm(ranks.process_comm())
                 return st
             if world == 1:
                 raise err
@@ -298,6 +292,7 @@ def main():
     def run_leg(arith, riemann, workload, nblocks=1, keep_state=False):
         """W untimed + K timed steps (+ nblocks - 1 further timed blocks of K) of the whole grid, then a short profiled pass."""
         bc = "outflow" if workload == "blast" else "periodic"
+        watch.phase("leg %s %s %s" % (arith, riemann, workload))
         native = state["stepper"] == "native" or bool(args.loopback_slabs)
         if native and args.warmup == 0:      # with W >= 1 the warm-up steps do this (and a profile of the run shows the workload's launches only)
             prime(arith, riemann)
@@ -335,11 +330,7 @@ def main():
             if native:
                 st.synchronize()
             fence()
-            elapsed = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
+            elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
             block_ms.append(elapsed / args.steps * 1e3)
         if scratch_to_close is not None:
             scratch_to_close.close()
@@ -421,6 +412,7 @@ def main():
             dist.all_gather(gathered, mine)
             every = [[int(x) for x in g.tolist()] for g in gathered]
         ok = None
+        watch.phase("partition check (rank 0 repeats the run on one GPU, the others wait at a barrier)")
         if rank == 0:
             try:                                   # nothing here may keep rank 0 from the barrier below
                 one = NativeSlabStepper((n, n), dl, gamma, args.theta, riemann, 2, "outflow", rank=0, world=1, device=local_rank,
@@ -511,10 +503,25 @@ def main():
                 ref = cpu_reference(gamma, args.theta)
                 if ref:
                     out["cpu_reference"] = ref
+        # The scalars of every leg and config once more, compact, in the two places a truncated record keeps: inside `config` (stored whole)
+        # and as the LAST key of the line (a tail of the output ends with it).
+        summary = {"headline": [round(res["value"], 1), round(res["roofline_step"]["frac"], 4)], "n_gpus": world, "stepper": state["stepper"]}
+        for key, leg in legs.items():
+            summary[key] = [round(leg["value"], 1), round(leg["roofline_step"]["frac"], 4)]
+        for cfg, line in (out.get("extra_configs") or {}).items():
+            if "value" in line:
+                rf = (line.get("roofline") or {}).get("frac")
+                strict = (line.get("arith_strict") or {})
+                summary[cfg] = [round(line["value"], 1), None if rf is None else round(rf, 4), None if "value" not in strict else round(strict["value"], 1)]
+            else:
+                summary[cfg] = "error"
+        if partition_ok is not None:
+            summary["slabs_bit_identical"] = bool(partition_ok)
+        summary["note"] = "leg: [Mcells/s, fraction of 8 TB/s at 200 B per zone-update]; c3-c5: [fast Mcells/s, stage-kernel HBM fraction, strict Mcells/s]"
+        out["config"]["summary"] = summary
+        out["summary"] = summary
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -36,37 +36,33 @@ def run_c3_bands(args):
     import torch
     import torch.distributed as dist
     from mara3_amd import binary
-    from mara3_amd.slab import native_comm_id
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import bench_launch
+    ranks = bench_launch.Ranks(args.gpus, args.deadline)
+    world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
     n = binary.grid_size(cfg)
     nbands = args.loopback_bands or world
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     res = {}
     for arith in ("fast", "strict"):
+        ranks.watch.phase("c3 %s" % arith)
         if args.loopback_bands:
             s = binary.BinaryBandGroup(cfg, world=nbands, device=local_rank, arith=arith)
         else:
-            s = binary.BinaryBand(cfg, rank, world, native_comm_id(rank, world, device="cuda"), device=local_rank, arith=arith)
+            # the band without a communicator first, then - once every rank holds its band - the process's one communicator
+            s, err = None, None
+            try:
+                s = binary.BinaryBand(cfg, rank, world, None, device=local_rank, arith=arith, comm=None, defer=True)
+            except Exception as e:
+                err = e
+            if not ranks.agree(s is not None):
+                raise SystemExit("c3: a rank could not create its band (%r) %s" % (err, bench_launch.NO_RETRY))
+            s.attach(ranks.process_comm())
         s.next(args.warmup)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ranks.fence()
         t0 = time.perf_counter()
         safe = s.next(args.steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        ranks.fence()
+        elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
         res[arith] = {"value": n * n * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "safe_mode_steps": safe}
         s.close()
     out = {
@@ -79,9 +75,7 @@ def run_c3_bands(args):
         "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
         "arith_strict": res["strict"],
     }
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     return out if rank == 0 else None
 
 
@@ -157,6 +151,8 @@ def run_c4(args):
         for arith in ("fast", "strict"):
             cmd = [exe, "cloud", "nr=%d" % nr, "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=%d" % total, "profile=1",
                    "outdir=out_" + arith, "arith=" + arith]
+            if args.gpus > 1:
+                cmd.append("gpus=%d" % args.gpus)      # radial slabs, one process driving N devices (the reference's evaluate_on<N> thread slabs)
             runs[arith] = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=1200)
             if runs[arith].returncode != 0:
                 raise SystemExit(runs[arith].stdout[-2000:] + runs[arith].stderr[-2000:])
@@ -175,7 +171,7 @@ def c4_parse(args, stdout, nr, arith):
     p.stdout = stdout
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
     shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches", p.stdout)
-    avg_ms, nl = float(shape.group(1)), int(shape.group(2))
+    avg_ms, nl = (float(shape.group(1)), int(shape.group(2))) if shape else (0.0, 0)
     m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
     vertices = (nr + 1) * (nq + 1)
@@ -184,13 +180,13 @@ def c4_parse(args, stdout, nr, arith):
     cells = nr * nq
     bytes_stage = cells * (80 + 120) / 2
     return {
-        "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, 1 GPU" % (nr, nq),
-        "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, %d GPU" % (nr, nq, args.gpus),
+        "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 arith=%s (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % (nr, arith),
                    "final_state_written": bool(m)},
-        "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith,
+        "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None, "kernel": "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith,
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
                      "timing": "HIP events on the launch stream, inside the timed region"},
     }
@@ -233,10 +229,9 @@ def run_c5_blocks(args):
     import torch.distributed as dist
     from mara3_amd import setups
     from mara3_amd.block import NativeBlock, NativeBlockGroup, block_layout
-    from mara3_amd.slab import native_comm_id
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import bench_launch
+    ranks = bench_launch.Ranks(args.gpus, args.deadline)
+    world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     nblocks = args.loopback_blocks or world
     n = args.grid or 512
     gamma = 5.0 / 3
@@ -244,29 +239,26 @@ def run_c5_blocks(args):
     shape = tuple(n * b for b in B)
     dl = tuple(1.0 / max(shape) for _ in shape)          # cubic cells; the domain is [0, N_a / max N] per axis
     dt = setups.baseline_dt(max(shape))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
+    fence = ranks.fence
     res = {}
     for arith in ("fast", "strict"):
+        ranks.watch.phase("c5 %s" % arith)
         if args.loopback_blocks:
             st = NativeBlockGroup(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", world=nblocks, device=local_rank, arith=arith)
             st.upload(blast_block(shape, (0, 0, 0), shape, gamma))
             probe = st.members[nblocks // 2]
         else:
-            st = NativeBlock(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", rank=rank, world=world, comm_id=None, device=local_rank, arith=arith)
+            st, err = None, None
+            try:
+                st = NativeBlock(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", rank=rank, world=world, comm_id=None, device=local_rank, arith=arith)
+            except Exception as e:      # e.g. hipMalloc of a 512^3 block: said on every rank before any of them enters a collective
+                err = e
+            if not ranks.agree(st is not None):
+                if st is not None:
+                    st.close()
+                raise SystemExit("c5: a rank could not create its block (%r) %s" % (err, bench_launch.NO_RETRY))
             if world > 1:
-                ok = torch.tensor([1], device="cuda")
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                st.connect(native_comm_id(rank, world, device="cuda"))
+                st.use_comm(ranks.process_comm())
             st.upload(blast_block(shape, st.start, st.count, gamma))
             probe = st
         st.step(dt, args.warmup)
@@ -276,11 +268,7 @@ def run_c5_blocks(args):
         st.step(dt, args.steps)
         st.synchronize()
         fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
         probe.profile(True)
         st.step(dt, 3)
         st.synchronize()
@@ -308,9 +296,7 @@ def run_c5_blocks(args):
                    "arith": "fast (headline of this line); strict beside it", "status_word": res["fast"]["status_word"]},
         "roofline": res["fast"]["roofline"], "messages": res["fast"]["messages"], "arith_strict": res["strict"],
     }
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     return out if rank == 0 else None
 
 
@@ -412,7 +398,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loopback-bands", type=int, default=0, help="c3: the mesh as this many bands (objects of one process on one GPU)")
     ap.add_argument("--loopback-blocks", type=int, default=0, help="c5: this many blocks (grid^3 cells each) as objects of one process on one GPU")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="c3 / c5: one process per GPU (this process starts them, bench_launch.py); c4: the compiled host's gpus=N (one process, N devices)")
+    ap.add_argument("--dry-launch", action="store_true", help="c3 / c5 with --gpus N > 1: print the multi-rank child's command line and stop")
+    ap.add_argument("--launch-timeout", type=int, default=900)
+    ap.add_argument("--deadline", type=int, default=600, help="N > 1: seconds after which a rank that is still waiting leaves with status 3")
     args = ap.parse_args()
+    if args.gpus > 1 and args.config in ("c3", "c5") and "WORLD_SIZE" not in os.environ:
+        import bench_launch
+        bench_launch.supervise(__file__, sys.argv[1:], args.gpus, timeout_s=args.launch_timeout, dry=args.dry_launch)
+    if args.dry_launch:
+        raise SystemExit("--dry-launch is for --config c3|c5 --gpus N > 1 without torch.distributed.run in front")
+    if args.config in ("c3", "c5") and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
     import mara3_amd
     lib = mara3_amd.load_library()
     if lib.mh_device_count() < 1:

@@ -187,7 +187,9 @@ typedef struct
     int    tail_chunk_rows;
 } mh_cloud_desc;
 
-/* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] */
+/* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] | per-row factors [nr_global][8] |
+ * per-column factors [nq][8] (the two factor tables are read by MH_ARITH_FAST only: the geometry products of
+ * src/subprog_cloud.cpp:260-290 split into a radial and a polar part) */
 size_t mh_cloud_geometry_doubles(const mh_cloud_desc* d);
 /* Host side: fill that block from the vertex arrays with the reference's libm calls
  * (dmu_j = -cos q_{j+1} - -cos q_j, sin q_j, cot = tan(pi/2 - (q_j + q_{j+1})/2); src/subprog_cloud.cpp:260-290,
@@ -245,6 +247,14 @@ typedef struct mh_slab mh_slab;
 
 /* RCCL unique id (128 bytes) created on one rank; the host distributes it to the others (any transport). */
 int  mh_comm_unique_id(void* id128);
+/* One communicator per PROCESS, lent to the steppers the host builds one after the other (mh_slab_use_comm, mh_block_use_comm,
+ * mh_binary_band_use_comm): ncclCommInitRank is collective and costs hundreds of milliseconds, so a host that sets up several steppers
+ * in a row (bench.py's legs) enters it once. mh_comm_create is collective over `world` ranks; the communicator must outlive every
+ * stepper that borrows it. The reference's analogue is the one thread pool a run creates (src/app_parallel.hpp:75-103 starts its
+ * workers per evaluation; src/subprog_binary_scheme.cpp:12 keeps one). */
+typedef struct mh_comm mh_comm;
+int  mh_comm_create(mh_comm** comm, const void* comm_id128, int rank, int world, int device_id);
+void mh_comm_destroy(mh_comm* comm);
 /* `global`: the description of the WHOLE grid (n[0] = global rows; bc_lo0/bc_hi0 = the physical boundary
  * condition). comm_id128 may be NULL when the rank has no neighbours. self_exchange != 0 with world == 1 and a
  * periodic axis 0 makes the rank exchange with itself (exercises the whole path on one GPU). */
@@ -254,6 +264,8 @@ int  mh_slab_create(mh_slab** slab, const mh_euler_cart_desc* global, int rk_ord
  * succeeded and only then calls mh_slab_connect on all of them (ncclCommInitRank is collective: a rank that failed earlier would
  * leave the others blocked inside it). */
 int  mh_slab_connect(mh_slab* slab, const void* comm_id128);
+/* ... or lend it the process's communicator (same rank / world / device); not collective */
+int  mh_slab_use_comm(mh_slab* slab, mh_comm* comm);
 /* `cloud` sub-program (BASELINE config 4: radial slabs + RCCL halo): CloudProblem::advance / next_solution
  * (src/subprog_cloud.cpp:511-584, :676-697) on rows partition_shape(nr, world)[rank] of the global grid. `global` describes the
  * WHOLE grid (nr == nr_global, row_offset 0); rank 0 keeps the nozzle-inflow boundary, the last rank the zero-gradient one, cut
@@ -313,6 +325,7 @@ typedef struct mh_block mh_block;
 int  mh_block_create(mh_block** block, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int self_exchange,
                      int device_id);          /* self_exchange != 0 with world == 1: periodic axes wrap through RCCL send/recv to self (exercises the exchange on one GPU) */
 int  mh_block_connect(mh_block* block, const void* comm_id128);
+int  mh_block_use_comm(mh_block* block, mh_comm* comm);
 void mh_block_destroy(mh_block* block);
 /* blocks per axis, this block's coordinates, first global cell and cell count per axis (any pointer may be NULL) */
 int  mh_block_extent(const mh_block* block, int blocks_per_axis[3], int coords[3], int start[3], int count[3]);
@@ -493,7 +506,14 @@ int  mh_binary_next(mh_binary* b, int nsteps, int* safe_mode_steps);
 int  mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
                            const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host, int rank, int world,
                            const void* comm_id128, int self_exchange /* world == 1: the RCCL halo and all-reduces, to self */);
+/* comm_id128 == NULL on a band with neighbours defers the communicator to mh_binary_band_use_comm. Both ways of connecting end with the
+ * exchange of the initial solution's ghost rows (collective), so mh_binary_next may follow directly. */
+int  mh_binary_band_use_comm(mh_binary* b, mh_comm* comm);
 int  mh_binary_band_rows(const mh_binary* b, int* row0, int* row1);
+/* What made an attempt of the most recent mh_binary_next call fail (before its safe-mode retry, or before MH_E_PHYSICS): OR of the status
+ * bits of every band and the first failing cell as a flat index into the WHOLE-mesh host array of mh_binary_set_solution; status 0 when
+ * no attempt of that call failed. The same on every band. */
+int  mh_binary_last_failure(const mh_binary* b, mh_step_result* result);
 int  mh_binary_group_create(mh_binary** bands, int world, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv_host,
                             const double* yv_host, const double* u_init_aos_host, const double* buffer_rate_host);
 int  mh_binary_group_set_solution(mh_binary** bands, int world, const double* u_aos_host, const mh_binary_state* state);

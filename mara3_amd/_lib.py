@@ -133,6 +133,9 @@ SYMBOLS = [
     ("mh_comm_unique_id", _i, [_vp]),
     ("mh_slab_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i, _i]),
     ("mh_slab_connect", _i, [_vp, _vp]),
+    ("mh_slab_use_comm", _i, [_vp, _vp]),
+    ("mh_comm_create", _i, [C.POINTER(_vp), _vp, _i, _i, _i]),
+    ("mh_comm_destroy", None, [_vp]),
     ("mh_slab_cloud_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i, _vp, _i]),
     ("mh_slab_set_inflow", _i, [_vp, _vp]),
     ("mh_slab_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
@@ -155,6 +158,7 @@ SYMBOLS = [
     ("mh_slab_profile_read", _i, [_vp, C.POINTER(_d), C.POINTER(_i), C.POINTER(_i)]),
     ("mh_block_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i, _vp, _i, _i]),
     ("mh_block_connect", _i, [_vp, _vp]),
+    ("mh_block_use_comm", _i, [_vp, _vp]),
     ("mh_block_destroy", None, [_vp]),
     ("mh_block_extent", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("mh_block_neighbours", _i, [_vp, C.POINTER(_i), C.POINTER(_sz)]),
@@ -206,6 +210,8 @@ SYMBOLS = [
     ("mh_binary_next", _i, [_vp, _i, C.POINTER(_i)]),
     ("mh_binary_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp, _i, _i, _vp, _i]),
     ("mh_binary_band_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("mh_binary_band_use_comm", _i, [_vp, _vp]),
+    ("mh_binary_last_failure", _i, [_vp, C.POINTER(StepResult)]),
     ("mh_binary_group_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
     ("mh_binary_group_set_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),
     ("mh_binary_group_get_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),

@@ -217,6 +217,12 @@ class BinarySolver:
     def last_dt(self):
         return self.lib.mh_binary_last_dt(self.handle)
 
+    def last_failure(self):
+        """(status bits, whole-mesh flat index of the first failing cell or None) of a failed attempt of the most recent next() call"""
+        r = L.StepResult()
+        L.check(self.lib.mh_binary_last_failure(self.handle, C.byref(r)))
+        return r.status, (None if r.status == 0 else int(r.first_bad_index))
+
     def disk_totals(self):
         """binary::disk_mass, binary::disk_angular_momentum (subprog_binary_diagnostics.cpp:21-46), reduced on the device."""
         m, l = C.c_double(), C.c_double()
@@ -352,6 +358,16 @@ class BinaryBandGroup:
     def last_dt(self):
         return self.lib.mh_binary_last_dt(C.c_void_p(self.handles[0]))
 
+    def last_failure(self):
+        """as BinarySolver.last_failure; the same record on every member"""
+        recs = []
+        for r in range(self.world):
+            res = L.StepResult()
+            L.check(self.lib.mh_binary_last_failure(C.c_void_p(self.handles[r]), C.byref(res)))
+            recs.append((res.status, None if res.status == 0 else int(res.first_bad_index)))
+        assert all(x == recs[0] for x in recs), recs
+        return recs[0]
+
     def close(self):
         # member 0 owns the stream the others run on: destroy it last
         for r in reversed(range(self.world)):
@@ -371,7 +387,9 @@ class BinaryBand(BinarySolver):
     mara3_amd.slab.native_comm_id). next() is collective over the ranks; solution() returns the whole-mesh array with this band's rows
     filled in (rows [row0, row1))."""
 
-    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict", self_exchange=False):
+    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict", self_exchange=False, comm=None, defer=False):
+        """comm: the process's communicator (mara3_amd.slab.NativeComm) instead of a unique id - no ncclCommInitRank of its own.
+        defer=True: neither; the caller attach()es the communicator once every rank holds its band."""
         self.lib = L.load_library()
         self.cfg = cfg
         self.n = grid_size(cfg)
@@ -395,6 +413,18 @@ class BinaryBand(BinarySolver):
         a, b = C.c_int(), C.c_int()
         L.check(self.lib.mh_binary_band_rows(self.handle, C.byref(a), C.byref(b)))
         self.row0, self.row1 = a.value, b.value
+        if comm is not None:
+            self.attach(comm)
+        elif not defer:
+            self._start()
+
+    def attach(self, comm):
+        """lend the band the process's communicator (ends with the exchange of the initial ghost rows: collective), then start from the initial state"""
+        L.check(self.lib.mh_binary_band_use_comm(self.handle, comm.handle))
+        self._comm = comm
+        self._start()
+
+    def _start(self):
         s = L.BinaryState()
-        s.orbital_elements = initial_elements(cfg)
+        s.orbital_elements = initial_elements(self.cfg)
         self.set_solution(None, s)

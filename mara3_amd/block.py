@@ -40,6 +40,11 @@ class NativeBlock:
     def connect(self, comm_id):
         L.check(self.lib.mh_block_connect(self.handle, C.create_string_buffer(bytes(comm_id), 128)))
 
+    def use_comm(self, comm):
+        """lend the block the process's communicator (mara3_amd.slab.NativeComm); not collective"""
+        L.check(self.lib.mh_block_use_comm(self.handle, comm.handle))
+        self._comm = comm
+
     def slices(self):
         return tuple(slice(s, s + k) for s, k in zip(self.start, self.count))
 

@@ -111,7 +111,11 @@ struct mh_binary
     mh_binary* peer_hi = nullptr;
     ncclComm_t comm = nullptr;
     bool owns_stream = true;                         // loopback members run on the first member's stream
+    bool owns_comm = true;                           // false: borrowed from an mh_comm (mh_binary_band_use_comm)
     double* reduced_dev = nullptr;                   // RCCL: the small block summed over the ranks (out of place: the local one stays local)
+    uint32_t* gather_dev = nullptr;                  // RCCL: every rank's two status words {bits, 0xFFFFFFFF - first failing whole-mesh index}
+    uint32_t* gather_host = nullptr;                 // pinned mirror of it
+    mh_step_result last_failure = {0, 0, UINT64_MAX};            // of the most recent failed attempt (mh_binary_last_failure)
 };
 
 enum { BAND_NONE = 0, BAND_RCCL = 1, BAND_LOOPBACK = 2 };
@@ -196,6 +200,15 @@ static int team_exchange(const Team& t, int k)
     return MH_OK;
 }
 
+// the merged status words of a FAILED attempt as the boundary's error pair; kept on every member until the next mh_binary_next call
+static void team_note_status(const Team& t)
+{
+    const HostMirror& m = *t.m[0]->mirror;
+    if (! m.status[0]) return;
+    const mh_step_result res = {m.status[0], 0, (uint64_t) (0xFFFFFFFFu - (uint32_t) m.status[1])};
+    for (int r = 0; r < t.n; ++r) t.m[r]->last_failure = res;
+}
+
 // bring the small block (2 x 18 totals, maximum wavespeed, status words) to the host of every member - summed / maximised over the bands
 static int team_fetch(const Team& t)
 {
@@ -210,12 +223,28 @@ static int team_fetch(const Team& t)
             const size_t nt = 2 * MH_BINARY_NTOTALS;
             MH_RCCL_TRY(api->AllReduce(b->dev_small, b->reduced_dev, nt, ncclDouble, ncclSum, b->comm, b->stream));
             MH_RCCL_TRY(api->AllReduce(b->dev_small + nt, b->reduced_dev + nt, 1, ncclUint64, ncclMax, b->comm, b->stream));     // wavespeeds are > 0: bit order = value order
-            MH_RCCL_TRY(api->AllReduce(b->dev_small + nt + 1, b->reduced_dev + nt + 1, 2, ncclUint32, ncclMax, b->comm, b->stream));   // largest status word / earliest cell of any rank
+            // status words: the bits are an OR, which no RCCL reduction forms (a max of {NEG_DENSITY} and {NAN} would drop the former), so
+            // every rank's pair is gathered and merged on the host below, exactly as the loopback members' are
+            MH_RCCL_TRY(api->AllGather(b->dev_small + nt + 1, b->gather_dev, 2, ncclUint32, b->comm, b->stream));
+            MH_HIP_TRY(hipMemcpyAsync(b->gather_host, b->gather_dev, (size_t) b->world * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
             src = b->reduced_dev;
         }
         MH_HIP_TRY(hipMemcpyAsync(b->mirror, src, sizeof(HostMirror), hipMemcpyDeviceToHost, b->stream));
     }
     for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipStreamSynchronize(t.m[r]->stream));
+    for (int r = 0; r < t.n; ++r)
+    {
+        mh_binary* b = t.m[r];
+        if (! (b->banded && b->backend == BAND_RCCL)) continue;
+        uint32_t bits = 0, key = 0;               // the kernels' keys are whole-mesh already: (row0 + r) n + col (binary.hip)
+        for (int q = 0; q < b->world; ++q)
+        {
+            bits |= b->gather_host[2 * q];
+            if (b->gather_host[2 * q + 1] > key) key = b->gather_host[2 * q + 1];
+        }
+        b->mirror->status[0] = (int32_t) bits;
+        b->mirror->status[1] = (int32_t) key;
+    }
     if (t.n > 1)
     {
         // loopback: the members' blocks are summed here, in band order
@@ -230,6 +259,7 @@ static int team_fetch(const Team& t)
         }
         for (int r = 0; r < t.n; ++r) *t.m[r]->mirror = sum;
     }
+    team_note_status(t);
     return MH_OK;
 }
 
@@ -333,6 +363,7 @@ static int team_next(const Team& t, int nsteps, int* safe_mode_steps)
 {
     mh_binary* b = t.m[0];
     if (safe_mode_steps) *safe_mode_steps = 0;
+    for (int r = 0; r < t.n; ++r) t.m[r]->last_failure = {0, 0, UINT64_MAX};
     for (int s = 0; s < nsteps; ++s)
     {
         // dt: subprog_binary.cpp:281-283
@@ -458,7 +489,12 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
     B_TRY(hipMemsetAsync(b->dev_small, 0, sizeof(HostMirror), b->stream));
     b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
-    if (b->backend == BAND_RCCL) B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
+    if (b->backend == BAND_RCCL)
+    {
+        B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
+        B_TRY(hipMalloc(&b->gather_dev, (size_t) world * 2 * sizeof(uint32_t)));
+        B_TRY(hipHostMalloc((void**) &b->gather_host, (size_t) world * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    }
     B_TRY(hipMalloc(&b->staging, n0 * n * 3 * sizeof(double)));
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
     B_TRY(hipMemcpyAsync(b->xv, xv, (n + 1) * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -476,6 +512,15 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     return MH_OK;
 }
 
+// the ghost rows of the initial solution (collective over the ranks, like the communicator it needs): a caller may step right after create
+static int band_initial_exchange(mh_binary* b)
+{
+    mh_binary* m[1] = {b};
+    if (int rc = team_exchange(Team{m, 1}, 0)) return rc;
+    MH_HIP_TRY(hipStreamSynchronize(b->stream));
+    return MH_OK;
+}
+
 int mh_binary_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const double* xv, const double* yv,
                      const double* u_init_aos, const double* br)
 {
@@ -487,16 +532,41 @@ int mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, 
 {
     mh_binary* b = nullptr;
     if (int rc = binary_create_common(&b, device, d, run, xv, yv, u_init_aos, br, rank, world, BAND_RCCL, nullptr, world == 1 && self_exchange)) return rc;
-    if (b->banded)
+    // comm_id128 == NULL on a band with neighbours defers the communicator (mh_binary_band_use_comm), as mh_slab_create does
+    if (b->banded && comm_id128)
     {
         RcclApi* api = rccl();
-        if (! api || ! comm_id128) { mh_binary_destroy(b); set_error("binary bands: RCCL not available or no unique id given"); return MH_E_STATE; }
+        if (! api) { mh_binary_destroy(b); set_error("binary bands: librccl.so.1 could not be loaded"); return MH_E_STATE; }
         ncclUniqueId id;
         memcpy(&id, comm_id128, sizeof id);
         ncclResult_t r = api->CommInitRank(&b->comm, world, id, rank);
         if (r != ncclSuccess) { mh_binary_destroy(b); return rccl_fail(r, "ncclCommInitRank"); }
+        if (int rc = band_initial_exchange(b)) { mh_binary_destroy(b); return rc; }
     }
     *out = b;
+    return MH_OK;
+}
+
+int mh_binary_band_use_comm(mh_binary* b, mh_comm* c)
+{
+    if (! b || ! c) return MH_E_INVALID;
+    if (! b->banded) return MH_OK;
+    if (b->backend != BAND_RCCL) { set_error("mh_binary_band_use_comm: not an RCCL band"); return MH_E_STATE; }
+    if (b->comm) { set_error("mh_binary_band_use_comm: the band has a communicator already"); return MH_E_STATE; }
+    if (c->world != b->world || c->rank != b->rank || c->device != b->device)
+    {
+        set_error("mh_binary_band_use_comm: communicator is rank %d of %d on device %d, the band rank %d of %d on device %d", c->rank, c->world, c->device, b->rank, b->world, b->device);
+        return MH_E_INVALID;
+    }
+    b->comm = c->comm;
+    b->owns_comm = false;
+    return band_initial_exchange(b);
+}
+
+int mh_binary_last_failure(const mh_binary* b, mh_step_result* result)
+{
+    if (! b || ! result) return MH_E_INVALID;
+    *result = b->last_failure;
     return MH_OK;
 }
 
@@ -599,7 +669,9 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals); (void) hipFree(b->work.tile_maxw);
     if (b->mirror) (void) hipHostFree(b->mirror);
     (void) hipFree(b->reduced_dev);
-    if (b->comm && rccl()) rccl()->CommDestroy(b->comm);
+    (void) hipFree(b->gather_dev);
+    if (b->gather_host) (void) hipHostFree(b->gather_host);
+    if (b->comm && b->owns_comm && rccl()) rccl()->CommDestroy(b->comm);
     if (b->stream && b->owns_stream) (void) hipStreamDestroy(b->stream);
     delete b;
 }

@@ -54,6 +54,7 @@ struct mh_block
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t ev_shell = nullptr, ev_interior = nullptr, ev_copied = nullptr, join = nullptr;
     ncclComm_t comm = nullptr;
+    bool owns_comm = true;            // false: borrowed from an mh_comm (mh_block_use_comm)
     mh_block* peer[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     double* cur_out = nullptr;
     bool profile = false;
@@ -366,6 +367,22 @@ int mh_block_connect(mh_block* b, const void* comm_id128)
     return MH_OK;
 }
 
+int mh_block_use_comm(mh_block* b, mh_comm* c)
+{
+    if (! b || ! c) return MH_E_INVALID;
+    if (! block_has_neighbours(b)) return MH_OK;
+    if (b->backend != BLOCK_EXCHANGE_RCCL) { set_error("mh_block_use_comm: not an RCCL block"); return block_fail(b, MH_E_STATE); }
+    if (b->comm) { set_error("mh_block_use_comm: the block has a communicator already"); return block_fail(b, MH_E_STATE); }
+    if (c->world != b->world || c->rank != b->rank || c->device != b->device)
+    {
+        set_error("mh_block_use_comm: communicator is rank %d of %d on device %d, the block rank %d of %d on device %d", c->rank, c->world, c->device, b->rank, b->world, b->device);
+        return block_fail(b, MH_E_INVALID);
+    }
+    b->comm = c->comm;
+    b->owns_comm = false;
+    return MH_OK;
+}
+
 int mh_block_create(mh_block** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world, const void* comm_id128, int self_exchange,
                     int device_id)
 {
@@ -398,7 +415,7 @@ void mh_block_destroy(mh_block* b)
     hipSetDevice(b->device);
     if (b->main) hipStreamSynchronize(b->main);
     if (b->side) hipStreamSynchronize(b->side);
-    if (b->comm && rccl()) rccl()->CommDestroy(b->comm);
+    if (b->comm && b->owns_comm && rccl()) rccl()->CommDestroy(b->comm);
     for (auto& v : b->events) for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& f : b->field) if (f) hipFree(f);
     for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) { if (b->sendbuf[a][s]) hipFree(b->sendbuf[a][s]); if (b->recvbuf[a][s]) hipFree(b->recvbuf[a][s]); }

@@ -18,6 +18,7 @@ struct RcclApi
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -25,5 +26,12 @@ RcclApi* rccl();                                        // nullptr when librccl 
 int rccl_fail(ncclResult_t r, const char* what);        // sets the thread's error text, returns MH_E_HIP
 
 } // namespace mh
+
+// A communicator the host creates once per process and lends to the steppers it builds (mh_comm_create / mh_*_use_comm, slab.hip)
+struct mh_comm
+{
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
 
 #define MH_RCCL_TRY(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) return mh::rccl_fail(_r, #call); } while (0)

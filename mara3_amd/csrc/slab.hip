@@ -55,9 +55,10 @@ RcclApi* rccl()
             MH_SYM(Send, "ncclSend");
             MH_SYM(Recv, "ncclRecv");
             MH_SYM(AllReduce, "ncclAllReduce");
+            MH_SYM(AllGather, "ncclAllGather");
             MH_SYM(GetErrorString, "ncclGetErrorString");
 #undef MH_SYM
-            if (! (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv && api.AllReduce))
+            if (! (api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv && api.AllReduce && api.AllGather))
             {
                 dlclose(api.handle);
                 api.handle = nullptr;
@@ -102,6 +103,7 @@ struct mh_slab
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t ev_edge = nullptr, ev_interior = nullptr, join = nullptr;
     ncclComm_t comm = nullptr;
+    bool owns_comm = true;                       // false: borrowed from an mh_comm (mh_slab_use_comm)
     mh_slab* peer_lo = nullptr;                  // EXCHANGE_LOOPBACK: the neighbour objects
     mh_slab* peer_hi = nullptr;
     hipEvent_t ev_copied = nullptr;              // EXCHANGE_LOOPBACK: this slab's copies out of its peers' rows have completed
@@ -477,9 +479,16 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
         for (mh_slab* p : {slabs[r]->peer_lo, slabs[r]->peer_hi})
             if (p && p->device != slabs[r]->device)
             {
-                MH_HIP_TRY(hipSetDevice(slabs[r]->device));
-                const hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_fail(e, "hipDeviceEnablePeerAccess");
+                hipError_t e = hipSetDevice(slabs[r]->device);
+                if (e == hipSuccess) e = hipDeviceEnablePeerAccess(p->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                {
+                    const int rc = hip_fail(e, "hipDeviceEnablePeerAccess");      // the error text before the destructors' own HIP calls
+                    const std::string text = mh_last_error(nullptr);
+                    for (int q = 0; q < world; ++q) { mh_slab_destroy(slabs[q]); slabs[q] = nullptr; }
+                    set_error("%s", text.c_str());
+                    return rc;
+                }
                 (void) hipGetLastError();
             }
     }
@@ -537,6 +546,46 @@ int mh_slab_connect(mh_slab* s, const void* comm_id128)
     return MH_OK;
 }
 
+int mh_comm_create(mh_comm** out, const void* comm_id128, int rank, int world, int device_id)
+{
+    if (! out || ! comm_id128 || world < 1 || rank < 0 || rank >= world) return MH_E_INVALID;
+    RcclApi* api = rccl();
+    if (! api) { set_error("librccl.so.1 could not be loaded"); return MH_E_STATE; }
+    MH_HIP_TRY(hipSetDevice(device_id));
+    ncclUniqueId id;
+    std::memcpy(&id, comm_id128, sizeof id);
+    mh_comm* c = new mh_comm;
+    c->rank = rank; c->world = world; c->device = device_id;
+    ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return rccl_fail(r, "ncclCommInitRank"); }
+    *out = c;
+    return MH_OK;
+}
+
+void mh_comm_destroy(mh_comm* c)
+{
+    if (! c) return;
+    hipSetDevice(c->device);
+    if (c->comm && rccl()) rccl()->CommDestroy(c->comm);
+    delete c;
+}
+
+int mh_slab_use_comm(mh_slab* s, mh_comm* c)
+{
+    if (! s || ! c) return MH_E_INVALID;
+    if (! has_neighbours(s)) return MH_OK;
+    if (s->backend != EXCHANGE_RCCL) { set_error("mh_slab_use_comm: not an RCCL slab"); return slab_fail(s, MH_E_STATE); }
+    if (s->comm) { set_error("mh_slab_use_comm: the slab has a communicator already"); return slab_fail(s, MH_E_STATE); }
+    if (c->world != s->world || c->rank != s->rank || c->device != s->device)
+    {
+        set_error("mh_slab_use_comm: communicator is rank %d of %d on device %d, the slab rank %d of %d on device %d", c->rank, c->world, c->device, s->rank, s->world, s->device);
+        return slab_fail(s, MH_E_INVALID);
+    }
+    s->comm = c->comm;
+    s->owns_comm = false;
+    return MH_OK;
+}
+
 int mh_slab_create(mh_slab** out, const mh_euler_cart_desc* global, int rk_order, int rank, int world,
                    const void* comm_id128, int self_exchange, int device_id)
 {
@@ -589,7 +638,7 @@ void mh_slab_destroy(mh_slab* s)
     if (s->main) hipStreamSynchronize(s->main);
     if (s->side) hipStreamSynchronize(s->side);
     if (s->exec) hipGraphExecDestroy(s->exec);
-    if (s->comm && rccl()) rccl()->CommDestroy(s->comm);
+    if (s->comm && s->owns_comm && rccl()) rccl()->CommDestroy(s->comm);
     for (auto& v : s->events) for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& f : s->field) if (f) hipFree(f);
     if (s->staging) hipFree(s->staging);
@@ -666,6 +715,7 @@ int mh_slab_group_download(mh_slab** g, int n, double* u_aos_global_host)
 int mh_slab_set_inflow(mh_slab* s, const double* inflow_prims_aos_host)
 {
     if (! s || s->kind != SLAB_CLOUD || ! inflow_prims_aos_host) { set_error("mh_slab_set_inflow: not a cloud slab"); return MH_E_STATE; }
+    if (s->row0 != 0) return MH_OK;              // only the slab that owns the nozzle-side boundary reads the row
     MH_HIP_TRY(hipSetDevice(s->device));
     const size_t nq = (size_t) s->n1;
     std::vector<double> soa(5 * nq);

@@ -100,9 +100,11 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     F[4] = v * (U[4] + p);
     const double c2 = g.gamma * p * rH;
     const double v2 = v * v;
-    // sqrt(x) = x rsqrt(x) without the correction step (an ulp or two: it only enters the signal speeds); x == 0 gives 0 * inf, which fmax turns into 0
+    // sqrt(x) = x rsqrt(x) without the correction step (an ulp or two: it only enters the signal speeds). x == 0 would give 0 * inf and is
+    // answered with 0; a NEGATIVE or NaN radicand (an unphysical face state: c2 outside [0, 1]) stays NaN, as the reference's sqrt makes it
+    // (src/physics_srhd.hpp:283-295) - riemann_hlle below carries it into the flux, so the next recover_primitive raises MH_STATUS_NAN
     const double k2 = c2 * (1 - vv) * (1 - vv * c2 - v2 * (1 - c2));
-    const double k0 = __builtin_fmax(k2 * fast::rsqrt_fast(k2), 0.0);
+    const double k0 = k2 == 0.0 ? 0.0 : k2 * fast::rsqrt_fast(k2);
     const double rden = H * H * rHB;
     const double a = v * (1 - c2);
     lam_m = (a - k0) * rden;
@@ -118,7 +120,10 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     const double ap = __builtin_fmax(0.0, __builtin_fmax(alp, arp));
     const double am = __builtin_fmin(0.0, __builtin_fmin(alm, arm));
     const double rden = fast::rcp_nr(ap - am);
-    const double wl = ap * rden, wr = am * rden, wu = wl * am;       // the three weights divided once (euler_device_fast.hpp)
+    // fmax / fmin drop a NaN signal speed (v_max_f64 returns the other operand); it re-enters through the weight of the jump term,
+    // so an invalid face state poisons the whole flux instead of being stepped over
+    const double poison = (alm + arm) * 0.0;
+    const double wl = ap * rden, wr = am * rden, wu = __builtin_fma(wl, am, poison);       // the three weights divided once (euler_device_fast.hpp)
     State5 F;
 #pragma unroll
     for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));

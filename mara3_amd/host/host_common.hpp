@@ -25,6 +25,13 @@ template<typename F> double time_ms(F&& f)
     return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
 }
 
+inline std::string hex_word(unsigned v)
+{
+    char buf[16];
+    std::snprintf(buf, sizeof buf, "0x%x", v);
+    return buf;
+}
+
 // A device stage cannot throw: it leaves status bits and the first failing cell (mh_step_result, include/mara_hip.h). Any bit ends the
 // run here with the exception the reference would have thrown for it - mara::srhd::recover_primitive's std::invalid_argument and its
 // four texts (src/physics_srhd.hpp:430-449) for the relativistic system; for mara::euler, whose recover_primitive never throws
@@ -32,7 +39,7 @@ template<typename F> double time_ms(F&& f)
 inline void throw_on_result(const mh_step_result& r, int system = MH_SYSTEM_EULER)
 {
     if (r.status == 0) return;
-    const std::string where = " (first failing cell: flat index " + std::to_string((unsigned long long) r.first_bad_index) + ", device status 0x" + std::to_string(r.status) + ")";
+    const std::string where = " (first failing cell: flat index " + std::to_string((unsigned long long) r.first_bad_index) + ", device status " + hex_word((unsigned) r.status) + ")";
     if (system == MH_SYSTEM_SRHD)
     {
         const std::string head = "mara::srhd::recover_primitive failure: ";

@@ -402,6 +402,11 @@ class NativeSlabStepper:
     def connect(self, comm_id):
         L.check(self.lib.mh_slab_connect(self.handle, C.create_string_buffer(bytes(comm_id), 128)))
 
+    def use_comm(self, comm):
+        """lend the slab the process's communicator (NativeComm); not collective"""
+        L.check(self.lib.mh_slab_use_comm(self.handle, comm.handle))
+        self._comm = comm          # keeps it alive
+
     def load_slab(self, u_aos_slab):
         u = self.np.ascontiguousarray(u_aos_slab, dtype=self.np.float64)
         assert u.shape == self.slab_shape, (u.shape, self.slab_shape)
@@ -466,18 +471,37 @@ def native_comm_id(rank, world, device=None):
     return bytes(t.cpu().tolist())
 
 
+class NativeComm:
+    """One RCCL communicator per process (mh_comm_create), lent to every stepper the process builds (use_comm): the collective
+    ncclCommInitRank is entered once. `comm_id` as for NativeSlabStepper (native_comm_id). Collective over the ranks."""
+
+    def __init__(self, comm_id, rank, world, device=0):
+        self.lib = L.load_library()
+        self.handle = C.c_void_p()
+        self.rank, self.world, self.device = rank, world, device
+        L.check(self.lib.mh_comm_create(C.byref(self.handle), C.create_string_buffer(bytes(comm_id), 128), rank, world, device))
+
+    def close(self):
+        if self.handle:
+            self.lib.mh_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class NativeSlabGroup:
     """All `world` slabs of a decomposition as objects of ONE process on one GPU, exchanging ghost rows through the native stepper's
     LOOPBACK backend (stream-ordered device-to-device copies under the event protocol of the RCCL ranks; include/mara_hip.h,
     mh_slab_group_*). Euler (2-D, 3-D) with global_shape / dl, or the `cloud` grid with r_vertices / q_vertices."""
 
     def __init__(self, global_shape=None, dl=None, gamma=5.0 / 3, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow", world=2,
-                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8):
+                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8, devices=None):
+        """devices: one device id per member (mh_slab_group_create_on: ONE process driving several GPUs, receives as peer copies)"""
         import numpy as np
         self.np = np
         self.lib = L.load_library()
         self.world = world
         self.handles = (C.c_void_p * world)()
+        ids = (C.c_int * world)(*[int(x) for x in devices]) if devices is not None else None
+        assert devices is None or len(devices) == world
         self.cloud = r_vertices is not None
         if self.cloud:
             rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
@@ -486,12 +510,19 @@ class NativeSlabGroup:
             d = L.CloudDesc(nr=nr, nq=nq, nr_global=nr, row_offset=0, gamma=gamma, plm_theta=plm_theta, temperature_floor=temperature_floor,
                             bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith],
                             chunk_rows=chunk_rows)
-            L.check(self.lib.mh_slab_cloud_group_create(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
-                                                        rk_order, world, device))
+            if ids is not None:
+                L.check(self.lib.mh_slab_cloud_group_create_on(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
+                                                               rk_order, world, ids))
+            else:
+                L.check(self.lib.mh_slab_cloud_group_create(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
+                                                            rk_order, world, device))
             self.global_shape = (nr, nq)
         else:
             d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
-            L.check(self.lib.mh_slab_group_create(self.handles, C.byref(d), rk_order, world, device))
+            if ids is not None:
+                L.check(self.lib.mh_slab_group_create_on(self.handles, C.byref(d), rk_order, world, ids))
+            else:
+                L.check(self.lib.mh_slab_group_create(self.handles, C.byref(d), rk_order, world, device))
             self.global_shape = tuple(global_shape)
         self.rows = []
         for r in range(world):

@@ -226,3 +226,79 @@ def test_binary_band_rccl_halo_and_allreduce_to_self():
         assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
         assert binary.state_as_dict(band.state()) == binary.state_as_dict(one.state())
     one.close(); band.close()
+
+
+def test_one_communicator_per_process_is_lent_to_every_stepper():
+    """bench.py at N > 1 enters ncclCommInitRank ONCE per process (mh_comm_create) and lends the communicator to the stepper of every leg
+    (mh_slab_use_comm / mh_block_use_comm / mh_binary_band_use_comm). Here with the exchange going to self: two slabs one after the other,
+    a block and a band all run on the same communicator, each bit-identical to the single-domain solver, and the communicator outlives
+    them; a stepper of another rank / world is refused."""
+    import numpy as np
+    import mara3_amd
+    from mara3_amd import setups, binary
+    from mara3_amd.slab import NativeSlabStepper, NativeComm, native_comm_id
+    from mara3_amd.block import NativeBlock
+    from mara3_amd.engine import EulerCartSolver
+    comm = NativeComm(native_comm_id(0, 1), 0, 1, device=0)
+    shape, gamma = (128, 200), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=11)
+    for riemann, arith in (("hllc", "fast"), ("hlle", "strict")):
+        ref = EulerCartSolver(shape, dl, gamma, 1.5, riemann, 2, "periodic", arith=arith)
+        ref.upload(u0); ref.step(1e-3, 4)
+        st = NativeSlabStepper(shape, dl, gamma, 1.5, riemann, 2, "periodic", rank=0, world=1, arith=arith, comm_id=None, self_exchange=True)
+        st.use_comm(comm)
+        with pytest.raises(mara3_amd.MaraHipError, match="already"):
+            st.use_comm(comm)
+        st.load_slab(u0); st.step(1e-3, 4); st.synchronize()
+        assert np.array_equal(st.slab_host().view(np.uint64), ref.download().view(np.uint64))
+        st.close(); ref.close()
+    shape3 = (24, 16, 70)
+    dl3 = tuple(1.0 / n for n in shape3)
+    u3 = setups.wave_ic(shape3, gamma, seed=13)
+    ref = EulerCartSolver(shape3, dl3, gamma, 1.5, "hllc", 2, "periodic", arith="fast")
+    ref.upload(u3); ref.step(1e-3, 3)
+    blk = NativeBlock(shape3, dl3, gamma, 1.5, "hllc", 2, "periodic", rank=0, world=1, comm_id=None, arith="fast", self_exchange=True)
+    blk.use_comm(comm)
+    blk.upload(u3); blk.step(1e-3, 3); blk.synchronize()
+    assert np.array_equal(blk.download().view(np.uint64), ref.download().view(np.uint64))
+    blk.close(); ref.close()
+    cfg = binary.config(depth=2, block_size=16)
+    one = binary.BinarySolver(cfg)
+    band = binary.BinaryBand(cfg, 0, 1, None, self_exchange=True, defer=True)
+    band.attach(comm)
+    assert one.next(3) == 0 and band.next(3) == 0
+    assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
+    assert binary.state_as_dict(band.state()) == binary.state_as_dict(one.state())
+    one.close(); band.close()
+    comm.close()
+
+
+def test_binary_band_steps_right_after_create_and_reports_the_failing_cell_of_the_whole_mesh():
+    """(i) A band created with a unique id exchanges the ghost rows of the initial solution itself (a C caller may call mh_binary_next
+    right after mh_binary_band_create). (ii) The status of a failed attempt is the OR of every band's bits with the first failing cell as
+    an index into the WHOLE-mesh host array (mh_binary_last_failure), the same through the RCCL gather and through the loopback merge."""
+    import numpy as np
+    from mara3_amd import binary
+    from mara3_amd import _lib as L
+    from mara3_amd.slab import native_comm_id
+    cfg = binary.config(depth=2, block_size=16, fixed_dt=1)
+    one = binary.BinarySolver(cfg)
+    band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), self_exchange=True)
+    grp = binary.BinaryBandGroup(cfg, world=4)
+    assert one.last_failure() == (0, None)
+    u = one.solution()
+    u[50, 20, 0] = 1e-14          # nearly empty cell next to full ones: the PLM step drives it negative (row 50 = band 3 of 4)
+    u[50, 20, 1:] = 0.0
+    s = one.state()
+    for solver in (one, band, grp):
+        solver.set_solution(u, s)
+    safe = [solver.next(1) for solver in (one, band, grp)]
+    assert safe[0] == 1 and safe == [safe[0]] * 3
+    fails = [solver.last_failure() for solver in (one, band, grp)]
+    assert fails[0][0] == L.STATUS_NEG_DENSITY and fails[0][1] is not None and fails[0][1] // 64 in range(48, 53)
+    assert fails[1] == fails[0] and fails[2] == fails[0]
+    assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
+    assert np.array_equal(grp.solution().view(np.uint64), one.solution().view(np.uint64))
+    assert one.next(1) == 0 and one.last_failure() == (0, None)
+    one.close(); band.close(); grp.close()
