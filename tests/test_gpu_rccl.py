@@ -274,10 +274,10 @@ def test_one_communicator_per_process_is_lent_to_every_stepper():
     comm.close()
 
 
-def test_binary_band_steps_right_after_create_and_reports_the_failing_cell_of_the_whole_mesh():
-    """(i) A band created with a unique id exchanges the ghost rows of the initial solution itself (a C caller may call mh_binary_next
-    right after mh_binary_band_create). (ii) The status of a failed attempt is the OR of every band's bits with the first failing cell as
-    an index into the WHOLE-mesh host array (mh_binary_last_failure), the same through the RCCL gather and through the loopback merge."""
+def test_binary_bands_report_the_failing_cell_of_the_whole_mesh():
+    """The status of a failed attempt is the OR of every band's bits with the first failing cell as an index into the WHOLE-mesh host
+    array (mh_binary_last_failure) - the same from the single-domain solver, through the RCCL gather of the bands' status words (here
+    over one rank) and through the loopback merge of four bands; the collective safe-mode retry then lands on the same bits."""
     import numpy as np
     from mara3_amd import binary
     from mara3_amd import _lib as L
@@ -287,18 +287,30 @@ def test_binary_band_steps_right_after_create_and_reports_the_failing_cell_of_th
     band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), self_exchange=True)
     grp = binary.BinaryBandGroup(cfg, world=4)
     assert one.last_failure() == (0, None)
-    u = one.solution()
-    u[50, 20, 0] = 1e-14          # nearly empty cell next to full ones: the PLM step drives it negative (row 50 = band 3 of 4)
-    u[50, 20, 1:] = 0.0
+    base = one.solution()
     s = one.state()
+    for boost in (10.0, 30.0, 100.0, 300.0):      # a hole next to a fast stream (as test_gpu_binary.py::test_safe_mode_retry), in band 3 of 4
+        u = base.copy()
+        u[50, 20, 0] *= 1e-2
+        u[50, 21, 1:] *= boost
+        u[51, 20, 1:] *= boost
+        one.set_solution(u, s)
+        try:
+            if one.next(1) == 1:
+                break
+        except Exception:
+            pass
+    else:
+        pytest.fail("no test state made the ordinary step fail")
     for solver in (one, band, grp):
         solver.set_solution(u, s)
     safe = [solver.next(1) for solver in (one, band, grp)]
-    assert safe[0] == 1 and safe == [safe[0]] * 3
+    assert safe == [1, 1, 1]
     fails = [solver.last_failure() for solver in (one, band, grp)]
     assert fails[0][0] == L.STATUS_NEG_DENSITY and fails[0][1] is not None and fails[0][1] // 64 in range(48, 53)
     assert fails[1] == fails[0] and fails[2] == fails[0]
     assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
     assert np.array_equal(grp.solution().view(np.uint64), one.solution().view(np.uint64))
+    one.set_solution(base, s)                   # a clean call clears the record
     assert one.next(1) == 0 and one.last_failure() == (0, None)
     one.close(); band.close(); grp.close()
