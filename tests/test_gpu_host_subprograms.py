@@ -423,3 +423,41 @@ def test_output_files_hold_what_the_reference_tools_read(tmp_path):
     rc = hdr[hdr.index('GROUP "run_config"'):]
     for item in ("mass_ratio", "eccentricity", "disk_mass", "begin_live_binary"):
         assert 'DATASET "%s"' % item in rc, item
+
+
+H5_REF = os.path.join(ROOT, "oracle", "_ref", "h5_ref")
+H5_REF_ENV = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu")
+
+
+def _h5dump_all(path):
+    out = subprocess.run([H5DUMP, "-m", "%.17g", path], check=True, capture_output=True, text=True).stdout
+    return out.split("\n", 1)[1]
+
+
+@pytest.mark.skipif(not (os.path.exists(H5DUMP) and os.path.exists(H5_REF)), reason="needs h5dump and the prebuilt oracle/_ref/h5_ref")
+@pytest.mark.parametrize("prog", ["sedov", "cloud"])
+def test_checkpoints_pass_through_the_reference_readers_and_writers_and_restart_from_its_file(tmp_path, prog):
+    """The file a real run of `mara_hip` writes is READ by the reference's own read_solution / read_schedule / read_config
+    (src/subprog_sedov.cpp:338-346, src/subprog_cloud.cpp:599-609, src/app_serialize.hpp:72-113) and WRITTEN again by its
+    write_solution / write_schedule / write_config (oracle/_ref/h5_ref, the reference's headers): the reference's file is the same file
+    (h5dump: every type, dataspace and value), and `mara_hip ... restart=<the reference-written file>` ends bit for bit where the
+    uninterrupted run ends."""
+    if prog == "sedov":
+        g = golden("sedov_newtonian_nr256")
+        dt = 0.4 * (g["vertices"][1] - g["vertices"][0])
+        args = ["sedov", "newtonian=1", "nr=256", "outer_radius=100", "tfinal=%r" % float(99.5 * dt), "cpi=%r" % float(8.5 * dt)]
+        more = []
+    else:
+        g = golden("cloud_nr32_plm_rk2")
+        args = ["cloud", "nr=32", "num_decades=1", "rk_order=2", "max_steps=3", "cpi=%r" % float(0.5 * float(g["dt"])), "dfi=0"]
+        more = ["max_steps=3"]
+    run(args + ["outdir=a"], str(tmp_path))
+    a = read_dump(os.path.join(tmp_path, "a", "final.bin"))
+    ours = os.path.join(tmp_path, "a", "chkpt.0001.h5")
+    spec, theirs = os.path.join(tmp_path, "spec.txt"), os.path.join(tmp_path, "reference_written.h5")
+    subprocess.run([H5_REF, "read", prog, ours, spec], check=True, env=H5_REF_ENV)
+    subprocess.run([H5_REF, "write", spec, theirs], check=True, env=H5_REF_ENV)
+    assert _h5dump_all(theirs) == _h5dump_all(ours)
+    run([prog, "restart=reference_written.h5", "outdir=b"] + more, str(tmp_path))
+    b = read_dump(os.path.join(tmp_path, "b", "final.bin"))
+    assert b["iteration"] == a["iteration"] and b["time"] == a["time"] and bits_equal(b["data"], a["data"])
