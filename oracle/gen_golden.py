@@ -16,7 +16,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, "_ref")
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("MARA_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")      # MARA_GOLDEN_OUT: regenerate elsewhere, to compare
 
 
 def hexf(x):
@@ -293,8 +293,59 @@ def gen_binary_tree():
     return 0
 
 
+def gen_binary_long():
+    """Mode `binary_long`: the three long / full-size `binary` fixtures (35 + 23 + 47 CPU-seconds of the reference-composed drivers).
+    binary_d4_b16_r8_200steps      256^2 uniform tree, 200 CFL-limited steps: final state and scalars           (tests/test_gpu_binary.py)
+    binary_tree_default_200steps   the sub-program's default graded tree, 200 steps: mesh, solver data, final state (tests/test_gpu_binary_tree.py)
+    binary_c3_fullsize_2steps_digest   BASELINE config 3 (2048^2), 2 steps; the 100 MB state as a digest: block means, one cell per block,
+                                   the 48 x 48 cells around the binary, the field scale                           (tests/test_gpu_binary.py)"""
+    import json
+
+    def args_of(cfg):
+        return ["%s=%s" % (k, repr(float(v))) for k, v in cfg.items()]
+
+    cfg = dict(depth=4, block_size=16, domain_radius=8.0, nsteps=200)
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "b")
+        run_ref("binary_ref", [prefix] + args_of(cfg))
+        n = cfg["block_size"] << cfg["depth"]
+        np.savez_compressed(os.path.join(OUT, "binary_d4_b16_r8_200steps.npz"), config=np.array(json.dumps(cfg)),
+                            stage_scalars=np.fromfile(prefix + ".stage_scalars.f64"), u_final=np.fromfile(prefix + ".u_final.f64").reshape(n, n, 3),
+                            scalars=np.fromfile(prefix + ".scalars.f64"))
+        print("binary_d4_b16_r8_200steps ok")
+
+    cfg = dict(nsteps=200)
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "b")
+        run_ref("binary_tree_ref", [prefix] + args_of(cfg))
+        bs = 24                                                        # the sub-program's default block_size (src/subprog_binary.cpp:57-99)
+        blocks = np.fromfile(prefix + ".blocks.i32", dtype=np.int32).reshape(-1, 3)
+        nb = len(blocks)
+        out = {"config": np.array(json.dumps(cfg)), "blocks": blocks}
+        for key, shape in (("xv", (nb, 2, bs + 1)), ("u_init", (nb, bs, bs, 3)), ("br", (nb, bs, bs)), ("stage_scalars", (-1,)),
+                           ("u_final", (nb, bs, bs, 3)), ("scalars", (-1,))):
+            out[key] = np.fromfile(prefix + "." + key + ".f64").reshape(shape)
+        np.savez_compressed(os.path.join(OUT, "binary_tree_default_200steps.npz"), **out)
+        print("binary_tree_default_200steps ok", nb, "blocks")
+
+    cfg = dict(depth=5, block_size=64, nsteps=2)
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "b")
+        run_ref("binary_ref", [prefix] + args_of(cfg))
+        n, bs = cfg["block_size"] << cfg["depth"], cfg["block_size"]
+        u = np.fromfile(prefix + ".u_final.f64").reshape(n, n, 3)
+        np.savez_compressed(os.path.join(OUT, "binary_c3_fullsize_2steps_digest.npz"), config=np.array(json.dumps(cfg)),
+                            block_means=u.reshape(n // bs, bs, n // bs, bs, 3).mean(axis=(1, 3)), samples=u[31::64, 17::64].copy(),
+                            centre=u[n // 2 - 24:n // 2 + 24, n // 2 - 24:n // 2 + 24].copy(), scale=np.abs(u).reshape(-1, 3).max(axis=0),
+                            scalars=np.fromfile(prefix + ".scalars.f64"), stage_scalars=np.fromfile(prefix + ".stage_scalars.f64"))
+        print("binary_c3_fullsize_2steps_digest ok")
+    return 0
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "binary_long":
+        return gen_binary_long()
     if len(sys.argv) > 1 and sys.argv[1] == "sedov_srhd":
         with tempfile.TemporaryDirectory() as d:
             sed = {}
