@@ -102,6 +102,10 @@ typedef struct
     int    chunk_rows;      /* rows marched per wave (0 = default) */
     int    tail_rows;       /* graded tail: the LAST tail_rows rows of a launch go to short waves of tail_chunk_rows rows */
     int    tail_chunk_rows; /* (0, 0 = the measured default on large grids; tail_rows < 0 = off). Read at configure time. */
+    int    fuse_stages;     /* RK2 step of a whole 2-D field as ONE launch (mara3_amd/csrc/euler2d_fused.hip: the first-stage field stays in LDS,
+                             * 80 instead of 200 B per zone-update): 0 = where available (MH_ARITH_FAST, PLM, no MH_BC_EXTERNAL side, rk_order 2, the
+                             * context and single-slab steppers), < 0 = never, > 0 = required (configure fails where it is not available). The
+                             * result is bit-identical to the two launches'. */
 } mh_euler_cart_desc;
 
 /* number of doubles one device field of this description occupies: (n0+4) * 5 * row_pitch */

@@ -33,6 +33,7 @@ class EulerCartDesc(C.Structure):
         ("chunk_rows", C.c_int),
         ("tail_rows", C.c_int),
         ("tail_chunk_rows", C.c_int),
+        ("fuse_stages", C.c_int),
     ]
 
 

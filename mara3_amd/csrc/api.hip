@@ -297,6 +297,11 @@ int mh_euler_cart_configure(mh_ctx* c, const mh_euler_cart_desc* d, int rk_order
     if (! c) return MH_E_INVALID;
     if (int rc = check_desc(d)) return ctx_fail(c, rc);
     if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return ctx_fail(c, MH_E_INVALID); }
+    if (d->fuse_stages > 0 && ! (rk_order == 2 && euler2d_fused_rk2_available(d)))
+    {
+        set_error("fuse_stages is required, but a fused RK2 step needs MH_ARITH_FAST, PLM, rk_order 2, rank 2 and physical (outflow / periodic) sides");
+        return ctx_fail(c, MH_E_INVALID);
+    }
     MH_HIP_TRY(hipSetDevice(c->device));
     release_fields(c);
     c->desc = *d;
@@ -589,6 +594,27 @@ static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, d
     return e;
 }
 
+// a whole-field RK2 step as one launch (the descriptor's fuse_stages; euler2d_fused.hip)
+static bool ctx_can_fuse(const mh_ctx* c)
+{
+    return c->kind == mh_ctx::KIND_EULER_CART && c->rk_order == 2 && c->desc.fuse_stages >= 0 && euler2d_fused_rk2_available(&c->desc);
+}
+
+static hipError_t timed_fused_step(mh_ctx* c, const double* in, double* out, double dt)
+{
+    LaunchEvents le;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (c->profile)
+    {
+        hipEventCreate(&ev.first);
+        hipEventCreate(&ev.second);
+        le.start = ev.first; le.stop = ev.second;
+    }
+    const hipError_t e = euler2d_fused_rk2_launch(&c->desc, in, out, dt, c->status, c->stream, le);
+    if (c->profile) c->events.push_back(ev);
+    return e;
+}
+
 int mh_step(mh_ctx* c, double dt, int nsteps)
 {
     if (! c || ! c->uploaded) { set_error("step before upload"); return ctx_fail(c, MH_E_STATE); }
@@ -624,11 +650,17 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
         }
         return MH_OK;
     }
+    const bool fused = ctx_can_fuse(c);
     for (int s = 0; s < nsteps; ++s)
     {
         if (c->rk_order == 1)
         {
             MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+            std::swap(c->field[0], c->field[1]);
+        }
+        else if (fused)
+        {
+            MH_HIP_TRY(timed_fused_step(c, c->field[0], c->field[1], dt));
             std::swap(c->field[0], c->field[1]);
         }
         else
@@ -691,6 +723,11 @@ int mh_step_checked(mh_ctx* c, double dt, mh_step_result* result)
     else if (c->rk_order == 1)
     {
         MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+        committed = c->field[1];
+    }
+    else if (ctx_can_fuse(c))
+    {
+        MH_HIP_TRY(timed_fused_step(c, c->field[0], c->field[1], dt));       // never in place: field[0] survives a failed step
         committed = c->field[1];
     }
     else

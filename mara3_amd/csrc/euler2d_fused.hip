@@ -1,0 +1,326 @@
+// Both stages of an RK2 step of the 2-D uniform-cartesian Euler scheme in ONE launch (gfx950 / MI355X), MH_ARITH_FAST + PLM only.
+//
+// What it replaces: `s0 * 0.5 + advance(advance(s0)) * 0.5` (src/subprog_cloud.cpp:676-697 with the `advance` of :511-584 specialised
+// to mara::euler on a cartesian grid, oracle/ref_drivers/euler_cart_compose.hpp) as two launches of euler2d_stage_kernel, which move
+// 80 + 120 B per zone-update through HBM (the first-stage field is written and read back, the step-start field is read twice). Here
+// the first-stage field never exists in memory: 40 B read + 40 B written per zone-update.
+//
+// Structure: a workgroup is a PAIR of waves that own the same strip of 64 columns (56 of them output) and march along axis 0:
+//   * the PRODUCER wave runs the first stage - the row loop of euler2d.hip on the step-start field, two rows ahead - and, instead of
+//     storing a row of u1, leaves it in a four-slot ring in LDS;
+//   * the CONSUMER wave runs the second stage on the rows of that ring (its "loads" are LDS reads), reads the step-start row for the
+//     RK average from memory (an L2 hit: the producer streamed it four rows earlier) and stores the result.
+//   One s_barrier per row keeps the two in lockstep; it waits for LDS only (the waves' global loads stay in flight across it). Both
+//   waves keep the register footprint of a single-stage kernel, so the launch still holds two waves per SIMD, and the two kinds of wave -
+//   one issue-bound, one with the stores - share every CU.
+//   * Ghost cells of the FIRST-STAGE field need no pass over memory: a ghost COLUMN is the LDS read of another lane (outflow: the edge
+//     lane; periodic: the lane already holds the wrapped column), a ghost ROW is another slot of the ring (outflow) or the producer's
+//     own work on the wrapped row (periodic).
+//   Redundancy against the two-launch form: 8 halo lanes of 64 instead of 4, and 4 + 4 pipeline-fill rows per chunk instead of 4.
+//
+// The arithmetic is FastArith's (euler_device_fast.hpp) on the same values in the same order as the two launches, so the result is
+// bit-identical to theirs (tests/test_gpu_fused_rk2.py) and inherits their tolerance against the reference (L1 <= 1e-12).
+// Not for: STRICT arithmetic (issue-bound at 2.5x the instructions: nothing to gain from less traffic), cut sides (MH_BC_EXTERNAL: the
+// multi-rank steppers exchange the first-stage field), RK1, piecewise-constant reconstruction.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <type_traits>
+#include "euler_device.hpp"
+#include "euler_device_fast.hpp"
+#include "launch.hpp"
+#include "status_device.hpp"
+#include "euler2d_rows.hpp"
+
+namespace mh {
+
+static constexpr int FWAVE = 64;
+static constexpr int FHALO = 4;                      // two per stage
+static constexpr int FSTRIP = FWAVE - 2 * FHALO;     // 56 output columns per pair
+static constexpr int FSLOTS = 8;                     // hand-off ring. The consumer reads rows b .. b+2 (four rows in its prologue) while the producer, at most
+                                                     // one barrier ahead, writes row b+3: five live slots, rounded up to a power of two
+
+struct Fused2dParams
+{
+    const double* u_in;
+    double*       u_out;
+    int32_t*      status;
+    long   plane_stride, row_stride;
+    int    n0, n1;
+    int    chunk_rows, nstrips, nchunks;
+    int    bc0, bc1;              // 0 outflow, 1 periodic (both sides of an axis alike: physical boundaries only)
+    double gamma, theta, cx, cy;
+};
+
+// LDS-only barrier of the pair: the waves' outstanding global loads and stores are not waited for
+__device__ inline void pair_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template<int RIEMANN>
+__global__ __launch_bounds__(2 * FWAVE, 2)
+void euler2d_fused_rk2_kernel(Fused2dParams p)
+{
+    using A = FastArith;
+    __shared__ double hand[FSLOTS][5][FWAVE];        // first-stage rows on their way from the producer to the consumer
+    __shared__ double own_rows[3][5][FWAVE];         // the producer's step-start rows waiting for their update (as euler2d.hip's ring)
+
+    int b = (int) blockIdx.x;
+    {
+        const int per_xcd = (int) gridDim.x >> 3;
+        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);      // neighbouring strips and chunks on one XCD (halo re-reads hit its L2)
+    }
+    const int pair = __builtin_amdgcn_readfirstlane(b);
+    const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int chunk = pair / p.nstrips;
+    const int strip = pair - chunk * p.nstrips;
+    const int n0 = p.n0, n1 = p.n1;
+    const int r0 = chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, n0);
+    const int nrows = r1 - r0;                         // >= 1 by construction of the grid
+
+    const int col = strip * FSTRIP - FHALO + lane;
+    int jc = col;
+    if (p.bc1 == 1) jc = jc < 0 ? jc + n1 : (jc >= n1 ? jc - n1 : jc);
+    jc = min(max(jc, 0), n1 - 1);
+    const unsigned jc8 = (unsigned) jc * 8u;
+
+    const long row_stride = p.row_stride;
+    const double* in = p.u_in;
+    const typename A::Gamma gl = A::gamma_law(p.gamma);
+    const typename A::Limiter lim = A::limiter(p.theta);
+    const uint32_t n1u = (uint32_t) n1, colu = (uint32_t) col;
+    StatusAcc acc;
+
+    if (role == 0)
+    {
+        // ================================================================ PRODUCER: first stage, rows r0 - 2 .. r1 + 1 ================
+        // step-start rows beyond the field: the periodic image, or (outflow) the edge row - what the stored ghost rows hold, two rows
+        // further out than they reach
+        const int bc0 = p.bc0;
+        auto row_of = [in, row_stride, n0, bc0] (int r)
+        {
+            const int m = bc0 == 1 ? (r < 0 ? r + n0 : (r >= n0 ? r - n0 : r)) : min(max(r, 0), n0 - 1);
+            return in + (long) (m + 2) * row_stride;
+        };
+        auto ring_put = [&] (int slot, const State5& raw)
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) own_rows[slot][q][lane] = raw[q];
+        };
+        auto ring_get = [&] (int slot) -> State5
+        {
+            State5 Uq;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Uq[q] = own_rows[slot][q][lane];
+            return Uq;
+        };
+        const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
+        const int a0 = r0 - 2;
+
+        State5 U[3], P[3], G[3], Fx[3], D[3];
+        {
+            const State5 Pa = A::c2p(load_row(row_of(a0 - 2), p.plane_stride, jc8), gl);
+            const State5 Pb = A::c2p(load_row(row_of(a0 - 1), p.plane_stride, jc8), gl);
+            U[0] = load_row(row_of(a0), p.plane_stride, jc8);
+            U[1] = load_row(row_of(a0 + 1), p.plane_stride, jc8);
+            U[2] = load_row(row_of(a0 + 2), p.plane_stride, jc8);
+            P[0] = A::c2p(U[0], gl);
+            P[1] = A::c2p(U[1], gl);
+            ring_put(0, U[0]);
+            ring_put(1, U[1]);
+            U[0] = load_row(row_of(a0 + 3), p.plane_stride, jc8);
+            const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
+            D[0] = A::difference(P[0], P[1]);
+            const State5 Gb = A::plm_from_differences(Dab, Db0, lim);
+            G[0] = A::plm_from_differences(Db0, D[0], lim);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb, lim), A::minus(P[0], G[0], lim), gl);
+        }
+        if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))
+        {
+            if (real_col && !(P[0][4] >= 0.0) && a0 >= 0) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) a0 * n1u + colu);
+            if (real_col && !(P[1][4] >= 0.0) && a0 + 1 >= 0 && a0 + 1 < n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a0 + 1) * n1u + colu);
+        }
+
+        auto row_step = [&] (int a, int t, auto k0) __attribute__((always_inline))
+        {
+            constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+            U[K1] = load_row(row_of(a + 4), p.plane_stride, jc8);
+            P[K2] = A::c2p(U[K2], gl);
+            ring_put(K2, U[K2]);
+            const bool bad_pressure = !(P[K2][4] >= 0.0);
+            D[K1] = A::difference(P[K1], P[K2]);
+            G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
+
+            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
+            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
+            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
+            const State5 Fy_hi = from_right(Fy_lo);
+
+            const State5 Uc = ring_get(K0);
+            State5 Un;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+            const bool bad_density = !(Un[0] > 0.0);
+            if (__any(bad_pressure || bad_density))
+            {
+                if (real_col && bad_pressure && a + 2 >= 0 && a + 2 < n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a + 2) * n1u + colu);
+                if (real_col && bad_density && a >= 0 && a < n0) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) a * n1u + colu);
+            }
+            const int slot = t & (FSLOTS - 1);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) hand[slot][q][lane] = Un[q];
+            pair_barrier();                                  // barrier #t: row a is in the ring
+        };
+
+        const int T = nrows + 4;
+        int t = 0;
+        for (; t + 3 <= T; t += 3)
+        {
+            row_step(a0 + t, t, std::integral_constant<int, 0>());
+            row_step(a0 + t + 1, t + 1, std::integral_constant<int, 1>());
+            row_step(a0 + t + 2, t + 2, std::integral_constant<int, 2>());
+        }
+        if (t < T) row_step(a0 + t, t, std::integral_constant<int, 0>());
+        if (t + 1 < T) row_step(a0 + t + 1, t + 1, std::integral_constant<int, 1>());
+    }
+    else
+    {
+        // ================================================================ CONSUMER: second stage + RK average, rows r0 .. r1 - 1 ========
+        const bool writes = lane >= FHALO && lane < FWAVE - FHALO && col < n1;
+        const unsigned col8 = (unsigned) (writes ? col : 0) * 8u;
+        // ghost columns of the first-stage field: outflow = the edge column's value, i.e. another lane's entry of the ring
+        int src_lane = lane;
+        if (p.bc1 != 1) src_lane = lane + (min(max(col, 0), n1 - 1) - col);
+        const int bc0 = p.bc0;
+        // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots
+        auto hand_row = [&] (int rr) -> State5
+        {
+            const int m = bc0 == 1 ? rr : min(max(rr, 0), n0 - 1);
+            const int slot = (m - (r0 - 2)) & (FSLOTS - 1);
+            State5 Uq;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Uq[q] = hand[slot][q][src_lane];
+            return Uq;
+        };
+        auto row_off = [row_stride] (int r) { return (long) (r + 2) * row_stride; };
+
+        pair_barrier(); pair_barrier(); pair_barrier(); pair_barrier();          // barriers #0..#3: rows r0 - 2 .. r0 + 1 are in the ring
+
+        State5 P[3], G[3], Fx[3], D[3];
+        {
+            const State5 Pa = A::c2p(hand_row(r0 - 2), gl);
+            const State5 Pb = A::c2p(hand_row(r0 - 1), gl);
+            P[0] = A::c2p(hand_row(r0), gl);
+            P[1] = A::c2p(hand_row(r0 + 1), gl);
+            const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
+            D[0] = A::difference(P[0], P[1]);
+            const State5 Gb = A::plm_from_differences(Dab, Db0, lim);
+            G[0] = A::plm_from_differences(Db0, D[0], lim);
+            Fx[0] = A::template flux<RIEMANN, 0>(A::plus(Pb, Gb, lim), A::minus(P[0], G[0], lim), gl);
+        }
+        if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))
+        {
+            if (writes && !(P[0][4] >= 0.0)) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) r0 * n1u + colu);
+            if (writes && !(P[1][4] >= 0.0) && r0 + 1 < n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r0 + 1) * n1u + colu);
+        }
+
+        auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
+        {
+            constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+            const State5 Ubase = load_row(in + row_off(r), p.plane_stride, jc8);        // the step-start row, for the average
+            pair_barrier();                                  // barrier #(r - r0 + 4): row r + 2 is in the ring
+            P[K2] = A::c2p(hand_row(r + 2), gl);
+            const bool bad_pressure = !(P[K2][4] >= 0.0);
+            D[K1] = A::difference(P[K1], P[K2]);
+            G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
+            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
+
+            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
+            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
+            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
+            const State5 Fy_hi = from_right(Fy_lo);
+
+            const State5 Uc = hand_row(r);
+            State5 Un;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Un[q] = A::combine(Ubase[q], A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy), 0.5);
+            const bool bad_density = !(Un[0] > 0.0);
+            if (__any(bad_pressure || bad_density))
+            {
+                if (writes && bad_pressure && r + 2 < n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r + 2) * n1u + colu);
+                if (writes && bad_density) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) r * n1u + colu);
+            }
+            if (writes)
+            {
+                store_row(p.u_out + row_off(r), p.plane_stride, col8, Un);
+                if (r < 2 || r >= n0 - 2)          // the stored ghost rows of the result (edge rows only: wave-uniform, cold)
+                {
+                    if (bc0 == 0 && r == 0) { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
+                    if (bc0 == 1 && r < 2) store_row(p.u_out + row_off(n0 + r), p.plane_stride, col8, Un);
+                    if (bc0 == 0 && r == n0 - 1) { store_row(p.u_out + row_off(n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(n0 + 1), p.plane_stride, col8, Un); }
+                    if (bc0 == 1 && r >= n0 - 2) store_row(p.u_out + row_off(r - n0), p.plane_stride, col8, Un);
+                }
+            }
+        };
+
+        int r = r0;
+        for (; r + 3 <= r1; r += 3)
+        {
+            row_step(r, std::integral_constant<int, 0>());
+            row_step(r + 1, std::integral_constant<int, 1>());
+            row_step(r + 2, std::integral_constant<int, 2>());
+        }
+        if (r < r1) row_step(r, std::integral_constant<int, 0>());
+        if (r + 1 < r1) row_step(r + 1, std::integral_constant<int, 1>());
+    }
+    acc.commit(p.status);
+}
+
+bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d)
+{
+    return d->rank == 2 && d->arith == MH_ARITH_FAST && d->plm_theta >= 0.0 && d->n[0] >= 8 && d->n[1] >= 8
+        && (d->bc_lo0 == MH_BC_OUTFLOW || d->bc_lo0 == MH_BC_PERIODIC) && d->bc_hi0 == d->bc_lo0
+        && (d->bc_transverse == MH_BC_OUTFLOW || d->bc_transverse == MH_BC_PERIODIC);
+}
+
+// u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 over the whole field (both with stored ghost rows, layout of include/mara_hip.h); the two
+// fields must differ. chunk_rows: the descriptor's, or 64 (a pair pays eight pipeline-fill rows per chunk).
+hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
+                                    LaunchEvents ev)
+{
+    if (! euler2d_fused_rk2_available(d) || u_in == u_out) return hipErrorInvalidValue;
+    Fused2dParams p;
+    p.u_in = u_in; p.u_out = u_out; p.status = status;
+    p.n0 = d->n[0]; p.n1 = d->n[1];
+    p.plane_stride = p.n1;
+    p.row_stride = 5L * p.n1;
+    p.nstrips = (p.n1 + FSTRIP - 1) / FSTRIP;
+    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 64;
+    p.nchunks = (p.n0 + p.chunk_rows - 1) / p.chunk_rows;
+    p.bc0 = d->bc_lo0 == MH_BC_PERIODIC ? 1 : 0;
+    p.bc1 = d->bc_transverse == MH_BC_PERIODIC ? 1 : 0;
+    p.gamma = d->gamma; p.theta = d->plm_theta;
+    p.cx = dt / d->dl[0]; p.cy = dt / d->dl[1];
+    const dim3 grid(p.nstrips * p.nchunks), block(2 * FWAVE);
+    if (d->riemann == MH_RIEMANN_HLLC)
+    {
+        if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<1>), grid, block, 0, stream, ev.start, ev.stop, 0, p);
+        else         hipLaunchKernelGGL((euler2d_fused_rk2_kernel<1>), grid, block, 0, stream, p);
+    }
+    else
+    {
+        if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<0>), grid, block, 0, stream, ev.start, ev.stop, 0, p);
+        else         hipLaunchKernelGGL((euler2d_fused_rk2_kernel<0>), grid, block, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+} // namespace mh

@@ -19,6 +19,11 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
                                  double dt, double weight, int a0, int a1, int b0, int b1, int32_t* status, hipStream_t stream,
                                  LaunchEvents ev = LaunchEvents());
 
+// both stages of an RK2 step of a whole 2-D field in one launch (euler2d_fused.hip): u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5
+bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d);
+hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
+                                    LaunchEvents ev = LaunchEvents());
+
 hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);
 

@@ -111,6 +111,10 @@ struct mh_slab
     bool skew_pending = false;                   // group member r >= 1: its first interior launch after an upload starts behind member r-1's
     hipGraphExec_t exec = nullptr;
     double graph_dt = 0.0;
+    // fused RK2 (euler2d_fused.hip): one launch per step from field[0] into field[1], then the two swap. One captured step per direction.
+    bool fused = false;
+    double* fused_src[2] = {nullptr, nullptr};
+    hipGraphExec_t fused_exec[2] = {nullptr, nullptr};
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];   // bulk launches of stage 1 / stage 2
     std::string error;
@@ -328,6 +332,30 @@ static int group_one_step(mh_slab** g, int n, double dt)
 
 static int slab_one_step(mh_slab* s, double dt) { return group_one_step(&s, 1, dt); }
 
+// a whole-field RK2 step as one launch (the descriptor's fuse_stages, include/mara_hip.h): lone 2-D Euler slabs with physical sides only
+static bool slab_can_fuse(const mh_slab* s)
+{
+    return s->kind == SLAB_EULER && s->rk_order == 2 && ! has_neighbours(s) && s->desc.fuse_stages >= 0 && euler2d_fused_rk2_available(&s->desc);
+}
+
+static int slab_fused_step(mh_slab* s, double dt)
+{
+    LaunchEvents ev;
+    std::pair<hipEvent_t, hipEvent_t> pe;
+    if (s->profile)
+    {
+        hipEventCreate(&pe.first);
+        hipEventCreate(&pe.second);
+        ev.start = pe.first; ev.stop = pe.second;
+    }
+    const hipError_t e = euler2d_fused_rk2_launch(&s->desc, s->field[0], s->field[1], dt, s->status, s->main, ev);
+    if (s->profile) s->events[1].push_back(pe);          // the step's one launch is reported in the second-stage slot; the first stays empty
+    MH_HIP_TRY(e);
+    std::swap(s->field[0], s->field[1]);
+    s->cur_out = s->field[0];
+    return MH_OK;
+}
+
 static int check_group(mh_slab** g, int n)
 {
     if (! g || n < 1 || n > 64) { set_error("mh_slab group: need 1..64 slabs"); return MH_E_INVALID; }
@@ -421,6 +449,13 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
             const long c = (rows + chunks_max - 1) / chunks_max;
             if (c <= 96) s->desc.chunk_rows = (int) (c < 4 ? 4 : c);
         }
+    }
+    s->fused = slab_can_fuse(s);
+    if (kind == SLAB_EULER && global->fuse_stages > 0 && ! s->fused)
+    {
+        delete s;
+        set_error("fuse_stages is required, but a fused RK2 step needs MH_ARITH_FAST, PLM, rk_order 2, rank 2 and a slab without neighbours");
+        return MH_E_INVALID;
     }
     if (const char* v = getenv("MH_SLAB_EVENT_ON_LAUNCH")) s->event_on_launch = atoi(v) != 0;
     if (const char* v = getenv("MH_SLAB_TEST_DELAY")) s->test_delay = atoi(v);
@@ -638,6 +673,7 @@ void mh_slab_destroy(mh_slab* s)
     if (s->main) hipStreamSynchronize(s->main);
     if (s->side) hipStreamSynchronize(s->side);
     if (s->exec) hipGraphExecDestroy(s->exec);
+    for (auto& g : s->fused_exec) if (g) hipGraphExecDestroy(g);
     if (s->comm && s->owns_comm && rccl()) rccl()->CommDestroy(s->comm);
     for (auto& v : s->events) for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (auto& f : s->field) if (f) hipFree(f);
@@ -735,6 +771,39 @@ int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
     // RCCL point-to-point inside a stream capture crashes this stack (RCCL 2.26 / HIP 7.0: segfault in
     // hipStreamEndCapture, also through torch), so only the neighbour-less step is replayed from a graph; with
     // neighbours the step is issued eagerly from this loop (about ten HIP/RCCL calls per stage, no host language).
+    if (s->fused)
+    {
+        for (int n = 0; n < nsteps; ++n)
+        {
+            if (! use_graph || s->profile) { if (int rc = slab_fused_step(s, dt)) return slab_fail(s, rc); continue; }
+            // one captured step per direction (field A -> B, B -> A): the pointers are part of the graph
+            const int k = s->field[0] == s->fused_src[0] ? 0 : 1;
+            if (s->graph_dt != dt || s->fused_src[k] != s->field[0] || ! s->fused_exec[k])
+            {
+                if (s->graph_dt != dt)
+                    for (int j = 0; j < 2; ++j) if (s->fused_exec[j]) { hipGraphExecDestroy(s->fused_exec[j]); s->fused_exec[j] = nullptr; }
+                if (s->fused_exec[k]) { hipGraphExecDestroy(s->fused_exec[k]); s->fused_exec[k] = nullptr; }
+                hipGraph_t graph = nullptr;
+                double* const src = s->field[0];
+                MH_HIP_TRY(hipStreamSynchronize(s->main));
+                MH_HIP_TRY(hipStreamBeginCapture(s->main, hipStreamCaptureModeRelaxed));
+                int rc = slab_fused_step(s, dt);
+                hipError_t e = hipStreamEndCapture(s->main, &graph);
+                if (rc) return slab_fail(s, rc);
+                if (e != hipSuccess) return slab_fail(s, hip_fail(e, "hipStreamEndCapture"));
+                std::swap(s->field[0], s->field[1]);          // the capture recorded the launch without running it
+                e = hipGraphInstantiate(&s->fused_exec[k], graph, nullptr, nullptr, 0);
+                hipGraphDestroy(graph);
+                if (e != hipSuccess) { s->fused_exec[k] = nullptr; return slab_fail(s, hip_fail(e, "hipGraphInstantiate")); }
+                s->fused_src[k] = src;
+                s->graph_dt = dt;
+            }
+            MH_HIP_TRY(hipGraphLaunch(s->fused_exec[k], s->main));
+            std::swap(s->field[0], s->field[1]);
+            s->cur_out = s->field[0];
+        }
+        return MH_OK;
+    }
     if (use_graph && s->rk_order == 2 && ! s->profile && ! has_neighbours(s) && s->kind == SLAB_EULER)
     {
         if (! s->exec || s->graph_dt != dt)

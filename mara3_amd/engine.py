@@ -31,8 +31,10 @@ class _StatusMixin:
 
 class EulerCartSolver(_StatusMixin):
     def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
-                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None):
-        """tail = (rows, chunk_rows) forces the graded tail of the stage launch (None: the library's default on large grids)"""
+                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None, fuse=None):
+        """tail = (rows, chunk_rows) forces the graded tail of the stage launch (None: the library's default on large grids).
+        fuse: the descriptor's fuse_stages - None = where available (one launch per RK2 step: FAST, PLM, physical sides), False = never,
+        True = required."""
         self.lib = L.load_library()
         self.shape = tuple(int(n) for n in shape)
         rank = len(self.shape)
@@ -52,6 +54,7 @@ class EulerCartSolver(_StatusMixin):
         d.chunk_rows = chunk_rows
         if tail is not None:
             d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
+        d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
         self.desc = d
         self.rk_order = rk_order
         self.ctx = C.c_void_p()

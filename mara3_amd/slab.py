@@ -356,7 +356,7 @@ class SlabCloudStepper(SlabEulerStepper):
     def fill_ghosts_physical_only(self, f):
         pass        # inflow / zero-gradient rows are formed inside the kernel from the nozzle row / the last real row
 
-def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=0, arith="strict"):
+def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=0, arith="strict", fuse=None):
     """mh_euler_cart_desc of a WHOLE uniform-cartesian grid (the form mh_slab_create / mh_slab_group_create take)"""
     rank_ = len(global_shape)
     d = L.EulerCartDesc()
@@ -370,6 +370,7 @@ def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=
     d.bc_lo0 = d.bc_hi0 = d.bc_transverse = phys
     d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
     d.chunk_rows = chunk_rows
+    d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
     return d
 
 
@@ -379,7 +380,7 @@ class NativeSlabStepper:
     `comm_id` is the 128-byte RCCL unique id every rank must share (see `native_comm_id`)."""
 
     def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
-                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict", handle=None):
+                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict", handle=None, fuse=None):
         """comm_id=None on a rank with neighbours defers the RCCL communicator to connect() (ncclCommInitRank is collective: the host
         first makes sure every rank got this far). handle: wrap a slab created elsewhere (a member of NativeSlabGroup)."""
         import numpy as np
@@ -388,7 +389,7 @@ class NativeSlabStepper:
         if handle is not None:
             self.handle = handle
         else:
-            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
+            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith, fuse)
             self.handle = C.c_void_p()
             idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
             L.check(self.lib.mh_slab_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf,
