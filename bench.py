@@ -62,7 +62,7 @@ def host_cores():
     return min(cores, int(os.environ.get("MARA_BENCH_CPU_THREADS", "64")))
 
 
-KERNEL_SOURCES = ("euler2d.hip", "euler3d.hip", "euler3d_fast.hip", "euler3d_kernel.hpp", "cloud.hip", "binary.hip", "euler_device.hpp", "euler_device_fast.hpp", "srhd_device.hpp",
+KERNEL_SOURCES = ("euler2d.hip", "euler2d_fused.hip", "euler2d_rows.hpp", "euler3d.hip", "euler3d_fast.hip", "euler3d_kernel.hpp", "cloud.hip", "binary.hip", "euler_device.hpp", "euler_device_fast.hpp", "srhd_device.hpp",
                   "srhd_device_fast.hpp", "iso2d_device.hpp", "binary_device.hpp", "status_device.hpp")
 
 
@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--precondition", type=int, default=60,
                     help="steps of a scratch grid run right BEFORE the W warm-up steps: the first ~25 launches after an idle period (building and "
                          "uploading the initial condition) run up to 25 %% slower while the clocks settle (kernel trace, DESIGN.md §6); 0 = off")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="headline leg as two launches per RK2 step instead of the fused one (euler2d_fused.hip; FAST arithmetic, one GPU)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -250,7 +252,7 @@ def main():
         import ctypes
         return ctypes.c_void_p(group.handles[r])
 
-    def make_stepper(arith, riemann, bc):
+    def make_stepper(arith, riemann, bc, fuse=None):
         if args.loopback_slabs:
             return GroupAsStepper(arith, riemann, bc)
         if state["stepper"] == "native":
@@ -258,7 +260,7 @@ def main():
             try:
                 # without a communicator first: ncclCommInitRank is collective, so every rank must have got this far before any enters it
                 st = NativeSlabStepper((n, n), dl, gamma, args.theta, riemann, 2, bc, rank=rank, world=world,
-                                       comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+                                       comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith, fuse=fuse)
             except mara3_amd.MaraHipError as e:
                 err = e
             if ranks.agree(st is not None):                       # every rank must take the same path
@@ -289,14 +291,15 @@ def main():
             return setups.blast_ic((n, n), gamma, row_range=(row0, row1))
         return setups.smooth_wave_ic((n, n), gamma, row_range=(row0, row1))
 
-    def run_leg(arith, riemann, workload, nblocks=1, keep_state=False):
-        """W untimed + K timed steps (+ nblocks - 1 further timed blocks of K) of the whole grid, then a short profiled pass."""
+    def run_leg(arith, riemann, workload, nblocks=1, keep_state=False, fuse=None):
+        """W untimed + K timed steps (+ nblocks - 1 further timed blocks of K) of the whole grid, then a short profiled pass.
+        fuse: None = the library's choice (one fused launch per RK2 step where it exists: FAST arithmetic on one GPU), False = two launches."""
         bc = "outflow" if workload == "blast" else "periodic"
         watch.phase("leg %s %s %s" % (arith, riemann, workload))
         native = state["stepper"] == "native" or bool(args.loopback_slabs)
         if native and args.warmup == 0:      # with W >= 1 the warm-up steps do this (and a profile of the run shows the workload's launches only)
             prime(arith, riemann)
-        st = make_stepper(arith, riemann, bc)
+        st = make_stepper(arith, riemann, bc, fuse)
         native = not isinstance(st, SlabEulerStepper)
         st.load_slab(initial_state(workload, st.row0, st.row1))
         if args.precondition > 0:
@@ -304,7 +307,7 @@ def main():
             # ms, and the first ~25 stage launches after an idle period run up to 25 % slower (kernel trace). A scratch grid of
             # this rank's size is stepped right before the W warm-up steps of the real one.
             rows = max(64, min(n, st.row1 - st.row0))
-            scratch = NativeSlabStepper((rows, n), dl, gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith)
+            scratch = NativeSlabStepper((rows, n), dl, gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith, fuse=fuse)
             scratch.load_slab(setups.blast_ic((rows, n), gamma))
             scratch.step(dt, args.precondition)
             if os.environ.get("MH_BENCH_PRECONDITION_GAP"):      # the first version: the scratch grid is released before the warm-up steps start
@@ -379,15 +382,26 @@ def main():
                                  "valu_busy": rec["valu_busy"], "note": "recorded counters (20-step blast), this run's duration"}
             return r
 
-        res = {
-            "value": value, "ms_per_step": ms, "status_word": st.status(),
-            "roofline": kernel_roofline(BYTES_STAGE2, avg2, nl2, "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, riemann),
-                                        "stage2_%s_%s_bytes_per_launch" % (arith, riemann)),
-            "roofline_stage1": kernel_roofline(BYTES_STAGE1, avg1, nl1, "euler2d_stage_kernel<%s,%s,PLM> (first RK2 stage)" % (arith, riemann),
-                                               "stage1_%s_%s_bytes_per_launch" % (arith, riemann)),
-            "roofline_step": {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
-                              "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"},
-        }
+        fused = native and nl1 == 0 and nl2 > 0          # the stepper took the fused step: its one launch is reported in the second-stage slot
+        res = {"value": value, "ms_per_step": ms, "status_word": st.status(), "launches_per_step": 1 if fused else 2}
+        if fused:
+            # SURVEY.md section 8d's algorithmic figure for an RK2 zone-update is 200 B (per stage: read U, write U'; the second stage also reads
+            # the step-start field). The fused launch advances every cell by a whole step, so by that convention it is charged 200 B per cell -
+            # while it moves 80 B per cell (the first-stage field never leaves LDS): `traffic` is then BELOW the algorithmic bytes.
+            r = kernel_roofline(BYTES_STEP, avg2, nl2, "euler2d_fused_rk2_kernel<%s> (both RK2 stages, one launch per step)" % riemann,
+                                "fused_%s_%s_bytes_per_launch" % (arith, riemann))
+            r["bytes_actually_moved_per_cell"] = 2 * 5 * 8
+            r["achieved_actual_traffic"] = cells_launch * 80 / (avg2 * 1e-3) / 1e9 if avg2 > 0 else None
+            r["convention"] = "200 B per zone-update (SURVEY.md 8d) over the step's one launch; the launch reads 40 B and writes 40 B per cell"
+            res["roofline"] = r
+            res["roofline_stage1"] = None
+        else:
+            res["roofline"] = kernel_roofline(BYTES_STAGE2, avg2, nl2, "euler2d_stage_kernel<%s,%s,PLM,COMBINE> (second RK2 stage)" % (arith, riemann),
+                                              "stage2_%s_%s_bytes_per_launch" % (arith, riemann))
+            res["roofline_stage1"] = kernel_roofline(BYTES_STAGE1, avg1, nl1, "euler2d_stage_kernel<%s,%s,PLM> (first RK2 stage)" % (arith, riemann),
+                                                     "stage1_%s_%s_bytes_per_launch" % (arith, riemann))
+        res["roofline_step"] = {"achieved": value * 1e6 * BYTES_STEP / 1e9 / world, "frac": value * 1e6 * BYTES_STEP / 1e9 / world / HBM_PEAK_GBS,
+                                "note": "per GPU, 200 B per zone-update over the whole timed step (launch gaps and halo exchange included)"}
         if nblocks > 1:
             rest = sorted(block_ms[1:])
             res["repeat_blocks"] = {"ms_per_step": block_ms[1:], "median_ms_per_step": rest[len(rest) // 2], "min": rest[0], "max": rest[-1],
@@ -436,7 +450,7 @@ def main():
     primary = args.arith
     other = "strict" if primary == "fast" else "fast"
     decomposed = world > 1 or bool(args.loopback_slabs)
-    res, u_primary, nsteps_primary = run_leg(primary, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True)
+    res, u_primary, nsteps_primary = run_leg(primary, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True, fuse=False if args.no_fuse else None)
     partition_ok = partition_check(primary, args.riemann, u_primary, nsteps_primary) if decomposed and state["stepper"] == "native" else None
 
     arith_note = {"strict": "strict: bit-identical to the reference CPU path (tests/test_gpu_parity.py, golden vectors from reference headers)",
@@ -461,11 +475,17 @@ def main():
             more = [("strict", other_riemann, "blast"), ("fast", other_riemann, "blast"), (primary, args.riemann, "smooth_wave"), ("strict", "hlle", "smooth_wave")]
         for (a, r, w) in more:
             legs["%s_%s_%s" % (a, r, w)] = run_leg(a, r, w)[0]
+        if not decomposed and res["launches_per_step"] == 1:
+            # the headline took the fused step: the same workload as the two launches it replaces (bit-identical results), with their per-stage rooflines
+            legs["%s_%s_blast_two_launches" % (primary, args.riemann)] = run_leg(primary, args.riemann, "blast", fuse=False)[0]
         for key, leg in legs.items():
             a, r, w = key.split("_", 2)
-            leg["note"] = "%s; %s; workload: %s" % (arith_note[a], pin_note[r],
-                                                    "Sedov-type blast, outflow" if w == "blast" else
-                                                    "smooth periodic wave rho = 1 + 0.2 sin(2 pi x) sin(2 pi y), p = rho^gamma, v = (0.5, 0.25) (SURVEY.md §8d)")
+            two = w.endswith("_two_launches")
+            w = w.replace("_two_launches", "")
+            leg["note"] = "%s; %s; workload: %s%s" % (arith_note[a], pin_note[r],
+                                                      "Sedov-type blast, outflow" if w == "blast" else
+                                                      "smooth periodic wave rho = 1 + 0.2 sin(2 pi x) sin(2 pi y), p = rho^gamma, v = (0.5, 0.25) (SURVEY.md §8d)",
+                                                      "; the two launches per step that the fused launch replaces" if two else "")
     del u_primary
 
     if rank == 0:
@@ -480,10 +500,14 @@ def main():
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
-                       "timed_region": "HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage",
+                       "timed_region": ("HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage")
+                                       + (" (ONE fused launch per RK2 step, mara3_amd/csrc/euler2d_fused.hip: results bit-identical to the two launches, tests/test_gpu_fused_rk2.py)"
+                                          if res["launches_per_step"] == 1 else " (two launches per RK2 step)"),
                        "preconditioning": res["preconditioning"]},
             "roofline": res["roofline"], "roofline_stage1": res["roofline_stage1"], "roofline_step": res["roofline_step"],
         }
+        if out["roofline_stage1"] is None:
+            del out["roofline_stage1"]
         if "repeat_blocks" in res:
             out["repeat_blocks"] = res["repeat_blocks"]
         if partition_ok is not None:

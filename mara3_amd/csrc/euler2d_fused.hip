@@ -7,9 +7,9 @@
 //
 // Structure: a workgroup is a PAIR of waves that own the same strip of 64 columns (56 of them output) and march along axis 0:
 //   * the PRODUCER wave runs the first stage - the row loop of euler2d.hip on the step-start field, two rows ahead - and, instead of
-//     storing a row of u1, leaves it in a four-slot ring in LDS;
+//     storing a row of u1, leaves it in a five-slot ring in LDS;
 //   * the CONSUMER wave runs the second stage on the rows of that ring (its "loads" are LDS reads), reads the step-start row for the
-//     RK average from memory (an L2 hit: the producer streamed it four rows earlier) and stores the result.
+//     RK average from a second LDS ring, where the producer parked it four rows earlier, and stores the result.
 //   One s_barrier per row keeps the two in lockstep; it waits for LDS only (the waves' global loads stay in flight across it). Both
 //   waves keep the register footprint of a single-stage kernel, so the launch still holds two waves per SIMD, and the two kinds of wave -
 //   one issue-bound, one with the stores - share every CU.
@@ -37,8 +37,9 @@ namespace mh {
 static constexpr int FWAVE = 64;
 static constexpr int FHALO = 4;                      // two per stage
 static constexpr int FSTRIP = FWAVE - 2 * FHALO;     // 56 output columns per pair
-static constexpr int FSLOTS = 8;                     // hand-off ring. The consumer reads rows b .. b+2 (four rows in its prologue) while the producer, at most
-                                                     // one barrier ahead, writes row b+3: five live slots, rounded up to a power of two
+static constexpr int FSLOTS = 5;                     // hand-off ring. The consumer reads rows b .. b+2 (four rows in its prologue) while the producer, at most
+                                                     // one barrier ahead, writes row b+3: five live slots
+static constexpr int USLOTS = 6;                     // step-start rows b .. b+4 (the producer converts row b+4 while the consumer averages with row b), and one ahead
 
 struct Fused2dParams
 {
@@ -66,7 +67,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
 {
     using A = FastArith;
     __shared__ double hand[FSLOTS][5][FWAVE];        // first-stage rows on their way from the producer to the consumer
-    __shared__ double own_rows[3][5][FWAVE];         // the producer's step-start rows waiting for their update (as euler2d.hip's ring)
+    __shared__ double start_rows[USLOTS][5][FWAVE];  // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
 
     int b = (int) blockIdx.x;
     {
@@ -107,16 +108,17 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const int m = bc0 == 1 ? (r < 0 ? r + n0 : (r >= n0 ? r - n0 : r)) : min(max(r, 0), n0 - 1);
             return in + (long) (m + 2) * row_stride;
         };
+        // slot of step-start row x: (x - a0) mod USLOTS
         auto ring_put = [&] (int slot, const State5& raw)
         {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) own_rows[slot][q][lane] = raw[q];
+            for (int q = 0; q < 5; ++q) start_rows[slot][q][lane] = raw[q];
         };
         auto ring_get = [&] (int slot) -> State5
         {
             State5 Uq;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Uq[q] = own_rows[slot][q][lane];
+            for (int q = 0; q < 5; ++q) Uq[q] = start_rows[slot][q][lane];
             return Uq;
         };
         const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
@@ -151,7 +153,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
             U[K1] = load_row(row_of(a + 4), p.plane_stride, jc8);
             P[K2] = A::c2p(U[K2], gl);
-            ring_put(K2, U[K2]);
+            ring_put((t + 2) % USLOTS, U[K2]);
             const bool bad_pressure = !(P[K2][4] >= 0.0);
             D[K1] = A::difference(P[K1], P[K2]);
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
@@ -163,7 +165,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
             const State5 Fy_hi = from_right(Fy_lo);
 
-            const State5 Uc = ring_get(K0);
+            const State5 Uc = ring_get(t % USLOTS);
             State5 Un;
 #pragma unroll
             for (int q = 0; q < 5; ++q) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
@@ -173,7 +175,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
                 if (real_col && bad_pressure && a + 2 >= 0 && a + 2 < n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a + 2) * n1u + colu);
                 if (real_col && bad_density && a >= 0 && a < n0) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) a * n1u + colu);
             }
-            const int slot = t & (FSLOTS - 1);
+            const int slot = t % FSLOTS;
 #pragma unroll
             for (int q = 0; q < 5; ++q) hand[slot][q][lane] = Un[q];
             pair_barrier();                                  // barrier #t: row a is in the ring
@@ -203,7 +205,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         auto hand_row = [&] (int rr) -> State5
         {
             const int m = bc0 == 1 ? rr : min(max(rr, 0), n0 - 1);
-            const int slot = (m - (r0 - 2)) & (FSLOTS - 1);
+            const int slot = (m - (r0 - 2)) % FSLOTS;
             State5 Uq;
 #pragma unroll
             for (int q = 0; q < 5; ++q) Uq[q] = hand[slot][q][src_lane];
@@ -234,8 +236,13 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
         {
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
-            const State5 Ubase = load_row(in + row_off(r), p.plane_stride, jc8);        // the step-start row, for the average
             pair_barrier();                                  // barrier #(r - r0 + 4): row r + 2 is in the ring
+            State5 Ubase;                                    // the step-start row, for the average: the producer kept it (slot of row r)
+            {
+                const int slot = (r - (r0 - 2)) % USLOTS;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) Ubase[q] = start_rows[slot][q][lane];
+            }
             P[K2] = A::c2p(hand_row(r + 2), gl);
             const bool bad_pressure = !(P[K2][4] >= 0.0);
             D[K1] = A::difference(P[K1], P[K2]);
@@ -292,7 +299,7 @@ bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d)
 }
 
 // u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 over the whole field (both with stored ghost rows, layout of include/mara_hip.h); the two
-// fields must differ. chunk_rows: the descriptor's, or 64 (a pair pays eight pipeline-fill rows per chunk).
+// fields must differ. chunk_rows: the descriptor's, or the default below.
 hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
                                     LaunchEvents ev)
 {
@@ -303,7 +310,20 @@ hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u
     p.plane_stride = p.n1;
     p.row_stride = 5L * p.n1;
     p.nstrips = (p.n1 + FSTRIP - 1) / FSTRIP;
-    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 64;
+    if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
+    else
+    {
+        // A pair pays eight pipeline-fill rows per chunk, so chunks are long; and 1024 pairs are resident at a time (four per CU), so the
+        // launch takes ceil(pairs / 1024) residency rounds of about (chunk + 8) rows each: the chunk is the shortest one that fills R rounds
+        // to the brim, for the smallest R that keeps it near 100 rows. Measured at 4096^2, 74 strips (profiles/r03/ab_fused_chunks.jsonl):
+        // 100 rows (41 chunks, 2.96 rounds) 0.631-0.638 ms per step; 106 rows (2.82 rounds) 0.658; 75-79 rows (3.8-4 rounds) 0.645;
+        // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
+        int rounds = 1;
+        auto chunk_for = [&] (int r) { const int nch = 1024 * r / p.nstrips > 0 ? 1024 * r / p.nstrips : 1; return (p.n0 + nch - 1) / nch; };
+        while (chunk_for(rounds) > 112) ++rounds;
+        p.chunk_rows = chunk_for(rounds);
+        if (p.chunk_rows < 8) p.chunk_rows = 8;
+    }
     p.nchunks = (p.n0 + p.chunk_rows - 1) / p.chunk_rows;
     p.bc0 = d->bc_lo0 == MH_BC_PERIODIC ? 1 : 0;
     p.bc1 = d->bc_transverse == MH_BC_PERIODIC ? 1 : 0;

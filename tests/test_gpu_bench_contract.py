@@ -24,15 +24,24 @@ def test_bench_json_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    # round 3: the FAST headline is ONE fused launch per RK2 step; it is charged the 200 B of SURVEY.md 8d and moves 80 B per cell
+    assert d["config"]["summary"] == d["summary"] and list(d)[-1] == "summary"
+    assert "fused" in r["kernel"] and r["bytes_actually_moved_per_cell"] == 80 and "roofline_stage1" not in d
+    assert r["algorithmic_bytes_per_launch"] == 200 * 4096 * 4096
+    assert r["traffic"] is None or r["traffic"] >= 80 * 4096 * 4096
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mcells/s" and c["sample"]
     assert d["config"]["status_word"] == 0
     # round 2: the pinned variant, the smooth wave and the other configs are in the driver-run line too, each with its own rooflines
     legs = d["legs"]
-    for key in ("strict_hllc_blast", "strict_hlle_blast", "fast_hlle_blast", "fast_hllc_smooth_wave", "strict_hlle_smooth_wave"):
+    for key in ("strict_hllc_blast", "strict_hlle_blast", "fast_hlle_blast", "fast_hllc_smooth_wave", "strict_hlle_smooth_wave", "fast_hllc_blast_two_launches"):
         assert key in legs and legs[key]["value"] > 0 and legs[key]["status_word"] == 0
-        assert 0.0 < legs[key]["roofline"]["frac"] < 1.0 and 0.0 < legs[key]["roofline_stage1"]["frac"] < 1.0
+        assert 0.0 < legs[key]["roofline"]["frac"] < 1.0
+        if key.startswith("fast") and not key.endswith("two_launches"):
+            assert legs[key]["launches_per_step"] == 1 and legs[key]["roofline_stage1"] is None
+        else:
+            assert legs[key]["launches_per_step"] == 2 and 0.0 < legs[key]["roofline_stage1"]["frac"] < 1.0
+        assert d["summary"][key][0] == pytest.approx(legs[key]["value"], rel=1e-3)
     assert len(d["repeat_blocks"]["ms_per_step"]) == 4
     assert any(k.startswith("l1_fast_vs_strict_after_") and d[k] <= 1e-12 for k in d)
     for cfg in ("c3", "c4", "c5"):
