@@ -531,7 +531,8 @@ size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band)
 
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band)
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
+                               const BinaryTotalsOverlap* overlap)
 {
     // xv: the x vertices of the WHOLE mesh; a band (rows [row0, row0 + n0), a multiple of the block size) sees its own slice of them
     const int n0 = band ? band->n0 : d->n, row0 = band ? band->row0 : 0;
@@ -567,6 +568,16 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 
+    // The per-block sink sums read the stage's INPUT and the fixed-order reduction is two small latency-bound launches (16 + 10 us at
+    // 2048^2 beside a ~120 us stage kernel): with `overlap` they run on a second stream - the sink sums beside the stage kernel, the
+    // reduction behind both - and the next stage does not wait for them (the caller waits once, before it reads the totals).
+    hipStream_t tstream = stream;
+    if (overlap)
+    {
+        tstream = overlap->stream;
+        if ((e = hipEventRecord(overlap->stage_done, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(tstream, overlap->input_ready, 0)) != hipSuccess) return e;
+    }
     BinarySinkParams s;
     s.u_in = u_in; s.xv = xv + row0; s.yv = yv;
     s.block_out = scratch + (long) nwaves * NPART;
@@ -574,10 +585,11 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     s.dt = dt;
     s.c = p.c;
     const int tree_blocks = (n0 / d->block_size) * s.nb;          // the band's rows of tree blocks x blocks per row
-    hipLaunchKernelGGL(binary_sink_kernel, dim3(tree_blocks), dim3(256), 0, stream, s);
+    hipLaunchKernelGGL(binary_sink_kernel, dim3(tree_blocks), dim3(256), 0, tstream, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, stream, p.partials, nwaves, s.block_out, tree_blocks, totals);
+    if (overlap && (e = hipStreamWaitEvent(tstream, overlap->stage_done, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, tstream, p.partials, nwaves, s.block_out, tree_blocks, totals);
     return hipGetLastError();
 }
 

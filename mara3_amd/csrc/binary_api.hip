@@ -29,7 +29,8 @@ namespace mh {
 size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band);
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band);
+                               double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
+                               const BinaryTotalsOverlap* overlap = nullptr);
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
                               double* result, hipStream_t stream, const BinaryBand* band);
 
@@ -111,6 +112,11 @@ struct mh_binary
     mh_binary* peer_hi = nullptr;
     ncclComm_t comm = nullptr;
     bool owns_stream = true;                         // loopback members run on the first member's stream
+    // the totals of a stage (sink sums, reduction) run on a second stream beside and behind the stage kernel (binary.hip: BinaryTotalsOverlap)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_input[2] = {nullptr, nullptr}, ev_stage[2] = {nullptr, nullptr}, ev_totals = nullptr;
+    size_t scratch_doubles = 0;                      // per RK stage: each stage has its own partial sums
+    bool totals_pending = false;
     bool owns_comm = true;                           // false: borrowed from an mh_comm (mh_binary_band_use_comm)
     double* reduced_dev = nullptr;                   // RCCL: the small block summed over the ranks (out of place: the local one stays local)
     uint32_t* gather_dev = nullptr;                  // RCCL: every rank's two status words {bits, 0xFFFFFFFF - first failing whole-mesh index}
@@ -146,8 +152,11 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     else
     {
         const BinaryBand band = band_of(b);
+        BinaryTotalsOverlap ov = {b->side, b->ev_input[slot], b->ev_stage[slot]};
+        if (b->side) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
         MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
-                                       totals_dev(b, slot), b->scratch, b->status, b->stream, &band));
+                                       totals_dev(b, slot), b->scratch + (size_t) slot * b->scratch_doubles, b->status, b->stream, &band, b->side ? &ov : nullptr));
+        b->totals_pending = b->side != nullptr;
     }
     if (b->profile)
     {
@@ -215,6 +224,12 @@ static int team_fetch(const Team& t)
     for (int r = 0; r < t.n; ++r)
     {
         mh_binary* b = t.m[r];
+        if (b->totals_pending)          // the totals of the stages issued since the last fetch: their stream joins the main one here
+        {
+            MH_HIP_TRY(hipEventRecord(b->ev_totals, b->side));
+            MH_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_totals, 0));
+            b->totals_pending = false;
+        }
         const double* src = b->dev_small;
         if (b->banded && b->backend == BAND_RCCL)
         {
@@ -485,7 +500,15 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     B_TRY(hipMalloc(&b->br, n0 * n * sizeof(double)));
     B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
     B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
-    B_TRY(hipMalloc(&b->scratch, binary_scratch_doubles(d, &band) * sizeof(double)));
+    b->scratch_doubles = binary_scratch_doubles(d, &band);
+    B_TRY(hipMalloc(&b->scratch, 2 * b->scratch_doubles * sizeof(double)));
+    B_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k)
+    {
+        B_TRY(hipEventCreateWithFlags(&b->ev_input[k], hipEventDisableTiming));
+        B_TRY(hipEventCreateWithFlags(&b->ev_stage[k], hipEventDisableTiming));
+    }
+    B_TRY(hipEventCreateWithFlags(&b->ev_totals, hipEventDisableTiming));
     B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
     B_TRY(hipMemsetAsync(b->dev_small, 0, sizeof(HostMirror), b->stream));
     b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
@@ -661,6 +684,8 @@ void mh_binary_destroy(mh_binary* b)
     if (! b) return;
     (void) hipSetDevice(b->device);
     if (b->stream) (void) hipStreamSynchronize(b->stream);
+    if (b->side) { (void) hipStreamSynchronize(b->side); (void) hipStreamDestroy(b->side); }
+    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals}) if (e) (void) hipEventDestroy(e);
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);

@@ -16,6 +16,10 @@ using iso2d::State3;
 // ext0: the ghost rows of the field belong to other bands (filled by the exchange) instead of being the periodic image of its own rows
 struct BinaryBand { int n0, row0, ext0; };
 
+// binary_stage_launch with the totals (per-block sink sums + reduction) on a second stream: `input_ready` was recorded by the caller on the
+// stage's stream before the launch (the stage's input field is complete), `stage_done` is recorded by the launcher behind the stage kernel
+struct BinaryTotalsOverlap { hipStream_t stream; hipEvent_t input_ready, stage_done; };
+
 struct BinaryConsts
 {
     double h;                 // grid spacing 2 R / block_size / 2^level of the grid or block being processed
@@ -113,13 +117,15 @@ struct BinFast
         const double r2 = rsqrt(__builtin_fma(e0, e0, __builtin_fma(e1, e1, c.rs2)));
         return __builtin_fma(c.body[0], r1, c.body[5] * r2) * k.inv_mach2;
     }
+    // a root that only scales the viscosity: x rsqrt(x) without the correction step (an ulp or two); x == 0 would give 0 * inf, answered with 0
+    static __device__ inline double root(double x) { return __builtin_fmax(x * fast::rsqrt_fast(x), 0.0); }
     static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
     {
-        const double radius = fast::sqrt_fast(__builtin_fma(x, x, y * y));
+        const double radius = root(__builtin_fma(x, x, y * y));
         const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
         if (c.nu > 0.0)
             return profile * c.nu;
-        return profile * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);
+        return profile * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);      // the same root as hlle's sound speed: formed once
     }
     // iso2d::riemann_hlle physics_iso2d.hpp:488-506 with one sound speed for both sides (the scheme passes cs2 twice, :288)
     template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v)
