@@ -101,11 +101,11 @@ struct BinStrict
 struct BinFast
 {
     static constexpr int arith = MH_ARITH_FAST;
-    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2; };
+    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2, half_h, inv_h2; };
     static __device__ inline Ctx make(const BinaryConsts& c)
     {
-        const double im = fast::rcp_nr(c.mach);
-        return {im, im * im, fast::rcp_nr(c.h), fast::rcp_nr(2.0 * c.s2)};
+        const double im = fast::rcp_nr(c.mach), ih = fast::rcp_nr(c.h);
+        return {im, im * im, ih, fast::rcp_nr(2.0 * c.s2), 0.5 * c.h, ih * ih};
     }
     static __device__ inline double rsqrt(double x) { return fast::rsqrt_fast(x); }
     static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
@@ -205,18 +205,46 @@ __device__ inline State3 binary_face_flux(const BinaryConsts& c, const typename 
     const State3& pl, const State3& pr, const State3& gl, const State3& gr, const State3& tl, const State3& tr)
 {
     State3 pl_hat, pr_hat;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
+    if constexpr (A::arith == MH_ARITH_FAST)
     {
-        pl_hat[q] = pl[q] + gl[q] * 0.5 * c.h;
-        pr_hat[q] = pr[q] - gr[q] * 0.5 * c.h;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            pl_hat[q] = __builtin_fma(gl[q], k.half_h, pl[q]);
+            pr_hat[q] = __builtin_fma(gr[q], -k.half_h, pr[q]);
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+        {
+            pl_hat[q] = pl[q] + gl[q] * 0.5 * c.h;
+            pr_hat[q] = pr[q] - gr[q] * 0.5 * c.h;
+        }
     }
     const double cs2 = A::cs2(c, k, xf, yf);
     const double nu = A::nu(c, k, xf, yf, cs2);
-    const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
     State3 F = A::template hlle<AXIS>(pl_hat, pr_hat, cs2);
-    if constexpr (AXIS == 0)
+    if constexpr (A::arith == MH_ARITH_FAST)
     {
+        // the same stress with the three factors 1/2 (of mu and of the two face averages) gathered: mu/2 = nu (sigma_l + sigma_r) / 4
+        const double muh = 0.25 * nu * (pl_hat[0] + pr_hat[0]);
+        const double g_ux = gl[1] + gr[1], g_uy = gl[2] + gr[2], t_ux = tl[1] + tr[1], t_uy = tl[2] + tr[2];      // along the face normal / transverse
+        if constexpr (AXIS == 0)
+        {
+            F[1] = __builtin_fma(-muh, g_ux - t_uy, F[1]);      // tauxx = mu (dx_ux - dy_uy)
+            F[2] = __builtin_fma(-muh, g_uy + t_ux, F[2]);      // tauxy = mu (dx_uy + dy_ux)
+        }
+        else
+        {
+            F[1] = __builtin_fma(-muh, t_uy + g_ux, F[1]);      // tauyx = mu (dx_uy + dy_ux)
+            F[2] = __builtin_fma(muh, t_ux - g_uy, F[2]);       // tauyy = -mu (dx_ux - dy_uy)
+        }
+    }
+    else if constexpr (AXIS == 0)
+    {
+        const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
         const double dx_ux = 0.5 * (gl[1] + gr[1]);
         const double dx_uy = 0.5 * (gl[2] + gr[2]);
         const double dy_ux = 0.5 * (tl[1] + tr[1]);
@@ -229,6 +257,7 @@ __device__ inline State3 binary_face_flux(const BinaryConsts& c, const typename 
     }
     else
     {
+        const double mu = 0.5 * nu * (pl_hat[0] + pr_hat[0]);
         const double dx_ux = 0.5 * (tl[1] + tr[1]);
         const double dx_uy = 0.5 * (tl[2] + tr[2]);
         const double dy_ux = 0.5 * (gl[1] + gr[1]);

@@ -113,7 +113,9 @@ def test_default_tree_through_200_steps_against_the_reference_composition(binary
 
 def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
     """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
-    policy arithmetic, so the two must agree to the last bit."""
+    policy arithmetic, so in STRICT mode the two must agree to the last bit. In FAST mode (round 3) the grid kernel gathers the common
+    factors of the scheme's glue and is compiled with FMA contraction (binary_fast.hip), the block kernels are not: the two agree
+    within the mode's own tolerance, 1e-12 of the field scale."""
     for tname, uname in (("binary_tree_d2_b16_uniform", "binary_d2_b16"), ("binary_tree_d2_b16_q_uniform", "binary_d2_b16_q")):
         _both_families(binary, golden(tname), golden(uname))
 
@@ -127,9 +129,17 @@ def _both_families(binary, g, gu):
         u.next(3)
         grid = u.solution()
         blocks = t.solution()
+        scale = np.abs(grid).reshape(-1, 3).max(axis=0)
         for k, (l, i, j) in enumerate(g["blocks"]):
-            assert np.array_equal(blocks[k], grid[i * 16:(i + 1) * 16, j * 16:(j + 1) * 16]), (arith, k)
-        assert t.last_dt == u.last_dt and t.state().time == u.state().time
+            mine = grid[i * 16:(i + 1) * 16, j * 16:(j + 1) * 16]
+            if arith == "strict":
+                assert np.array_equal(blocks[k], mine), (arith, k)
+            else:
+                assert np.all(np.abs(blocks[k] - mine).reshape(-1, 3).max(axis=0) <= 1e-12 * scale), (arith, k)
+        if arith == "strict":
+            assert t.last_dt == u.last_dt and t.state().time == u.state().time
+        else:          # the time steps follow the states' largest wavespeeds
+            assert abs(t.last_dt - u.last_dt) <= 1e-11 * u.last_dt and abs(t.state().time - u.state().time) <= 1e-11 * u.state().time
         t.close(); u.close()
 
 
