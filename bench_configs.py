@@ -193,7 +193,25 @@ def c4_parse(args, stdout, nr, arith):
 
 
 def cloud_cpu_baseline():
+    """the reference's own composition of `cloud` (oracle/_ref/cloud_ref: its headers, lazy arrays, one thread) at nr=256 num_decades=1 - the same
+    sub-program options as the timed config at a size one core finishes in seconds; where that binary is absent, the C port on its golden case"""
     import numpy as np
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "cloud_ref")
+    if os.path.exists(exe):
+        try:
+            nr, few, many = 256, 2, 62
+            with tempfile.TemporaryDirectory() as d:
+                def run(nsteps):
+                    t0 = time.perf_counter()
+                    subprocess.run([exe, str(nr), "1", "2", "2", "1.2", str(nsteps), os.path.join(d, "c")], check=True, capture_output=True, timeout=600)
+                    return time.perf_counter() - t0
+                t = run(many) - run(few)             # set-up, diagnostics and file output cancel
+            return {"value": nr * nr * (many - few) / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "reference",
+                    "sample": "%d RK2 steps of cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 (%d x %d zones), the reference's headers composed as in "
+                              "oracle/ref_drivers/cloud_ref.cpp, 1 thread" % (many - few, nr, nr, nr)}
+        except Exception:
+            pass
     mo = oracle()
     g = np.load(os.path.join(ROOT, "tests", "golden", "cloud_nr32_plm_rk2.npz"))
     rv, qv, u0 = g["rv"], g["qv"], g["u0"]

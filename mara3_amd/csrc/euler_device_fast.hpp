@@ -205,6 +205,9 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     // (the reciprocal + square root form cost 2.5 % of the smooth-wave step, where one side of nearly every face takes this branch)
     const double xl = __builtin_fma(g.gfac, pstar - pl, pl), xr = __builtin_fma(g.gfac, pstar - pr, pr);
     // x <= p_K exactly when p* <= p_K, where the root is <= 1: fmax picks the 1 (and turns the NaN of p_K == 0 into it)
+    // (measured and not taken, profiles/r03/ab_fused_hllc_qskip.jsonl: a wave-wide vote that skips both inverse roots where no face of the
+    // wave has p* > p_K - most of the blast's quiescent gas - costs more than it saves: 0.636 against 0.630 ms per fused 4096^2 step on the
+    // blast, 0.667 against 0.651 on the smooth wave)
     const double ql = __builtin_fmax(xl * rsqrt_fast(xl * pl), 1.0);
     const double qr = __builtin_fmax(xr * rsqrt_fast(xr * pr), 1.0);
     const double sl = __builtin_fma(-al, ql, ul);
