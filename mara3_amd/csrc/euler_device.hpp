@@ -70,8 +70,15 @@ __device__ inline void divide_group(double (&x)[N], const Recip& R)
         bool unused;
         ds[k] = __builtin_amdgcn_div_scale(x[k], R.den, false, &unused);
         ns[k] = __builtin_amdgcn_div_scale(x[k], R.den, true, &flag[k]);
-        same = same && (__double_as_longlong(ds[k]) == __double_as_longlong(R.ds));
+        // A ZERO numerator makes v_div_scale return NaN for both of its forms (there is nothing to scale), which is not the refined
+        // denominator - but it needs none: v_div_fixup answers 0 / den from the operands' signs alone, whatever quotient it is handed. Without
+        // this case every group with an identically zero component took the fallback: the third momentum of a 2-D run, the momenta of
+        // gas at rest (round 3: -14 % of the STRICT 2-D kernels' executed instructions, profiles/r03/strict_zero_numerators.md).
+        same = same && ((__double_as_longlong(ds[k]) == __double_as_longlong(R.ds)) | (x[k] == 0.0));
     }
+#ifdef MH_PROBE_NO_DIV_FALLBACK      // instruction-count probes only (scripts/strict_isa_table.py): the hot path without the branch around it
+    same = true;
+#endif
     if (__builtin_expect(same, 1))
     {
 #pragma unroll
