@@ -186,9 +186,13 @@ void binary_stage_kernel(BinaryStageParams p)
     StatusAcc acc;        // validate_u (scheme.cpp:726-752) as status bits + first failing cell r * n + col (status_device.hpp)
     double sigma_new = 0.0;
 
+    // x vertices of the row in flight, carried from row to row: one scalar load per row, requested a row before its first use (loading
+    // xv[r], xv[r + 1] at the top of row r parked the wave on the scalar cache's latency every row: SQ_WAIT_ANY 40 % of the wave cycles)
+    double xv_lo = p.xv[r0], xv_hi = p.xv[r0 + 1];
     auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
     {
         constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+        const double xv_next = p.xv[min(r + 2, n0)];
         State3 Unext;
         if constexpr (lds_ring) U[K1] = load_row3(in + row_off(min(r + 4, n0 + 1)), n, jc8);       // row r + 1 was converted a row ago
         else                    Unext = load_row3(in + row_off(min(r + 4, n0 + 1)), n, jc8);
@@ -197,7 +201,7 @@ void binary_stage_kernel(BinaryStageParams p)
         State3 Ubase;
         if constexpr (COMBINE) Ubase = load_row3(p.u_base + row_off(r), n, jc8);
 
-        const double xlo = p.xv[r], xhi = p.xv[r + 1];
+        const double xlo = xv_lo, xhi = xv_hi;
         const double xc = (xlo + xhi) * 0.5;
         const double dx = xhi - xlo;
 
@@ -362,6 +366,8 @@ void binary_stage_kernel(BinaryStageParams p)
             U[K0] = Upre;
             Upre = Unext;
         }
+        xv_lo = xv_hi;
+        xv_hi = xv_next;
     };
 
     int r = r0;

@@ -8,8 +8,9 @@ import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import csrc_fingerprint
-OUT = os.path.join(ROOT, "gpurun_out", "prof_r2")
-DST = os.path.join(ROOT, "profiles", "r02")
+ROUND = os.environ.get("MH_PROF_ROUND", "r02")           # r03: scripts/profile_r3.sh -> gpurun_out/prof_r3 -> profiles/r03
+OUT = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND.replace("0", ""))
+DST = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
 
 
@@ -45,8 +46,8 @@ def calibration():
 
 def table(tags, part):
     ffac, wfac = calibration()
-    lines = ["# rocprofv3 summary, round 2 (%s), one MI355X" % part, "",
-             "Source: `scripts/profile_r2.sh %s` (one rocprofv3 pass per counter group; program directly after `--`), collated by `scripts/pmc_collate.py`." % part,
+    lines = ["# rocprofv3 summary, round %s (%s), one MI355X" % (ROUND[-1], part), "",
+             ("Source: `scripts/profile_r" + ROUND[-1] + ".sh %s` (one rocprofv3 pass per counter group; program directly after `--`), collated by `scripts/pmc_collate.py`.") % part,
              "Calibration on `mh::stream_copy_kernel` (671 088 640 B read and written, 8 B per lane): bytes / (FETCH_SIZE KB x 1024) = %.3f, bytes / (WRITE_SIZE KB x 1024) = %.3f"
              % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
              "| run | kernel | avg us (kernel trace) | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
@@ -59,7 +60,7 @@ def table(tags, part):
         sq, _ = counters(tag, "sq")
         fl, fdur = counters(tag, "flop")
         for k in sorted(tr):
-            if not any(x in k for x in ("stage_kernel", "update_kernel", "flux_kernel", "gradient_kernel", "sink_kernel")):
+            if not any(x in k for x in ("stage_kernel", "fused_rk2_kernel", "update_kernel", "flux_kernel", "gradient_kernel", "sink_kernel")):
                 continue
             avg, calls = tr[k]
             hbm = None
@@ -88,16 +89,17 @@ def table(tags, part):
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "headline"
     if part == "headline":
-        tr, ex = table(["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"], "headline")
+        tags = ["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"] if ROUND == "r02" else ["fast_hllc", "fast_hllc_two", "fast_hlle", "strict_hlle", "strict_hllc"]
+        tr, ex = table([t for t in tags if glob.glob(os.path.join(OUT, t + "_trace"))], "headline")
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         out = {"csrc_sha16": csrc_fingerprint(),
                "_comment": "HBM bytes per launch of the RK2 stage kernels at 4096^2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 20 "
                            "--warmup 3 --single-arith`, scripts/profile_r2.sh): 2 x FETCH_SIZE + WRITE_SIZE, calibrated on mh::stream_copy_kernel in the same script "
-                           "(profiles/r02/kernels_headline.md). Keyed by the hash of the stage kernels' sources and device headers (bench.py: KERNEL_SOURCES): bench.py reports `traffic` only for the sources "
+                           "(profiles/" + ROUND + "/kernels_headline.md). Keyed by the hash of the stage kernels' sources and device headers (bench.py: KERNEL_SOURCES): bench.py reports `traffic` only for the sources "
                            "these numbers were measured on."}
         for (tag, k), v in tr.items():
-            arith, riemann = tag.split("_")
-            stage = "stage2" if k.endswith("true>") else "stage1"
+            arith, riemann = tag.split("_")[:2]
+            stage = "fused" if "fused" in k else ("stage2" if k.endswith("true>") else "stage1")
             out["%s_%s_%s_bytes_per_launch" % (stage, arith, riemann)] = v
             if (tag, k) in ex:
                 out["%s_%s_%s_fp64" % (stage, arith, riemann)] = ex[(tag, k)]
