@@ -295,6 +295,7 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     hipLaunchKernelGGL(binary_sink_kernel, dim3(tree_blocks), dim3(256), 0, tstream, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (overlap && overlap->sink_done && (e = hipEventRecord(overlap->sink_done, tstream)) != hipSuccess) return e;
     if (overlap && (e = hipStreamWaitEvent(tstream, overlap->stage_done, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, tstream, p.partials, nwaves, s.block_out, tree_blocks, totals);
     return hipGetLastError();

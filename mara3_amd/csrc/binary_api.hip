@@ -115,8 +115,17 @@ struct mh_binary
     // the totals of a stage (sink sums, reduction) run on a second stream beside and behind the stage kernel (binary.hip: BinaryTotalsOverlap)
     hipStream_t side = nullptr;
     hipEvent_t ev_input[2] = {nullptr, nullptr}, ev_stage[2] = {nullptr, nullptr}, ev_totals = nullptr;
-    size_t scratch_doubles = 0;                      // per RK stage: each stage has its own partial sums
+    hipEvent_t ev_sink[2] = {nullptr, nullptr}, ev_fetch = nullptr;
+    size_t scratch_doubles = 0;                      // per RK stage and parity: each stage has its own partial sums
     bool totals_pending = false;
+    // The FIRST STAGE OF THE NEXT STEP, issued before this step's totals have come back (binary_attempt): it writes its totals and status
+    // into the OTHER small block and partial-sum buffers (`parity`), and this step's fetch runs on the second stream beside it.
+    double* small[2] = {nullptr, nullptr};           // dev_small = small[parity]
+    int parity = 0;
+    bool fetch_on_side = false;                      // ev_fetch is recorded: the pending fetch does not wait for what the main stream got since
+    bool eager_valid = false;                        // the first stage of the step from (eager_for, eager_dt) is in flight in the other parity
+    mh_binary_state eager_for;
+    double eager_dt = 0.0;
     bool owns_comm = true;                           // false: borrowed from an mh_comm (mh_binary_band_use_comm)
     double* reduced_dev = nullptr;                   // RCCL: the small block summed over the ranks (out of place: the local one stays local)
     uint32_t* gather_dev = nullptr;                  // RCCL: every rank's two status words {bits, 0xFFFFFFFF - first failing whole-mesh index}
@@ -129,6 +138,13 @@ static BinaryBand band_of(const mh_binary* b) { return BinaryBand{b->n0, b->row0
 
 static double* totals_dev(mh_binary* b, int stage) { return b->dev_small + stage * MH_BINARY_NTOTALS; }
 static double* maxw_dev(mh_binary* b) { return b->dev_small + 2 * MH_BINARY_NTOTALS; }
+static int32_t* status_of(double* small_block) { return reinterpret_cast<int32_t*>(small_block + 2 * MH_BINARY_NTOTALS + 1); }
+static void use_parity(mh_binary* b, int parity)
+{
+    b->parity = parity;
+    b->dev_small = b->small[parity];
+    b->status = status_of(b->dev_small);
+}
 
 static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_body_t* B)
 {
@@ -137,8 +153,10 @@ static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_bod
 
 // Bnext (graded trees only): the stage also leaves the time-step bound of the state it writes, evaluated with these bodies, in maxw_dev
 static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, double* u_out, const mh_two_body_t& B, double dt,
-                        double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr)
+                        double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr, int parity = -1)
 {
+    if (parity < 0) parity = b->parity;
+    double* const small_block = b->small[parity] ? b->small[parity] : b->dev_small;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->profile)
     {
@@ -152,10 +170,11 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     else
     {
         const BinaryBand band = band_of(b);
-        BinaryTotalsOverlap ov = {b->side, b->ev_input[slot], b->ev_stage[slot]};
+        BinaryTotalsOverlap ov = {b->side, b->ev_input[slot], b->ev_stage[slot], b->ev_sink[slot]};
         if (b->side) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
         MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
-                                       totals_dev(b, slot), b->scratch + (size_t) slot * b->scratch_doubles, b->status, b->stream, &band, b->side ? &ov : nullptr));
+                                       small_block + slot * MH_BINARY_NTOTALS, b->scratch + (size_t) (2 * parity + slot) * b->scratch_doubles,
+                                       status_of(small_block), b->stream, &band, b->side ? &ov : nullptr));
         b->totals_pending = b->side != nullptr;
     }
     if (b->profile)
@@ -224,6 +243,15 @@ static int team_fetch(const Team& t)
     for (int r = 0; r < t.n; ++r)
     {
         mh_binary* b = t.m[r];
+        if (b->fetch_on_side)
+        {
+            // the main stream already runs the next step's first stage: this step's block travelled on the second stream (binary_attempt)
+            MH_HIP_TRY(hipEventSynchronize(b->ev_totals));        // the copy queued by binary_attempt ahead of the eager stage
+            b->fetch_on_side = false;
+            b->totals_pending = false;
+            team_note_status(t);
+            return MH_OK;                 // (only ever set for a team of one)
+        }
         if (b->totals_pending)          // the totals of the stages issued since the last fetch: their stream joins the main one here
         {
             MH_HIP_TRY(hipEventRecord(b->ev_totals, b->side));
@@ -300,7 +328,17 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
     *failed = false;
     mh_two_body_t B1, B2;
     if (int rc = binary_bodies(S0.orbital_elements, S0.time, &B1)) return rc;
-    for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipMemsetAsync(t.m[r]->status, 0, 2 * sizeof(int32_t), t.m[r]->stream));
+    // Eager first stage (uniform mesh, one domain, fixed time step, binary not live, RK2): while the binary is not live the first stage of
+    // the NEXT step needs nothing of this step's totals - its bodies follow from the elements and the time - so the previous attempt may
+    // have issued it already, into the other parity's small block and partial sums; this step's fetch then ran beside it instead of
+    // leaving the GPU idle for a host round trip per step (~50 of 260 us at 2048^2). It is used only if it was issued for exactly this
+    // state and time step; a failed step discards it (the safe-mode retry starts from u[0], which the eager stage never writes).
+    const bool eager_ok = t.n == 1 && ! b->banded && ! b->tree && b->side && b->small[1] && b->run.fixed_dt && b->run.rk_order == 2 && ! safe_mode
+                          && ! (S0.time > b->run.begin_live_binary);
+    const bool eager_used = eager_ok && b->eager_valid && same_point(b->eager_for, S0) && b->eager_dt == dt;
+    b->eager_valid = false;
+    if (eager_used) use_parity(b, b->parity ^ 1);          // its totals and status words are in the other block
+    else for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipMemsetAsync(t.m[r]->status, 0, 2 * sizeof(int32_t), t.m[r]->stream));
 
     auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot, const mh_two_body_t* Bnext = nullptr) -> int
     {
@@ -318,7 +356,7 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
         return MH_OK;
     }
 
-    if (int rc = stage(0, -1, 1, B1, dt, 1.0, theta, 0)) return rc;
+    if (! eager_used) if (int rc = stage(0, -1, 1, B1, dt, 1.0, theta, 0)) return rc;
     mh_binary_state S1;
     const bool live = S0.time > b->run.begin_live_binary;
     if (live)
@@ -346,6 +384,29 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
     if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1, launched_ahead && b->tree ? &Bn : nullptr)) return rc;
     if (launched_ahead && ! b->tree)
         if (int rc = team_maxw(t, 2, Bn)) return rc;
+    if (eager_ok && prefetch_maxw)          // (prefetch_maxw: another step follows in this call)
+    {
+        mh_binary_state nxt = S0;
+        nxt.time = S0.time * 0.5 + ((S0.time + dt) + dt) * 0.5;          // binary_combine_scalars' expression; the elements do not change while not live
+        mh_two_body_t Be;
+        if (! (nxt.time > b->run.begin_live_binary) && binary_bodies(nxt.orbital_elements, nxt.time, &Be) == MH_OK)
+        {
+            // this step's fetch goes onto the second stream NOW, ahead of the eager stage's own sink sums and reduction: behind this step's
+            // last reduction (stream order) and behind the main stream up to here (ev_fetch: the status words are complete)
+            MH_HIP_TRY(hipEventRecord(b->ev_fetch, b->stream));
+            MH_HIP_TRY(hipStreamWaitEvent(b->side, b->ev_fetch, 0));
+            MH_HIP_TRY(hipMemcpyAsync(b->mirror, b->dev_small, sizeof(HostMirror), hipMemcpyDeviceToHost, b->side));
+            MH_HIP_TRY(hipEventRecord(b->ev_totals, b->side));
+            b->fetch_on_side = true;
+            MH_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sink[1], 0));      // the second stage's sink sums read u[1], which the eager stage overwrites
+            const int other = b->parity ^ 1;
+            MH_HIP_TRY(hipMemsetAsync(status_of(b->small[other]), 0, 2 * sizeof(int32_t), b->stream));
+            if (int rc = launch_stage(b, b->u[2], nullptr, b->u[1], Be, dt, 1.0, b->desc.plm_theta, 0, nullptr, other)) return rc;
+            b->eager_valid = true;
+            b->eager_for = nxt;
+            b->eager_dt = dt;
+        }
+    }
     if (int rc = team_fetch(t)) return rc;
     if (b->mirror->status[0]) { *failed = true; return MH_OK; }
     if (! live && binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, &S1) != MH_OK) { *failed = true; return MH_OK; }
@@ -378,7 +439,7 @@ static int team_next(const Team& t, int nsteps, int* safe_mode_steps)
 {
     mh_binary* b = t.m[0];
     if (safe_mode_steps) *safe_mode_steps = 0;
-    for (int r = 0; r < t.n; ++r) t.m[r]->last_failure = {0, 0, UINT64_MAX};
+    for (int r = 0; r < t.n; ++r) { t.m[r]->last_failure = {0, 0, UINT64_MAX}; t.m[r]->eager_valid = false; }
     for (int s = 0; s < nsteps; ++s)
     {
         // dt: subprog_binary.cpp:281-283
@@ -404,6 +465,7 @@ static int team_next(const Team& t, int nsteps, int* safe_mode_steps)
         if (int rc = binary_attempt(t, dt, false, s + 1 < nsteps, &next, &failed)) return rc;
         if (failed)
         {
+            for (int r = 0; r < t.n; ++r) t.m[r]->eager_valid = false;          // an eager first stage started from the rejected result
             if (safe_mode_steps) ++*safe_mode_steps;
             dt = dt * 0.1;
             for (int r = 0; r < t.n; ++r) t.m[r]->maxw_ready = false;
@@ -501,17 +563,22 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
     B_TRY(hipMalloc(&b->yv, (n + 1) * sizeof(double)));
     b->scratch_doubles = binary_scratch_doubles(d, &band);
-    B_TRY(hipMalloc(&b->scratch, 2 * b->scratch_doubles * sizeof(double)));
+    B_TRY(hipMalloc(&b->scratch, 4 * b->scratch_doubles * sizeof(double)));          // [parity][stage]
     B_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k)
     {
         B_TRY(hipEventCreateWithFlags(&b->ev_input[k], hipEventDisableTiming));
         B_TRY(hipEventCreateWithFlags(&b->ev_stage[k], hipEventDisableTiming));
+        B_TRY(hipEventCreateWithFlags(&b->ev_sink[k], hipEventDisableTiming));
     }
+    B_TRY(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     B_TRY(hipEventCreateWithFlags(&b->ev_totals, hipEventDisableTiming));
-    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
-    B_TRY(hipMemsetAsync(b->dev_small, 0, sizeof(HostMirror), b->stream));
-    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
+    for (int k = 0; k < 2; ++k)
+    {
+        B_TRY(hipMalloc(&b->small[k], sizeof(HostMirror)));
+        B_TRY(hipMemsetAsync(b->small[k], 0, sizeof(HostMirror), b->stream));
+    }
+    use_parity(b, 0);
     if (b->backend == BAND_RCCL)
     {
         B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
@@ -661,8 +728,8 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     B_TRY(hipMalloc(&b->work.block_out, (size_t) nb * ((bs * bs + 255) / 256) * 16 * sizeof(double)));      // [nb][tiles of 256 cells][16 partial sums]
     B_TRY(hipMalloc(&b->work.block_vals, (size_t) nb * MH_BINARY_NTOTALS * sizeof(double)));
     B_TRY(hipMalloc(&b->work.tile_maxw, (size_t) nb * ((bs * bs + 255) / 256) * sizeof(double)));
-    B_TRY(hipMalloc(&b->dev_small, sizeof(HostMirror)));
-    b->status = reinterpret_cast<int32_t*>(b->dev_small + 2 * MH_BINARY_NTOTALS + 1);
+    B_TRY(hipMalloc(&b->small[0], sizeof(HostMirror)));
+    use_parity(b, 0);
     B_TRY(hipHostMalloc((void**) &b->mirror, sizeof(HostMirror), hipHostMallocDefault));
     b->geom = {b->topo_dev, b->level_dev, b->edges_dev, nb, bs};
     B_TRY(hipMemcpyAsync(b->topo_dev, topo.data(), topo.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
@@ -685,11 +752,11 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipSetDevice(b->device);
     if (b->stream) (void) hipStreamSynchronize(b->stream);
     if (b->side) { (void) hipStreamSynchronize(b->side); (void) hipStreamDestroy(b->side); }
-    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals}) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_sink[0], b->ev_sink[1], b->ev_fetch, b->ev_totals}) if (e) (void) hipEventDestroy(e);
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
-    (void) hipFree(b->scratch); (void) hipFree(b->dev_small); (void) hipFree(b->staging);      // status lives inside dev_small
+    (void) hipFree(b->scratch); (void) hipFree(b->small[0]); (void) hipFree(b->small[1]); (void) hipFree(b->staging);      // status lives inside the small blocks
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
     (void) hipFree(b->work.prim); (void) hipFree(b->work.gx); (void) hipFree(b->work.gy); (void) hipFree(b->work.fx); (void) hipFree(b->work.fy); (void) hipFree(b->work.block_out); (void) hipFree(b->work.block_vals); (void) hipFree(b->work.tile_maxw);
     if (b->mirror) (void) hipHostFree(b->mirror);

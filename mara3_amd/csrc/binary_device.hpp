@@ -18,7 +18,8 @@ struct BinaryBand { int n0, row0, ext0; };
 
 // binary_stage_launch with the totals (per-block sink sums + reduction) on a second stream: `input_ready` was recorded by the caller on the
 // stage's stream before the launch (the stage's input field is complete), `stage_done` is recorded by the launcher behind the stage kernel
-struct BinaryTotalsOverlap { hipStream_t stream; hipEvent_t input_ready, stage_done; };
+// sink_done (optional): recorded by the launcher behind the sink-sums kernel - the last reader of the stage's input on that stream
+struct BinaryTotalsOverlap { hipStream_t stream; hipEvent_t input_ready, stage_done, sink_done; };
 
 struct BinaryConsts
 {
