@@ -318,3 +318,38 @@ def test_full_size_point_symmetry_and_positivity(mods):
     assert st["iteration"] == 3 and st["mass_accreted_on"][0] > 0
     assert abs(st["mass_accreted_on"][0] - st["mass_accreted_on"][1]) <= 1e-9 * st["mass_accreted_on"][0]
     s.close()
+
+
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_eager_first_stage_of_the_next_step_changes_no_bit(mods, arith):
+    """With a fixed time step and the binary not live, a call for several steps issues the first stage of step n + 1 before the totals of
+    step n have come back (mara3_amd/csrc/binary_api.hip: binary_attempt; the reference's data flow needs them only for the accumulators,
+    src/subprog_binary.cpp:258-293). One step per call never does. Same field, same scalars, bit for bit - also when a step in the
+    middle of the call is rejected and retried in safe mode, which discards the eager stage."""
+    lib, binary, engine, L = mods
+    cfg = binary.config(depth=2, block_size=16, domain_radius=4.0, fixed_dt=1)
+    a, b = binary.BinarySolver(cfg, arith=arith), binary.BinarySolver(cfg, arith=arith)
+    assert a.next(7) == 0
+    for _ in range(7):
+        assert b.next(1) == 0
+    assert bits_equal(a.solution(), b.solution())
+    assert binary.state_as_dict(a.state()) == binary.state_as_dict(b.state())
+    # a state that makes the NEXT ordinary step fail: the call's first step is retried in safe mode, the others run eagerly again
+    base, s = a.solution(), a.state()
+    for boost in (10.0, 30.0, 100.0, 300.0):
+        u = base.copy()
+        u[20, 20, 0] *= 1e-2
+        u[20, 21, 1:] *= boost
+        u[21, 20, 1:] *= boost
+        b.set_solution(u, s)
+        if b.next(1) == 1:
+            break
+    else:
+        pytest.skip("no test state made the ordinary step fail")
+    a.set_solution(u, s); b.set_solution(u, s)
+    na = a.next(5)
+    nb = sum(b.next(1) for _ in range(5))
+    assert na == nb >= 1
+    assert bits_equal(a.solution(), b.solution())
+    assert binary.state_as_dict(a.state()) == binary.state_as_dict(b.state())
+    a.close(); b.close()
