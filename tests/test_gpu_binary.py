@@ -11,7 +11,7 @@ import ctypes as C
 import json
 import numpy as np
 import pytest
-from conftest import golden
+from conftest import golden, bits_equal
 
 pytestmark = pytest.mark.gpu
 REL = 1e-12
