@@ -250,13 +250,14 @@ size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band)
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
                                double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
-                               const BinaryTotalsOverlap* overlap)
+                               const BinaryTotalsOverlap* overlap, int32_t* status_clear)
 {
     // xv: the x vertices of the WHOLE mesh; a band (rows [row0, row0 + n0), a multiple of the block size) sees its own slice of them
     const int n0 = band ? band->n0 : d->n, row0 = band ? band->row0 : 0;
     BinaryStageParams p;
     p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.u_init = u_init; p.br = br; p.xv = xv + row0; p.xvg = xv; p.yv = yv;
     p.status = status;
+    p.status_clear = status_clear;
     p.n = d->n;
     p.n0 = n0; p.row0 = row0; p.ext0 = band ? band->ext0 : 0;
     p.nstrips = (d->n + BSTRIP - 1) / BSTRIP;
@@ -278,6 +279,7 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     // The per-block sink sums read the stage's INPUT and the fixed-order reduction is two small latency-bound launches (16 + 10 us at
     // 2048^2 beside a ~120 us stage kernel): with `overlap` they run on a second stream - the sink sums beside the stage kernel, the
     // reduction behind both - and the next stage does not wait for them (the caller waits once, before it reads the totals).
+    // overlap->input_ready is an event of `stream` behind which u_in is complete (the previous stage's stage_done, or one the caller recorded).
     hipStream_t tstream = stream;
     if (overlap)
     {

@@ -30,7 +30,7 @@ size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band);
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
                                double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
-                               const BinaryTotalsOverlap* overlap = nullptr);
+                               const BinaryTotalsOverlap* overlap = nullptr, int32_t* status_clear = nullptr);
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
                               double* result, hipStream_t stream, const BinaryBand* band);
 
@@ -78,7 +78,7 @@ struct mh_binary
     mh_binary_run run;
     double h = 0.0;
     size_t field_doubles = 0;
-    double* u[3] = {nullptr, nullptr, nullptr};     // [0] solution, [1] first-stage result, [2] step result
+    double* u[4] = {nullptr, nullptr, nullptr, nullptr};     // [0] solution, [1] first-stage result, [2] step result, [3] (uniform mesh, one domain) the eager stage's
     double* u_init = nullptr;
     double* br = nullptr;
     double* xv = nullptr;
@@ -115,14 +115,13 @@ struct mh_binary
     // the totals of a stage (sink sums, reduction) run on a second stream beside and behind the stage kernel (binary.hip: BinaryTotalsOverlap)
     hipStream_t side = nullptr;
     hipEvent_t ev_input[2] = {nullptr, nullptr}, ev_stage[2] = {nullptr, nullptr}, ev_totals = nullptr;
-    hipEvent_t ev_sink[2] = {nullptr, nullptr}, ev_fetch = nullptr;
     size_t scratch_doubles = 0;                      // per RK stage and parity: each stage has its own partial sums
     bool totals_pending = false;
     // The FIRST STAGE OF THE NEXT STEP, issued before this step's totals have come back (binary_attempt): it writes its totals and status
     // into the OTHER small block and partial-sum buffers (`parity`), and this step's fetch runs on the second stream beside it.
     double* small[2] = {nullptr, nullptr};           // dev_small = small[parity]
     int parity = 0;
-    bool fetch_on_side = false;                      // ev_fetch is recorded: the pending fetch does not wait for what the main stream got since
+    bool fetch_on_side = false;                      // the pending fetch is queued on the second stream already: it does not wait for what the main stream got since
     bool eager_valid = false;                        // the first stage of the step from (eager_for, eager_dt) is in flight in the other parity
     mh_binary_state eager_for;
     double eager_dt = 0.0;
@@ -153,8 +152,10 @@ static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_bod
 
 // Bnext (graded trees only): the stage also leaves the time-step bound of the state it writes, evaluated with these bodies, in maxw_dev
 static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, double* u_out, const mh_two_body_t& B, double dt,
-                        double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr, int parity = -1)
+                        double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr, int parity = -1,
+                        hipEvent_t input_event = nullptr, int32_t* status_clear = nullptr)
 {
+    // input_event: an event of the main stream behind which u_in is complete (a stage's ev_stage), or null: one is recorded here
     if (parity < 0) parity = b->parity;
     double* const small_block = b->small[parity] ? b->small[parity] : b->dev_small;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -170,11 +171,11 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     else
     {
         const BinaryBand band = band_of(b);
-        BinaryTotalsOverlap ov = {b->side, b->ev_input[slot], b->ev_stage[slot], b->ev_sink[slot]};
-        if (b->side) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
+        BinaryTotalsOverlap ov = {b->side, input_event ? input_event : b->ev_input[slot], b->ev_stage[slot], nullptr};
+        if (b->side && ! input_event) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
         MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
                                        small_block + slot * MH_BINARY_NTOTALS, b->scratch + (size_t) (2 * parity + slot) * b->scratch_doubles,
-                                       status_of(small_block), b->stream, &band, b->side ? &ov : nullptr));
+                                       status_of(small_block), b->stream, &band, b->side ? &ov : nullptr, status_clear));
         b->totals_pending = b->side != nullptr;
     }
     if (b->profile)
@@ -337,13 +338,20 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
                           && ! (S0.time > b->run.begin_live_binary);
     const bool eager_used = eager_ok && b->eager_valid && same_point(b->eager_for, S0) && b->eager_dt == dt;
     b->eager_valid = false;
-    if (eager_used) use_parity(b, b->parity ^ 1);          // its totals and status words are in the other block
+    if (eager_used)
+    {
+        use_parity(b, b->parity ^ 1);          // its totals and status words are in the other block,
+        double* tmp = b->u[1]; b->u[1] = b->u[3]; b->u[3] = tmp;          // its result in the fourth field
+    }
     else for (int r = 0; r < t.n; ++r) MH_HIP_TRY(hipMemsetAsync(t.m[r]->status, 0, 2 * sizeof(int32_t), t.m[r]->stream));
 
-    auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot, const mh_two_body_t* Bnext = nullptr) -> int
+    // clear: the second stage also zeroes the status words of the OTHER small block, for the eager stage issued right behind it
+    auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot, const mh_two_body_t* Bnext = nullptr,
+                       hipEvent_t input_event = nullptr, int32_t* clear = nullptr) -> int
     {
         for (int r = 0; r < t.n; ++r)
-            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot, Bnext)) return rc;
+            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot, Bnext, -1,
+                                      input_event, clear)) return rc;
         return team_exchange(t, outk);
     };
 
@@ -381,31 +389,34 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
         ahead.time = S0.time * 0.5 + ((S0.time + dt) + dt) * 0.5;
         launched_ahead = binary_bodies(ahead.orbital_elements, ahead.time, &Bn) == MH_OK;
     }
-    if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1, launched_ahead && b->tree ? &Bn : nullptr)) return rc;
-    if (launched_ahead && ! b->tree)
-        if (int rc = team_maxw(t, 2, Bn)) return rc;
+    // the eager stage of the next step (see above): decided before the second stage is issued, which prepares its status words
+    mh_two_body_t Be;
+    mh_binary_state nxt = S0;
+    bool eager_next = false;
     if (eager_ok && prefetch_maxw)          // (prefetch_maxw: another step follows in this call)
     {
-        mh_binary_state nxt = S0;
         nxt.time = S0.time * 0.5 + ((S0.time + dt) + dt) * 0.5;          // binary_combine_scalars' expression; the elements do not change while not live
-        mh_two_body_t Be;
-        if (! (nxt.time > b->run.begin_live_binary) && binary_bodies(nxt.orbital_elements, nxt.time, &Be) == MH_OK)
-        {
-            // this step's fetch goes onto the second stream NOW, ahead of the eager stage's own sink sums and reduction: behind this step's
-            // last reduction (stream order) and behind the main stream up to here (ev_fetch: the status words are complete)
-            MH_HIP_TRY(hipEventRecord(b->ev_fetch, b->stream));
-            MH_HIP_TRY(hipStreamWaitEvent(b->side, b->ev_fetch, 0));
-            MH_HIP_TRY(hipMemcpyAsync(b->mirror, b->dev_small, sizeof(HostMirror), hipMemcpyDeviceToHost, b->side));
-            MH_HIP_TRY(hipEventRecord(b->ev_totals, b->side));
-            b->fetch_on_side = true;
-            MH_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_sink[1], 0));      // the second stage's sink sums read u[1], which the eager stage overwrites
-            const int other = b->parity ^ 1;
-            MH_HIP_TRY(hipMemsetAsync(status_of(b->small[other]), 0, 2 * sizeof(int32_t), b->stream));
-            if (int rc = launch_stage(b, b->u[2], nullptr, b->u[1], Be, dt, 1.0, b->desc.plm_theta, 0, nullptr, other)) return rc;
-            b->eager_valid = true;
-            b->eager_for = nxt;
-            b->eager_dt = dt;
-        }
+        eager_next = ! (nxt.time > b->run.begin_live_binary) && binary_bodies(nxt.orbital_elements, nxt.time, &Be) == MH_OK;
+    }
+    const int other = b->parity ^ 1;
+    // (the other block was fetched - the host waited for the copy - before this attempt began: nothing reads or writes it now)
+    if (int rc = stage(1, 0, 2, B2, dt, 0.5, theta, 1, launched_ahead && b->tree ? &Bn : nullptr, t.n == 1 && b->side && ! b->tree && ! b->banded ? b->ev_stage[0] : nullptr,
+                       eager_next ? status_of(b->small[other]) : nullptr)) return rc;
+    if (launched_ahead && ! b->tree)
+        if (int rc = team_maxw(t, 2, Bn)) return rc;
+    if (eager_next)
+    {
+        // This step's fetch goes onto the second stream NOW, ahead of the eager stage's own sink sums and reduction. Stream order there puts
+        // it behind this step's last reduction, which itself waited for the second stage (ev_stage[1]): totals and status words are complete.
+        MH_HIP_TRY(hipMemcpyAsync(b->mirror, b->dev_small, sizeof(HostMirror), hipMemcpyDeviceToHost, b->side));
+        MH_HIP_TRY(hipEventRecord(b->ev_totals, b->side));
+        b->fetch_on_side = true;
+        // The eager stage follows the second stage on the main stream with nothing in between: it writes the FOURTH field (the second
+        // stage's sink sums may still be reading u[1]; u[3] was last read a whole step ago, before a fetch the host has waited for).
+        if (int rc = launch_stage(b, b->u[2], nullptr, b->u[3], Be, dt, 1.0, b->desc.plm_theta, 0, nullptr, other, b->ev_stage[1])) return rc;
+        b->eager_valid = true;
+        b->eager_for = nxt;
+        b->eager_dt = dt;
     }
     if (int rc = team_fetch(t)) return rc;
     if (b->mirror->status[0]) { *failed = true; return MH_OK; }
@@ -557,7 +568,7 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
 #define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
     if (shared_stream) { b->stream = shared_stream; b->owns_stream = false; }
     else B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
+    for (int k = 0; k < (b->banded ? 3 : 4); ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
     B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
     B_TRY(hipMalloc(&b->br, n0 * n * sizeof(double)));
     B_TRY(hipMalloc(&b->xv, (n + 1) * sizeof(double)));
@@ -569,9 +580,7 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
     {
         B_TRY(hipEventCreateWithFlags(&b->ev_input[k], hipEventDisableTiming));
         B_TRY(hipEventCreateWithFlags(&b->ev_stage[k], hipEventDisableTiming));
-        B_TRY(hipEventCreateWithFlags(&b->ev_sink[k], hipEventDisableTiming));
     }
-    B_TRY(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     B_TRY(hipEventCreateWithFlags(&b->ev_totals, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k)
     {
@@ -752,9 +761,9 @@ void mh_binary_destroy(mh_binary* b)
     (void) hipSetDevice(b->device);
     if (b->stream) (void) hipStreamSynchronize(b->stream);
     if (b->side) { (void) hipStreamSynchronize(b->side); (void) hipStreamDestroy(b->side); }
-    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_sink[0], b->ev_sink[1], b->ev_fetch, b->ev_totals}) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals}) if (e) (void) hipEventDestroy(e);
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
-    for (int k = 0; k < 3; ++k) (void) hipFree(b->u[k]);
+    for (int k = 0; k < 4; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
     (void) hipFree(b->scratch); (void) hipFree(b->small[0]); (void) hipFree(b->small[1]); (void) hipFree(b->staging);      // status lives inside the small blocks
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);

@@ -30,6 +30,7 @@ struct BinaryStageParams
     const double* yv;
     double*       partials;   // [nwaves][NPART]
     int32_t*      status;
+    int32_t*      status_clear;   // or null: two status words of ANOTHER block, zeroed by this launch for the stage issued behind it (binary_api.hip: eager stage)
     const double* xvg;        // x vertices of the WHOLE mesh (xv = xvg + row0: this band's)
     int    n, chunk_rows, nstrips, nchunks;
     int    n0, row0, ext0;    // band of the mesh held by this field: rows [row0, row0 + n0); ext0: its ghost rows belong to other bands
@@ -387,6 +388,7 @@ void binary_stage_kernel(BinaryStageParams p)
         if (lane == 0) p.partials[(long) w * NPART + k] = s;
     }
     acc.commit(p.status);
+    if (p.status_clear && w == 0 && lane == 0) { p.status_clear[0] = 0; p.status_clear[1] = 0; }
 }
 
 // launches the instantiation (COMBINE, QFORM) of arithmetic A; the FAST ones live in binary_fast.hip

@@ -53,11 +53,39 @@ struct Fused2dParams
     double gamma, theta, cx, cy;
 };
 
+// Lane-to-lane movement of a row's five values: DPP moves (two VALU instructions per double) or, per exchange, the LDS crossbar
+// (ds_bpermute_b32: no VALU issue, LDS latency). MH_FUSED_XCHG is a mask of the exchanges that go through the crossbar:
+// 1 = primitives from the right, 2 = differences from the left, 4 = face states from the left, 8 = fluxes from the right.
+#ifndef MH_FUSED_XCHG
+#define MH_FUSED_XCHG 0
+#endif
+template<int BIT>
+__device__ inline State5 lane_from(const State5& s, int addr_left, int addr_right, bool left)
+{
+    if constexpr ((MH_FUSED_XCHG & BIT) != 0)
+    {
+        State5 r;
+        const int addr = left ? addr_left : addr_right;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+        {
+            const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(s[q]));
+            const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(s[q]));
+            r[q] = __hiloint2double(hi, lo);
+        }
+        return r;
+    }
+    else
+        return left ? from_left(s) : from_right(s);
+}
+
 // LDS-only barrier of the pair: the waves' outstanding global loads and stores are not waited for
 __device__ inline void pair_barrier()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#ifndef MH_PROBE_NO_PAIR_BARRIER           // timing probe only (scripts/build_variant_one.sh): what the lockstep costs; the result is wrong without it
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
@@ -77,6 +105,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     const int pair = __builtin_amdgcn_readfirstlane(b);
     const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    const int al = ((lane - 1) & 63) * 4, ar = ((lane + 1) & 63) * 4;
     const int chunk = pair / p.nstrips;
     const int strip = pair - chunk * p.nstrips;
     const int n0 = p.n0, n1 = p.n1;
@@ -159,11 +188,11 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
             Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
-            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
-            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
-            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
+            const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
+            const State5 SL = lane_from<4>(A::plus(P[K0], Gy, lim), al, ar, true);
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
-            const State5 Fy_hi = from_right(Fy_lo);
+            const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
 
             const State5 Uc = ring_get(t % USLOTS);
             State5 Un;
@@ -249,11 +278,11 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
             Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
-            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
-            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
-            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
+            const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
+            const State5 SL = lane_from<4>(A::plus(P[K0], Gy, lim), al, ar, true);
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
-            const State5 Fy_hi = from_right(Fy_lo);
+            const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
 
             const State5 Uc = hand_row(r);
             State5 Un;
