@@ -514,6 +514,15 @@ int  mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d,
  * exchange of the initial solution's ghost rows (collective), so mh_binary_next may follow directly. */
 int  mh_binary_band_use_comm(mh_binary* b, mh_comm* comm);
 int  mh_binary_band_rows(const mh_binary* b, int* row0, int* row1);
+/* A band with neighbours may step its EDGE rows first - the first and last `rows` rows, one small launch: RCCL bands run it on their
+ * exchange stream with the ghost exchange of the stage behind it, both beside the launch of the interior rows on the main stream, which
+ * waits for the exchange only behind the interior. The field does not depend on the cut bit for bit (either arithmetic mode); the totals
+ * keep one fixed order of summation per cut (edge waves first). rows == 0 (the state after create): one launch per stage with the
+ * exchange behind it; rows < 0: the recommended cut (2 rows: what a neighbour needs; 0 when the band is too thin); else 2 <= rows < n0 / 2.
+ * OFF by default because it does not pay where it could be measured (one GPU, exchange to self through RCCL: 0.31 against 0.27 ms per
+ * step at 2048^2 - an edge wave's 6 rows take 11 us, and two cross-stream events cost what the send / recv kernel costs).
+ * The reference's analogue is the order in which the pool's workers take the blocks (src/core_tree.hpp:615-625): no result depends on it. */
+int  mh_binary_band_set_edge_rows(mh_binary* b, int rows);
 /* What made an attempt of the most recent mh_binary_next call fail (before its safe-mode retry, or before MH_E_PHYSICS): OR of the status
  * bits of every band and the first failing cell as a flat index into the WHOLE-mesh host array of mh_binary_set_solution; status 0 when
  * no attempt of that call failed. The same on every band. */
@@ -555,6 +564,24 @@ int  mh_binary_tree_solver_data(const mh_binary_model* m, int block_size, const 
  * source_term_softening times the smallest vertex spacing of any block. */
 int  mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks,
                            int nblocks, const double* edges_host, const double* u_init_host, const double* buffer_rate_host);
+/* Multi-GPU for GRADED trees. The leaves are ordered along the Hilbert curve of the finest level present (mh_binary_tree_curve_order) and
+ * member r of N owns the r-th of N runs of equal length of that order (partition_shape's formula, src/core_ndarray.hpp:820-836). Every
+ * member holds the whole tree; per stage it runs each of the three block kernels on its own blocks and the members' results are gathered
+ * behind each kernel (primitives + slopes, fluxes, new field + per-tile sums). Totals and time-step bound are then formed by every member
+ * over all blocks in the CALLER's block order: field, totals and scalars are the single-domain solver's bit for bit, with a live binary
+ * too. The reference hands the leaves to its thread pool in traversal order (tree.map(fn, pool), src/core_tree.hpp:615-625); it declares
+ * a hilbert_index (src/core_tree.hpp:1033-1069) that no sub-program uses. Arrays at this boundary (blocks, edges, u, buffer rate, the
+ * failing-cell index) stay in the caller's block order. RCCL form: one process per GPU, comm_id128 or (NULL) mh_binary_band_use_comm;
+ * LOOPBACK group: all members as objects of one process on one GPU, driven by the mh_binary_group_* calls. */
+int  mh_binary_tree_curve_order(const mh_tree_block* blocks, int nblocks, int32_t* order /* [nblocks]: order[k] = the block standing k-th along the curve */);
+int  mh_binary_tree_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks,
+                                int nblocks, const double* edges_host, const double* u_init_aos_host, const double* buffer_rate_host,
+                                int rank, int world, const void* comm_id128);
+int  mh_binary_tree_group_create(mh_binary** members, int world, int device, const mh_binary_desc* d, const mh_binary_run* run,
+                                 const mh_tree_block* blocks, int nblocks, const double* edges_host, const double* u_init_aos_host,
+                                 const double* buffer_rate_host);
+/* the blocks (caller's numbering, in curve order) a member runs the block kernels on; ids may be NULL */
+int  mh_binary_tree_owned_blocks(const mh_binary* b, int32_t* ids, int* count);
 
 /* device utilities used by bench / tests without torch */
 int  mh_device_count(void);

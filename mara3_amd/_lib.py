@@ -204,6 +204,10 @@ SYMBOLS = [
     ("mh_binary_tree_vertices", _i, [_i, _d, _vp, _i, _vp]),
     ("mh_binary_tree_solver_data", _i, [C.POINTER(BinaryModel), _i, _vp, _i, _vp, _vp, _vp, C.POINTER(_d)]),
     ("mh_binary_tree_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _i, _vp, _vp, _vp]),
+    ("mh_binary_tree_curve_order", _i, [_vp, _i, _vp]),
+    ("mh_binary_tree_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    ("mh_binary_tree_group_create", _i, [_vp, _i, _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _i, _vp, _vp, _vp]),
+    ("mh_binary_tree_owned_blocks", _i, [_vp, _vp, C.POINTER(_i)]),
     ("mh_binary_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
     ("mh_binary_destroy", None, [_vp]),
     ("mh_binary_set_solution", _i, [_vp, _vp, C.POINTER(BinaryState)]),
@@ -212,6 +216,7 @@ SYMBOLS = [
     ("mh_binary_band_create", _i, [C.POINTER(_vp), _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp, _i, _i, _vp, _i]),
     ("mh_binary_band_rows", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     ("mh_binary_band_use_comm", _i, [_vp, _vp]),
+    ("mh_binary_band_set_edge_rows", _i, [_vp, _i]),
     ("mh_binary_last_failure", _i, [_vp, C.POINTER(StepResult)]),
     ("mh_binary_group_create", _i, [C.POINTER(_vp), _i, _i, C.POINTER(BinaryDesc), C.POINTER(BinaryRun), _vp, _vp, _vp, _vp]),
     ("mh_binary_group_set_solution", _i, [C.POINTER(_vp), _i, _vp, C.POINTER(BinaryState)]),

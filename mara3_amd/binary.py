@@ -301,12 +301,139 @@ class BinaryTreeSolver(BinarySolver):
         return u
 
 
+def tree_curve_order(blocks):
+    """order[k] = the block (row of `blocks`) standing k-th along the Hilbert curve through the leaves (mh_binary_tree_curve_order)"""
+    lib = L.load_library()
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    order = np.empty(len(blocks), dtype=np.int32)
+    L.check(lib.mh_binary_tree_curve_order(blocks.ctypes.data_as(C.c_void_p), len(blocks), order.ctypes.data_as(C.c_void_p)))
+    return order
+
+
+class _TreeSetup:
+    """what BinaryTreeSolver's constructor prepares, for the distributed forms"""
+
+    def __init__(self, cfg, blocks=None, arith="strict"):
+        self.lib = L.load_library()
+        self.cfg = cfg
+        self.bs = int(cfg["block_size"])
+        self.blocks = tree_blocks(cfg) if blocks is None else np.ascontiguousarray(blocks, dtype=np.int32)
+        self.edges = tree_vertices(cfg, self.blocks)
+        self.u_init, self.buffer_rate, recommended_time_step = tree_solver_data(cfg, self.blocks, self.edges)
+        self.u_init = np.ascontiguousarray(self.u_init, dtype=np.float64)
+        self.buffer_rate = np.ascontiguousarray(self.buffer_rate, dtype=np.float64)
+        self.desc = make_desc(config(**{**cfg, "conserve_linear_p": 1}), arith=arith)
+        if not int(cfg["conserve_linear_p"]):
+            self.desc.angmom_form = 1
+            self.desc.gst_suppr_radius = float(cfg["source_term_softening"]) * float(np.diff(self.edges, axis=2).min())
+        run = L.BinaryRun()
+        run.rk_order = int(cfg["rk_order"])
+        run.fixed_dt = int(cfg["fixed_dt"])
+        run.no_accretion_force = int(cfg["no_accretion_force"])
+        run.cfl_number = float(cfg["cfl_number"])
+        run.recommended_time_step = float(recommended_time_step)
+        run.begin_live_binary = float(cfg["begin_live_binary"])
+        self.run = run
+
+    def pointers(self):
+        return (self.blocks.ctypes.data_as(C.c_void_p), len(self.blocks), self.edges.ctypes.data_as(C.c_void_p),
+                self.u_init.ctypes.data_as(C.c_void_p), self.buffer_rate.ctypes.data_as(C.c_void_p))
+
+
+class BinaryTreeGroup:
+    """A GRADED tree distributed over `world` members - runs of the Hilbert curve through its leaves - as objects of one process on one
+    GPU (LOOPBACK; include/mara_hip.h: mh_binary_tree_group_create). Arrays are the whole tree in the caller's block order,
+    [nblocks][bs][bs][3], as BinaryTreeSolver's."""
+
+    def __init__(self, cfg, world=2, device=0, blocks=None, arith="strict"):
+        t = _TreeSetup(cfg, blocks, arith)
+        self.lib, self.cfg, self.world, self.setup = t.lib, cfg, world, t
+        self.blocks, self.bs = t.blocks, t.bs
+        self.handles = (C.c_void_p * world)()
+        L.check(self.lib.mh_binary_tree_group_create(self.handles, world, device, C.byref(t.desc), C.byref(t.run), *t.pointers()))
+        self.owned = []
+        for r in range(world):
+            n = C.c_int()
+            ids = np.empty(len(self.blocks), dtype=np.int32)
+            L.check(self.lib.mh_binary_tree_owned_blocks(C.c_void_p(self.handles[r]), ids.ctypes.data_as(C.c_void_p), C.byref(n)))
+            self.owned.append(ids[:n.value].copy())
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
+
+    def set_solution(self, u, state):
+        up = None if u is None else np.ascontiguousarray(u, dtype=np.float64).ctypes.data_as(C.c_void_p)
+        L.check(self.lib.mh_binary_group_set_solution(self.handles, self.world, up, C.byref(state)))
+
+    def state(self):
+        s = L.BinaryState()
+        L.check(self.lib.mh_binary_group_get_solution(self.handles, self.world, None, C.byref(s)))
+        return s
+
+    def solution(self):
+        u = np.empty((len(self.blocks), self.bs, self.bs, 3))
+        L.check(self.lib.mh_binary_group_get_solution(self.handles, self.world, u.ctypes.data_as(C.c_void_p), None))
+        return u
+
+    def member_solution(self, r):
+        """the whole tree as member r holds it (every member holds every block)"""
+        u = np.empty((len(self.blocks), self.bs, self.bs, 3))
+        L.check(self.lib.mh_binary_get_solution(C.c_void_p(self.handles[r]), u.ctypes.data_as(C.c_void_p), None))
+        return u
+
+    def next(self, nsteps=1):
+        safe = C.c_int(0)
+        L.check(self.lib.mh_binary_group_next(self.handles, self.world, int(nsteps), C.byref(safe)))
+        return safe.value
+
+    @property
+    def last_dt(self):
+        return self.lib.mh_binary_last_dt(C.c_void_p(self.handles[0]))
+
+    def last_failure(self):
+        r = L.StepResult()
+        L.check(self.lib.mh_binary_last_failure(C.c_void_p(self.handles[0]), C.byref(r)))
+        return r.status, (None if r.status == 0 else int(r.first_bad_index))
+
+    def close(self):
+        for r in range(self.world):
+            if self.handles[r]:
+                self.lib.mh_binary_destroy(C.c_void_p(self.handles[r]))
+                self.handles[r] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BinaryTreeBand(BinaryTreeSolver):
+    """ONE member of a distributed graded tree in this process (RCCL: one process per GPU; mh_binary_tree_band_create)."""
+
+    def __init__(self, cfg, rank, world, comm_id, device=0, blocks=None, arith="strict", comm=None):
+        t = _TreeSetup(cfg, blocks, arith)
+        self.lib, self.cfg, self.setup = t.lib, cfg, t
+        self.blocks, self.bs, self.edges, self.u_init, self.buffer_rate, self.desc, self.run = t.blocks, t.bs, t.edges, t.u_init, t.buffer_rate, t.desc, t.run
+        self.handle = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
+        L.check(self.lib.mh_binary_tree_band_create(C.byref(self.handle), device, C.byref(t.desc), C.byref(t.run), *t.pointers(), rank, world, idbuf))
+        if comm is not None:
+            L.check(self.lib.mh_binary_band_use_comm(self.handle, comm.handle))
+            self._comm = comm
+        s = L.BinaryState()
+        s.orbital_elements = initial_elements(cfg)
+        self.set_solution(None, s)
+
+
 class BinaryBandGroup:
     """The uniform-depth mesh cut into `world` BANDS of whole rows of tree blocks, as objects of one process on one GPU exchanging ghost
     rows through the LOOPBACK backend (include/mara_hip.h: mh_binary_group_*; the RCCL form is mh_binary_band_create, one process per
     GPU). Same interface as BinarySolver where it applies; arrays are the WHOLE mesh [n][n][3]."""
 
-    def __init__(self, cfg, world=2, device=0, chunk_rows=0, arith="strict"):
+    def __init__(self, cfg, world=2, device=0, chunk_rows=0, arith="strict", edge_rows=None):
+        """edge_rows: None or 0 = one launch per stage (the library's default); -1 = the recommended cut of every band into edge rows
+        (stepped first) and interior; else that many rows per side (mh_binary_band_set_edge_rows)"""
         self.lib = L.load_library()
         self.cfg, self.world = cfg, world
         self.n = grid_size(cfg)
@@ -331,6 +458,8 @@ class BinaryBandGroup:
             a, b = C.c_int(), C.c_int()
             L.check(self.lib.mh_binary_band_rows(C.c_void_p(self.handles[r]), C.byref(a), C.byref(b)))
             self.rows.append((a.value, b.value))
+            if edge_rows is not None:
+                L.check(self.lib.mh_binary_band_set_edge_rows(C.c_void_p(self.handles[r]), int(edge_rows)))
         s = L.BinaryState()
         s.orbital_elements = initial_elements(cfg)
         self.set_solution(None, s)
@@ -387,7 +516,7 @@ class BinaryBand(BinarySolver):
     mara3_amd.slab.native_comm_id). next() is collective over the ranks; solution() returns the whole-mesh array with this band's rows
     filled in (rows [row0, row1))."""
 
-    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict", self_exchange=False, comm=None, defer=False):
+    def __init__(self, cfg, rank, world, comm_id, device=0, chunk_rows=0, arith="strict", self_exchange=False, comm=None, defer=False, edge_rows=None):
         """comm: the process's communicator (mara3_amd.slab.NativeComm) instead of a unique id - no ncclCommInitRank of its own.
         defer=True: neither; the caller attach()es the communicator once every rank holds its band."""
         self.lib = L.load_library()
@@ -413,6 +542,8 @@ class BinaryBand(BinarySolver):
         a, b = C.c_int(), C.c_int()
         L.check(self.lib.mh_binary_band_rows(self.handle, C.byref(a), C.byref(b)))
         self.row0, self.row1 = a.value, b.value
+        if edge_rows is not None:          # (BinaryBandGroup's docstring)
+            L.check(self.lib.mh_binary_band_set_edge_rows(self.handle, int(edge_rows)))
         if comm is not None:
             self.attach(comm)
         elif not defer:

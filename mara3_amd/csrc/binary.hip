@@ -229,20 +229,30 @@ BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]
     return c;
 }
 
-static int binary_chunk_rows(const mh_binary_desc* d, int nstrips, int rows)
+// reserved: wave slots held by a launch that runs beside this one (a band's edge rows beside its interior)
+static int binary_chunk_rows(const mh_binary_desc* d, int nstrips, int rows, int reserved = 0)
 {
     if (d->chunk_rows > 0) return d->chunk_rows;
-    const long chunks_max = 2048 / nstrips > 0 ? 2048 / nstrips : 1;     // one residency round at 2 waves / SIMD
+    const long chunks_max = (2048 - reserved) / nstrips > 0 ? (2048 - reserved) / nstrips : 1;     // one residency round at 2 waves / SIMD
     const long c = (rows + chunks_max - 1) / chunks_max;
     return (int) (c > 96 ? 32 : (c < 4 ? 4 : c));
 }
 
+// the recommended cut of a band whose edge rows are stepped first: the two rows a neighbour needs, no more - an edge wave marches its four
+// pipeline-fill rows and then these, and how long that takes (11 us; 22 us with eight rows) is the head start the exchange loses
+int binary_edge_rows(int n0)
+{
+    return n0 >= 5 ? 2 : 0;
+}
+
+// partial sums of the waves + per-block sink results of one stage. Sized for the most waves any cut of the rows can make (the shortest
+// chunk the launcher picks is 4 rows, or the descriptor's; two edge chunks per strip when a band runs its edges first): a few MB at most.
 size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band)
 {
     const int rows = band ? band->n0 : d->n;
     const int nstrips = (d->n + BSTRIP - 1) / BSTRIP;
-    const int chunk = binary_chunk_rows(d, nstrips, rows);
-    const long nwaves = (long) nstrips * ((rows + chunk - 1) / chunk);
+    const int shortest = d->chunk_rows > 0 && d->chunk_rows < 4 ? d->chunk_rows : 4;
+    const long nwaves = (long) nstrips * (2 + (rows + shortest - 1) / shortest);
     const long nb = d->n / d->block_size;
     return (size_t) (nwaves * NPART + (long) (rows / d->block_size) * nb * NBLK);
 }
@@ -250,10 +260,12 @@ size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band)
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
                                double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
-                               const BinaryTotalsOverlap* overlap, int32_t* status_clear)
+                               const BinaryTotalsOverlap* overlap, int32_t* status_clear, const BinaryRows* rows)
 {
     // xv: the x vertices of the WHOLE mesh; a band (rows [row0, row0 + n0), a multiple of the block size) sees its own slice of them
     const int n0 = band ? band->n0 : d->n, row0 = band ? band->row0 : 0;
+    const int part = rows ? rows->part : BIN_ROWS_ALL, edge = rows ? rows->edge : 0;
+    if (part != BIN_ROWS_ALL && (edge < 2 || n0 - 2 * edge < 1)) return hipErrorInvalidValue;
     BinaryStageParams p;
     p.u_in = u_in; p.u_base = u_base; p.u_out = u_out; p.u_init = u_init; p.br = br; p.xv = xv + row0; p.xvg = xv; p.yv = yv;
     p.status = status;
@@ -261,20 +273,40 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     p.n = d->n;
     p.n0 = n0; p.row0 = row0; p.ext0 = band ? band->ext0 : 0;
     p.nstrips = (d->n + BSTRIP - 1) / BSTRIP;
-    p.chunk_rows = binary_chunk_rows(d, p.nstrips, n0);
-    p.nchunks = (n0 + p.chunk_rows - 1) / p.chunk_rows;
+    p.seg1_begin = p.seg1_end = 0;
+    p.wave_base = 0;
+    if (part == BIN_ROWS_EDGES)
+    {
+        // one chunk per strip and side: rows [0, edge) and [n0 - edge, n0)
+        p.chunk_rows = edge;
+        p.seg0_begin = 0; p.seg0_end = edge; p.seg0_chunks = 1;
+        p.seg1_begin = n0 - edge; p.seg1_end = n0;
+        p.nchunks = 2;
+    }
+    else
+    {
+        const int lo = part == BIN_ROWS_INTERIOR ? edge : 0, hi = part == BIN_ROWS_INTERIOR ? n0 - edge : n0;
+        // (interior: the edge launch's 2 x nstrips waves run beside it - together they must not spill into a second residency round, or the
+        // last interior waves start when the first ones end: 137 instead of 102 us at 2048^2, kernel trace)
+        p.chunk_rows = binary_chunk_rows(d, p.nstrips, hi - lo, part == BIN_ROWS_INTERIOR ? 2 * p.nstrips : 0);
+        p.nchunks = (hi - lo + p.chunk_rows - 1) / p.chunk_rows;
+        p.seg0_begin = lo; p.seg0_end = hi; p.seg0_chunks = p.nchunks;
+        if (part == BIN_ROWS_INTERIOR) p.wave_base = 2 * p.nstrips;
+    }
     p.theta = theta;
     p.dt = dt;
     p.weight = weight;
     p.c = binary_make_consts(d, bodies);
-    const int nwaves = p.nstrips * p.nchunks;
+    const int launch_waves = p.nstrips * p.nchunks;
+    const int nwaves = p.wave_base + launch_waves;          // of the whole stage, once its last part is issued
     p.partials = scratch;
-    const int nblocks = (nwaves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
+    const int nblocks = (launch_waves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
     const dim3 grid(nblocks), block(BWAVE * BWAVES_PER_BLOCK);
     const bool combine = weight != 1.0;
     hipError_t e = d->arith == MH_ARITH_FAST ? binary_stage_dispatch_fast(p, grid, block, stream, combine, d->angmom_form != 0)
                                              : binary_stage_dispatch<BinStrict>(p, grid, block, stream, combine, d->angmom_form != 0);
     if (e != hipSuccess) return e;
+    if (part == BIN_ROWS_EDGES) return hipSuccess;          // the totals follow the interior
 
     // The per-block sink sums read the stage's INPUT and the fixed-order reduction is two small latency-bound launches (16 + 10 us at
     // 2048^2 beside a ~120 us stage kernel): with `overlap` they run on a second stream - the sink sums beside the stage kernel, the
@@ -299,6 +331,7 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     if (e != hipSuccess) return e;
     if (overlap && overlap->sink_done && (e = hipEventRecord(overlap->sink_done, tstream)) != hipSuccess) return e;
     if (overlap && (e = hipStreamWaitEvent(tstream, overlap->stage_done, 0)) != hipSuccess) return e;
+    if (rows && rows->edges_done && (e = hipStreamWaitEvent(tstream, rows->edges_done, 0)) != hipSuccess) return e;      // the edge launch ran on another stream
     hipLaunchKernelGGL(binary_reduce_kernel, dim3(1), dim3(1024), 0, tstream, p.partials, nwaves, s.block_out, tree_blocks, totals);
     return hipGetLastError();
 }

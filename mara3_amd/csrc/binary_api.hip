@@ -30,16 +30,20 @@ size_t binary_scratch_doubles(const mh_binary_desc* d, const BinaryBand* band);
 hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u_in, const double* u_base,
                                double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
                                double theta, double* totals, double* scratch, int32_t* status, hipStream_t stream, const BinaryBand* band,
-                               const BinaryTotalsOverlap* overlap = nullptr, int32_t* status_clear = nullptr);
+                               const BinaryTotalsOverlap* overlap = nullptr, int32_t* status_clear = nullptr, const BinaryRows* rows = nullptr);
+int binary_edge_rows(int n0);
 hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const double* yv, const double* u, const double bodies[10],
                               double* result, hipStream_t stream, const BinaryBand* band);
 
 // graded trees (binary_tree.hip)
 struct TreeGeom { const int32_t* topo; const int32_t* level; const double* edges; int nb, bs; };
 struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals, *tile_maxw; };
+enum { TREE_PRIM_GRAD = 1, TREE_FLUX = 2, TREE_UPDATE = 4, TREE_TOTALS = 8, TREE_ALL = 15 };
+struct TreeRun { int phases, b0, b1; const int32_t* order; const int32_t* ids; };
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result);
+                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result,
+                                    const TreeRun* part = nullptr);
 hipError_t binary_tree_min_dt_launch(const mh_binary_desc* d, const TreeGeom& g, const double* u, const double bodies[10], double* result, hipStream_t stream);
 
 // diagnostics (binary_diag.hip)
@@ -96,6 +100,7 @@ struct mh_binary
     mh_binary_state maxw_for;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    hipEvent_t profile_e0 = nullptr;
     // graded tree (mh_binary_tree_create): block-major fields [nb][3][bs][bs], neighbour table, per-stage work arrays
     bool tree = false;
     TreeGeom geom = {nullptr, nullptr, nullptr, 0, 0};
@@ -104,6 +109,16 @@ struct mh_binary
     int32_t* level_dev = nullptr;
     double* edges_dev = nullptr;
     std::vector<double> host_staging;
+    // DISTRIBUTED graded tree (mh_binary_tree_band_create / _group_create): every member holds the whole tree, stored in the order of the
+    // Hilbert curve through its leaves (binary_host.cpp: binary_tree_curve_order), and runs the block kernels on its own run of that curve,
+    // blocks [tb0, tb1); the members' results are gathered after each kernel (tree_stage_distributed). Totals and time-step bound are then
+    // formed by every member over all blocks, in the caller's block order: the same bits on every member as on one domain.
+    bool tdist = false;
+    int tb0 = 0, tb1 = 0;
+    std::vector<int32_t> perm;                       // perm[k]: the caller's number of the block stored k-th
+    std::vector<int> tcut;                           // world + 1 offsets of the members' runs
+    int32_t* order_dev = nullptr;                    // where the caller's k-th block is stored
+    int32_t* ids_dev = nullptr;                      // = perm, on the device
     // band decomposition (see the header comment): rows [row0, row0 + n0) of the mesh; world == 1: the whole mesh
     int rank = 0, world = 1, row0 = 0, n0 = 0;
     bool banded = false;                             // ghost rows come from an exchange (world > 1, or the RCCL path to self at world 1)
@@ -125,6 +140,11 @@ struct mh_binary
     bool eager_valid = false;                        // the first stage of the step from (eager_for, eager_dt) is in flight in the other parity
     mh_binary_state eager_for;
     double eager_dt = 0.0;
+    // Edge rows first (bands): the stage kernel runs the first and last `edge` rows of the band in one small launch, their exchange travels
+    // on `xstream` (RCCL) beside the interior launch, and the main stream waits for it behind the interior (team_exchange_begin / _end).
+    int edge = 0;                                    // 0: one launch per stage, the exchange behind it on the main stream
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_edge = nullptr, ev_edone = nullptr, ev_xchg = nullptr;
     bool owns_comm = true;                           // false: borrowed from an mh_comm (mh_binary_band_use_comm)
     double* reduced_dev = nullptr;                   // RCCL: the small block summed over the ranks (out of place: the local one stays local)
     uint32_t* gather_dev = nullptr;                  // RCCL: every rank's two status words {bits, 0xFFFFFFFF - first failing whole-mesh index}
@@ -153,17 +173,25 @@ static int binary_bodies(const mh_full_orbital_elements& E, double t, mh_two_bod
 // Bnext (graded trees only): the stage also leaves the time-step bound of the state it writes, evaluated with these bodies, in maxw_dev
 static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, double* u_out, const mh_two_body_t& B, double dt,
                         double weight, double theta, int slot, const mh_two_body_t* Bnext = nullptr, int parity = -1,
-                        hipEvent_t input_event = nullptr, int32_t* status_clear = nullptr)
+                        hipEvent_t input_event = nullptr, int32_t* status_clear = nullptr, int part = BIN_ROWS_ALL, hipStream_t on = nullptr,
+                        hipEvent_t edges_done = nullptr)
 {
+    // on: the stream of this launch (the edge rows of an RCCL band run on its exchange stream), default the main stream
+    hipStream_t stream = on ? on : b->stream;
     // input_event: an event of the main stream behind which u_in is complete (a stage's ev_stage), or null: one is recorded here
     if (parity < 0) parity = b->parity;
     double* const small_block = b->small[parity] ? b->small[parity] : b->dev_small;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->profile)
+    if (b->profile)          // one pair per stage: from the edge launch (if any) to the end of the interior's
     {
-        MH_HIP_TRY(hipEventCreate(&e0));
-        MH_HIP_TRY(hipEventCreate(&e1));
-        MH_HIP_TRY(hipEventRecord(e0, b->stream));
+        if (part == BIN_ROWS_INTERIOR && b->profile_e0) { e0 = b->profile_e0; b->profile_e0 = nullptr; }
+        else
+        {
+            MH_HIP_TRY(hipEventCreate(&e0));
+            MH_HIP_TRY(hipEventRecord(e0, stream));
+        }
+        if (part == BIN_ROWS_EDGES) b->profile_e0 = e0;
+        else MH_HIP_TRY(hipEventCreate(&e1));
     }
     if (b->tree)
         MH_HIP_TRY(binary_tree_stage_launch(&b->desc, b->geom, b->work, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
@@ -172,13 +200,14 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     {
         const BinaryBand band = band_of(b);
         BinaryTotalsOverlap ov = {b->side, input_event ? input_event : b->ev_input[slot], b->ev_stage[slot], nullptr};
-        if (b->side && ! input_event) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
+        if (b->side && ! input_event && part != BIN_ROWS_EDGES) MH_HIP_TRY(hipEventRecord(b->ev_input[slot], b->stream));
+        const BinaryRows rows = {part, b->edge, edges_done};
         MH_HIP_TRY(binary_stage_launch(&b->desc, b->xv, b->yv, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
                                        small_block + slot * MH_BINARY_NTOTALS, b->scratch + (size_t) (2 * parity + slot) * b->scratch_doubles,
-                                       status_of(small_block), b->stream, &band, b->side ? &ov : nullptr, status_clear));
-        b->totals_pending = b->side != nullptr;
+                                       status_of(small_block), stream, &band, b->side ? &ov : nullptr, status_clear, part == BIN_ROWS_ALL ? nullptr : &rows));
+        if (part != BIN_ROWS_EDGES) b->totals_pending = b->side != nullptr;
     }
-    if (b->profile)
+    if (b->profile && e1)
     {
         MH_HIP_TRY(hipEventRecord(e1, b->stream));
         b->events.emplace_back(e0, e1);
@@ -196,8 +225,10 @@ static bool same_point(const mh_binary_state& a, const mh_binary_state& c)
 struct Team { mh_binary** m; int n; };
 static int check_binary_group(mh_binary** g, int n);
 
-// two ghost rows per side of field u[k] of every member, from its periodic neighbours (after the stage launches that wrote them)
-static int team_exchange(const Team& t, int k)
+// two ghost rows per side of field u[k] of every member, from its periodic neighbours (after the launches that wrote the rows they send).
+// A member that runs its edge rows first (edge > 0, RCCL) sends from its second stream, behind the edge launch only; team_exchange_end
+// makes the main stream wait for it. Loopback members share one stream: the copies are queued where they stand.
+static int team_exchange(const Team& t, int k, bool behind_edge_launch = false)
 {
     for (int r = 0; r < t.n; ++r)
     {
@@ -207,7 +238,7 @@ static int team_exchange(const Team& t, int k)
         double* f = b->u[k];
         if (b->backend == BAND_LOOPBACK)
         {
-            // members share one stream: every stage launch of the team is already queued in front of these copies
+            // members share one stream: every launch of the team that writes the rows sent is already queued in front of these copies
             const double* lo = b->peer_lo->u[k] + (size_t) b->peer_lo->n0 * 3 * n;          // the low neighbour's last two rows
             const double* hi = b->peer_hi->u[k] + blk;                                        // the high neighbour's first two rows
             MH_HIP_TRY(hipMemcpyAsync(f, lo, blk * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
@@ -217,14 +248,26 @@ static int team_exchange(const Team& t, int k)
         {
             RcclApi* api = rccl();
             if (! api || ! b->comm) { set_error("binary bands: RCCL communicator missing"); return MH_E_STATE; }
+            // within a stage: behind the edge launch, which ran on the exchange stream (team_exchange_end joins it); else on the main stream
+            hipStream_t xs = behind_edge_launch && b->edge > 0 && b->xstream ? b->xstream : b->stream;
             const int lo = (b->rank + b->world - 1) % b->world, hi = (b->rank + 1) % b->world;
             MH_RCCL_TRY(api->GroupStart());
-            MH_RCCL_TRY(api->Send(f + blk, blk, ncclDouble, lo, b->comm, b->stream));                                   // rows 0, 1
-            MH_RCCL_TRY(api->Send(f + (size_t) b->n0 * 3 * n, blk, ncclDouble, hi, b->comm, b->stream));                // rows n0 - 2, n0 - 1
-            MH_RCCL_TRY(api->Recv(f + (size_t) (b->n0 + 2) * 3 * n, blk, ncclDouble, hi, b->comm, b->stream));          // order as slab.hip (lo == hi at world 2)
-            MH_RCCL_TRY(api->Recv(f, blk, ncclDouble, lo, b->comm, b->stream));
+            MH_RCCL_TRY(api->Send(f + blk, blk, ncclDouble, lo, b->comm, xs));                                   // rows 0, 1
+            MH_RCCL_TRY(api->Send(f + (size_t) b->n0 * 3 * n, blk, ncclDouble, hi, b->comm, xs));                // rows n0 - 2, n0 - 1
+            MH_RCCL_TRY(api->Recv(f + (size_t) (b->n0 + 2) * 3 * n, blk, ncclDouble, hi, b->comm, xs));          // order as slab.hip (lo == hi at world 2)
+            MH_RCCL_TRY(api->Recv(f, blk, ncclDouble, lo, b->comm, xs));
             MH_RCCL_TRY(api->GroupEnd());
+            if (xs != b->stream) MH_HIP_TRY(hipEventRecord(b->ev_xchg, xs));
         }
+    }
+    return MH_OK;
+}
+static int team_exchange_end(const Team& t)
+{
+    for (int r = 0; r < t.n; ++r)
+    {
+        mh_binary* b = t.m[r];
+        if (b->banded && b->backend == BAND_RCCL && b->edge > 0 && b->xstream) MH_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_xchg, 0));
     }
     return MH_OK;
 }
@@ -260,18 +303,21 @@ static int team_fetch(const Team& t)
             b->totals_pending = false;
         }
         const double* src = b->dev_small;
-        if (b->banded && b->backend == BAND_RCCL)
+        if ((b->banded || b->tdist) && b->backend == BAND_RCCL)
         {
             RcclApi* api = rccl();
             if (! api || ! b->comm) { set_error("binary bands: RCCL communicator missing"); return MH_E_STATE; }
             const size_t nt = 2 * MH_BINARY_NTOTALS;
+            if (! b->tdist)          // (a distributed tree's totals and time-step bound are formed by every member over all blocks: nothing to reduce)
+            {
             MH_RCCL_TRY(api->AllReduce(b->dev_small, b->reduced_dev, nt, ncclDouble, ncclSum, b->comm, b->stream));
             MH_RCCL_TRY(api->AllReduce(b->dev_small + nt, b->reduced_dev + nt, 1, ncclUint64, ncclMax, b->comm, b->stream));     // wavespeeds are > 0: bit order = value order
+            src = b->reduced_dev;
+            }
             // status words: the bits are an OR, which no RCCL reduction forms (a max of {NEG_DENSITY} and {NAN} would drop the former), so
             // every rank's pair is gathered and merged on the host below, exactly as the loopback members' are
             MH_RCCL_TRY(api->AllGather(b->dev_small + nt + 1, b->gather_dev, 2, ncclUint32, b->comm, b->stream));
             MH_HIP_TRY(hipMemcpyAsync(b->gather_host, b->gather_dev, (size_t) b->world * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-            src = b->reduced_dev;
         }
         MH_HIP_TRY(hipMemcpyAsync(b->mirror, src, sizeof(HostMirror), hipMemcpyDeviceToHost, b->stream));
     }
@@ -279,7 +325,7 @@ static int team_fetch(const Team& t)
     for (int r = 0; r < t.n; ++r)
     {
         mh_binary* b = t.m[r];
-        if (! (b->banded && b->backend == BAND_RCCL)) continue;
+        if (! ((b->banded || b->tdist) && b->backend == BAND_RCCL)) continue;
         uint32_t bits = 0, key = 0;               // the kernels' keys are whole-mesh already: (row0 + r) n + col (binary.hip)
         for (int q = 0; q < b->world; ++q)
         {
@@ -296,8 +342,11 @@ static int team_fetch(const Team& t)
         for (int r = 1; r < t.n; ++r)
         {
             const HostMirror& o = *t.m[r]->mirror;
-            for (int s2 = 0; s2 < 2; ++s2) for (int k = 0; k < MH_BINARY_NTOTALS; ++k) sum.totals[s2][k] = sum.totals[s2][k] + o.totals[s2][k];
-            if (o.maxw > sum.maxw) sum.maxw = o.maxw;
+            if (! t.m[0]->tdist)          // (distributed tree: every member holds the totals of the whole tree already)
+            {
+                for (int s2 = 0; s2 < 2; ++s2) for (int k = 0; k < MH_BINARY_NTOTALS; ++k) sum.totals[s2][k] = sum.totals[s2][k] + o.totals[s2][k];
+                if (o.maxw > sum.maxw) sum.maxw = o.maxw;
+            }
             sum.status[0] |= o.status[0];
             if ((uint32_t) o.status[1] > (uint32_t) sum.status[1]) sum.status[1] = o.status[1];
         }
@@ -316,6 +365,73 @@ static int team_maxw(const Team& t, int k, const mh_two_body_t& B)
         else { const BinaryBand band = band_of(b); MH_HIP_TRY(binary_maxw_launch(&b->desc, b->xv, b->yv, b->u[k], B.body1, maxw_dev(b), b->stream, &band)); }
     }
     return MH_OK;
+}
+
+// The members' runs of one block-major array, gathered onto every member: `doubles` per block; ptr(m) = the array of member m.
+template<class Ptr>
+static int tree_gather(const Team& t, size_t doubles, Ptr ptr)
+{
+    mh_binary* b0 = t.m[0];
+    if (b0->backend == BAND_LOOPBACK)
+    {
+        // members share one stream: the launches that wrote the runs are queued in front of these copies
+        for (int r = 0; r < t.n; ++r)
+        {
+            const size_t off = (size_t) t.m[r]->tb0 * doubles, cnt = (size_t) (t.m[r]->tb1 - t.m[r]->tb0) * doubles;
+            if (cnt == 0) continue;
+            for (int q = 0; q < t.n; ++q)
+                if (q != r) MH_HIP_TRY(hipMemcpyAsync(ptr(t.m[q]) + off, ptr(t.m[r]) + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, b0->stream));
+        }
+        return MH_OK;
+    }
+    if (b0->backend != BAND_RCCL || b0->world < 2) return MH_OK;          // (one rank: its run is the whole tree)
+    RcclApi* api = rccl();
+    if (! api || ! b0->comm) { set_error("binary tree: RCCL communicator missing"); return MH_E_STATE; }
+    double* a = ptr(b0);
+    MH_RCCL_TRY(api->GroupStart());
+    for (int q = 0; q < b0->world; ++q)
+    {
+        if (q == b0->rank) continue;
+        const size_t mine = (size_t) (b0->tb1 - b0->tb0) * doubles, theirs = (size_t) (b0->tcut[q + 1] - b0->tcut[q]) * doubles;
+        if (mine) MH_RCCL_TRY(api->Send(a + (size_t) b0->tb0 * doubles, mine, ncclDouble, q, b0->comm, b0->stream));
+        if (theirs) MH_RCCL_TRY(api->Recv(a + (size_t) b0->tcut[q] * doubles, theirs, ncclDouble, q, b0->comm, b0->stream));
+    }
+    MH_RCCL_TRY(api->GroupEnd());
+    return MH_OK;
+}
+
+// One stage of a DISTRIBUTED graded tree: each of the three block kernels on the member's own run of blocks, the members' results
+// gathered behind each (primitives and slopes; fluxes; the new field with its per-tile sums and wavespeeds), then the totals - and, behind
+// a step's last stage, the time-step bound - formed by every member over ALL blocks in the caller's block order.
+static int tree_stage_distributed(const Team& t, int in, int base, int outk, const mh_two_body_t& B, double dt, double weight, double theta, int slot,
+                                  const mh_two_body_t* Bnext)
+{
+    const int bs = t.m[0]->geom.bs;
+    const size_t cell = (size_t) 3 * bs * bs, face = (size_t) 3 * (bs + 1) * bs, tiles = (size_t) (bs * bs + 255) / 256;
+    auto run = [&] (int phases) -> int
+    {
+        for (int r = 0; r < t.n; ++r)
+        {
+            mh_binary* m = t.m[r];
+            const bool own = (phases & TREE_TOTALS) == 0;
+            const TreeRun part = {phases, own ? m->tb0 : 0, own ? m->tb1 : m->geom.nb, m->order_dev, m->ids_dev};
+            MH_HIP_TRY(binary_tree_stage_launch(&m->desc, m->geom, m->work, m->u[in], base < 0 ? nullptr : m->u[base], m->u[outk], m->u_init, m->br, B.body1,
+                                                dt, weight, theta, totals_dev(m, slot), m->status, m->stream, Bnext ? Bnext->body1 : nullptr, maxw_dev(m), &part));
+        }
+        return MH_OK;
+    };
+    if (int rc = run(TREE_PRIM_GRAD)) return rc;
+    if (int rc = tree_gather(t, cell, [] (mh_binary* m) { return m->work.prim; })) return rc;
+    if (int rc = tree_gather(t, cell, [] (mh_binary* m) { return m->work.gx; })) return rc;
+    if (int rc = tree_gather(t, cell, [] (mh_binary* m) { return m->work.gy; })) return rc;
+    if (int rc = run(TREE_FLUX)) return rc;
+    if (int rc = tree_gather(t, face, [] (mh_binary* m) { return m->work.fx; })) return rc;
+    if (int rc = tree_gather(t, face, [] (mh_binary* m) { return m->work.fy; })) return rc;
+    if (int rc = run(TREE_UPDATE)) return rc;
+    if (int rc = tree_gather(t, cell, [outk] (mh_binary* m) { return m->u[outk]; })) return rc;
+    if (int rc = tree_gather(t, tiles * 16, [] (mh_binary* m) { return m->work.block_out; })) return rc;
+    if (Bnext) if (int rc = tree_gather(t, tiles, [] (mh_binary* m) { return m->work.tile_maxw; })) return rc;
+    return run(TREE_TOTALS);
 }
 
 // one attempt at a full step from (u[0], state); on success the new solution is in u[2] of every member and *out
@@ -349,10 +465,39 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
     auto stage = [&t] (int in, int base, int outk, const mh_two_body_t& B, double dt_, double w, double th, int slot, const mh_two_body_t* Bnext = nullptr,
                        hipEvent_t input_event = nullptr, int32_t* clear = nullptr) -> int
     {
+        if (t.m[0]->tdist) return tree_stage_distributed(t, in, base, outk, B, dt_, w, th, slot, Bnext);
+        // Members with neighbours: the edge rows - RCCL: on the exchange stream, which first waits for what the main stream holds so far -
+        // their exchange behind them, and the interior on the main stream beside both; the main stream (and the reduction of the totals)
+        // wait for the exchange behind the interior. Loopback members share one stream: edge launches, copies, interior launches in a row.
+        // A member too thin to split, or told not to, runs whole before the exchange.
+        auto own_xstream = [] (const mh_binary* m) { return m->edge > 0 && m->backend == BAND_RCCL && m->xstream != nullptr; };
         for (int r = 0; r < t.n; ++r)
-            if (int rc = launch_stage(t.m[r], t.m[r]->u[in], base < 0 ? nullptr : t.m[r]->u[base], t.m[r]->u[outk], B, dt_, w, th, slot, Bnext, -1,
-                                      input_event, clear)) return rc;
-        return team_exchange(t, outk);
+        {
+            mh_binary* m = t.m[r];
+            if (own_xstream(m))
+            {
+                MH_HIP_TRY(hipEventRecord(m->ev_edge, m->stream));
+                MH_HIP_TRY(hipStreamWaitEvent(m->xstream, m->ev_edge, 0));
+            }
+            if (int rc = launch_stage(m, m->u[in], base < 0 ? nullptr : m->u[base], m->u[outk], B, dt_, w, th, slot, Bnext, -1, input_event, clear,
+                                      m->edge > 0 ? BIN_ROWS_EDGES : BIN_ROWS_ALL, own_xstream(m) ? m->xstream : nullptr)) return rc;
+        }
+        // RCCL: the interior launch is issued BEFORE the send / recv group - enqueueing the group costs the host tens of microseconds, during
+        // which the GPU would otherwise hold the edge rows only (kernel trace, profiles/r03/binary_band_edges.md)
+        const bool exchange_last = own_xstream(t.m[0]);
+        if (! exchange_last) if (int rc = team_exchange(t, outk, true)) return rc;
+        for (int r = 0; r < t.n; ++r)
+        {
+            mh_binary* m = t.m[r];
+            if (m->edge > 0)
+            {
+                if (own_xstream(m)) MH_HIP_TRY(hipEventRecord(m->ev_edone, m->xstream));          // the edge waves' partial sums are complete behind it
+                if (int rc = launch_stage(m, m->u[in], base < 0 ? nullptr : m->u[base], m->u[outk], B, dt_, w, th, slot, Bnext, -1, input_event, clear,
+                                          BIN_ROWS_INTERIOR, nullptr, own_xstream(m) ? m->ev_edone : nullptr)) return rc;
+            }
+        }
+        if (exchange_last) if (int rc = team_exchange(t, outk, true)) return rc;
+        return team_exchange_end(t);
     };
 
     if (b->run.rk_order == 1)
@@ -499,9 +644,12 @@ static void tree_to_device_layout(const mh_binary* b, const double* aos, double*
 {
     const int bs = b->geom.bs;
     for (int k = 0; k < b->geom.nb; ++k)
+    {
+        const size_t from = b->perm.empty() ? (size_t) k : (size_t) b->perm[k];          // (a distributed tree stores the caller's blocks in curve order)
         for (int q = 0; q < 3; ++q)
             for (int c = 0; c < bs * bs; ++c)
-                out[((size_t) k * 3 + q) * bs * bs + c] = aos[((size_t) k * bs * bs + c) * 3 + q];
+                out[((size_t) k * 3 + q) * bs * bs + c] = aos[(from * bs * bs + c) * 3 + q];
+    }
 }
 
 extern "C" {
@@ -588,8 +736,13 @@ static int binary_create_common(mh_binary** out, int device, const mh_binary_des
         B_TRY(hipMemsetAsync(b->small[k], 0, sizeof(HostMirror), b->stream));
     }
     use_parity(b, 0);
+    b->edge = 0;          // one launch per stage unless mh_binary_band_set_edge_rows says otherwise (measured: DESIGN.md 7.1)
     if (b->backend == BAND_RCCL)
     {
+        B_TRY(hipStreamCreateWithFlags(&b->xstream, hipStreamNonBlocking));
+        B_TRY(hipEventCreateWithFlags(&b->ev_edge, hipEventDisableTiming));
+        B_TRY(hipEventCreateWithFlags(&b->ev_xchg, hipEventDisableTiming));
+        B_TRY(hipEventCreateWithFlags(&b->ev_edone, hipEventDisableTiming));
         B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
         B_TRY(hipMalloc(&b->gather_dev, (size_t) world * 2 * sizeof(uint32_t)));
         B_TRY(hipHostMalloc((void**) &b->gather_host, (size_t) world * 2 * sizeof(uint32_t), hipHostMallocDefault));
@@ -649,7 +802,7 @@ int mh_binary_band_create(mh_binary** out, int device, const mh_binary_desc* d, 
 int mh_binary_band_use_comm(mh_binary* b, mh_comm* c)
 {
     if (! b || ! c) return MH_E_INVALID;
-    if (! b->banded) return MH_OK;
+    if (! b->banded && ! b->tdist) return MH_OK;
     if (b->backend != BAND_RCCL) { set_error("mh_binary_band_use_comm: not an RCCL band"); return MH_E_STATE; }
     if (b->comm) { set_error("mh_binary_band_use_comm: the band has a communicator already"); return MH_E_STATE; }
     if (c->world != b->world || c->rank != b->rank || c->device != b->device)
@@ -659,7 +812,17 @@ int mh_binary_band_use_comm(mh_binary* b, mh_comm* c)
     }
     b->comm = c->comm;
     b->owns_comm = false;
-    return band_initial_exchange(b);
+    return b->tdist ? MH_OK : band_initial_exchange(b);
+}
+
+int mh_binary_band_set_edge_rows(mh_binary* b, int rows)
+{
+    if (! b) return MH_E_INVALID;
+    if (! b->banded || b->tree) { set_error("mh_binary_band_set_edge_rows: not a band with neighbours"); return MH_E_STATE; }
+    if (rows < 0) { b->edge = binary_edge_rows(b->n0); return MH_OK; }
+    if (rows != 0 && (rows < 2 || b->n0 - 2 * rows < 1)) { set_error("mh_binary_band_set_edge_rows: %d edge rows per side do not fit a band of %d rows (2 <= rows, 2 rows < n0)", rows, b->n0); return MH_E_INVALID; }
+    b->edge = rows;
+    return MH_OK;
 }
 
 int mh_binary_last_failure(const mh_binary* b, mh_step_result* result)
@@ -700,14 +863,40 @@ int mh_binary_band_rows(const mh_binary* b, int* row0, int* row1)
     return MH_OK;
 }
 
-int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks, int nblocks,
-                          const double* edges, const double* u_init_aos, const double* br)
+} // extern "C"
+
+// rank, world, backend: a member of a distributed tree (world == 1 with BAND_RCCL: the RCCL calls of the fetch, to self); BAND_NONE: one domain
+static int binary_tree_create_common(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks_in, int nblocks,
+                                     const double* edges_in, const double* u_init_aos, const double* br_in, int rank, int world, int backend, hipStream_t shared_stream)
 {
+    const mh_tree_block* blocks = blocks_in;
+    const double* edges = edges_in;
+    const double* br = br_in;
     if (! out || ! d || ! run || ! blocks || ! edges || ! u_init_aos || ! br || nblocks < 1) { set_error("binary tree create: null argument"); return MH_E_INVALID; }
     if (d->block_size < 2 || d->block_size % 2 != 0) { set_error("binary tree: block_size must be even"); return MH_E_INVALID; }
     if (run->rk_order != 1 && run->rk_order != 2) { set_error("binary::next_solution: rk_order must be 1 or 2"); return MH_E_INVALID; }
     if (! (d->mach_number > 0.0) || ! (d->sink_radius > 0.0) || ! (d->domain_radius > 0.0)) { set_error("binary: mach_number, sink_radius and domain_radius must be positive"); return MH_E_INVALID; }
     const int bs = d->block_size, nb = nblocks;
+    // a distributed tree is stored along the Hilbert curve through its leaves, so that a member's blocks are one run of every array
+    const bool dist = backend != BAND_NONE;
+    std::vector<int32_t> perm, order;
+    std::vector<mh_tree_block> blocks_p;
+    std::vector<double> edges_p, br_p;
+    if (dist)
+    {
+        if (rank < 0 || rank >= world || world > 64) { set_error("binary tree: rank %d of %d", rank, world); return MH_E_INVALID; }
+        perm.resize(nb); order.resize(nb);
+        if (int rc = binary_tree_curve_order(blocks_in, nb, perm.data())) return rc;
+        blocks_p.resize(nb); edges_p.resize((size_t) nb * 2 * (bs + 1)); br_p.resize((size_t) nb * bs * bs);
+        for (int k = 0; k < nb; ++k)
+        {
+            order[perm[k]] = k;
+            blocks_p[k] = blocks_in[perm[k]];
+            memcpy(&edges_p[(size_t) k * 2 * (bs + 1)], edges_in + (size_t) perm[k] * 2 * (bs + 1), (size_t) 2 * (bs + 1) * sizeof(double));
+            memcpy(&br_p[(size_t) k * bs * bs], br_in + (size_t) perm[k] * bs * bs, (size_t) bs * bs * sizeof(double));
+        }
+        blocks = blocks_p.data(); edges = edges_p.data(); br = br_p.data();
+    }
     std::vector<int32_t> topo((size_t) nb * 12), level(nb);
     if (int rc = binary_tree_topology(blocks, nb, topo.data())) return rc;
     for (int k = 0; k < nb; ++k) level[k] = blocks[k].level;
@@ -718,12 +907,41 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     b->desc.n = 0;
     b->run = *run;
     b->tree = true;
+    b->rank = rank; b->world = world;
+    b->backend = backend;
+    b->tdist = dist;
+    b->perm = perm;
+    if (dist)
+    {
+        b->tcut.resize(world + 1);
+        for (int r = 0; r < world; ++r)
+        {
+            size_t a, e;
+            mh_partition_rows((size_t) nb, (size_t) world, (size_t) r, &a, &e);          // runs of equal length (every block has bs^2 cells), nd::partition_shape's formula
+            b->tcut[r] = (int) a; b->tcut[r + 1] = (int) e;
+        }
+        b->tb0 = b->tcut[rank]; b->tb1 = b->tcut[rank + 1];
+    }
     b->field_doubles = (size_t) nb * 3 * bs * bs;
     b->host_staging.resize(b->field_doubles);
     auto fail = [&] (hipError_t e, const char* what) { mh_binary_destroy(b); return hip_fail(e, what); };
 #define B_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(_e, #call); } while (0)
-    B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (shared_stream) { b->stream = shared_stream; b->owns_stream = false; }
+    else B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for (int k = 0; k < 3; ++k) B_TRY(hipMalloc(&b->u[k], b->field_doubles * sizeof(double)));
+    if (dist)
+    {
+        B_TRY(hipMalloc(&b->order_dev, (size_t) nb * sizeof(int32_t)));
+        B_TRY(hipMalloc(&b->ids_dev, (size_t) nb * sizeof(int32_t)));
+        B_TRY(hipMemcpyAsync(b->order_dev, order.data(), (size_t) nb * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+        B_TRY(hipMemcpyAsync(b->ids_dev, perm.data(), (size_t) nb * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+        if (backend == BAND_RCCL)
+        {
+            B_TRY(hipMalloc(&b->reduced_dev, sizeof(HostMirror)));
+            B_TRY(hipMalloc(&b->gather_dev, (size_t) world * 2 * sizeof(uint32_t)));
+            B_TRY(hipHostMalloc((void**) &b->gather_host, (size_t) world * 2 * sizeof(uint32_t), hipHostMallocDefault));
+        }
+    }
     B_TRY(hipMalloc(&b->u_init, b->field_doubles * sizeof(double)));
     B_TRY(hipMalloc(&b->br, (size_t) nb * bs * bs * sizeof(double)));
     B_TRY(hipMalloc(&b->topo_dev, topo.size() * sizeof(int32_t)));
@@ -755,15 +973,65 @@ int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, 
     return MH_OK;
 }
 
+extern "C" {
+
+int mh_binary_tree_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks, int nblocks,
+                          const double* edges, const double* u_init_aos, const double* br)
+{
+    return binary_tree_create_common(out, device, d, run, blocks, nblocks, edges, u_init_aos, br, 0, 1, BAND_NONE, nullptr);
+}
+
+int mh_binary_tree_band_create(mh_binary** out, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks, int nblocks,
+                               const double* edges, const double* u_init_aos, const double* br, int rank, int world, const void* comm_id128)
+{
+    if (world < 1) { set_error("binary tree band: world %d", world); return MH_E_INVALID; }
+    if (int rc = binary_tree_create_common(out, device, d, run, blocks, nblocks, edges, u_init_aos, br, rank, world, BAND_RCCL, nullptr)) return rc;
+    if (! comm_id128) return MH_OK;          // the communicator follows: mh_binary_band_use_comm
+    mh_binary* b = *out;
+    RcclApi* api = rccl();
+    if (! api) { mh_binary_destroy(b); *out = nullptr; set_error("binary tree: librccl.so.1 could not be loaded"); return MH_E_STATE; }
+    ncclUniqueId id;
+    memcpy(&id, comm_id128, sizeof id);
+    const ncclResult_t r = api->CommInitRank(&b->comm, world, id, rank);
+    if (r != ncclSuccess) { b->comm = nullptr; mh_binary_destroy(b); *out = nullptr; return rccl_fail(r, "ncclCommInitRank"); }
+    return MH_OK;
+}
+
+int mh_binary_tree_group_create(mh_binary** members, int world, int device, const mh_binary_desc* d, const mh_binary_run* run, const mh_tree_block* blocks,
+                                int nblocks, const double* edges, const double* u_init_aos, const double* br)
+{
+    if (! members || world < 1 || world > 64) { set_error("binary tree group: need 1..64 members"); return MH_E_INVALID; }
+    for (int r = 0; r < world; ++r) members[r] = nullptr;
+    for (int r = 0; r < world; ++r)
+        if (int rc = binary_tree_create_common(&members[r], device, d, run, blocks, nblocks, edges, u_init_aos, br, r, world, BAND_LOOPBACK, r == 0 ? nullptr : members[0]->stream))
+        {
+            for (int q = r - 1; q >= 0; --q) { mh_binary_destroy(members[q]); members[q] = nullptr; }
+            return rc;
+        }
+    return MH_OK;
+}
+
+int mh_binary_tree_owned_blocks(const mh_binary* b, int32_t* ids, int* count)
+{
+    if (! b || ! count) return MH_E_INVALID;
+    if (! b->tree) { set_error("mh_binary_tree_owned_blocks: not a tree solver"); return MH_E_STATE; }
+    const int b0 = b->tdist ? b->tb0 : 0, b1 = b->tdist ? b->tb1 : b->geom.nb;
+    *count = b1 - b0;
+    if (ids) for (int k = b0; k < b1; ++k) ids[k - b0] = b->perm.empty() ? k : b->perm[k];
+    return MH_OK;
+}
+
 void mh_binary_destroy(mh_binary* b)
 {
     if (! b) return;
     (void) hipSetDevice(b->device);
     if (b->stream) (void) hipStreamSynchronize(b->stream);
     if (b->side) { (void) hipStreamSynchronize(b->side); (void) hipStreamDestroy(b->side); }
-    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals}) if (e) (void) hipEventDestroy(e);
+    if (b->xstream) { (void) hipStreamSynchronize(b->xstream); (void) hipStreamDestroy(b->xstream); }
+    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals, b->ev_edge, b->ev_edone, b->ev_xchg, b->profile_e0}) if (e) (void) hipEventDestroy(e);
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (int k = 0; k < 4; ++k) (void) hipFree(b->u[k]);
+    (void) hipFree(b->order_dev); (void) hipFree(b->ids_dev);
     (void) hipFree(b->u_init); (void) hipFree(b->br); (void) hipFree(b->xv); (void) hipFree(b->yv);
     (void) hipFree(b->scratch); (void) hipFree(b->small[0]); (void) hipFree(b->small[1]); (void) hipFree(b->staging);      // status lives inside the small blocks
     (void) hipFree(b->topo_dev); (void) hipFree(b->level_dev); (void) hipFree(b->edges_dev);
@@ -823,7 +1091,11 @@ int mh_binary_group_set_solution(mh_binary** g, int n, const double* u_aos, cons
 int mh_binary_group_get_solution(mh_binary** g, int n, double* u_aos, mh_binary_state* state)
 {
     if (int rc = check_binary_group(g, n)) return rc;
-    for (int r = 0; r < n; ++r) if (int rc = mh_binary_get_solution(g[r], u_aos, r == 0 ? state : nullptr)) return rc;
+    for (int r = 0; r < n; ++r)
+    {
+        if (r > 0 && g[r]->tdist) break;          // (every member of a distributed tree holds the whole tree)
+        if (int rc = mh_binary_get_solution(g[r], u_aos, r == 0 ? state : nullptr)) return rc;
+    }
     return MH_OK;
 }
 
@@ -837,9 +1109,12 @@ int mh_binary_get_solution(mh_binary* b, double* u_aos, mh_binary_state* state)
         MH_HIP_TRY(hipStreamSynchronize(b->stream));
         const int bs = b->geom.bs;
         for (int k = 0; k < b->geom.nb; ++k)                         // device [nb][3][bs][bs] -> host [nb][bs][bs][3]
+        {
+            const size_t to = b->perm.empty() ? (size_t) k : (size_t) b->perm[k];
             for (int q = 0; q < 3; ++q)
                 for (int c = 0; c < bs * bs; ++c)
-                    u_aos[((size_t) k * bs * bs + c) * 3 + q] = b->host_staging[((size_t) k * 3 + q) * bs * bs + c];
+                    u_aos[(to * bs * bs + c) * 3 + q] = b->host_staging[((size_t) k * 3 + q) * bs * bs + c];
+        }
     }
     else if (u_aos)
     {
@@ -911,7 +1186,7 @@ int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaun
 int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_momentum)
 {
     if (! b) { set_error("binary disk_totals: null solver"); return MH_E_INVALID; }
-    if (b->banded) { set_error("binary disk_totals: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
+    if (b->banded || b->tdist) { set_error("binary disk_totals: not built for band / distributed-tree decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* partial = b->u[2];
@@ -929,7 +1204,7 @@ int mh_binary_disk_totals(mh_binary* b, double* disk_mass, double* disk_angular_
 int mh_binary_diagnostic_fields(mh_binary* b, double* sigma, double* radial_velocity, double* phi_velocity)
 {
     if (! b) { set_error("binary diagnostic_fields: null solver"); return MH_E_INVALID; }
-    if (b->banded) { set_error("binary diagnostic_fields: not built for band decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
+    if (b->banded || b->tdist) { set_error("binary diagnostic_fields: not built for band / distributed-tree decompositions (gather the solution and use a whole-mesh solver)"); return MH_E_STATE; }
     MH_HIP_TRY(hipSetDevice(b->device));
     const size_t ncell = b->tree ? (size_t) b->geom.nb * b->geom.bs * b->geom.bs : (size_t) b->desc.n * b->desc.n;
     double* fields = b->u[1];

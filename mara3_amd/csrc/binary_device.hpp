@@ -15,6 +15,11 @@ using iso2d::State3;
 // A band of the uniform-depth mesh held by one device field: rows [row0, row0 + n0) of the n x n cells (whole rows of tree blocks);
 // ext0: the ghost rows of the field belong to other bands (filled by the exchange) instead of being the periodic image of its own rows
 struct BinaryBand { int n0, row0, ext0; };
+// The rows of a band one call of binary_stage_launch covers. A band with neighbours runs its EDGE rows first (the first and the last
+// `edge` rows, one small launch), so that their exchange travels beside the INTERIOR launch; the stage's sink sums and reduction
+// follow the interior. The partial sums keep one fixed order: edge waves, then interior waves.
+enum { BIN_ROWS_ALL = 0, BIN_ROWS_EDGES = 1, BIN_ROWS_INTERIOR = 2 };
+struct BinaryRows { int part, edge; hipEvent_t edges_done; };          // edges_done (interior, or null): the reduction also waits for it
 
 // binary_stage_launch with the totals (per-block sink sums + reduction) on a second stream: `input_ready` was recorded by the caller on the
 // stage's stream before the launch (the stage's input field is complete), `stage_done` is recorded by the launcher behind the stage kernel
@@ -41,6 +46,7 @@ struct BinaryConsts
 //            (which already differs from the reference through libm): 1e-12 of the field scale, tests/test_gpu_binary.py.
 struct BinStrict
 {
+    static __device__ inline double carried(double x) { return x; }          // (no contraction in this mode: nothing to settle)
     static constexpr int arith = MH_ARITH_STRICT;
     struct Ctx { Recip rmach, rh; };
     static __device__ inline Ctx make(const BinaryConsts& c) { return {make_recip(c.mach, 1.0), make_recip(c.h, 1.0)}; }
@@ -99,9 +105,18 @@ struct BinStrict
     static __device__ inline void over_area(double (&l)[3], double dA) { divide_group<3>(l, make_recip(dA, 1.0)); }
 };
 
+// binary_fast.hip is compiled with -ffp-contract=fast, and the compiler then fuses a product into EVERY sum that uses it - also across
+// the inlined function that formed it. A row's primitives and slopes are used in the iteration that forms them and carried to the next
+// two; fused into the first use and rounded in the later ones, a face computed in a chunk's prologue (everything fresh) would differ in
+// the last bit from the same face computed in the row loop (one operand fresh, one carried), i.e. the field would depend on how the rows
+// are cut into chunks and launches. Values that are carried are therefore SETTLED where they are formed: an empty asm the optimiser
+// cannot see through (no instruction).
+__device__ inline double settled(double x) { asm("" : "+v"(x)); return x; }
+
 struct BinFast
 {
     static constexpr int arith = MH_ARITH_FAST;
+    static __device__ inline double carried(double x) { return settled(x); }
     struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2, half_h, inv_h2; };
     static __device__ inline Ctx make(const BinaryConsts& c)
     {
@@ -160,7 +175,7 @@ struct BinFast
     {
         State3 g;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) g[q] = fast::plm_gradient(l[q], m[q], r[q], theta) * k.inv_h;
+        for (int q = 0; q < 3; ++q) g[q] = settled(fast::plm_gradient(l[q], m[q], r[q], theta) * k.inv_h);
         return g;
     }
     template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
@@ -172,13 +187,13 @@ struct BinFast
         {
             const double sr = U[1] * rs, lz = U[2] * rs;
             const double rr2 = fast::rcp_nr(__builtin_fma(xc, xc, yc * yc));
-            P[1] = __builtin_fma(sr, xc, -lz * yc) * rr2;
-            P[2] = __builtin_fma(sr, yc, lz * xc) * rr2;
+            P[1] = settled(__builtin_fma(sr, xc, -lz * yc) * rr2);
+            P[2] = settled(__builtin_fma(sr, yc, lz * xc) * rr2);
         }
         else
         {
-            P[1] = U[1] * rs;
-            P[2] = U[2] * rs;
+            P[1] = settled(U[1] * rs);
+            P[2] = settled(U[2] * rs);
         }
         return P;
     }

@@ -290,9 +290,53 @@ int binary_tree_topology(const mh_tree_block* blocks, int nb, int32_t* topo)
     return MH_OK;
 }
 
+// Position of each leaf along the Hilbert curve of the finest level present: a leaf of level l at (i, j) covers an aligned square of
+// 4^(D - l) finest cells, which the curve visits in one piece, so the curve index of ANY of its cells orders the leaves; the lower-left
+// one is taken. order[k] = the block that stands k-th along the curve. (The reference declares a hilbert_index for tree indexes,
+// src/core_tree.hpp:1033-1069, which no sub-program calls; it walks the bits below `level`, not below 2^level, so it cannot order a
+// tree. This is the curve it names - https://en.wikipedia.org/wiki/Hilbert_curve, xy2d - applied to the leaves.)
+int binary_tree_curve_order(const mh_tree_block* blocks, int nb, int32_t* order)
+{
+    int depth = 0;
+    for (int b = 0; b < nb; ++b)
+    {
+        if (blocks[b].level < 0 || blocks[b].level > 30) { set_error("binary tree: level %d of block %d out of range", blocks[b].level, b); return MH_E_INVALID; }
+        if (blocks[b].level > depth) depth = blocks[b].level;
+    }
+    std::vector<std::pair<uint64_t, int>> key(nb);
+    for (int b = 0; b < nb; ++b)
+    {
+        const int shift = depth - blocks[b].level;
+        uint64_t x = (uint64_t) blocks[b].i << shift, y = (uint64_t) blocks[b].j << shift, d = 0;
+        const uint64_t n = (uint64_t) 1 << depth;
+        for (uint64_t s2 = n / 2; s2 > 0; s2 /= 2)
+        {
+            const uint64_t rx = (x & s2) > 0, ry = (y & s2) > 0;
+            d += s2 * s2 * ((3 * rx) ^ ry);
+            if (ry == 0)
+            {
+                if (rx == 1) { x = n - 1 - x; y = n - 1 - y; }
+                const uint64_t tmp = x; x = y; y = tmp;
+            }
+        }
+        key[b] = {d, b};
+    }
+    std::sort(key.begin(), key.end());
+    for (int k = 0; k + 1 < nb; ++k)
+        if (key[k].first == key[k + 1].first) { set_error("binary tree: blocks %d and %d overlap", key[k].second, key[k + 1].second); return MH_E_INVALID; }
+    for (int k = 0; k < nb; ++k) order[k] = key[k].second;
+    return MH_OK;
+}
+
 } // namespace mh
 
 extern "C" {
+
+int mh_binary_tree_curve_order(const mh_tree_block* blocks, int nblocks, int32_t* order)
+{
+    if (! blocks || ! order || nblocks < 1) { mh::set_error("mh_binary_tree_curve_order: null argument"); return MH_E_INVALID; }
+    return mh::binary_tree_curve_order(blocks, nblocks, order);
+}
 
 int mh_binary_tree_build(int bs, int depth, double focus_factor, double focus_index, mh_tree_block* out, int capacity)
 {

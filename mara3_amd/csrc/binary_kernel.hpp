@@ -33,6 +33,9 @@ struct BinaryStageParams
     int32_t*      status_clear;   // or null: two status words of ANOTHER block, zeroed by this launch for the stage issued behind it (binary_api.hip: eager stage)
     const double* xvg;        // x vertices of the WHOLE mesh (xv = xvg + row0: this band's)
     int    n, chunk_rows, nstrips, nchunks;
+    // the rows this launch covers: chunks [0, seg0_chunks) cut rows [seg0_begin, seg0_end), the others [seg1_begin, seg1_end) (one launch
+    // for both edges of a band, binary.hip); wave_base: where this launch's waves stand in the partial sums of the stage
+    int    seg0_begin, seg0_end, seg0_chunks, seg1_begin, seg1_end, wave_base;
     int    n0, row0, ext0;    // band of the mesh held by this field: rows [row0, row0 + n0); ext0: its ghost rows belong to other bands
     double theta, dt, weight;
     BinaryConsts c;
@@ -103,11 +106,13 @@ void binary_stage_kernel(BinaryStageParams p)
     const int w = __builtin_amdgcn_readfirstlane(b * BWAVES_PER_BLOCK + (int) (threadIdx.x >> 6));
     if (w >= p.nstrips * p.nchunks) return;
     const int lane = threadIdx.x & 63;
-    const int chunk = w / p.nstrips;
-    const int strip = w - chunk * p.nstrips;
+    const int chunk_of_launch = w / p.nstrips;
+    const int strip = w - chunk_of_launch * p.nstrips;
     const int n = p.n, n0 = p.n0;
-    const int r0 = chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, n0);
+    const bool second = chunk_of_launch >= p.seg0_chunks;
+    const int chunk = second ? chunk_of_launch - p.seg0_chunks : chunk_of_launch;
+    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
 
     // column of this lane: `col` is the un-wrapped index (positions), `jc` the periodic image (data)
     const int col = strip * BSTRIP - BHALO + lane;
@@ -176,7 +181,7 @@ void binary_stage_kernel(BinaryStageParams p)
         Gy[0] = A::plm_per_length(bdpp_left(P[0]), P[0], bdpp_right(P[0]), theta, k);
         Fx[0] = binary_face_flux<A, 0, QFORM>(c, k, p.xv[r0], yc, Pb, P[0], Gxb, Gx[0], Gyb, Gy[0]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Fx[0][q] = Fx[0][q] * dy;
+        for (int q = 0; q < 3; ++q) Fx[0][q] = A::carried(Fx[0][q] * dy);
     }
     State3 Upre;
     if constexpr (! lds_ring) Upre = load_row3(in + row_off(min(r0 + 3, n0 + 1)), n, jc8);
@@ -213,7 +218,7 @@ void binary_stage_kernel(BinaryStageParams p)
         Gy[K1] = A::plm_per_length(bdpp_left(P[K1]), P[K1], bdpp_right(P[K1]), theta, k);
         Fx[K1] = binary_face_flux<A, 0, QFORM>(c, k, xhi, yc, P[K0], P[K1], Gx[K0], Gx[K1], Gy[K0], Gy[K1]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) Fx[K1][q] = Fx[K1][q] * dy;
+        for (int q = 0; q < 3; ++q) Fx[K1][q] = A::carried(Fx[K1][q] * dy);
 
         // ---- axis 1: this lane's LEFT face (at y = yv[col]), handed to the left neighbour as its right face
         State3 Fy_lo = binary_face_flux<A, 1, QFORM>(c, k, xc, yv_lo, bdpp_left(P[K0]), P[K0], bdpp_left(Gy[K0]), Gy[K0], bdpp_left(Gx[K0]), Gx[K0]);
@@ -385,7 +390,7 @@ void binary_stage_kernel(BinaryStageParams p)
     for (int k = 0; k < NPART; ++k)
     {
         const double s = wave_sum(part[k]);
-        if (lane == 0) p.partials[(long) w * NPART + k] = s;
+        if (lane == 0) p.partials[(long) (p.wave_base + w) * NPART + k] = s;
     }
     acc.commit(p.status);
     if (p.status_clear && w == 0 && lane == 0) { p.status_clear[0] = 0; p.status_clear[1] = 0; }

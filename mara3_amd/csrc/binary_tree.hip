@@ -103,9 +103,9 @@ __device__ inline double spacing_of(const BinaryConsts& c, int level) { return c
 // slopes need no earlier pass over the tree.
 template<class A, bool QFORM>
 __global__ __launch_bounds__(256)
-void tree_prim_grad_kernel(const double* u, double* prim, double* gx, double* gy, TreeGeom g, BinaryConsts c, double theta)
+void tree_prim_grad_kernel(const double* u, double* prim, double* gx, double* gy, TreeGeom g, BinaryConsts c, double theta, int b0)
 {
-    const int b = blockIdx.x, bs = g.bs;
+    const int b = b0 + blockIdx.x, bs = g.bs;          // (b0: a member of a distributed tree runs its own blocks [b0, b1) only)
     BinaryConsts cb = c;
     cb.h = spacing_of(c, g.level[b]);
     const typename A::Ctx k = A::make(cb);
@@ -138,9 +138,9 @@ __device__ inline long fy_index(int bs, int b, int q, int i, int j) { return (((
 
 template<class A, bool QFORM>
 __global__ __launch_bounds__(256)
-void tree_flux_kernel(const double* prim, const double* gx, const double* gy, double* fx, double* fy, TreeGeom g, BinaryConsts c)
+void tree_flux_kernel(const double* prim, const double* gx, const double* gy, double* fx, double* fy, TreeGeom g, BinaryConsts c, int b0)
 {
-    const int b = blockIdx.x, bs = g.bs;
+    const int b = b0 + blockIdx.x, bs = g.bs;
     BinaryConsts cb = c;
     cb.h = spacing_of(c, g.level[b]);
     const typename A::Ctx k = A::make(cb);
@@ -212,9 +212,11 @@ template<class A, bool COMBINE, bool QFORM, bool MAXW>
 __global__ __launch_bounds__(256)
 void tree_update_kernel(const double* u_in, const double* u_base, double* u_out, const double* u_init, const double* br, const double* prim,
                         const double* fx, const double* fy, TreeGeom g, BinaryConsts c, BinaryConsts c_next, double dt, double weight, double* block_out,
-                        double* tile_maxw, int32_t* status)
+                        double* tile_maxw, int32_t* status, int b0, const int32_t* ids)
 {
-    const int b = blockIdx.x, bs = g.bs;
+    // ids (or null): the caller's number of the block stored at each position (a distributed tree stores its blocks in curve order)
+    const int b = b0 + blockIdx.x, bs = g.bs;
+    const uint32_t b_id = ids ? (uint32_t) ids[b] : (uint32_t) b;
     double wmax = 0.0;        // MAXW: as tree_maxw_kernel, on the state this launch writes, with the bodies of the next step's start
     const double* xv = g.edges + (long) b * 2 * (bs + 1);
     const double* yv = xv + bs + 1;
@@ -299,7 +301,7 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
         {
             const double s = s_grav[0][q] + s_grav[1][q] + s_sink[0][q] + s_sink[1][q] + s_buffer[q] + s_floor[q];
             const double u1 = u0[q] - l[q] + s;
-            if (q == 0 && !(u1 >= 0.0)) sacc.note_value(u1, MH_STATUS_NEG_DENSITY, ((uint32_t) b * (uint32_t) bs + (uint32_t) i) * (uint32_t) bs + (uint32_t) j);
+            if (q == 0 && !(u1 >= 0.0)) sacc.note_value(u1, MH_STATUS_NEG_DENSITY, (b_id * (uint32_t) bs + (uint32_t) i) * (uint32_t) bs + (uint32_t) j);
             double un = u1;
             if constexpr (COMBINE) un = u_base[cell_index(bs, b, q, i, j)] * (1.0 - weight) + u1 * weight;
             u_out[cell_index(bs, b, q, i, j)] = un;
@@ -346,8 +348,10 @@ void tree_update_kernel(const double* u_in, const double* u_base, double* u_out,
 // (13 us for 64 blocks, 100 us with the tile sums inside it).
 __global__ __launch_bounds__(1024)
 void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c, int qform, double* block_vals, double* totals,
-                        const double* tile_maxw, const int32_t* level, double* maxw_result)
+                        const double* tile_maxw, const int32_t* level, double* maxw_result, const int32_t* order)
 {
+    // order (or null): where the caller's k-th block is stored; the block values are added in the CALLER's order, so that a tree stored in
+    // curve order (distributed) forms the same sums, bit for bit, as the tree stored as given
     auto block_sum = [&] (int b, int k)
     {
         double v = 0.0;
@@ -404,11 +408,11 @@ void tree_totals_kernel(const double* partial, int nb, int tiles, BinaryConsts c
     {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = block_vals[(long) (b + k) * MH_BINARY_NTOTALS + t];
+        for (int k = 0; k < 8; ++k) v[k] = block_vals[(long) (order ? order[b + k] : b + k) * MH_BINARY_NTOTALS + t];
 #pragma unroll
         for (int k = 0; k < 8; ++k) s = s + v[k];
     }
-    for (; b < nb; ++b) s = s + block_vals[(long) b * MH_BINARY_NTOTALS + t];
+    for (; b < nb; ++b) s = s + block_vals[(long) (order ? order[b] : b) * MH_BINARY_NTOTALS + t];
     totals[t] = s;
 }
 
@@ -453,34 +457,47 @@ BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]
 
 struct TreeBuffers { double *prim, *gx, *gy, *fx, *fy, *block_out, *block_vals, *tile_maxw; };
 
+// What one call of binary_tree_stage_launch runs. A member of a DISTRIBUTED tree (binary_api.hip) runs the three block kernels on its own
+// blocks [b0, b1) only, one call per kernel with the other members' results gathered in between, and then the totals over all blocks.
+enum { TREE_PRIM_GRAD = 1, TREE_FLUX = 2, TREE_UPDATE = 4, TREE_TOTALS = 8, TREE_ALL = 15 };
+struct TreeRun { int phases, b0, b1; const int32_t* order; const int32_t* ids; };          // order, ids: tree_totals_kernel / tree_update_kernel
+
 // bodies_next != nullptr: the stage also leaves min over blocks of spacing / largest wavespeed of the state it writes, evaluated with
 // those bodies, in *maxw_result (what binary_tree_min_dt_launch computes in two launches of its own)
 hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, const TreeBuffers& w, const double* u_in, const double* u_base,
                                     double* u_out, const double* u_init, const double* br, const double bodies[10], double dt, double weight,
-                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result)
+                                    double theta, double* totals, int32_t* status, hipStream_t stream, const double* bodies_next, double* maxw_result,
+                                    const TreeRun* part)
 {
     BinaryConsts c = binary_make_consts(d, bodies);
     BinaryConsts cn = bodies_next ? binary_make_consts(d, bodies_next) : c;
     const dim3 blk(256);
     const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0, q = d->angmom_form != 0, maxw = bodies_next != nullptr;
+    const int phases = part ? part->phases : TREE_ALL, b0 = part ? part->b0 : 0, b1 = part ? part->b1 : g.nb;
+    const int32_t* ids = part ? part->ids : nullptr;
+    if (b0 < 0 || b1 > g.nb || b0 > b1) return hipErrorInvalidValue;
     auto run = [&] (auto policy, auto qform)
     {
         using A = decltype(policy);
         constexpr bool Q = decltype(qform)::value;
         const unsigned cell_tiles = (unsigned) ((g.bs * g.bs + 255) / 256), face_tiles = (unsigned) (((g.bs + 1) * g.bs + 255) / 256);
-        hipLaunchKernelGGL((tree_prim_grad_kernel<A, Q>), dim3(g.nb, cell_tiles), blk, 0, stream, u_in, w.prim, w.gx, w.gy, g, c, theta);
-        hipLaunchKernelGGL((tree_flux_kernel<A, Q>), dim3(g.nb, 2 * face_tiles), blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c);
-        const dim3 ugrid(g.nb, cell_tiles);
+        const unsigned own = (unsigned) (b1 - b0);
+        if (own == 0) return;
+        if (phases & TREE_PRIM_GRAD) hipLaunchKernelGGL((tree_prim_grad_kernel<A, Q>), dim3(own, cell_tiles), blk, 0, stream, u_in, w.prim, w.gx, w.gy, g, c, theta, b0);
+        if (phases & TREE_FLUX) hipLaunchKernelGGL((tree_flux_kernel<A, Q>), dim3(own, 2 * face_tiles), blk, 0, stream, w.prim, w.gx, w.gy, w.fx, w.fy, g, c, b0);
+        if (! (phases & TREE_UPDATE)) return;
+        const dim3 ugrid(own, cell_tiles);
 #define MH_TREE_UPDATE(COMBINE, MAXW) hipLaunchKernelGGL((tree_update_kernel<A, COMBINE, Q, MAXW>), ugrid, blk, 0, stream, u_in, u_base, u_out, u_init, br, \
-                                                         w.prim, w.fx, w.fy, g, c, cn, dt, weight, w.block_out, w.tile_maxw, status)
+                                                         w.prim, w.fx, w.fy, g, c, cn, dt, weight, w.block_out, w.tile_maxw, status, b0, ids)
         if (combine) { if (maxw) MH_TREE_UPDATE(true, true); else MH_TREE_UPDATE(true, false); }
         else         { if (maxw) MH_TREE_UPDATE(false, true); else MH_TREE_UPDATE(false, false); }
 #undef MH_TREE_UPDATE
     };
     if (fast) { if (q) run(BinFast(), std::true_type()); else run(BinFast(), std::false_type()); }
     else      { if (q) run(BinStrict(), std::true_type()); else run(BinStrict(), std::false_type()); }
-    hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(1024), 0, stream, w.block_out, g.nb, (g.bs * g.bs + 255) / 256, c, (int) q, w.block_vals, totals,
-                       maxw ? w.tile_maxw : nullptr, g.level, maxw_result);
+    if (phases & TREE_TOTALS)
+        hipLaunchKernelGGL(tree_totals_kernel, dim3(1), dim3(1024), 0, stream, w.block_out, g.nb, (g.bs * g.bs + 255) / 256, c, (int) q, w.block_vals, totals,
+                           maxw ? w.tile_maxw : nullptr, g.level, maxw_result, part ? part->order : nullptr);
     return hipGetLastError();
 }
 

@@ -67,6 +67,38 @@ def test_bands_equal_single_domain(binary, overrides, world, arith):
     one.close(); grp.close()
 
 
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+@pytest.mark.parametrize("overrides, world", [(dict(depth=2, block_size=16), 2), (dict(depth=2, block_size=16, conserve_linear_p=0), 3),
+                                              (dict(depth=3, block_size=8, fixed_dt=1), 4), (dict(depth=3, block_size=32, fixed_dt=1), 2)])
+def test_edge_rows_first_changes_no_bit_of_the_field(binary, overrides, world, arith):
+    """Round 3: a band steps its first and last rows in one small launch, then the interior (so that, between GPUs, the ghost exchange of
+    the stage travels beside the interior launch - here, loopback, the copies stand between the two). Whatever the cut - none, the
+    recommended one, 2, 3 rows - the field is the single-domain field bit for bit; the scalars agree to the order of summation."""
+    cfg = binary.config(**overrides)
+    one = binary.BinarySolver(cfg, arith=arith)
+    safe = one.next(4)          # (the 8-zone blocks at fixed_dt need a safe-mode step: the bands must take the same one)
+    want, ws = one.solution(), scalars(binary, one.state())
+    n0_min = min(b - a for a, b in binary.BinaryBandGroup(cfg, world=world).rows)
+    for edge in (None, -1, 2, 3):
+        if edge and edge > 0 and n0_min - 2 * edge < 1:
+            continue
+        grp = binary.BinaryBandGroup(cfg, world=world, arith=arith, edge_rows=edge)
+        assert grp.next(1) + grp.next(3) == safe
+        assert bits_equal(grp.solution(), want), (overrides, world, edge)
+        assert scalars_close(scalars(binary, grp.state()), ws)
+        grp.close()
+    one.close()
+
+
+def test_edge_rows_that_do_not_fit_are_refused(binary):
+    from mara3_amd import _lib as L
+    cfg = binary.config(depth=2, block_size=16)
+    with pytest.raises(L.MaraHipError, match="edge rows"):
+        binary.BinaryBandGroup(cfg, world=4, edge_rows=8)          # bands of 16 rows: 2 x 8 leave no interior
+    with pytest.raises(L.MaraHipError, match="edge rows"):
+        binary.BinaryBandGroup(cfg, world=4, edge_rows=1)
+
+
 @pytest.mark.parametrize("name", ["binary_d2_b16", "binary_d3_b8_axisym", "binary_d2_b32", "binary_d2_b16_q"])
 def test_bands_reproduce_the_reference_vectors(binary, name):
     """The vectors of the reference-composed driver (tests/golden/binary_*.npz) through 4 bands, at the single-domain test's tolerance

@@ -1,0 +1,152 @@
+"""Multi-GPU decomposition of `binary` on a GRADED block tree (mara3_amd/csrc/binary_api.hip: tree_stage_distributed),
+executed on ONE GPU: the leaves ordered along the Hilbert curve through them, member r of N running the block kernels on the r-th run of
+that order, the members' results gathered behind each kernel - as 2, 3, 4 and 7 member objects of one process (LOOPBACK), and as one RCCL
+member whose status words travel through ncclAllGather. The reference hands the leaves to its thread pool in traversal order
+(tree.map(fn, pool), src/core_tree.hpp:615-625).
+
+Every member forms the totals over ALL blocks in the caller's block order, so nothing depends on the partition: field, accumulators,
+orbital elements and time steps are the single-domain solver's BIT FOR BIT - with a live binary too (where bands of the uniform mesh only
+agree to the order of summation)."""
+import numpy as np
+import pytest
+from conftest import bits_equal
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+@pytest.fixture(scope="module")
+def binary():
+    import mara3_amd
+    from mara3_amd import binary
+    assert mara3_amd.load_library().mh_device_count() >= 1
+    return binary
+
+
+def hilbert_d(n, x, y):
+    """https://en.wikipedia.org/wiki/Hilbert_curve xy2d, the function src/core_tree.hpp:1033-1069 names"""
+    d, s = 0, n // 2
+    while s > 0:
+        rx, ry = int((x & s) > 0), int((y & s) > 0)
+        d += s * s * ((3 * rx) ^ ry)
+        if ry == 0:
+            if rx == 1:
+                x, y = n - 1 - x, n - 1 - y
+            x, y = y, x
+        s //= 2
+    return d
+
+
+@pytest.mark.parametrize("overrides", [dict(depth=3, block_size=8), dict(depth=4, block_size=8, focus_factor=2.0), dict(depth=2, block_size=16, focus_factor=1e9)])
+def test_curve_order_of_the_leaves(binary, overrides):
+    """a permutation; positions along the curve of the finest level increase; consecutive leaves touch (edge or corner: the curve never
+    jumps), which the tree's own traversal order (Z) does not manage"""
+    cfg = binary.config(**overrides)
+    blocks = binary.tree_blocks(cfg)
+    order = binary.tree_curve_order(blocks)
+    assert sorted(order.tolist()) == list(range(len(blocks)))
+    depth = int(blocks[:, 0].max())
+    keys = [hilbert_d(1 << depth, int(i) << (depth - l), int(j) << (depth - l)) for l, i, j in blocks[order]]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+
+    def touching(a, b):
+        (la, ia, ja), (lb, ib, jb) = a, b
+        sa, sb = 1 << (depth - la), 1 << (depth - lb)
+        ax0, ay0, bx0, by0 = ia * sa, ja * sa, ib * sb, jb * sb
+        return ax0 <= bx0 + sb and bx0 <= ax0 + sa and ay0 <= by0 + sb and by0 <= ay0 + sa
+    seq = [tuple(int(v) for v in blocks[k]) for k in order]
+    assert all(touching(a, b) for a, b in zip(seq, seq[1:]))
+    if len(np.unique(blocks[:, 0])) > 1:
+        z = [tuple(int(v) for v in b) for b in blocks]
+        assert not all(touching(a, b) for a, b in zip(z, z[1:]))
+
+
+def state_bits(binary, s):
+    d = binary.state_as_dict(s)
+    flat = [d["time"], float(d["iteration"]), d["mass_ejected"], d["angular_momentum_ejected"]]
+    for k in ("mass_accreted_on", "angular_momentum_accreted_on", "integrated_torque_on", "work_done_on", "orbital_elements_acc", "orbital_elements_grav", "orbital_elements"):
+        flat += list(d[k])
+    return np.array(flat)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 7])
+@pytest.mark.parametrize("overrides", [
+    dict(depth=3, block_size=8),                                                         # the graded default focus, CFL time step
+    dict(depth=4, block_size=8, focus_factor=2.0, rk_order=1),
+    dict(depth=3, block_size=8, conserve_linear_p=0),                                    # advance_q
+    dict(depth=3, block_size=12, nu=1e-3, alpha=0.0, fixed_dt=1),
+    dict(depth=3, block_size=8, begin_live_binary=0.0, mass_ratio=0.7),                  # live binary: the second stage depends on the first stage's totals
+])
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_distributed_tree_equals_single_domain_bit_for_bit(binary, overrides, world, arith):
+    cfg = binary.config(**overrides)
+    one = binary.BinaryTreeSolver(cfg, arith=arith)
+    grp = binary.BinaryTreeGroup(cfg, world=world, arith=arith)
+    nb = len(one.blocks)
+    owned = np.concatenate(grp.owned)
+    assert sorted(owned.tolist()) == list(range(nb)) and bits_equal(owned, binary.tree_curve_order(one.blocks))
+    assert max(len(o) for o in grp.owned) - min(len(o) for o in grp.owned) <= 1
+    for nsteps in (1, 3):
+        assert one.next(nsteps) == grp.next(nsteps)
+        assert grp.last_dt == one.last_dt
+        want = one.solution()
+        assert bits_equal(grp.solution(), want), (overrides, world, nsteps)
+        assert bits_equal(state_bits(binary, grp.state()), state_bits(binary, one.state()))
+    for r in range(world):          # every member holds the whole tree
+        assert bits_equal(grp.member_solution(r), want)
+    one.close(); grp.close()
+
+
+def test_distributed_tree_default_configuration_20_steps(binary):
+    """the sub-program's default mesh (depth 4, 24-zone blocks, 64 leaves) on 4 members"""
+    cfg = binary.config()
+    one = binary.BinaryTreeSolver(cfg)
+    grp = binary.BinaryTreeGroup(cfg, world=4)
+    assert one.next(20) == grp.next(20)
+    assert bits_equal(grp.solution(), one.solution())
+    assert bits_equal(state_bits(binary, grp.state()), state_bits(binary, one.state()))
+    one.close(); grp.close()
+
+
+def test_distributed_tree_safe_mode_retry_and_failing_cell(binary):
+    """a nearly empty cell in ONE member's block: every member retries (dt * 0.1, theta = 0) and the failing cell is reported as the flat
+    index into the caller's array - the same index the single-domain solver reports, although the members store the blocks in curve order"""
+    cfg = binary.config(depth=3, block_size=8, fixed_dt=1)
+    one = binary.BinaryTreeSolver(cfg)
+    grp = binary.BinaryTreeGroup(cfg, world=3)
+    u0, s0 = one.solution(), one.state()
+    blk = int(grp.owned[2][1])          # a block of the last member
+    for boost in (10.0, 100.0, 1e3, 1e4, 1e5):          # a hole next to a fast stream, fast enough for the ordinary step to overshoot below zero
+        u = u0.copy()
+        u[blk, 3, 4, 0] *= 1e-2
+        u[blk, 3, 5, 1:] *= boost
+        u[blk, 4, 4, 1:] *= boost
+        one.set_solution(u, s0)
+        sa = one.next(1)
+        if sa == 1:
+            break
+    assert sa == 1, "the test state must fail the ordinary step"
+    grp.set_solution(u, s0)
+    assert grp.next(1) == 1
+    assert grp.last_failure() == one.last_failure() and one.last_failure()[1] is not None
+    assert one.last_failure()[1] // (8 * 8) == blk
+    assert bits_equal(grp.solution(), one.solution())
+    one.close(); grp.close()
+
+
+def test_distributed_tree_member_over_rccl(binary):
+    """world 1 through the RCCL form: the member's status words go through ncclAllGather (over one rank), the rest is the distributed
+    stage with a run that is the whole tree - stored in curve order, totals added in the caller's order: bit-identical to BinaryTreeSolver"""
+    from mara3_amd.slab import native_comm_id, NativeComm
+    cfg = binary.config(depth=3, block_size=8)
+    one = binary.BinaryTreeSolver(cfg)
+    for how in ("id", "comm"):
+        comm = NativeComm(native_comm_id(0, 1), 0, 1) if how == "comm" else None
+        band = binary.BinaryTreeBand(cfg, 0, 1, native_comm_id(0, 1) if how == "id" else None, comm=comm)
+        one2 = binary.BinaryTreeSolver(cfg)
+        assert one2.next(3) == band.next(3)
+        assert bits_equal(band.solution(), one2.solution())
+        assert bits_equal(state_bits(binary, band.state()), state_bits(binary, one2.state()))
+        band.close(); one2.close()
+        if comm is not None:
+            comm.close()
+    one.close()

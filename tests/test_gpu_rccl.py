@@ -209,22 +209,52 @@ def test_native_block_rccl_exchange_to_self_on_all_three_axes(shape):
     blk.close()
 
 
-def test_binary_band_rccl_halo_and_allreduce_to_self():
+@pytest.mark.parametrize("edge_rows", [None, -1, 5])
+def test_binary_band_rccl_halo_and_allreduce_to_self(edge_rows):
     """`binary` over bands, RCCL backend, on one GPU: a single band whose periodic ghost rows travel through ncclSend / ncclRecv to self and
-    whose totals, wavespeed and status go through the three ncclAllReduce calls (over one rank: the identity) - field AND scalars
-    bit-identical to the whole-mesh solver, CFL time step included."""
+    whose totals, wavespeed and status go through the three ncclAllReduce calls (over one rank: the identity). edge_rows None: one launch per
+    stage, the exchange behind it - field AND scalars bit-identical to the whole-mesh solver, CFL time step included. Otherwise (round 3) the
+    band's edge rows are stepped first and their exchange runs on a second stream beside the interior launch: the field is still
+    bit-identical, the scalars agree to the order in which the waves' partial sums are added (edge waves first)."""
     import numpy as np
     from mara3_amd import binary
     from mara3_amd.slab import native_comm_id
     cfg = binary.config(depth=2, block_size=16)
     one = binary.BinarySolver(cfg)
-    band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), self_exchange=True)
+    band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), self_exchange=True, edge_rows=edge_rows)
     assert (band.row0, band.row1) == (0, 64)
     for nsteps in (1, 3):
         assert one.next(nsteps) == 0 and band.next(nsteps) == 0
         assert band.last_dt == one.last_dt
         assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
-        assert binary.state_as_dict(band.state()) == binary.state_as_dict(one.state())
+        a, b = binary.state_as_dict(band.state()), binary.state_as_dict(one.state())
+        if edge_rows is None:
+            assert a == b
+        else:
+            assert a["time"] == b["time"] and a["iteration"] == b["iteration"]
+            for k in ("mass_accreted_on", "integrated_torque_on", "work_done_on", "orbital_elements"):
+                assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-13 * max(1.0, float(np.abs(b[k]).max()))), k
+    one.close(); band.close()
+
+
+def test_binary_band_edge_rows_beside_the_interior_at_a_size_where_they_overlap():
+    """1024^2 (the launches last long enough to run side by side): one RCCL band whose edge launch and exchange run on the exchange stream
+    beside the interior launch - the field is the single-domain field bit for bit after every call, from a set solution too (whose ghost
+    exchange must be complete before the first stage reads it)."""
+    import numpy as np
+    from mara3_amd import binary
+    from mara3_amd.slab import native_comm_id
+    cfg = binary.config(depth=4, block_size=64, fixed_dt=1, plm_theta=1.8)
+    one = binary.BinarySolver(cfg, arith="fast")
+    band = binary.BinaryBand(cfg, 0, 1, native_comm_id(0, 1), arith="fast", self_exchange=True, edge_rows=-1)
+    for nsteps in (1, 4):
+        assert one.next(nsteps) == 0 and band.next(nsteps) == 0
+        assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
+    u, st = one.solution(), one.state()
+    u[3, :, 0] *= 1.001
+    one.set_solution(u, st); band.set_solution(u, st)
+    assert one.next(3) == 0 and band.next(3) == 0
+    assert np.array_equal(band.solution().view(np.uint64), one.solution().view(np.uint64))
     one.close(); band.close()
 
 
