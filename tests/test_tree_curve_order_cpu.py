@@ -1,0 +1,56 @@
+"""Host logic of the distributed graded tree (mara3_amd/csrc/binary_host.cpp: binary_tree_curve_order), no GPU: the order of the leaves
+along the Hilbert curve of the finest level present. The reference declares a hilbert_index for tree indexes (src/core_tree.hpp:1033-1069)
+that no sub-program calls; the curve it names is restated here from its public definition to check the library's."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def binary():
+    from mara3_amd import binary
+    return binary
+
+
+def hilbert_d(n, x, y):
+    """https://en.wikipedia.org/wiki/Hilbert_curve xy2d, the function src/core_tree.hpp:1033-1069 names"""
+    d, s = 0, n // 2
+    while s > 0:
+        rx, ry = int((x & s) > 0), int((y & s) > 0)
+        d += s * s * ((3 * rx) ^ ry)
+        if ry == 0:
+            if rx == 1:
+                x, y = n - 1 - x, n - 1 - y
+            x, y = y, x
+        s //= 2
+    return d
+
+
+@pytest.mark.parametrize("overrides", [dict(depth=3, block_size=8), dict(depth=4, block_size=8, focus_factor=2.0), dict(depth=2, block_size=16, focus_factor=1e9)])
+def test_curve_order_of_the_leaves(binary, overrides):
+    """a permutation; positions along the curve of the finest level increase; consecutive leaves touch (edge or corner: the curve never
+    jumps), which the tree's own traversal order (Z) does not manage"""
+    cfg = binary.config(**overrides)
+    blocks = binary.tree_blocks(cfg)
+    order = binary.tree_curve_order(blocks)
+    assert sorted(order.tolist()) == list(range(len(blocks)))
+    depth = int(blocks[:, 0].max())
+    keys = [hilbert_d(1 << depth, int(i) << (depth - l), int(j) << (depth - l)) for l, i, j in blocks[order]]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+
+    def touching(a, b):
+        (la, ia, ja), (lb, ib, jb) = a, b
+        sa, sb = 1 << (depth - la), 1 << (depth - lb)
+        ax0, ay0, bx0, by0 = ia * sa, ja * sa, ib * sb, jb * sb
+        return ax0 <= bx0 + sb and bx0 <= ax0 + sa and ay0 <= by0 + sb and by0 <= ay0 + sa
+    seq = [tuple(int(v) for v in blocks[k]) for k in order]
+    assert all(touching(a, b) for a, b in zip(seq, seq[1:]))
+    if len(np.unique(blocks[:, 0])) > 1:
+        z = [tuple(int(v) for v in b) for b in blocks]
+        assert not all(touching(a, b) for a, b in zip(z, z[1:]))
+
+
+def test_curve_order_refuses_overlapping_leaves(binary):
+    from mara3_amd import _lib as L
+    blocks = np.array([[1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1], [2, 0, 0]], dtype=np.int32)          # (2, 0, 0) lies inside (1, 0, 0)
+    with pytest.raises(L.MaraHipError, match="overlap"):
+        binary.tree_curve_order(blocks)
