@@ -18,7 +18,8 @@ contract keys plus
   extra_configs                              BASELINE configs 3, 4, 5 on this GPU (bench_configs.py), N = 1 only
   cpu_baseline / cpu_reference               N = 1 only: the oracle and the reference's own lazy-array composition on the host cores
 
-Timing: the timed region is the product path (HIP-graph replay at N = 1, eager two-stream issue with RCCL at N > 1), no events in it.
+Timing: the timed region is the product path (N = 1: the fused step's one launch per step issued as it is, the two-launch step replayed from a HIP graph;
+N > 1: eager two-stream issue with RCCL), no events in it.
 The per-kernel durations behind the rooflines come from HIP events riding on the launches, in a short separate pass right after it.
 """
 import argparse
@@ -338,9 +339,13 @@ def main():
         if scratch_to_close is not None:
             scratch_to_close.close()
         # HIP events around every bulk stage launch, on the stream it is launched on: a separate short pass, so that the timed region
-        # is the un-instrumented product path (graph replay without neighbours)
+        # is the un-instrumented product path (without neighbours: one plain launch per fused step, or the graph replay of the two-launch step)
         nprof = 5
+        # releasing the scratch grid above idles the GPU for milliseconds, and the first launches after an idle period run slow: `nlead`
+        # un-instrumented steps lead straight into the instrumented ones (no synchronisation between them)
+        nlead = 15 if native else 0
         if native:
+            st.step(dt, nlead)
             st.profile(True)
         else:
             st.timers = []
@@ -362,7 +367,11 @@ def main():
         cells_launch = bulk_rows * n
         ms = block_ms[0]
         value = n * n / ms / 1e3
-        timing = "HIP events riding on the launches, %d extra steps right after the timed region" % nprof
+        timing = "HIP events riding on the launches, %d extra steps after the timed region and %d un-instrumented ones that lead into them" % (nprof, nlead)
+        if native and nl1 == 0 and nl2 > 0:
+            # (events riding on each launch of the fused kernel read 3 % long - longer than the timed steps themselves)
+            timing = ("one pair of HIP events around the %d launches of %d extra steps (the gaps between the launches included), after the timed region and %d "
+                      "un-instrumented steps that lead into them" % (nl2, nprof, nlead))
 
         def kernel_roofline(nbytes, avg, nl, name, traffic_key):
             ach = cells_launch * nbytes / (avg * 1e-3) / 1e9 if avg > 0 else None
@@ -413,7 +422,7 @@ def main():
             st.close()
         res["preconditioning"] = ("%d steps of a scratch grid of the same size right before the warm-up steps, released after the timed blocks (clock settling after "
                                   "the idle upload phase; not part of the workload)" % args.precondition if args.precondition > 0 else "none")
-        return res, final, args.warmup + nblocks * args.steps + nprof
+        return res, final, args.warmup + nblocks * args.steps + nlead + nprof
 
     def partition_check(arith, riemann, u_mine, nsteps_total):
         """N > 1 (or --loopback-slabs): the union of the ranks' slabs against the SAME run on one GPU (rank 0 repeats it alone, outside the
@@ -500,7 +509,7 @@ def main():
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
-                       "timed_region": ("HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage")
+                       "timed_region": ("one launch per step, issued as it is (a one-node graph replay costs 29 us more per step); two-launch legs: HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage")
                                        + (" (ONE fused launch per RK2 step, mara3_amd/csrc/euler2d_fused.hip: results bit-identical to the two launches, tests/test_gpu_fused_rk2.py)"
                                           if res["launches_per_step"] == 1 else " (two launches per RK2 step)"),
                        "preconditioning": res["preconditioning"]},
@@ -514,7 +523,7 @@ def main():
             out["slabs_bit_identical_to_one_gpu_run"] = bool(partition_ok)
         if legs:
             out["legs"] = compact(legs)
-            out["legs_note"] = ("each leg: the same measurement as the headline's (graph replay, scratch-grid preconditioning, HIP events riding on 5 further steps; "
+            out["legs_note"] = ("each leg: the same measurement as the headline's (fused legs: plain launches, two-launch legs: graph replay; scratch-grid preconditioning, HIP events riding on 5 further steps; "
                                 "roofline = second RK2 stage, roofline_stage1 = first, both against 8000 GB/s and, as fp64, 78.6 TFLOP/s with the recorded counters)")
         if l1 is not None:
             out["l1_fast_vs_strict_after_%d_steps" % nsteps_primary] = l1

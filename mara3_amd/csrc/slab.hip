@@ -117,6 +117,7 @@ struct mh_slab
     hipGraphExec_t fused_exec[2] = {nullptr, nullptr};
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];   // bulk launches of stage 1 / stage 2
+    std::vector<int> event_launches[2];                          // launches between the two events of each pair
     std::string error;
 };
 
@@ -292,6 +293,7 @@ static int stage_finish(mh_slab* s, StageArgs& st)
     {
         if (! profile_on_launch) hipEventRecord(pe.second, s->main);
         s->events[st.which].push_back(pe);
+        s->event_launches[st.which].push_back(1);
     }
     MH_HIP_TRY(be);
     if (! alone && ! on_launch) MH_HIP_TRY(hipEventRecord(s->ev_interior, s->main));
@@ -340,17 +342,7 @@ static bool slab_can_fuse(const mh_slab* s)
 
 static int slab_fused_step(mh_slab* s, double dt)
 {
-    LaunchEvents ev;
-    std::pair<hipEvent_t, hipEvent_t> pe;
-    if (s->profile)
-    {
-        hipEventCreate(&pe.first);
-        hipEventCreate(&pe.second);
-        ev.start = pe.first; ev.stop = pe.second;
-    }
-    const hipError_t e = euler2d_fused_rk2_launch(&s->desc, s->field[0], s->field[1], dt, s->status, s->main, ev);
-    if (s->profile) s->events[1].push_back(pe);          // the step's one launch is reported in the second-stage slot; the first stays empty
-    MH_HIP_TRY(e);
+    MH_HIP_TRY(euler2d_fused_rk2_launch(&s->desc, s->field[0], s->field[1], dt, s->status, s->main, LaunchEvents()));
     std::swap(s->field[0], s->field[1]);
     s->cur_out = s->field[0];
     return MH_OK;
@@ -773,9 +765,32 @@ int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
     // neighbours the step is issued eagerly from this loop (about ten HIP/RCCL calls per stage, no host language).
     if (s->fused)
     {
+        // One launch per step, issued as it is: replaying it from a one-node graph costs 29 us MORE per step on this stack (4096^2, HIP 7.0:
+        // 0.633 against 0.604 ms per step, alternating in one process, profiles/r03/fused_step_overhead.jsonl) - a graph pays where it
+        // replaces several launches and their event traffic, and here there is one launch and none. MH_SLAB_FUSED_GRAPH=1 brings the replay
+        // back for that measurement.
+        const char* const env = getenv("MH_SLAB_FUSED_GRAPH");
+        const bool replay = env && atoi(env) > 0;
+        // profile: ONE pair of events around the call's launches (reported in the second-stage slot; the first stays empty). Events riding
+        // on each launch (hipExtLaunchKernelGGL) read 3 % long for this kernel - longer than the steps of the timed region they follow.
+        std::pair<hipEvent_t, hipEvent_t> pe = {nullptr, nullptr};
+        if (s->profile && nsteps > 0)
+        {
+            MH_HIP_TRY(hipEventCreate(&pe.first));
+            MH_HIP_TRY(hipEventCreate(&pe.second));
+            MH_HIP_TRY(hipEventRecord(pe.first, s->main));
+        }
+        auto close_profile = [&] () -> int
+        {
+            if (! pe.first) return MH_OK;
+            MH_HIP_TRY(hipEventRecord(pe.second, s->main));
+            s->events[1].push_back(pe);
+            s->event_launches[1].push_back(nsteps);
+            return MH_OK;
+        };
         for (int n = 0; n < nsteps; ++n)
         {
-            if (! use_graph || s->profile) { if (int rc = slab_fused_step(s, dt)) return slab_fail(s, rc); continue; }
+            if (! replay || ! use_graph) { if (int rc = slab_fused_step(s, dt)) return slab_fail(s, rc); continue; }
             // one captured step per direction (field A -> B, B -> A): the pointers are part of the graph
             const int k = s->field[0] == s->fused_src[0] ? 0 : 1;
             if (s->graph_dt != dt || s->fused_src[k] != s->field[0] || ! s->fused_exec[k])
@@ -802,7 +817,7 @@ int mh_slab_step(mh_slab* s, double dt, int nsteps, int use_graph)
             std::swap(s->field[0], s->field[1]);
             s->cur_out = s->field[0];
         }
-        return MH_OK;
+        return close_profile();
     }
     if (use_graph && s->rk_order == 2 && ! s->profile && ! has_neighbours(s) && s->kind == SLAB_EULER)
     {
@@ -882,6 +897,7 @@ int mh_slab_profile_enable(mh_slab* s, int on)
 {
     if (! s) return MH_E_INVALID;
     for (auto& v : s->events) { for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } v.clear(); }
+    for (auto& v : s->event_launches) v.clear();
     s->profile = on != 0;
     return MH_OK;
 }
@@ -900,8 +916,10 @@ int mh_slab_profile_read(mh_slab* s, double avg_ms[2], int nlaunches[2], int* bu
             MH_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
             total += ms;
         }
-        if (avg_ms) avg_ms[k] = s->events[k].empty() ? 0.0 : total / s->events[k].size();
-        if (nlaunches) nlaunches[k] = (int) s->events[k].size();
+        int count = 0;
+        for (int c : s->event_launches[k]) count += c;
+        if (avg_ms) avg_ms[k] = count == 0 ? 0.0 : total / count;
+        if (nlaunches) nlaunches[k] = count;
     }
     // rows of a bulk launch; with staggered edges the average over the period (edges of 2 (k + 1) rows per side, k = 0 .. S-1)
     if (bulk_rows) *bulk_rows = s->n0 - 2 * (s->stagger ? s->edge_rows * (s->stagger + 1) / 2 : s->edge_rows);

@@ -75,8 +75,12 @@ def test_fused_step_on_the_blast_with_the_default_chunks(eng):
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_native_slab_stepper_takes_the_fused_step_and_replays_it_from_graphs(eng, graph):
+def test_native_slab_stepper_takes_the_fused_step_and_replays_it_from_graphs(eng, graph, monkeypatch):
+    """(the stepper issues the fused step as a plain launch - a one-node graph replay is 29 us per step slower on this stack - and keeps
+    the replay behind MH_SLAB_FUSED_GRAPH=1, which the graph=True case sets: both ways, the same bits)"""
     from mara3_amd import setups
+    if graph:
+        monkeypatch.setenv("MH_SLAB_FUSED_GRAPH", "1")
     from mara3_amd.slab import NativeSlabStepper
     shape, gamma = (256, 300), 1.4
     dl = (1.0 / shape[0], 1.0 / shape[1])
