@@ -120,7 +120,7 @@ def c3_run(args, binary, cfg, n, arith):
                      "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "binary_stage_kernel + binary_sink_kernel + binary_reduce_kernel (one stage)",
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
-                     "timing": "HIP events on the launch stream, 5 extra steps after the timed region"},
+                     "timing": "one pair of HIP events on the launch stream around the 10 stage launches of 5 extra steps after the timed region (gaps between the stages included, the end-of-call fetch not)"},
     }
     return out
 
@@ -188,7 +188,7 @@ def c4_parse(args, stdout, nr, arith):
         "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None, "kernel": "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith,
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
-                     "timing": "HIP events on the launch stream, inside the timed region"},
+                     "timing": "one pair of HIP events on the launch stream around the two stage launches of each step, inside the timed region"},
     }
 
 
@@ -349,7 +349,7 @@ def run_c5(args):
                                    "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                    "kernel": "euler3d_stage_kernel<%s,%s,PLM> (mean of both RK2 stages)" % (arith, args.riemann),
                                    "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
-                                   "timing": "HIP events on the launch stream, inside the timed region"}}
+                                   "timing": "one pair of HIP events on the launch stream around the stage launches of the timed call, inside the timed region"}}
     out = {
         "metric": "zone-updates/sec (Mcells/s), 3D Euler blast %d^3 PLM+%s RK2, 1 GPU" % (n, args.riemann.upper()),
         "value": res["fast"]["value"], "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

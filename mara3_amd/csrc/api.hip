@@ -188,7 +188,11 @@ struct mh_ctx
     size_t staging_doubles = 0;
     int32_t* status = nullptr;
     bool profile = false;
+    // profile: ONE pair of events around the stage launches of each mh_step / mh_step_checked call, and how many launches lie between
+    // them (events around every launch put two markers between consecutive kernels and read 3 % long on the sub-millisecond ones)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<int> event_launches;
+    int span_launches = 0;
     std::string error;
 };
 
@@ -574,24 +578,33 @@ int mh_download(mh_ctx* c, double* u_aos_host, size_t ncell)
     return MH_OK;
 }
 
-static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, double* out, double dt, double w)
+// the stage launches of one API call between two events (mh_profile_read divides by the launches)
+struct ProfileSpan
 {
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (c->profile)
+    mh_ctx* c;
+    std::pair<hipEvent_t, hipEvent_t> ev = {nullptr, nullptr};
+    explicit ProfileSpan(mh_ctx* ctx) : c(ctx)
     {
-        hipEventCreate(&ev.first);
-        hipEventCreate(&ev.second);
+        if (! c->profile) return;
+        c->span_launches = 0;
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) { ev = {nullptr, nullptr}; return; }
         hipEventRecord(ev.first, c->stream);
     }
-    hipError_t e = c->kind == mh_ctx::KIND_CLOUD
+    ~ProfileSpan()
+    {
+        if (! ev.first) return;
+        hipEventRecord(ev.second, c->stream);
+        if (c->span_launches > 0) { c->events.push_back(ev); c->event_launches.push_back(c->span_launches); }
+        else { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    }
+};
+
+static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, double* out, double dt, double w)
+{
+    if (c->profile) ++c->span_launches;
+    return c->kind == mh_ctx::KIND_CLOUD
         ? cloud_stage_launch(&c->cloud, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream)
         : cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
-    if (c->profile)
-    {
-        hipEventRecord(ev.second, c->stream);
-        c->events.push_back(ev);
-    }
-    return e;
 }
 
 // a whole-field RK2 step as one launch (the descriptor's fuse_stages; euler2d_fused.hip)
@@ -602,17 +615,8 @@ static bool ctx_can_fuse(const mh_ctx* c)
 
 static hipError_t timed_fused_step(mh_ctx* c, const double* in, double* out, double dt)
 {
-    LaunchEvents le;
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (c->profile)
-    {
-        hipEventCreate(&ev.first);
-        hipEventCreate(&ev.second);
-        le.start = ev.first; le.stop = ev.second;
-    }
-    const hipError_t e = euler2d_fused_rk2_launch(&c->desc, in, out, dt, c->status, c->stream, le);
-    if (c->profile) c->events.push_back(ev);
-    return e;
+    if (c->profile) ++c->span_launches;
+    return euler2d_fused_rk2_launch(&c->desc, in, out, dt, c->status, c->stream, LaunchEvents());
 }
 
 int mh_step(mh_ctx* c, double dt, int nsteps)
@@ -633,6 +637,7 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
         }
         return MH_OK;
     }
+    const ProfileSpan span(c);
     if (c->kind == mh_ctx::KIND_CLOUD)
     {
         for (int s = 0; s < nsteps; ++s)
@@ -711,6 +716,8 @@ int mh_step_checked(mh_ctx* c, double dt, mh_step_result* result)
     MH_HIP_TRY(hipSetDevice(c->device));
     MH_HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int32_t), c->stream));       // the result speaks about THIS step only
     double* committed = nullptr;              // the buffer that holds the step's result
+    {
+    const ProfileSpan span(c);
     if (c->kind == mh_ctx::KIND_SEDOV)
     {
         const int n = c->sedov.nz;
@@ -741,6 +748,7 @@ int mh_step_checked(mh_ctx* c, double dt, mh_step_result* result)
         MH_HIP_TRY(timed_stage(c, c->field[1], c->field[0], c->third, dt, 0.5));       // NOT in place: field[0] survives a failed step
         committed = c->third;
     }
+    }
     if (int rc = mh_status(c, result)) return ctx_fail(c, rc);
     if (result->status != 0)
     {
@@ -763,6 +771,7 @@ int mh_profile_enable(mh_ctx* c, int on)
     if (! c) return MH_E_INVALID;
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     c->events.clear();
+    c->event_launches.clear();
     c->profile = on != 0;
     return MH_OK;
 }
@@ -779,8 +788,10 @@ int mh_profile_read(mh_ctx* c, double* avg_stage_ms, int* nlaunches)
         MH_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
         total += ms;
     }
-    if (avg_stage_ms) *avg_stage_ms = c->events.empty() ? 0.0 : total / c->events.size();
-    if (nlaunches) *nlaunches = (int) c->events.size();
+    int count = 0;
+    for (int k : c->event_launches) count += k;
+    if (avg_stage_ms) *avg_stage_ms = count == 0 ? 0.0 : total / count;
+    if (nlaunches) *nlaunches = count;
     return MH_OK;
 }
 

@@ -99,8 +99,13 @@ struct mh_binary
     double maxw_value = 0.0;
     mh_binary_state maxw_for;
     bool profile = false;
+    // profile: ONE pair of events around the stage launches of each mh_binary_next call - from in front of its first stage to behind its
+    // last one (the end-of-call fetch excluded) - and the number of stages between them. (Events around every stage put two more markers
+    // between consecutive kernels: 5 - 8 us each on this stack, on a 100 us stage.)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    hipEvent_t profile_e0 = nullptr;
+    std::vector<int> event_stages;
+    hipEvent_t prof_end = nullptr;
+    int prof_stages = 0;
     // graded tree (mh_binary_tree_create): block-major fields [nb][3][bs][bs], neighbour table, per-stage work arrays
     bool tree = false;
     TreeGeom geom = {nullptr, nullptr, nullptr, 0, 0};
@@ -181,18 +186,7 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
     // input_event: an event of the main stream behind which u_in is complete (a stage's ev_stage), or null: one is recorded here
     if (parity < 0) parity = b->parity;
     double* const small_block = b->small[parity] ? b->small[parity] : b->dev_small;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->profile)          // one pair per stage: from the edge launch (if any) to the end of the interior's
-    {
-        if (part == BIN_ROWS_INTERIOR && b->profile_e0) { e0 = b->profile_e0; b->profile_e0 = nullptr; }
-        else
-        {
-            MH_HIP_TRY(hipEventCreate(&e0));
-            MH_HIP_TRY(hipEventRecord(e0, stream));
-        }
-        if (part == BIN_ROWS_EDGES) b->profile_e0 = e0;
-        else MH_HIP_TRY(hipEventCreate(&e1));
-    }
+    if (b->profile && part != BIN_ROWS_EDGES) ++b->prof_stages;
     if (b->tree)
         MH_HIP_TRY(binary_tree_stage_launch(&b->desc, b->geom, b->work, u_in, u_base, u_out, b->u_init, b->br, B.body1, dt, weight, theta,
                                             totals_dev(b, slot), b->status, b->stream, Bnext ? Bnext->body1 : nullptr, maxw_dev(b)));
@@ -206,11 +200,6 @@ static int launch_stage(mh_binary* b, const double* u_in, const double* u_base, 
                                        small_block + slot * MH_BINARY_NTOTALS, b->scratch + (size_t) (2 * parity + slot) * b->scratch_doubles,
                                        status_of(small_block), stream, &band, b->side ? &ov : nullptr, status_clear, part == BIN_ROWS_ALL ? nullptr : &rows));
         if (part != BIN_ROWS_EDGES) b->totals_pending = b->side != nullptr;
-    }
-    if (b->profile && e1)
-    {
-        MH_HIP_TRY(hipEventRecord(e1, b->stream));
-        b->events.emplace_back(e0, e1);
     }
     return MH_OK;
 }
@@ -406,6 +395,7 @@ static int tree_gather(const Team& t, size_t doubles, Ptr ptr)
 static int tree_stage_distributed(const Team& t, int in, int base, int outk, const mh_two_body_t& B, double dt, double weight, double theta, int slot,
                                   const mh_two_body_t* Bnext)
 {
+    if (t.m[0]->profile) ++t.m[0]->prof_stages;
     const int bs = t.m[0]->geom.bs;
     const size_t cell = (size_t) 3 * bs * bs, face = (size_t) 3 * (bs + 1) * bs, tiles = (size_t) (bs * bs + 255) / 256;
     auto run = [&] (int phases) -> int
@@ -500,9 +490,16 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
         return team_exchange_end(t);
     };
 
+    // profile: behind the last stage launch of the call (team_next)
+    auto mark_profile_end = [&] () -> int
+    {
+        if (b->profile && b->prof_end && ! prefetch_maxw) MH_HIP_TRY(hipEventRecord(b->prof_end, b->stream));
+        return MH_OK;
+    };
     if (b->run.rk_order == 1)
     {
         if (int rc = stage(0, -1, 2, B1, dt, 1.0, theta, 0)) return rc;
+        if (int rc = mark_profile_end()) return rc;
         if (int rc = team_fetch(t)) return rc;
         if (b->mirror->status[0]) { *failed = true; return MH_OK; }
         if (binary_apply_totals(S0, B1, b->mirror->totals[0], dt, naf, b->run.begin_live_binary, out) != MH_OK) { *failed = true; return MH_OK; }
@@ -549,6 +546,7 @@ static int binary_attempt(const Team& t, double dt, bool safe_mode, bool prefetc
                        eager_next ? status_of(b->small[other]) : nullptr)) return rc;
     if (launched_ahead && ! b->tree)
         if (int rc = team_maxw(t, 2, Bn)) return rc;
+    if (int rc = mark_profile_end()) return rc;
     if (eager_next)
     {
         // This step's fetch goes onto the second stream NOW, ahead of the eager stage's own sink sums and reduction. Stream order there puts
@@ -596,6 +594,24 @@ static int team_next(const Team& t, int nsteps, int* safe_mode_steps)
     mh_binary* b = t.m[0];
     if (safe_mode_steps) *safe_mode_steps = 0;
     for (int r = 0; r < t.n; ++r) { t.m[r]->last_failure = {0, 0, UINT64_MAX}; t.m[r]->eager_valid = false; }
+    std::pair<hipEvent_t, hipEvent_t> span = {nullptr, nullptr};
+    if (b->profile && nsteps > 0)
+    {
+        MH_HIP_TRY(hipEventCreate(&span.first));
+        MH_HIP_TRY(hipEventCreate(&span.second));
+        MH_HIP_TRY(hipEventRecord(span.first, b->stream));
+        b->prof_end = span.second;
+        b->prof_stages = 0;
+    }
+    auto close_span = [&] ()
+    {
+        if (! span.first) return;
+        b->prof_end = nullptr;
+        if (b->prof_stages > 0) { b->events.push_back(span); b->event_stages.push_back(b->prof_stages); }
+        else { (void) hipEventDestroy(span.first); (void) hipEventDestroy(span.second); }
+        span = {nullptr, nullptr};
+    };
+    struct SpanGuard { decltype(close_span)& f; ~SpanGuard() { f(); } } span_guard{close_span};
     for (int s = 0; s < nsteps; ++s)
     {
         // dt: subprog_binary.cpp:281-283
@@ -1028,7 +1044,7 @@ void mh_binary_destroy(mh_binary* b)
     if (b->stream) (void) hipStreamSynchronize(b->stream);
     if (b->side) { (void) hipStreamSynchronize(b->side); (void) hipStreamDestroy(b->side); }
     if (b->xstream) { (void) hipStreamSynchronize(b->xstream); (void) hipStreamDestroy(b->xstream); }
-    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals, b->ev_edge, b->ev_edone, b->ev_xchg, b->profile_e0}) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : {b->ev_input[0], b->ev_input[1], b->ev_stage[0], b->ev_stage[1], b->ev_totals, b->ev_edge, b->ev_edone, b->ev_xchg}) if (e) (void) hipEventDestroy(e);
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (int k = 0; k < 4; ++k) (void) hipFree(b->u[k]);
     (void) hipFree(b->order_dev); (void) hipFree(b->ids_dev);
@@ -1167,17 +1183,20 @@ int mh_binary_profile(mh_binary* b, int enable, double* avg_stage_ms, int* nlaun
     {
         MH_HIP_TRY(hipStreamSynchronize(b->stream));
         double total = 0.0;
-        for (auto& e : b->events)
+        int count = 0;
+        for (size_t k = 0; k < b->events.size(); ++k)
         {
             float ms = 0.f;
-            MH_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+            if (hipEventElapsedTime(&ms, b->events[k].first, b->events[k].second) != hipSuccess) continue;          // (a call that failed before its last stage)
             total += ms;
+            count += b->event_stages[k];
         }
-        if (avg_stage_ms) *avg_stage_ms = b->events.empty() ? 0.0 : total / b->events.size();
-        if (nlaunches) *nlaunches = (int) b->events.size();
+        if (avg_stage_ms) *avg_stage_ms = count == 0 ? 0.0 : total / count;
+        if (nlaunches) *nlaunches = count;
     }
     for (auto& e : b->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     b->events.clear();
+    b->event_stages.clear();
     b->profile = enable != 0;
     return MH_OK;
 }

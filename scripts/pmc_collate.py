@@ -33,7 +33,7 @@ def trace(tag):
         for r in csv.DictReader(open(f)):
             k = r["Name"]
             if "mh::" in k:
-                out[k.split("(")[0].replace("void mh::", "").replace("mh::", "")] = (float(r["AverageNs"]), int(r["Calls"]))
+                out[k.split("(")[0].replace("void mh::", "").replace("mh::", "")] = (float(r["AverageNs"]), int(r["Calls"]), float(r["MinNs"]))
     return out
 
 
@@ -50,8 +50,8 @@ def table(tags, part):
              ("Source: `scripts/profile_r" + ROUND[-1] + ".sh %s` (one rocprofv3 pass per counter group; program directly after `--`), collated by `scripts/pmc_collate.py`.") % part,
              "Calibration on `mh::stream_copy_kernel` (671 088 640 B read and written, 8 B per lane): bytes / (FETCH_SIZE KB x 1024) = %.3f, bytes / (WRITE_SIZE KB x 1024) = %.3f"
              % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
-             "| run | kernel | avg us (kernel trace) | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
-             "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+             "| run | kernel | avg us (kernel trace, ALL launches of the run: cold first ones included) | min us | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
+             "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     traffic, extra = {}, {}
     for tag in tags:
         tr = trace(tag)
@@ -62,7 +62,7 @@ def table(tags, part):
         for k in sorted(tr):
             if not any(x in k for x in ("stage_kernel", "fused_rk2_kernel", "update_kernel", "flux_kernel", "gradient_kernel", "sink_kernel")):
                 continue
-            avg, calls = tr[k]
+            avg, calls, tmin = tr[k]
             hbm = None
             if (k, "FETCH_SIZE") in fe and (k, "WRITE_SIZE") in wr:
                 hbm = (round(ffac) * fe[(k, "FETCH_SIZE")] + round(wfac) * wr[(k, "WRITE_SIZE")]) * 1024
@@ -78,7 +78,7 @@ def table(tags, part):
                 tf = flops / (avg * 1e-9) / 1e12
                 extra[(tag, k)] = {"fp64_flops_per_launch": flops, "valu_busy": busy, "valu_instructions_per_launch": valu}
             fmt = lambda x, f: "" if x is None else f % x
-            lines.append("| %s | `%s` | %.1f | %d | %s | %s | %s | %s | %s | %s |" % (tag, k, avg / 1e3, calls, fmt(hbm and hbm / 1e6, "%.1f"), fmt(valu, "%.3g"),
+            lines.append("| %s | `%s` | %.1f | %.1f | %d | %s | %s | %s | %s | %s | %s |" % (tag, k, avg / 1e3, tmin / 1e3, calls, fmt(hbm and hbm / 1e6, "%.1f"), fmt(valu, "%.3g"),
                          fmt(busy, "%.2f"), fmt(wait, "%.2f"), fmt(tf, "%.1f"), fmt(tf and tf / 78.6, "%.2f")))
     lines += ["", "VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32): the counter ticks in quad-cycles per SIMD, SQ_BUSY_CYCLES per shader engine of 32 SIMDs.",
               "wait-on-instr = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES. fp64 FLOP/s = 64 x (ADD + MUL + 2 FMA + TRANS of SQ_INSTS_VALU_*_F64) / avg duration."]
