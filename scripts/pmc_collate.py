@@ -52,6 +52,11 @@ def table(tags, part):
              % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
              "| run | kernel | avg us (kernel trace, ALL launches of the run: cold first ones included) | min us | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    if part == "headline" and ROUND == "r03":
+        lines[3:3] = ["Kernel traces of the headline variants: `scripts/profile_r3.sh headline_trace` (`bench.py --steps 200`: 283 launches per kernel, so that the cold launches - the first ~25 after",
+                      "an idle period run up to twice as long - do not carry the average; the counters come from the 20-step runs of `headline` / `headline2`). The same command's own bench line is",
+                      "`bench_under_rocprof_trace_<run>.json`: for the fused kernel 0.605 ms per launch (one pair of events around five launches, gaps included) and 0.603 ms per timed step against",
+                      "this trace's 0.624 average / 0.589 minimum.", ""]
     traffic, extra = {}, {}
     for tag in tags:
         tr = trace(tag)

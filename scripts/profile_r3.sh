@@ -25,6 +25,16 @@ if [ $PART = headline ]; then
   pmc_passes strict_hlle $B --arith strict --riemann hlle
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python3 scripts/calib_fetch.py > $OUT/calib_f.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python3 scripts/calib_fetch.py > $OUT/calib_w.log 2>&1
+elif [ $PART = headline_trace ]; then
+  # kernel trace only, over a run long enough for the cold launches (the first ~25 after an idle period run up to twice as long) not to
+  # carry the average: 200 timed steps instead of 20
+  B="python3 bench.py --steps 200 --warmup 3 --no-cpu-baseline --single-arith --blocks 1"
+  for v in "fast_hllc --arith fast --riemann hllc" "fast_hllc_two --arith fast --riemann hllc --no-fuse" "strict_hlle --arith strict --riemann hlle" "fast_hlle --arith fast --riemann hlle" "strict_hllc --arith strict --riemann hllc"; do
+    set -- $v; tag=$1; shift
+    rm -rf $OUT/${tag}_trace
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_trace -- $B "$@" > $OUT/${tag}_trace.json 2> $OUT/${tag}_trace.err
+    echo "done $tag"
+  done
 elif [ $PART = headline2 ]; then
   B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --single-arith --blocks 1"
   pmc_passes fast_hlle $B --arith fast --riemann hlle
