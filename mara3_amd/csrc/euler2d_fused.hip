@@ -49,7 +49,13 @@ struct Fused2dParams
     long   plane_stride, row_stride;
     int    n0, n1;
     int    chunk_rows, nstrips, nchunks;
-    int    bc0, bc1;              // 0 outflow, 1 periodic (both sides of an axis alike: physical boundaries only)
+    // the rows this launch covers: chunks [0, seg0_chunks) cut rows [seg0_begin, seg0_end), the others [seg1_begin, seg1_end) - a slab with
+    // neighbours runs both of its edge strips in one launch and the rest in another (slab.hip); a whole field is one segment
+    int    seg0_begin, seg0_end, seg0_chunks, seg1_begin, seg1_end;
+    int    bc0_lo, bc0_hi;        // axis 0, per side: 0 outflow, 1 periodic (both sides then), 2 EXTERNAL - a cut of a slab decomposition: rows
+                                  // -4 .. -1 / n0 .. n0 + 3 of u_in hold the neighbour's rows (four per side: two per stage), nothing is
+                                  // clamped or wrapped there, and the result's ghost rows on that side are the next exchange's to fill
+    int    bc1;                   // axis 1: 0 outflow, 1 periodic
     double gamma, theta, cx, cy;
 };
 
@@ -106,11 +112,13 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int al = ((lane - 1) & 63) * 4, ar = ((lane + 1) & 63) * 4;
-    const int chunk = pair / p.nstrips;
-    const int strip = pair - chunk * p.nstrips;
+    const int chunk_of_launch = pair / p.nstrips;
+    const int strip = pair - chunk_of_launch * p.nstrips;
     const int n0 = p.n0, n1 = p.n1;
-    const int r0 = chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, n0);
+    const bool second = chunk_of_launch >= p.seg0_chunks;
+    const int chunk = second ? chunk_of_launch - p.seg0_chunks : chunk_of_launch;
+    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
     const int nrows = r1 - r0;                         // >= 1 by construction of the grid
 
     const int col = strip * FSTRIP - FHALO + lane;
@@ -131,11 +139,14 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         // ================================================================ PRODUCER: first stage, rows r0 - 2 .. r1 + 1 ================
         // step-start rows beyond the field: the periodic image, or (outflow) the edge row - what the stored ghost rows hold, two rows
         // further out than they reach
-        const int bc0 = p.bc0;
-        auto row_of = [in, row_stride, n0, bc0] (int r)
+        const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
+        auto row_of = [in, row_stride, n0, bc0_lo, bc0_hi] (int r)
         {
-            const int m = bc0 == 1 ? (r < 0 ? r + n0 : (r >= n0 ? r - n0 : r)) : min(max(r, 0), n0 - 1);
-            return in + (long) (m + 2) * row_stride;
+            // (the row loop requests rows up to two beyond the last one it uses: EXTERNAL sides stop at the four rows that exist)
+            int m = r;
+            if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? max(r, -4) : 0);
+            else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? min(r, n0 + 3) : n0 - 1);
+            return in + (long) (m + 2) * row_stride;          // (EXTERNAL: rows -4, -3 and n0 + 2, n0 + 3 lie outside the stored ghost rows: the slab stepper allocates them)
         };
         // slot of step-start row x: (x - a0) mod USLOTS
         auto ring_put = [&] (int slot, const State5& raw)
@@ -229,11 +240,12 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         // ghost columns of the first-stage field: outflow = the edge column's value, i.e. another lane's entry of the ring
         int src_lane = lane;
         if (p.bc1 != 1) src_lane = lane + (min(max(col, 0), n1 - 1) - col);
-        const int bc0 = p.bc0;
-        // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots
+        const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
+        // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots (periodic and EXTERNAL: the producer
+        // worked on the wrapped row / on the neighbour's rows)
         auto hand_row = [&] (int rr) -> State5
         {
-            const int m = bc0 == 1 ? rr : min(max(rr, 0), n0 - 1);
+            const int m = rr < 0 ? (bc0_lo == 0 ? 0 : rr) : (rr >= n0 ? (bc0_hi == 0 ? n0 - 1 : rr) : rr);
             const int slot = (m - (r0 - 2)) % FSLOTS;
             State5 Uq;
 #pragma unroll
@@ -299,10 +311,10 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
                 store_row(p.u_out + row_off(r), p.plane_stride, col8, Un);
                 if (r < 2 || r >= n0 - 2)          // the stored ghost rows of the result (edge rows only: wave-uniform, cold)
                 {
-                    if (bc0 == 0 && r == 0) { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
-                    if (bc0 == 1 && r < 2) store_row(p.u_out + row_off(n0 + r), p.plane_stride, col8, Un);
-                    if (bc0 == 0 && r == n0 - 1) { store_row(p.u_out + row_off(n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(n0 + 1), p.plane_stride, col8, Un); }
-                    if (bc0 == 1 && r >= n0 - 2) store_row(p.u_out + row_off(r - n0), p.plane_stride, col8, Un);
+                    if (bc0_lo == 0 && r == 0) { store_row(p.u_out + row_off(-1), p.plane_stride, col8, Un); store_row(p.u_out + row_off(-2), p.plane_stride, col8, Un); }
+                    if (bc0_hi == 1 && r < 2) store_row(p.u_out + row_off(n0 + r), p.plane_stride, col8, Un);
+                    if (bc0_hi == 0 && r == n0 - 1) { store_row(p.u_out + row_off(n0), p.plane_stride, col8, Un); store_row(p.u_out + row_off(n0 + 1), p.plane_stride, col8, Un); }
+                    if (bc0_lo == 1 && r >= n0 - 2) store_row(p.u_out + row_off(r - n0), p.plane_stride, col8, Un);
                 }
             }
         };
@@ -320,19 +332,31 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     acc.commit(p.status);
 }
 
-bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d)
+// with_cuts: MH_BC_EXTERNAL sides are accepted too - the caller (slab.hip) keeps FOUR rows of the neighbour beyond such a side
+bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d, bool with_cuts)
 {
+    auto side_ok = [with_cuts] (int bc) { return bc == MH_BC_OUTFLOW || bc == MH_BC_PERIODIC || (with_cuts && bc == MH_BC_EXTERNAL); };
     return d->rank == 2 && d->arith == MH_ARITH_FAST && d->plm_theta >= 0.0 && d->n[0] >= 8 && d->n[1] >= 8
-        && (d->bc_lo0 == MH_BC_OUTFLOW || d->bc_lo0 == MH_BC_PERIODIC) && d->bc_hi0 == d->bc_lo0
+        && side_ok(d->bc_lo0) && side_ok(d->bc_hi0) && ((d->bc_lo0 == MH_BC_PERIODIC) == (d->bc_hi0 == MH_BC_PERIODIC))
         && (d->bc_transverse == MH_BC_OUTFLOW || d->bc_transverse == MH_BC_PERIODIC);
 }
 
 // u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 over the whole field (both with stored ghost rows, layout of include/mara_hip.h); the two
 // fields must differ. chunk_rows: the descriptor's, or the default below.
 hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
-                                    LaunchEvents ev)
+                                    LaunchEvents ev, bool with_cuts)
 {
-    if (! euler2d_fused_rk2_available(d) || u_in == u_out) return hipErrorInvalidValue;
+    return euler2d_fused_rk2_launch_rows(d, u_in, u_out, dt, 0, d->n[0], 0, 0, status, stream, ev, with_cuts);
+}
+
+// ... over rows [a, b) and, in the same launch, [a2, b2) (b2 <= a2: none) of the field
+hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int a, int b, int a2, int b2,
+                                         int32_t* status, hipStream_t stream, LaunchEvents ev, bool with_cuts)
+{
+    if (! euler2d_fused_rk2_available(d, with_cuts) || u_in == u_out) return hipErrorInvalidValue;
+    if (a < 0 || b > d->n[0] || b <= a || (b2 > a2 && (a2 < b || b2 > d->n[0]))) return hipErrorInvalidValue;
+    const int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
+    const int longest = rows0 > rows1 ? rows0 : rows1;
     Fused2dParams p;
     p.u_in = u_in; p.u_out = u_out; p.status = status;
     p.n0 = d->n[0]; p.n1 = d->n[1];
@@ -348,13 +372,20 @@ hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u
         // 100 rows (41 chunks, 2.96 rounds) 0.631-0.638 ms per step; 106 rows (2.82 rounds) 0.658; 75-79 rows (3.8-4 rounds) 0.645;
         // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
         int rounds = 1;
-        auto chunk_for = [&] (int r) { const int nch = 1024 * r / p.nstrips > 0 ? 1024 * r / p.nstrips : 1; return (p.n0 + nch - 1) / nch; };
+        // (a slab's interior launch does NOT leave room for its edge launch's pairs: measured slower, 125 against 112 us per step at 512 rows)
+        auto chunk_for = [&] (int r) { const int nch = 1024 * r / p.nstrips > 0 ? 1024 * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
         while (chunk_for(rounds) > 112) ++rounds;
         p.chunk_rows = chunk_for(rounds);
         if (p.chunk_rows < 8) p.chunk_rows = 8;
     }
-    p.nchunks = (p.n0 + p.chunk_rows - 1) / p.chunk_rows;
-    p.bc0 = d->bc_lo0 == MH_BC_PERIODIC ? 1 : 0;
+    if (p.chunk_rows > longest) p.chunk_rows = longest;
+    p.seg0_begin = a; p.seg0_end = b;
+    p.seg0_chunks = (rows0 + p.chunk_rows - 1) / p.chunk_rows;
+    p.seg1_begin = a2; p.seg1_end = rows1 ? b2 : a2;
+    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.chunk_rows - 1) / p.chunk_rows : 0);
+    auto side = [] (int bc) { return bc == MH_BC_PERIODIC ? 1 : (bc == MH_BC_EXTERNAL ? 2 : 0); };
+    p.bc0_lo = side(d->bc_lo0);
+    p.bc0_hi = side(d->bc_hi0);
     p.bc1 = d->bc_transverse == MH_BC_PERIODIC ? 1 : 0;
     p.gamma = d->gamma; p.theta = d->plm_theta;
     p.cx = dt / d->dl[0]; p.cy = dt / d->dl[1];

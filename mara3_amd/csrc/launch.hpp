@@ -20,9 +20,14 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
                                  LaunchEvents ev = LaunchEvents());
 
 // both stages of an RK2 step of a whole 2-D field in one launch (euler2d_fused.hip): u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5
-bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d);
+// with_cuts: MH_BC_EXTERNAL sides on axis 0 too - the field then holds FOUR rows of the neighbour beyond such a side (rows -4 .. -1 /
+// n0 .. n0 + 3 at the usual row pitch: two more than the stored ghost rows), which the caller allocates and exchanges once per step
+bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d, bool with_cuts = false);
 hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
-                                    LaunchEvents ev = LaunchEvents());
+                                    LaunchEvents ev = LaunchEvents(), bool with_cuts = false);
+// ... over rows [a, b) and, in the same launch, [a2, b2) (none if b2 <= a2): a slab with neighbours runs its two edge strips, then the rest
+hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int a, int b, int a2, int b2,
+                                         int32_t* status, hipStream_t stream, LaunchEvents ev = LaunchEvents(), bool with_cuts = false);
 
 hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);

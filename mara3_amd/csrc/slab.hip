@@ -113,6 +113,11 @@ struct mh_slab
     double graph_dt = 0.0;
     // fused RK2 (euler2d_fused.hip): one launch per step from field[0] into field[1], then the two swap. One captured step per direction.
     bool fused = false;
+    // ... and WITH neighbours (round 3): the slab keeps FOUR rows of each neighbour (two per RK stage) and exchanges once per step - the
+    // fused launch recomputes the neighbours' first-stage rows it needs instead of receiving them between two launches (group_fused_cut_step)
+    bool fused_cut = false;
+    mh_euler_cart_desc fused_desc;               // desc with the caller's chunk_rows (desc.chunk_rows is tuned for the two-launch interior)
+    size_t pad_doubles = 0;                      // doubles allocated in front of (and behind) each field for rows -4, -3 (n0 + 2, n0 + 3)
     double* fused_src[2] = {nullptr, nullptr};
     hipGraphExec_t fused_exec[2] = {nullptr, nullptr};
     bool profile = false;
@@ -137,6 +142,7 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
     else
     {
         const mh_euler_cart_desc* d = edge ? &s->edge_desc : &s->desc;
+        if (s->fused_cut) return euler2d_fused_rk2_launch_rows(&s->fused_desc, in, out, dt, a, b, a2, b2, s->status, stream, ev, true);
         if (d->rank == 2) return euler2d_stage_launch2(d, in, base, out, dt, w, a, b, a2, b2, s->status, stream, ev);
         if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a, b, s->status, stream)) return e;
         if (b2 > a2) if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a2, b2, s->status, stream)) return e;
@@ -147,19 +153,24 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
 }
 static bool launch_carries_events(const mh_slab* s) { return s->kind == SLAB_EULER && s->desc.rank == 2; }
 
-static size_t ghost_block_doubles(const mh_slab* s) { return (size_t) 2 * 5 * s->n1; }      // two rows, all variables: contiguous
+static int ghost_rows(const mh_slab* s) { return s->fused_cut ? 4 : 2; }
+static size_t row_doubles(const mh_slab* s) { return (size_t) 5 * s->n1; }
+// row r of a field (r = -2: its first stored ghost row; a fused slab with neighbours also owns rows -4, -3 and n0 + 2, n0 + 3)
+static double* row_ptr(const mh_slab* s, double* f, long r) { return f + (r + 2) * (long) row_doubles(s); }
+static size_t ghost_block_doubles(const mh_slab* s) { return (size_t) ghost_rows(s) * row_doubles(s); }      // the rows of one side, all variables: contiguous
 
 static int exchange_rccl(mh_slab* s, double* f, hipStream_t stream)
 {
     RcclApi* a = rccl();
     if (! a || ! s->comm) { set_error("mh_slab: neighbours exist but the RCCL communicator was not connected (mh_slab_connect)"); return MH_E_STATE; }
     const size_t blk = ghost_block_doubles(s);
+    const int G = ghost_rows(s);
     MH_RCCL_TRY(a->GroupStart());
-    if (s->lo >= 0) MH_RCCL_TRY(a->Send(f + blk, blk, ncclDouble, s->lo, s->comm, stream));                             // rows 0,1
-    if (s->hi >= 0) MH_RCCL_TRY(a->Send(f + (size_t) s->n0 * 5 * s->n1, blk, ncclDouble, s->hi, s->comm, stream));      // rows n0-2,n0-1
+    if (s->lo >= 0) MH_RCCL_TRY(a->Send(row_ptr(s, f, 0), blk, ncclDouble, s->lo, s->comm, stream));                    // rows 0 .. G-1
+    if (s->hi >= 0) MH_RCCL_TRY(a->Send(row_ptr(s, f, s->n0 - G), blk, ncclDouble, s->hi, s->comm, stream));            // rows n0-G .. n0-1
     // receive order mirrors the neighbours' send order (low rows first): matters when lo == hi
-    if (s->hi >= 0) MH_RCCL_TRY(a->Recv(f + (size_t) (s->n0 + 2) * 5 * s->n1, blk, ncclDouble, s->hi, s->comm, stream)); // ghosts n0,n0+1
-    if (s->lo >= 0) MH_RCCL_TRY(a->Recv(f, blk, ncclDouble, s->lo, s->comm, stream));                                   // ghosts -2,-1
+    if (s->hi >= 0) MH_RCCL_TRY(a->Recv(row_ptr(s, f, s->n0), blk, ncclDouble, s->hi, s->comm, stream));                // ghosts n0 .. n0+G-1
+    if (s->lo >= 0) MH_RCCL_TRY(a->Recv(row_ptr(s, f, -G), blk, ncclDouble, s->lo, s->comm, stream));                   // ghosts -G .. -1
     MH_RCCL_TRY(a->GroupEnd());
     return MH_OK;
 }
@@ -170,21 +181,22 @@ static int exchange_rccl(mh_slab* s, double* f, hipStream_t stream)
 static int exchange_loopback(mh_slab* s, double* f, hipStream_t stream, bool initial)
 {
     const size_t blk = ghost_block_doubles(s), bytes = blk * sizeof(double);
+    const int G = ghost_rows(s);
     if (s->hi >= 0)
     {
         mh_slab* p = s->peer_hi;
         if (! p) { set_error("mh_slab: loopback peer missing"); return MH_E_STATE; }
-        const double* src = (initial ? p->field[0] : p->cur_out) + blk;                                  // peer rows 0,1
+        const double* src = row_ptr(p, initial ? p->field[0] : p->cur_out, 0);                           // peer rows 0 .. G-1
         if (! initial) MH_HIP_TRY(hipStreamWaitEvent(stream, p->ev_edge, 0));
-        MH_HIP_TRY(hipMemcpyAsync(f + (size_t) (s->n0 + 2) * 5 * s->n1, src, bytes, hipMemcpyDeviceToDevice, stream));
+        MH_HIP_TRY(hipMemcpyAsync(row_ptr(s, f, s->n0), src, bytes, hipMemcpyDeviceToDevice, stream));
     }
     if (s->lo >= 0)
     {
         mh_slab* p = s->peer_lo;
         if (! p) { set_error("mh_slab: loopback peer missing"); return MH_E_STATE; }
-        const double* src = (initial ? p->field[0] : p->cur_out) + (size_t) p->n0 * 5 * p->n1;           // peer rows n0-2,n0-1
+        const double* src = row_ptr(p, initial ? p->field[0] : p->cur_out, p->n0 - G);                   // peer rows n0-G .. n0-1
         if (! initial) MH_HIP_TRY(hipStreamWaitEvent(stream, p->ev_edge, 0));
-        MH_HIP_TRY(hipMemcpyAsync(f, src, bytes, hipMemcpyDeviceToDevice, stream));
+        MH_HIP_TRY(hipMemcpyAsync(row_ptr(s, f, -G), src, bytes, hipMemcpyDeviceToDevice, stream));
     }
     MH_HIP_TRY(hipEventRecord(s->ev_copied, stream));
     return MH_OK;
@@ -315,13 +327,16 @@ static StageArgs stage_args(const mh_slab* s, int i, double dt)
     StageArgs st;
     if (i == 0) { st.in = s->field[0]; st.base = nullptr; st.out = s->field[1]; st.w = 1.0; }
     else        { st.in = s->field[1]; st.base = s->field[0]; st.out = s->field[0]; st.w = 0.5; }
-    st.dt = dt; st.which = i;
+    st.dt = dt; st.which = s->fused_cut ? 1 : i;          // (a fused step's launch is reported in the second-stage slot, as without neighbours)
     return st;
 }
 
 static int group_one_step(mh_slab** g, int n, double dt)
 {
-    const int nstages = g[0]->rk_order;
+    // Fused across cuts: the whole RK2 step is ONE "stage" of the two-chain schedule - both edge strips (four rows each: what the
+    // neighbours need for BOTH of their stages) in one fused launch on the side stream with the step's one exchange behind it, the rest of
+    // the rows in a fused launch on the main stream, which never waits for the exchange (its rows [4, n0 - 4) read rows 0 .. n0 - 1 only).
+    const int nstages = g[0]->fused_cut ? 1 : g[0]->rk_order;
     StageArgs st[64];
     for (int i = 0; i < nstages; ++i)
     {
@@ -338,6 +353,21 @@ static int slab_one_step(mh_slab* s, double dt) { return group_one_step(&s, 1, d
 static bool slab_can_fuse(const mh_slab* s)
 {
     return s->kind == SLAB_EULER && s->rk_order == 2 && ! has_neighbours(s) && s->desc.fuse_stages >= 0 && euler2d_fused_rk2_available(&s->desc);
+}
+
+// ... with neighbours. Every member of the decomposition must decide alike (the exchange moves four rows instead of two), so the
+// decision rests on the global descriptor and the thinnest share of the rows only. It pays for THICK slabs: a fused pair pays eight
+// pipeline-fill rows per chunk, and a thin slab has few rows per chunk to spread them over - measured on one GPU with the exchange to
+// self, 4096 columns, us per step, two launches / fused across cuts: 2048 rows 380 / 356, 1024 rows 194 / 202, 512 rows 98 / 112
+// (profiles/r03/slab_fused_across_cuts.jsonl). MH_SLAB_FUSED_CUTS: 0 never, 1 wherever it can run (12 rows), unset: from 1536 rows.
+static bool slab_can_fuse_cut(const mh_slab* s, const mh_euler_cart_desc* global)
+{
+    int least = 1536;
+    if (const char* v = getenv("MH_SLAB_FUSED_CUTS")) { if (atoi(v) == 0) return false; least = 12; }          /* 12: two edge strips of four rows and an interior */
+    mh_euler_cart_desc d = s->desc;
+    d.n[0] = 8;          // (the member's own row count must not enter: only the thinnest share below does)
+    return s->kind == SLAB_EULER && s->rk_order == 2 && has_neighbours(s) && global->fuse_stages >= 0 && global->n[0] / s->world >= least
+        && euler2d_fused_rk2_available(&d, true);
 }
 
 static int slab_fused_step(mh_slab* s, double dt)
@@ -443,10 +473,19 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
         }
     }
     s->fused = slab_can_fuse(s);
-    if (kind == SLAB_EULER && global->fuse_stages > 0 && ! s->fused)
+    s->fused_cut = kind == SLAB_EULER && slab_can_fuse_cut(s, global);
+    if (s->fused_cut)
+    {
+        s->fused_desc = s->desc;
+        s->fused_desc.chunk_rows = global->chunk_rows;
+        s->pad_doubles = 2 * row_doubles(s);
+        s->edge_rows = 4;          // the rows a neighbour needs for both of its stages; every step synchronises both chains (no stagger)
+        s->stagger = 0;
+    }
+    if (kind == SLAB_EULER && global->fuse_stages > 0 && ! s->fused && ! s->fused_cut)
     {
         delete s;
-        set_error("fuse_stages is required, but a fused RK2 step needs MH_ARITH_FAST, PLM, rk_order 2, rank 2 and a slab without neighbours");
+        set_error("fuse_stages is required, but a fused RK2 step needs MH_ARITH_FAST, PLM, rk_order 2, rank 2 (and, with neighbours, twelve rows per slab)");
         return MH_E_INVALID;
     }
     if (const char* v = getenv("MH_SLAB_EVENT_ON_LAUNCH")) s->event_on_launch = atoi(v) != 0;
@@ -462,11 +501,13 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
         hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess)
     { cleanup(); set_error("mh_slab: stream/event creation failed"); return MH_E_HIP; }
-    const size_t doubles = (size_t) 5 * (s->n0 + 4) * s->n1;
+    const size_t doubles = (size_t) 5 * (s->n0 + 4) * s->n1 + 2 * s->pad_doubles;
     for (auto& f : s->field)
     {
-        if (hipMalloc((void**) &f, doubles * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab: hipMalloc failed"); return MH_E_NOMEM; }
-        hipMemsetAsync(f, 0, doubles * sizeof(double), s->main);
+        double* base = nullptr;
+        if (hipMalloc((void**) &base, doubles * sizeof(double)) != hipSuccess) { cleanup(); set_error("mh_slab: hipMalloc failed"); return MH_E_NOMEM; }
+        hipMemsetAsync(base, 0, doubles * sizeof(double), s->main);
+        f = base + s->pad_doubles;          // (freed as f - pad_doubles)
     }
     if (hipMalloc((void**) &s->status, 2 * sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     hipMemsetAsync(s->status, 0, 2 * sizeof(int32_t), s->main);
@@ -668,7 +709,7 @@ void mh_slab_destroy(mh_slab* s)
     for (auto& g : s->fused_exec) if (g) hipGraphExecDestroy(g);
     if (s->comm && s->owns_comm && rccl()) rccl()->CommDestroy(s->comm);
     for (auto& v : s->events) for (auto& ev : v) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    for (auto& f : s->field) if (f) hipFree(f);
+    for (auto& f : s->field) if (f) hipFree(f - s->pad_doubles);
     if (s->staging) hipFree(s->staging);
     if (s->status) hipFree(s->status);
     if (s->geom) hipFree(s->geom);

@@ -82,15 +82,47 @@ def test_group_equals_single_domain_with_staggered_edges(eng, world, bc, riemann
     grp.close()
 
 
+@pytest.mark.parametrize("cuts", ["0", "1"])
+@pytest.mark.parametrize("riemann", ["hllc", "hlle"])
+@pytest.mark.parametrize("shape, world, bc", [((250, 300), 2, "outflow"), ((250, 300), 3, "periodic"), ((41, 100), 5, "outflow"), ((61, 130), 5, "periodic"), ((96, 130), 8, "periodic"),
+                                              ((97, 61), 4, "outflow")])
+def test_group_fused_step_across_cuts_and_the_two_launch_schedule(eng, shape, world, bc, riemann, cuts, monkeypatch):
+    """Round 3: FAST RK2 slabs WITH neighbours take the fused step too - four rows of each neighbour, one exchange per step, the
+    neighbours' first-stage rows recomputed inside the launch (slab.hip: group_fused_cut_step) - unless MH_SLAB_FUSED_CUTS=0 keeps the
+    two-launch schedule with its exchange per stage. Both are the one-domain result bit for bit: slabs down to twelve rows (thinner ones keep the two-launch schedule), ranks with one
+    and with two neighbours, periodic cuts (both sides external on every rank), ragged column counts, a download in between."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", cuts)
+    gamma = 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=23)
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, riemann, 2, bc, arith="fast")
+    ref.upload(u0)
+    grp = NativeSlabGroup(shape, dl, gamma, 1.5, riemann, 2, bc, world=world, arith="fast")
+    grp.upload(u0)
+    for nsteps in (1, 2, 4):
+        ref.step(4e-4, nsteps)
+        grp.step(4e-4, nsteps)
+        grp.synchronize()
+        assert bits_equal(grp.download(), ref.download()), (shape, world, bc, cuts, nsteps)
+    assert grp.status() == (0, None)
+    grp.close(); ref.close()
+
+
+@pytest.mark.parametrize("cuts", ["1", "0"])
 @pytest.mark.parametrize("on_launch", [1, 0])
 @pytest.mark.parametrize("delay", [1, 2, 3])
 @pytest.mark.parametrize("stagger", [0, 4])
-def test_group_dependencies_hold_under_shifted_timing(eng, delay, stagger, on_launch, monkeypatch):
+def test_group_dependencies_hold_under_shifted_timing(eng, delay, stagger, on_launch, cuts, monkeypatch):
     """Three slabs (outflow: a rank with only a hi neighbour, one with both, one with only a lo neighbour) with a ~150 us sleeping wave
     queued in front of every edge launch (1), every interior launch (2) or both (3): the events alone must order the two chains of every
     rank AND the copies between ranks. With and without staggered edges, events carried by the launches or recorded behind them."""
     from mara3_amd import setups
     from mara3_amd.slab import NativeSlabGroup
+    if cuts == "1" and (stagger or not on_launch):
+        pytest.skip("the fused step across cuts has one schedule: the stagger / event switches belong to the two-launch one")
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", cuts)
     monkeypatch.setenv("MH_SLAB_TEST_DELAY", str(delay))
     monkeypatch.setenv("MH_SLAB_STAGGER", str(stagger))
     monkeypatch.setenv("MH_SLAB_EVENT_ON_LAUNCH", str(on_launch))
@@ -108,10 +140,12 @@ def test_group_dependencies_hold_under_shifted_timing(eng, delay, stagger, on_la
     grp.close()
 
 
-def test_group_baseline_cut_4096_over_8(eng):
+@pytest.mark.parametrize("world", [8, 2])
+def test_group_baseline_cut_4096_over_8(eng, world):
     """The BASELINE cut itself: 4096^2 over 8 ranks (512 x 4096 cells per rank, the staggered schedule and the one-residency-round
     chunk heuristic active), PLM + HLLC RK2 FAST as bench.py runs it, 6 steps, bit-identical to the one-domain run; per-rank bit
-    fingerprints as bench.py's partition_check forms them."""
+    fingerprints as bench.py's partition_check forms them. And over 2 ranks, where the slabs (2048 rows: from 1536 on) take the fused
+    step across their cut by the library's own choice."""
     import torch
     from mara3_amd import setups
     from mara3_amd.slab import NativeSlabGroup, slab_fingerprint, partition_rows
@@ -124,14 +158,14 @@ def test_group_baseline_cut_4096_over_8(eng):
     ref.step(dt, 6)
     whole = ref.download()
     ref.close()
-    grp = NativeSlabGroup((n, n), dl, gamma, 1.5, "hllc", 2, "outflow", world=8, arith="fast")
+    grp = NativeSlabGroup((n, n), dl, gamma, 1.5, "hllc", 2, "outflow", world=world, arith="fast")
     grp.upload(u0)
     grp.step(dt, 6)
     grp.synchronize()
     assert grp.status() == (0, None)
-    for r in range(8):
-        a, b = partition_rows(n, 8, r)
-        assert (a, b) == grp.rows[r] == (512 * r, 512 * (r + 1))
+    for r in range(world):
+        a, b = partition_rows(n, world, r)
+        assert (a, b) == grp.rows[r] == (n // world * r, n // world * (r + 1))
         mine = grp.member_host(r)
         assert slab_fingerprint(torch.from_numpy(mine)) == slab_fingerprint(torch.from_numpy(whole[a:b])), r
         assert bits_equal(mine, whole[a:b]), r
