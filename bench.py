@@ -368,7 +368,9 @@ def main():
         ms = block_ms[0]
         value = n * n / ms / 1e3
         timing = "HIP events riding on the launches, %d extra steps after the timed region and %d un-instrumented ones that lead into them" % (nprof, nlead)
-        if native and nl1 == 0 and nl2 > 0:
+        if native and nl1 == 0 and nl2 > 0 and (world > 1 or args.loopback_slabs):
+            timing = "HIP events around the interior launch of each of %d extra steps after the timed region and %d un-instrumented ones that lead into them" % (nprof, nlead)
+        elif native and nl1 == 0 and nl2 > 0:
             # (events riding on each launch of the fused kernel read 3 % long - longer than the timed steps themselves)
             timing = ("one pair of HIP events around the %d launches of %d extra steps (the gaps between the launches included), after the timed region and %d "
                       "un-instrumented steps that lead into them" % (nl2, nprof, nlead))
@@ -505,11 +507,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
-                       "decomposition": ("axis-0 slabs x%d (nd::partition_shape formula), 2-row RCCL halo per stage, %s stepper" % (world, state["stepper"]))
+                       "decomposition": ("axis-0 slabs x%d (nd::partition_shape formula), %s, %s stepper" % (world, "4-row RCCL halo once per step (fused step across the cuts)" if res["launches_per_step"] == 1 else "2-row RCCL halo per stage", state["stepper"]))
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
-                       "timed_region": ("one launch per step, issued as it is (a one-node graph replay costs 29 us more per step); two-launch legs: HIP-graph replay of the step" if not decomposed else "eager two-stream issue, one exchange per stage")
+                       "timed_region": ("one launch per step, issued as it is (a one-node graph replay costs 29 us more per step); two-launch legs: HIP-graph replay of the step" if not decomposed else ("eager two-stream issue, one exchange per step" if res["launches_per_step"] == 1 else "eager two-stream issue, one exchange per stage"))
                                        + (" (ONE fused launch per RK2 step, mara3_amd/csrc/euler2d_fused.hip: results bit-identical to the two launches, tests/test_gpu_fused_rk2.py)"
                                           if res["launches_per_step"] == 1 else " (two launches per RK2 step)"),
                        "preconditioning": res["preconditioning"]},
