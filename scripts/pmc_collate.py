@@ -53,10 +53,19 @@ def table(tags, part):
              "| run | kernel | avg us (kernel trace, ALL launches of the run: cold first ones included) | min us | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     if part == "headline" and ROUND == "r03":
+        own = {}
+        try:
+            for l in open(os.path.join(OUT, "fast_hllc_trace.json")):
+                if l.startswith("{"):
+                    own = json.loads(l)
+        except OSError:
+            pass
+        tr0 = trace("fast_hllc").get("euler2d_fused_rk2_kernel<1>", (0.0, 0, 0.0))
         lines[3:3] = ["Kernel traces of the headline variants: `scripts/profile_r3.sh headline_trace` (`bench.py --steps 200`: 283 launches per kernel, so that the cold launches - the first ~25 after",
                       "an idle period run up to twice as long - do not carry the average; the counters come from the 20-step runs of `headline` / `headline2`). The same command's own bench line is",
-                      "`bench_under_rocprof_trace_<run>.json`: for the fused kernel 0.605 ms per launch (one pair of events around five launches, gaps included) and 0.603 ms per timed step against",
-                      "this trace's 0.624 average / 0.589 minimum.", ""]
+                      "`bench_under_rocprof_trace_<run>.json`: for the fused kernel %.3f ms per launch (one pair of events around five launches, gaps included) and %.3f ms per timed step against"
+                      % (own.get("roofline", {}).get("avg_launch_ms", 0.0), own.get("ms_per_step", 0.0)),
+                      "this trace's %.3f ms average / %.3f ms minimum (same process, same box; boxes differ by 2 - 3 %%)." % (tr0[0] / 1e6, tr0[2] / 1e6), ""]
     traffic, extra = {}, {}
     for tag in tags:
         tr = trace(tag)

@@ -294,12 +294,15 @@ def test_cloud_config4_as_configured_4096_over_4_slabs(eng, arith):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("cuts", ["0", "1"])
 @pytest.mark.parametrize("world,shape", [(8, (1000, 600)), (5, (333, 1030))])
-def test_group_long_run_stays_bit_identical(eng, world, shape):
+def test_group_long_run_stays_bit_identical(eng, world, shape, cuts, monkeypatch):
     """300 steps (600 stages, 75 stagger periods) of an uneven cut: an ordering hole between the two chains of a rank, or between ranks,
-    that only opens now and then would show up here as a single differing bit."""
+    that only opens now and then would show up here as a single differing bit. Both schedules: two launches with an exchange per stage,
+    and the fused step across the cuts with one exchange per step."""
     from mara3_amd import setups
     from mara3_amd.slab import NativeSlabGroup
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", cuts)
     gamma = 1.4
     dl = (1.0 / shape[0], 1.0 / shape[1])
     u0 = setups.wave_ic(shape, gamma, seed=51)
