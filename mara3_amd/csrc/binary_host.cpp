@@ -303,12 +303,14 @@ int binary_tree_curve_order(const mh_tree_block* blocks, int nb, int32_t* order)
         if (blocks[b].level < 0 || blocks[b].level > 30) { set_error("binary tree: level %d of block %d out of range", blocks[b].level, b); return MH_E_INVALID; }
         if (blocks[b].level > depth) depth = blocks[b].level;
     }
+    // key = the first curve index of the leaf's square (the curve visits an aligned square of 4^(D - l) cells in one aligned run)
     std::vector<std::pair<uint64_t, int>> key(nb);
     for (int b = 0; b < nb; ++b)
     {
         const int shift = depth - blocks[b].level;
         uint64_t x = (uint64_t) blocks[b].i << shift, y = (uint64_t) blocks[b].j << shift, d = 0;
         const uint64_t n = (uint64_t) 1 << depth;
+        if (blocks[b].i < 0 || blocks[b].j < 0 || x >= n || y >= n) { set_error("binary tree: block %d (%d, %d, %d) lies outside the domain", b, blocks[b].level, blocks[b].i, blocks[b].j); return MH_E_INVALID; }
         for (uint64_t s2 = n / 2; s2 > 0; s2 /= 2)
         {
             const uint64_t rx = (x & s2) > 0, ry = (y & s2) > 0;
@@ -319,11 +321,15 @@ int binary_tree_curve_order(const mh_tree_block* blocks, int nb, int32_t* order)
                 const uint64_t tmp = x; x = y; y = tmp;
             }
         }
-        key[b] = {d, b};
+        const uint64_t cells = (uint64_t) 1 << (2 * shift);
+        key[b] = {d - d % cells, b};
     }
     std::sort(key.begin(), key.end());
     for (int k = 0; k + 1 < nb; ++k)
-        if (key[k].first == key[k + 1].first) { set_error("binary tree: blocks %d and %d overlap", key[k].second, key[k + 1].second); return MH_E_INVALID; }
+    {
+        const uint64_t cells = (uint64_t) 1 << (2 * (depth - blocks[key[k].second].level));
+        if (key[k + 1].first < key[k].first + cells) { set_error("binary tree: blocks %d and %d overlap", key[k].second, key[k + 1].second); return MH_E_INVALID; }
+    }
     for (int k = 0; k < nb; ++k) order[k] = key[k].second;
     return MH_OK;
 }

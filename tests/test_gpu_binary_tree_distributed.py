@@ -112,3 +112,35 @@ def test_distributed_tree_member_over_rccl(binary):
         if comm is not None:
             comm.close()
     one.close()
+
+
+def test_boundary_refuses_what_it_cannot_run(binary):
+    """error behaviour of the round-3 entry points: a message and a negative code, never a launch"""
+    import ctypes as C
+    from mara3_amd import _lib as L
+    cfg = binary.config(depth=3, block_size=8)
+    t = binary._TreeSetup(cfg)
+    lib = t.lib
+    h = C.c_void_p()
+    # a rank outside the world, a world of zero
+    for rank, world in ((3, 3), (-1, 2), (0, 0)):
+        assert lib.mh_binary_tree_band_create(C.byref(h), 0, C.byref(t.desc), C.byref(t.run), *t.pointers(), rank, world, None) < 0
+        assert not h.value
+    # overlapping leaves cannot be ordered along the curve
+    bad = np.array([[1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1], [2, 1, 1]], dtype=np.int32)
+    order = np.empty(5, dtype=np.int32)
+    assert lib.mh_binary_tree_curve_order(bad.ctypes.data_as(C.c_void_p), 5, order.ctypes.data_as(C.c_void_p)) < 0
+    assert lib.mh_binary_tree_curve_order(None, 5, order.ctypes.data_as(C.c_void_p)) < 0
+    # edge rows are a property of bands of the uniform mesh
+    one = binary.BinaryTreeSolver(cfg)
+    assert lib.mh_binary_band_set_edge_rows(one.handle, 2) < 0
+    n = C.c_int(-1)
+    assert lib.mh_binary_tree_owned_blocks(one.handle, None, C.byref(n)) == 0 and n.value == len(one.blocks)          # one domain: every block
+    uni = binary.BinarySolver(binary.config(depth=2, block_size=16))
+    assert lib.mh_binary_tree_owned_blocks(uni.handle, None, C.byref(n)) < 0
+    assert lib.mh_binary_band_set_edge_rows(uni.handle, 2) < 0          # not a band with neighbours
+    # the diagnostics of a distributed tree are refused (they would come out in curve order)
+    grp = binary.BinaryTreeGroup(cfg, world=2)
+    dm, dl = C.c_double(), C.c_double()
+    assert lib.mh_binary_disk_totals(C.c_void_p(grp.handles[0]), C.byref(dm), C.byref(dl)) < 0
+    one.close(); uni.close(); grp.close()

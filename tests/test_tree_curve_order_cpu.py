@@ -54,3 +54,9 @@ def test_curve_order_refuses_overlapping_leaves(binary):
     blocks = np.array([[1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1], [2, 0, 0]], dtype=np.int32)          # (2, 0, 0) lies inside (1, 0, 0)
     with pytest.raises(L.MaraHipError, match="overlap"):
         binary.tree_curve_order(blocks)
+    blocks[4] = (2, 1, 1)          # inside (1, 0, 0) too, but not at its corner
+    with pytest.raises(L.MaraHipError, match="overlap"):
+        binary.tree_curve_order(blocks)
+    blocks[4] = (2, 4, 0)          # outside the domain of a depth-2 tree
+    with pytest.raises(L.MaraHipError, match="outside"):
+        binary.tree_curve_order(blocks)
