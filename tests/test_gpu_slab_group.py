@@ -318,3 +318,34 @@ def test_group_long_run_stays_bit_identical(eng, world, shape, cuts, monkeypatch
     assert grp.status() == (0, None) and ref.status() == 0
     assert bits_equal(grp.download(), ref.download())
     grp.close()
+
+
+@pytest.mark.timeout(600)
+def test_group_fused_step_across_cuts_on_random_shapes(eng, monkeypatch):
+    """Twenty seeded random decompositions (rows 24 .. 400, columns 8 .. 300, 2 .. 9 slabs of at least 12 rows, either boundary kind, either
+    Riemann solver, chunk lengths from the library's choice down to 2 rows): the fused step across the cuts against the one-domain run, bit
+    for bit, after an odd and an even number of steps."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    rng = np.random.default_rng(20261004)
+    for case in range(20):
+        world = int(rng.integers(2, 10))
+        n0 = int(rng.integers(12 * world, max(12 * world + 1, 401)))
+        n1 = int(rng.integers(8, 301))
+        bc = ("outflow", "periodic")[int(rng.integers(0, 2))]
+        riemann = ("hllc", "hlle")[int(rng.integers(0, 2))]
+        chunk = int(rng.choice([0, 0, 2, 3, 7, 16]))
+        shape, gamma = (n0, n1), 1.4
+        dl = (1.0 / n0, 1.0 / n1)
+        u0 = setups.wave_ic(shape, gamma, seed=100 + case)
+        ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, riemann, 2, bc, arith="fast")
+        ref.upload(u0)
+        grp = NativeSlabGroup(shape, dl, gamma, 1.5, riemann, 2, bc, world=world, arith="fast", chunk_rows=chunk)
+        grp.upload(u0)
+        dt = 0.2 * min(dl) / 2.0
+        for nsteps in (3, 2):
+            ref.step(dt, nsteps); grp.step(dt, nsteps); grp.synchronize()
+            assert bits_equal(grp.download(), ref.download()), (case, shape, world, bc, riemann, chunk, nsteps)
+        assert grp.status() == (0, None)
+        grp.close(); ref.close()
