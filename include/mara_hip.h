@@ -104,7 +104,7 @@ typedef struct
     int    tail_chunk_rows; /* (0, 0 = the measured default on large grids; tail_rows < 0 = off). Read at configure time. */
     int    fuse_stages;     /* RK2 step of a whole 2-D field as ONE launch (mara3_amd/csrc/euler2d_fused.hip: the first-stage field stays in LDS,
                              * 80 instead of 200 B per zone-update): 0 = where available and worth it (MH_ARITH_FAST, PLM, rk_order 2: the context
-                             * stepper and slabs without neighbours; slabs WITH neighbours from 1536 rows per slab on - they then keep four
+                             * stepper and slabs without neighbours; slabs WITH neighbours from 384 rows per slab on - they then keep four
                              * rows of each neighbour and exchange once per step), < 0 = never, > 0 = required (configure fails
                              * where it is not available). The result is bit-identical to the two launches'. */
 } mh_euler_cart_desc;

@@ -5,18 +5,24 @@
 // 80 + 120 B per zone-update through HBM (the first-stage field is written and read back, the step-start field is read twice). Here
 // the first-stage field never exists in memory: 40 B read + 40 B written per zone-update.
 //
-// Structure: a workgroup is a PAIR of waves that own the same strip of 64 columns (56 of them output) and march along axis 0:
+// Structure: a PAIR of waves owns a strip of 64 columns and marches along axis 0:
 //   * the PRODUCER wave runs the first stage - the row loop of euler2d.hip on the step-start field, two rows ahead - and, instead of
 //     storing a row of u1, leaves it in a five-slot ring in LDS;
 //   * the CONSUMER wave runs the second stage on the rows of that ring (its "loads" are LDS reads), reads the step-start row for the
 //     RK average from a second LDS ring, where the producer parked it four rows earlier, and stores the result.
-//   One s_barrier per row keeps the two in lockstep; it waits for LDS only (the waves' global loads stay in flight across it). Both
+//   One s_barrier per row keeps them in lockstep; it waits for LDS only (the waves' global loads stay in flight across it). Both
 //   waves keep the register footprint of a single-stage kernel, so the launch still holds two waves per SIMD, and the two kinds of wave -
 //   one issue-bound, one with the stores - share every CU.
+//   * A WORKGROUP is TWO such pairs on strips 60 columns apart (MH_FUSED_PAIRS). A producer's first-stage values are valid in its lanes
+//     2 .. 61; a consumer needs them two lanes beyond its outputs, and where its own producer has none (lanes 0, 1, 62, 63) the
+//     neighbouring pair's ring holds the column. So the two pairs overlap by the first stage's halo only: 58 output columns per pair
+//     (116 per workgroup) where a lone pair has 56 - 4 % fewer pairs, and measured 5.5 % less time per 4096^2 step (0.582 against
+//     0.616 ms on one box; four pairs per workgroup: 0.639, the barrier then holds eight waves and a CU one workgroup;
+//     profiles/r03/ab_fused_pairs_per_workgroup.jsonl).
 //   * Ghost cells of the FIRST-STAGE field need no pass over memory: a ghost COLUMN is the LDS read of another lane (outflow: the edge
 //     lane; periodic: the lane already holds the wrapped column), a ghost ROW is another slot of the ring (outflow) or the producer's
 //     own work on the wrapped row (periodic).
-//   Redundancy against the two-launch form: 8 halo lanes of 64 instead of 4, and 4 + 4 pipeline-fill rows per chunk instead of 4.
+//   Redundancy against the two-launch form: 6 halo lanes of 64 instead of 4, and 4 + 4 pipeline-fill rows per chunk instead of 4.
 //
 // The arithmetic is FastArith's (euler_device_fast.hpp) on the same values in the same order as the two launches, so the result is
 // bit-identical to theirs (tests/test_gpu_fused_rk2.py) and inherits their tolerance against the reference (L1 <= 1e-12).
@@ -36,7 +42,15 @@ namespace mh {
 
 static constexpr int FWAVE = 64;
 static constexpr int FHALO = 4;                      // two per stage
-static constexpr int FSTRIP = FWAVE - 2 * FHALO;     // 56 output columns per pair
+// MH_FUSED_PAIRS pairs make a workgroup, on neighbouring strips 60 columns apart. A consumer whose own producer has no valid first-stage
+// value in its two outermost lanes per side takes them from the neighbouring pair's ring, so the pairs of a workgroup overlap by the
+// FIRST stage's halo only: 60 output columns per inner pair and 58 per outer one instead of 56, one barrier for all waves per row.
+#ifndef MH_FUSED_PAIRS
+#define MH_FUSED_PAIRS 2
+#endif
+static constexpr int FPAIRS = MH_FUSED_PAIRS;
+static constexpr int FPITCH = FWAVE - 4;                                       // columns between neighbouring pairs of a workgroup
+static constexpr int FGROUP = FPITCH * FPAIRS - 4;                             // output columns per workgroup: 56, 116, 236
 static constexpr int FSLOTS = 5;                     // hand-off ring. The consumer reads rows b .. b+2 (four rows in its prologue) while the producer, at most
                                                      // one barrier ahead, writes row b+3: five live slots
 static constexpr int USLOTS = 6;                     // step-start rows b .. b+4 (the producer converts row b+4 while the consumer averages with row b), and one ahead
@@ -96,12 +110,12 @@ __device__ inline void pair_barrier()
 }
 
 template<int RIEMANN>
-__global__ __launch_bounds__(2 * FWAVE, 2)
+__global__ __launch_bounds__(2 * FWAVE * FPAIRS, 2)
 void euler2d_fused_rk2_kernel(Fused2dParams p)
 {
     using A = FastArith;
-    __shared__ double hand[FSLOTS][5][FWAVE];        // first-stage rows on their way from the producer to the consumer
-    __shared__ double start_rows[USLOTS][5][FWAVE];  // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
+    __shared__ double hand_all[FPAIRS][FSLOTS][5][FWAVE];        // first-stage rows on their way from the producer to the consumer
+    __shared__ double start_all[FPAIRS][USLOTS][5][FWAVE];       // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
 
     int b = (int) blockIdx.x;
     {
@@ -109,7 +123,11 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);      // neighbouring strips and chunks on one XCD (halo re-reads hit its L2)
     }
     const int pair = __builtin_amdgcn_readfirstlane(b);
-    const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int wave_of_group = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int role = wave_of_group & 1;
+    const int pp = wave_of_group >> 1;                  // which pair of the workgroup
+    double (*hand)[5][FWAVE] = hand_all[pp];
+    double (*start_rows)[5][FWAVE] = start_all[pp];
     const int lane = threadIdx.x & 63;
     const int al = ((lane - 1) & 63) * 4, ar = ((lane + 1) & 63) * 4;
     const int chunk_of_launch = pair / p.nstrips;
@@ -121,7 +139,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
     const int nrows = r1 - r0;                         // >= 1 by construction of the grid
 
-    const int col = strip * FSTRIP - FHALO + lane;
+    const int col = strip * FGROUP - FHALO + pp * FPITCH + lane;
     int jc = col;
     if (p.bc1 == 1) jc = jc < 0 ? jc + n1 : (jc >= n1 ? jc - n1 : jc);
     jc = min(max(jc, 0), n1 - 1);
@@ -235,11 +253,21 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     else
     {
         // ================================================================ CONSUMER: second stage + RK average, rows r0 .. r1 - 1 ========
-        const bool writes = lane >= FHALO && lane < FWAVE - FHALO && col < n1;
+        const int out_lo = pp > 0 ? 2 : FHALO, out_hi = pp < FPAIRS - 1 ? FWAVE - 2 : FWAVE - FHALO;
+        const bool writes = lane >= out_lo && lane < out_hi && col < n1;
         const unsigned col8 = (unsigned) (writes ? col : 0) * 8u;
         // ghost columns of the first-stage field: outflow = the edge column's value, i.e. another lane's entry of the ring
         int src_lane = lane;
         if (p.bc1 != 1) src_lane = lane + (min(max(col, 0), n1 - 1) - col);
+        // the neighbouring pair's ring where this pair's producer has no valid value for the column (its lanes 0, 1, 62, 63)
+        int other = pp, src_lane_other = src_lane;
+        if (src_lane < 2 && pp > 0) { other = pp - 1; src_lane_other = src_lane + FPITCH; }
+        else if (src_lane > FWAVE - 3 && pp < FPAIRS - 1) { other = pp + 1; src_lane_other = src_lane - FPITCH; }
+        const bool from_other = other != pp && src_lane_other >= 2 && src_lane_other <= FWAVE - 3;
+        src_lane = min(max(src_lane, 0), FWAVE - 1);
+        // one LDS read per value either way: the lane's offset into the rings of all pairs, [pair][slot][variable][lane] flattened
+        const double* const hand_flat = &hand_all[0][0][0][0];
+        const int hand_off = from_other ? other * (FSLOTS * 5 * FWAVE) + src_lane_other : pp * (FSLOTS * 5 * FWAVE) + src_lane;
         const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
         // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots (periodic and EXTERNAL: the producer
         // worked on the wrapped row / on the neighbour's rows)
@@ -249,7 +277,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const int slot = (m - (r0 - 2)) % FSLOTS;
             State5 Uq;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Uq[q] = hand[slot][q][src_lane];
+            for (int q = 0; q < 5; ++q) Uq[q] = hand_flat[hand_off + (slot * 5 + q) * FWAVE];
             return Uq;
         };
         auto row_off = [row_stride] (int r) { return (long) (r + 2) * row_stride; };
@@ -362,7 +390,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     p.n0 = d->n[0]; p.n1 = d->n[1];
     p.plane_stride = p.n1;
     p.row_stride = 5L * p.n1;
-    p.nstrips = (p.n1 + FSTRIP - 1) / FSTRIP;
+    p.nstrips = (p.n1 + FGROUP - 1) / FGROUP;
     if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
     else
     {
@@ -373,7 +401,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
         int rounds = 1;
         // (a slab's interior launch does NOT leave room for its edge launch's pairs: measured slower, 125 against 112 us per step at 512 rows)
-        auto chunk_for = [&] (int r) { const int nch = 1024 * r / p.nstrips > 0 ? 1024 * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
+        auto chunk_for = [&] (int r) { const int nch = (1024 / FPAIRS) * r / p.nstrips > 0 ? (1024 / FPAIRS) * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
         while (chunk_for(rounds) > 112) ++rounds;
         p.chunk_rows = chunk_for(rounds);
         if (p.chunk_rows < 8) p.chunk_rows = 8;
@@ -389,7 +417,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     p.bc1 = d->bc_transverse == MH_BC_PERIODIC ? 1 : 0;
     p.gamma = d->gamma; p.theta = d->plm_theta;
     p.cx = dt / d->dl[0]; p.cy = dt / d->dl[1];
-    const dim3 grid(p.nstrips * p.nchunks), block(2 * FWAVE);
+    const dim3 grid(p.nstrips * p.nchunks), block(2 * FWAVE * FPAIRS);
     if (d->riemann == MH_RIEMANN_HLLC)
     {
         if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<1>), grid, block, 0, stream, ev.start, ev.stop, 0, p);

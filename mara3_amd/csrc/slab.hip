@@ -356,13 +356,14 @@ static bool slab_can_fuse(const mh_slab* s)
 }
 
 // ... with neighbours. Every member of the decomposition must decide alike (the exchange moves four rows instead of two), so the
-// decision rests on the global descriptor and the thinnest share of the rows only. It pays for THICK slabs: a fused pair pays eight
-// pipeline-fill rows per chunk, and a thin slab has few rows per chunk to spread them over - measured on one GPU with the exchange to
-// self, 4096 columns, us per step, two launches / fused across cuts: 2048 rows 380 / 356, 1024 rows 194 / 202, 512 rows 98 / 112
-// (profiles/r03/slab_fused_across_cuts.jsonl). MH_SLAB_FUSED_CUTS: 0 never, 1 wherever it can run (12 rows), unset: from 1536 rows.
+// decision rests on the global descriptor and the thinnest share of the rows only. Measured on one GPU with the exchange to self through
+// RCCL, 4096 columns, us per step, two launches / fused across cuts (profiles/r03/slab_fused_across_cuts.jsonl): 2048 rows 380 / 332,
+// 1024 rows 191 / 179, 512 rows 99 / 92 (with one pair per workgroup the fused form lost below 1536 rows; with two it wins down to the
+// 512 rows of the 8-GPU cut). Thinner slabs were not measured and keep the two launches. MH_SLAB_FUSED_CUTS: 0 never, 1 wherever it can
+// run (12 rows), unset: from 384 rows per slab.
 static bool slab_can_fuse_cut(const mh_slab* s, const mh_euler_cart_desc* global)
 {
-    int least = 1536;
+    int least = 384;
     if (const char* v = getenv("MH_SLAB_FUSED_CUTS")) { if (atoi(v) == 0) return false; least = 12; }          /* 12: two edge strips of four rows and an interior */
     mh_euler_cart_desc d = s->desc;
     d.n[0] = 8;          // (the member's own row count must not enter: only the thinnest share below does)

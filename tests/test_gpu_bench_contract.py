@@ -50,12 +50,18 @@ def test_bench_json_line_contract():
         assert r["fp64"]["peak"] == 78.6 and 0.0 < r["fp64"]["frac"] < 1.0 and 0.0 < r["fp64"]["valu_busy"] <= 1.0
 
 
-def test_bench_loopback_rehearsal_of_the_multi_gpu_path():
+@pytest.mark.parametrize("cuts", [None, "0"])
+def test_bench_loopback_rehearsal_of_the_multi_gpu_path(cuts):
     """`bench.py --loopback-slabs 4`: the N > 1 code path of the bench (decomposed stepper, timing, per-rank fingerprints, partition check
-    against a one-GPU run) on one GPU through the native stepper's loopback backend."""
+    against a one-GPU run) on one GPU through the native stepper's loopback backend - with the library's own choice of schedule (the fused
+    step across the cuts, one launch per step) and with the two-launch schedule (MH_SLAB_FUSED_CUTS=0)."""
+    env = dict(os.environ)
+    if cuts is not None:
+        env["MH_SLAB_FUSED_CUTS"] = cuts
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--loopback-slabs", "4", "--single-arith", "--no-cpu-baseline",
-                          "--blocks", "2"], cwd=ROOT, capture_output=True, text=True, timeout=280)
+                          "--blocks", "2"], cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["slabs_bit_identical_to_one_gpu_run"] is True
     assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["status_word"] == 0
+    assert ("one exchange per step" in d["config"]["timed_region"]) == (cuts is None)

@@ -144,8 +144,9 @@ def test_group_dependencies_hold_under_shifted_timing(eng, delay, stagger, on_la
 def test_group_baseline_cut_4096_over_8(eng, world):
     """The BASELINE cut itself: 4096^2 over 8 ranks (512 x 4096 cells per rank, the staggered schedule and the one-residency-round
     chunk heuristic active), PLM + HLLC RK2 FAST as bench.py runs it, 6 steps, bit-identical to the one-domain run; per-rank bit
-    fingerprints as bench.py's partition_check forms them. And over 2 ranks, where the slabs (2048 rows: from 1536 on) take the fused
-    step across their cut by the library's own choice."""
+    fingerprints as bench.py's partition_check forms them. And over 2 ranks. Since late round 3 both cuts take the fused step across
+    their cuts by the library's own choice (slabs of 384 rows and more); the two-launch schedule at this size is covered by
+    tests/test_gpu_bench_contract.py with MH_SLAB_FUSED_CUTS=0 and by the parametrised tests above."""
     import torch
     from mara3_amd import setups
     from mara3_amd.slab import NativeSlabGroup, slab_fingerprint, partition_rows
