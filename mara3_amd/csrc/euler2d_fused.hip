@@ -49,6 +49,12 @@ static constexpr int FHALO = 4;                      // two per stage
 #define MH_FUSED_PAIRS 2
 #endif
 static constexpr int FPAIRS = MH_FUSED_PAIRS;
+// MH_FUSED_MASK_HALO = 1: lanes whose result nobody uses sit out the axis-0 flux and the update (EXEC-masked: the instructions issue all the
+// same, the lanes do not switch). Measured and NOT taken: 0.585 against 0.580 ms per 4096^2 step (profiles/r03/ab_fused_mask_halo.jsonl) -
+// what the two-pair workgroup gained beyond its 4 % fewer pairs is not the idle lanes' switching.
+#ifndef MH_FUSED_MASK_HALO
+#define MH_FUSED_MASK_HALO 0
+#endif
 static constexpr int FPITCH = FWAVE - 4;                                       // columns between neighbouring pairs of a workgroup
 static constexpr int FGROUP = FPITCH * FPAIRS - 4;                             // output columns per workgroup: 56, 116, 236
 static constexpr int FSLOTS = 5;                     // hand-off ring. The consumer reads rows b .. b+2 (four rows in its prologue) while the producer, at most
@@ -181,6 +187,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         };
         const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
         const int a0 = r0 - 2;
+        const bool works = ! MH_FUSED_MASK_HALO || (lane >= 2 && lane < FWAVE - 2);
 
         State5 U[3], P[3], G[3], Fx[3], D[3];
         {
@@ -215,7 +222,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const bool bad_pressure = !(P[K2][4] >= 0.0);
             D[K1] = A::difference(P[K1], P[K2]);
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
-            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
+            if (works) Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
             const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
             const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
@@ -224,9 +231,12 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
 
             const State5 Uc = ring_get(t % USLOTS);
-            State5 Un;
+            State5 Un = Uc;
+            if (works)
+            {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+                for (int q = 0; q < 5; ++q) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+            }
             const bool bad_density = !(Un[0] > 0.0);
             if (__any(bad_pressure || bad_density))
             {
@@ -255,6 +265,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         // ================================================================ CONSUMER: second stage + RK average, rows r0 .. r1 - 1 ========
         const int out_lo = pp > 0 ? 2 : FHALO, out_hi = pp < FPAIRS - 1 ? FWAVE - 2 : FWAVE - FHALO;
         const bool writes = lane >= out_lo && lane < out_hi && col < n1;
+        const bool works = ! MH_FUSED_MASK_HALO || (lane >= out_lo && lane < out_hi);
         const unsigned col8 = (unsigned) (writes ? col : 0) * 8u;
         // ghost columns of the first-stage field: outflow = the edge column's value, i.e. another lane's entry of the ring
         int src_lane = lane;
@@ -316,7 +327,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const bool bad_pressure = !(P[K2][4] >= 0.0);
             D[K1] = A::difference(P[K1], P[K2]);
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
-            Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
+            if (works) Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
             const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
             const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
@@ -325,9 +336,12 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
 
             const State5 Uc = hand_row(r);
-            State5 Un;
+            State5 Un = Uc;
+            if (works)
+            {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Un[q] = A::combine(Ubase[q], A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy), 0.5);
+                for (int q = 0; q < 5; ++q) Un[q] = A::combine(Ubase[q], A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy), 0.5);
+            }
             const bool bad_density = !(Un[0] > 0.0);
             if (__any(bad_pressure || bad_density))
             {
