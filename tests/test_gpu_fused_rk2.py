@@ -135,3 +135,27 @@ def test_fused_step_reports_the_failing_cell_and_the_checked_step_keeps_the_old_
         res.append((r.status, int(r.first_bad_index)))
         s.close()
     assert res[0] == res[1] and res[0][0] & L.STATUS_NEG_PRESSURE and res[0][1] == 40 * shape[1] + 57
+
+
+def test_every_position_of_the_domain_edge_within_a_workgroup(eng):
+    """A workgroup is two producer / consumer pairs that share the first stage's halo through LDS (116 output columns): every column count
+    from 8 to 260, and a few around the next multiples, so that the domain's edge falls on every lane of either pair - both boundary kinds,
+    both Riemann solvers, the library's chunking and short chunks - against the two launches, bit for bit (262 cases, 3 steps each)."""
+    from mara3_amd import setups
+    gamma = 1.4
+    rng = np.random.default_rng(7)
+    for n1 in list(range(8, 261)) + [347, 348, 349, 463, 464, 465, 579, 580, 581]:
+        n0 = int(rng.choice([8, 9, 13, 31, 64, 101]))
+        bc = ("outflow", "periodic")[n1 % 2]
+        riemann = ("hllc", "hlle")[(n1 // 2) % 2]
+        chunk = int(rng.choice([0, 0, 2, 5, 11]))
+        shape, dl = (n0, n1), (1.0 / n0, 1.0 / n1)
+        u0 = setups.wave_ic(shape, gamma, seed=n1)
+        res = []
+        for fuse in (False, True):
+            s = eng.EulerCartSolver(shape, dl, gamma, 1.5, riemann, 2, bc, arith="fast", fuse=fuse, chunk_rows=chunk)
+            s.upload(u0); s.step(0.2 * min(dl) / 2.0, 3)
+            res.append(s.download())
+            assert s.status() == 0
+            s.close()
+        assert bits_equal(res[0], res[1]), (n0, n1, bc, riemann, chunk)
