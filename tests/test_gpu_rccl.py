@@ -344,3 +344,28 @@ def test_binary_bands_report_the_failing_cell_of_the_whole_mesh():
     one.set_solution(base, s)                   # a clean call clears the record
     assert one.next(1) == 0 and one.last_failure() == (0, None)
     one.close(); band.close(); grp.close()
+
+
+@pytest.mark.parametrize("cuts", [None, "0"])
+def test_native_slab_at_the_eight_gpu_cut_size_through_rccl_to_self(cuts, monkeypatch):
+    """One rank's slab of the 8-GPU cut (512 x 4096, FAST HLLC RK2) with both sides cut and its ghost rows travelling through ncclSend /
+    ncclRecv to itself: the library's own schedule at this size (the fused step across the cuts: four rows, one exchange per step) and the
+    two-launch schedule (MH_SLAB_FUSED_CUTS=0), 12 steps, bit-identical to the kernel's own periodic handling."""
+    import numpy as np
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabStepper, native_comm_id
+    if cuts is not None:
+        monkeypatch.setenv("MH_SLAB_FUSED_CUTS", cuts)
+    shape, gamma = (512, 4096), 5.0 / 3
+    dl = (1.0 / 4096, 1.0 / 4096)
+    u0 = setups.wave_ic(shape, gamma, seed=77)
+    ref = NativeSlabStepper(shape, dl, gamma, 1.5, "hllc", 2, "periodic", arith="fast")
+    ref.load_slab(u0); ref.step(2e-5, 12); ref.synchronize()
+    st = NativeSlabStepper(shape, dl, gamma, 1.5, "hllc", 2, "periodic", rank=0, world=1, arith="fast", comm_id=native_comm_id(0, 1), self_exchange=True)
+    st.load_slab(u0); st.step(2e-5, 5); st.step(2e-5, 7); st.synchronize()
+    assert st.status() == 0
+    assert np.array_equal(st.slab_host().view(np.uint64), ref.slab_host().view(np.uint64))
+    st.profile(True); st.step(2e-5, 3); st.synchronize()
+    (ms1, ms2), (n1, n2), rows = st.profile_read()
+    assert (n1, n2, rows) == ((0, 3, 504) if cuts is None else (3, 3, rows))          # fused: one interior launch per step over rows 4 .. n0 - 4
+    st.close(); ref.close()
