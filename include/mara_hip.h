@@ -190,6 +190,10 @@ typedef struct
     int    chunk_rows;          /* rows marched per wave (0 = default) */
     int    tail_rows;           /* graded tail, as in the cartesian descriptor: 0, 0 = default; tail_rows < 0 = off */
     int    tail_chunk_rows;
+    int    fuse_stages;         /* RK2 step of a whole field (both radial sides physical) as ONE launch - the first-stage field stays in LDS,
+                                 * csrc/cloud_fused.hip; next_solution's s0 * 1/2 + advance(advance(s0)) * 1/2, src/subprog_cloud.cpp:676-697,
+                                 * with the step-start nozzle row in both stages (:524): 0 = where available (MH_ARITH_FAST, PLM, rk_order 2;
+                                 * results bit-identical to the two launches), < 0 = never, > 0 = required (configure fails otherwise) */
 } mh_cloud_desc;
 
 /* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] | per-row factors [nr_global][8] |
@@ -591,6 +595,14 @@ int  mh_free(void* ptr);
 int  mh_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int  mh_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int  mh_device_synchronize(void);
+
+/* Row-range guard of the row-marching kernels (csrc/row_check.hpp; a library built with -DMH_CHECK_ROWS, `make -C mara3_amd/csrc check`):
+ * {smallest, largest} axis-0 row (plane) index the kernels of a family REQUESTED since the last reset - a check build holds every access
+ * to the rows that exist and reports which kernel would have left them (the stored rows are -2 .. n0 + 1; -4 .. n0 + 3 on the cut sides of
+ * the fused 2-D step). family: */
+enum { MH_ROWS_EULER2D = 0, MH_ROWS_EULER2D_FUSED = 1, MH_ROWS_CLOUD = 2, MH_ROWS_CLOUD_FUSED = 3, MH_ROWS_EULER3D_STRICT = 4, MH_ROWS_EULER3D_FAST = 5 };
+/* MH_E_STATE from a product build (no guard compiled in); lo_hi = {INT_MAX, INT_MIN} when nothing was requested */
+int  mh_debug_row_range(int family, int32_t lo_hi[2], int reset);
 
 #ifdef __cplusplus
 }

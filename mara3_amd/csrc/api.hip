@@ -427,6 +427,11 @@ int mh_cloud_configure(mh_ctx* c, const mh_cloud_desc* d, const double* rv, cons
     if (int rc = check_cloud(d)) return ctx_fail(c, rc);
     if (d->bc_lo0 != MH_BC_INFLOW || d->bc_hi0 != MH_BC_OUTFLOW) { set_error("cloud context: single-device form needs both radial sides physical"); return ctx_fail(c, MH_E_INVALID); }
     if (rk_order != 1 && rk_order != 2) { set_error("rk_order must be 1 or 2"); return ctx_fail(c, MH_E_INVALID); }
+    if (d->fuse_stages > 0 && ! (rk_order == 2 && cloud_fused_rk2_available(d)))
+    {
+        set_error("cloud: fuse_stages is required, but a fused RK2 step needs MH_ARITH_FAST, PLM, rk_order 2 and both radial sides physical");
+        return ctx_fail(c, MH_E_INVALID);
+    }
     MH_HIP_TRY(hipSetDevice(c->device));
     release_fields(c);
     std::vector<double> geom(mh_cloud_geometry_doubles(d));
@@ -607,15 +612,17 @@ static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, d
         : cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
 }
 
-// a whole-field RK2 step as one launch (the descriptor's fuse_stages; euler2d_fused.hip)
+// a whole-field RK2 step as one launch (the descriptors' fuse_stages; euler2d_fused.hip, cloud_fused.hip)
 static bool ctx_can_fuse(const mh_ctx* c)
 {
+    if (c->kind == mh_ctx::KIND_CLOUD) return c->rk_order == 2 && c->cloud.fuse_stages >= 0 && cloud_fused_rk2_available(&c->cloud);
     return c->kind == mh_ctx::KIND_EULER_CART && c->rk_order == 2 && c->desc.fuse_stages >= 0 && euler2d_fused_rk2_available(&c->desc);
 }
 
 static hipError_t timed_fused_step(mh_ctx* c, const double* in, double* out, double dt)
 {
     if (c->profile) ++c->span_launches;
+    if (c->kind == mh_ctx::KIND_CLOUD) return cloud_fused_rk2_launch(&c->cloud, c->geom, c->inflow, in, out, dt, c->status, c->stream);
     return euler2d_fused_rk2_launch(&c->desc, in, out, dt, c->status, c->stream, LaunchEvents());
 }
 
@@ -640,11 +647,17 @@ int mh_step(mh_ctx* c, double dt, int nsteps)
     const ProfileSpan span(c);
     if (c->kind == mh_ctx::KIND_CLOUD)
     {
+        const bool fused_cloud = ctx_can_fuse(c);
         for (int s = 0; s < nsteps; ++s)
         {
             if (c->rk_order == 1)
             {
                 MH_HIP_TRY(timed_stage(c, c->field[0], nullptr, c->field[1], dt, 1.0));
+                std::swap(c->field[0], c->field[1]);
+            }
+            else if (fused_cloud)
+            {
+                MH_HIP_TRY(timed_fused_step(c, c->field[0], c->field[1], dt));
                 std::swap(c->field[0], c->field[1]);
             }
             else
@@ -981,5 +994,23 @@ int mh_free(void* ptr) { MH_HIP_TRY(hipFree(ptr)); return MH_OK; }
 int mh_memcpy_h2d(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MH_OK; }
 int mh_memcpy_d2h(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MH_OK; }
 int mh_device_synchronize(void) { MH_HIP_TRY(hipDeviceSynchronize()); return MH_OK; }
+
+int mh_debug_row_range(int family, int32_t lo_hi[2], int reset)
+{
+    if (! lo_hi) { set_error("row range: null argument"); return MH_E_INVALID; }
+    bool ok = false;
+    switch (family)
+    {
+        case MH_ROWS_EULER2D:        ok = rows_requested_euler2d(lo_hi, reset); break;
+        case MH_ROWS_EULER2D_FUSED:  ok = rows_requested_euler2d_fused(lo_hi, reset); break;
+        case MH_ROWS_CLOUD:          ok = rows_requested_cloud(lo_hi, reset); break;
+        case MH_ROWS_CLOUD_FUSED:    ok = rows_requested_cloud_fused(lo_hi, reset); break;
+        case MH_ROWS_EULER3D_STRICT: ok = rows_requested_euler3d(lo_hi, reset); break;
+        case MH_ROWS_EULER3D_FAST:   ok = rows_requested_euler3d_fast(lo_hi, reset); break;
+        default: set_error("row range: unknown kernel family %d", family); return MH_E_INVALID;
+    }
+    if (! ok) { set_error("row range: this library was built without the row-range guard (-DMH_CHECK_ROWS; make -C mara3_amd/csrc check)"); return MH_E_STATE; }
+    return MH_OK;
+}
 
 } // extern "C"

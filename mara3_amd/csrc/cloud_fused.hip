@@ -1,0 +1,518 @@
+// Both stages of an RK2 step of the `cloud` sub-program (2-D axisymmetric spherical-polar SRHD, BASELINE config 4) in ONE launch
+// (gfx950 / MI355X), MH_ARITH_FAST + PLM, both radial sides physical (nozzle inflow inside, zero gradient outside).
+//
+// What it replaces: `s0 * 0.5 + advance(advance(s0)) * 0.5` (src/subprog_cloud.cpp:676-697, `advance` :511-584) as two launches of
+// cloud_stage_kernel (cloud.hip). Both stages use the nozzle row of the step-START time (:466-493, :524) and the same geometry, so the
+// second stage needs nothing from the host between the two: the first-stage field lives in LDS only.
+//
+// Structure (that of euler2d_fused.hip): a PAIR of waves owns 64 polar columns and marches radially;
+//   * the PRODUCER runs cloud.hip's first-stage row loop on the step-start field and leaves each row of u1 in a five-slot LDS ring;
+//   * the CONSUMER runs the second-stage row loop on the rows of that ring (its loads are LDS reads), reads the step-start row for the RK
+//     average from memory (as the second launch does; that read is not what bounds this kernel) and stores the result;
+//   * one s_barrier per row keeps them in lockstep (LDS-only release: global loads and stores stay in flight across it);
+//   * a WORKGROUP is two pairs on strips 60 columns apart: a consumer takes the two outermost first-stage columns per side, which its own
+//     producer cannot form, from the neighbouring pair's ring - 116 output columns per workgroup.
+// Physical radial sides cost no first-stage ghost rows: the inner ghost rows of BOTH stages are the nozzle primitives, the outer ones a copy of
+// the last row's primitives, so the producer covers rows max(r0 - 2, 0) .. min(r1 + 2, nr) - 1 of a chunk [r0, r1) and nothing beyond the grid.
+// Every lane of the consumer converts a valid cell (ghost and out-of-range columns read the clamped column, lanes without a source a neighbour's):
+// recover_primitive iterates, and one lane on garbage would hold its wave for fifty Newton steps.
+//
+// The arithmetic is SrhdFast's on the same values in the same order as the two launches: the result is bit-identical to theirs
+// (tests/test_gpu_cloud_fused.py) and inherits their tolerance against the reference.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <type_traits>
+#include "launch.hpp"
+#include "status_device.hpp"
+#include "euler_device.hpp"
+#include "srhd_device.hpp"
+#include "srhd_device_fast.hpp"
+#include "cloud_rows.hpp"
+#include "row_check.hpp"
+
+namespace mh {
+
+static constexpr int QWAVE = 64;
+static constexpr int QHALO = 4;                      // two per stage
+#ifndef MH_CLOUD_FUSED_PAIRS
+#define MH_CLOUD_FUSED_PAIRS 2
+#endif
+static constexpr int QPAIRS = MH_CLOUD_FUSED_PAIRS;
+static constexpr int QPITCH = QWAVE - 4;                                       // columns between neighbouring pairs of a workgroup
+static constexpr int QGROUP = QPITCH * QPAIRS - 4;                             // output columns per workgroup: 56, 116
+static constexpr int QSLOTS = 5;                     // hand-off ring: the consumer reads rows r .. r+2 (r0-2 .. r0+1 in its prologue) while the producer,
+                                                     // at most one barrier ahead, writes row r+3
+static constexpr int OSLOTS = 3;                     // the producer's own rows r .. r+2 waiting for their update (cloud.hip's ring)
+// waves per SIMD the launch asks for: 3 = cloud.hip's (168 registers); 2 leaves the compiler 256
+#ifndef MH_CLOUD_FUSED_WAVES
+#define MH_CLOUD_FUSED_WAVES 3
+#endif
+// 1: the register window as three-slot rings with the row loop unrolled by three (no rotation moves; wants the 256 registers of two waves per
+// SIMD); 0: cloud.hip's rotating window (fits the 168 registers of three waves per SIMD)
+#ifndef MH_CLOUD_FUSED_RINGS
+#define MH_CLOUD_FUSED_RINGS (MH_CLOUD_FUSED_WAVES < 3)
+#endif
+
+struct CloudFusedParams
+{
+    const double* u_in;
+    double*       u_out;
+    const double* cotq;        // [nq]   tan(pi/2 - theta_c)
+    const double* rowf;        // [nr_global][8] per-row factors (mh_cloud_pack_geometry)
+    const double* colf;        // [nq][8]        per-column factors
+    const double* inflow;      // [5][nq] primitives of the inner ghost rows, step-start time
+    int32_t*      status;
+    long   plane_stride, row_stride;
+    int    n0, n1, row_offset;
+    int    chunk_rows, nstrips, nchunks;
+    double gamma, theta, tfloor, dt;
+};
+
+__device__ inline void cloud_pair_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(2 * QWAVE * QPAIRS, MH_CLOUD_FUSED_WAVES)
+void cloud_fused_rk2_kernel(CloudFusedParams p)
+{
+    using S = SrhdFast;
+    __shared__ double hand_all[QPAIRS][QSLOTS][5][QWAVE];        // first-stage rows on their way from the producer to the consumer
+    __shared__ double own_all[QPAIRS][OSLOTS][5][QWAVE];         // step-start rows waiting for the producer's update
+
+    int b = (int) blockIdx.x;
+    {
+        const int per_xcd = (int) gridDim.x >> 3;
+        if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);      // neighbouring strips and chunks on one XCD
+    }
+    const int group = __builtin_amdgcn_readfirstlane(b);
+    const int wave_of_group = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int role = wave_of_group & 1;
+    const int pp = wave_of_group >> 1;                  // which pair of the workgroup
+    const int lane = threadIdx.x & 63;
+    const int chunk = group / p.nstrips;
+    const int strip = group - chunk * p.nstrips;
+    const int n0 = p.n0, n1 = p.n1;
+    const int r0 = chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, n0);
+    // rows of the first-stage field this chunk needs: nothing beyond the grid (physical sides)
+    const int a_begin = max(r0 - 2, 0), a_end = min(r1 + 2, n0);
+
+    const int col = strip * QGROUP - QHALO + pp * QPITCH + lane;
+    const int jc = min(max(col, 0), n1 - 1);
+    const bool pole_lo = col == 0, pole_hi = col == n1 - 1;
+
+    const srhd::Gamma g = srhd::make_gamma(p.gamma);
+    const double tfloor = p.tfloor;
+    const typename S::Limiter lim = S::limiter(p.theta);
+    const double cot = p.cotq[jc];
+    double col_ar, col_dv, col_inv_dv, col_aq_lo, col_aq_hi;
+    {
+        const double* cf = p.colf + 8L * jc;
+        col_ar = cf[0]; col_dv = cf[1]; col_inv_dv = cf[2]; col_aq_lo = cf[3]; col_aq_hi = cf[4];
+    }
+    // the poles (extend_zeros on the polar slopes and fluxes, :563 / :570): zero lane constants, as cloud.hip's FAST kernel
+    typename S::Limiter lim_polar = lim;
+    if (pole_lo) col_aq_lo = 0.0;
+    if (pole_hi) col_aq_hi = 0.0;
+    if (pole_lo || pole_hi) lim_polar.half_theta = 0.0;
+    auto cell_geometry = [&] (int i) -> CellGeom
+    {
+        CellGeom c;
+        const double* rf = p.rowf + 8L * i;          // wave-uniform: scalar loads
+        c.dv = rf[2] * col_dv;
+        c.inv_dv = rf[3] * col_inv_dv;
+        c.nAr_lo = -(rf[0] * col_ar);
+        c.nAr_hi = -(rf[1] * col_ar);
+        c.nAq_lo = -(rf[4] * col_aq_lo);
+        c.nAq_hi = -(rf[4] * col_aq_hi);
+        c.rc = rf[5];
+        c.inv_rc = rf[6];
+        return c;
+    };
+
+    const long row_stride = p.row_stride, plane = p.plane_stride;
+    auto row_off = [row_stride, n0] (int r) { (void) n0; return (long) (MH_ROW(r, -2, n0 + 1) + 2) * row_stride; };
+    const unsigned jc8 = (unsigned) jc * 8u;
+    const uint32_t n1u = (uint32_t) n1, colu = (uint32_t) col;
+    StatusAcc acc;
+
+    auto inflow_row = [&] () -> State5
+    {
+        State5 P;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) P[q] = p.inflow[(long) q * n1 + jc];
+        return P;
+    };
+
+    if (role == 0)
+    {
+        // ================================================================ PRODUCER: first stage, rows a_begin .. a_end - 1 ================
+        // (cloud.hip's row loop with COMBINE = false; the row goes to the hand-off ring instead of memory)
+        double (*hand)[5][QWAVE] = hand_all[pp];
+        double (*own)[5][QWAVE] = own_all[pp];
+        const double* in = p.u_in;
+        const bool real_col = lane >= 2 && lane < QWAVE - 2 && col >= 0 && col < n1;       // a cell of the grid whose first-stage value is valid here
+        // the row loop requests rows up to three beyond the one it updates: held to the rows of the grid (the stored ghost rows hold nothing here)
+        auto load_raw = [&] (int r) -> State5
+        {
+            const int rr = min(max(r, 0), n0 - 1);
+            return cloud_load_row(in + row_off(rr), plane, jc8);
+        };
+        auto ring_put = [&] (int slot, const State5& raw)
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) own[slot][q][lane] = raw[q];
+        };
+        auto ring_get = [&] (int slot) -> State5
+        {
+            State5 U;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) U[q] = own[slot][q][lane];
+            return U;
+        };
+        auto prim_of_raw = [&] (int r, const State5& raw) -> State5
+        {
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            double x[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) x[q] = raw[q];
+            S::to_density(x, c.dv, c.inv_dv);
+            State5 U, P;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) U[q] = x[q];
+            const int st = S::c2p(U, g, tfloor, P);
+            if (__any(st != 0))
+            {
+                if (real_col && st != 0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);
+            }
+            return P;
+        };
+        auto prim_bc_raw = [&] (int r, const State5& last, const State5& raw) -> State5
+        {
+            if (r < 0) return inflow_row();
+            if (r >= n0) return last;                    // zero-gradient outer: copy of the last real row
+            return prim_of_raw(r, raw);
+        };
+        auto prim_bc = [&] (int r, const State5& last) -> State5
+        {
+            if (r < 0) return inflow_row();
+            if (r >= n0) return last;
+            return prim_of_raw(r, load_raw(r));
+        };
+
+#if MH_CLOUD_FUSED_RINGS
+        // register window as three-slot rings (slot = (row - a_begin) mod 3, compile-time in the loop unrolled by three): no
+        // register-to-register rotation of the primitives, slopes, radial fluxes and the row in flight
+        State5 U[3], P[3], G[3], Fx[3];
+        {
+            State5 dummy = {};
+            const State5 Pb = prim_bc(a_begin - 1, dummy);
+            const State5 raw0 = load_raw(a_begin);
+            U[1] = load_raw(a_begin + 1);
+            ring_put(0, raw0);
+            ring_put(1, U[1]);
+            P[0] = prim_of_raw(a_begin, raw0);
+            P[1] = prim_bc_raw(a_begin + 1, P[0], U[1]);
+            G[0] = S::plm(Pb, P[0], P[1], lim);
+            State5 Gb;
+            if (a_begin == 0) Gb = times_zero(G[0]);                         // extend_zeros on G
+            else              Gb = S::plm(prim_bc(a_begin - 2, dummy), Pb, P[0], lim);
+            Fx[0] = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P[0], G[0], lim), g);
+        }
+        U[2] = load_raw(a_begin + 2);
+        int hslot = (a_begin - (r0 - 2)) % QSLOTS;      // hand-off slot of row r: (r - (r0 - 2)) mod QSLOTS
+
+        auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
+        {
+            constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+            U[K0] = load_raw(r + 3);                     // (row r's own values wait in the LDS ring)
+
+            P[K2] = prim_bc_raw(r + 2, P[K1], U[K2]);
+            ring_put(K2, U[K2]);
+            if (r + 1 == n0) G[K1] = times_zero(G[K0]);
+            else             G[K1] = S::plm(P[K0], P[K1], P[K2], lim);
+            Fx[K1] = S::template hlle<0>(S::plus(P[K0], G[K0], lim), S::minus(P[K1], G[K1], lim), g);
+
+            const State5 Gy = S::plm(dpp_left(P[K0]), P[K0], dpp_right(P[K0]), lim);          // (a pole lane's lim_polar gives it no weight)
+            const State5 SL = dpp_left(S::plus(P[K0], Gy, lim_polar));
+            const State5 Fy_lo = S::template hlle<1>(SL, S::minus(P[K0], Gy, lim_polar), g);
+            const State5 Fy_hi = dpp_right(Fy_lo);
+
+            const State5 U0 = ring_get(K0);
+            __builtin_amdgcn_sched_barrier(0);
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            const State5 Src = S::source(P[K0], c.rc, c.inv_rc, cot, g);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                hand[hslot][q][lane] = S::update(U0[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
+            cloud_pair_barrier();                            // row r is in the ring
+            hslot = hslot == QSLOTS - 1 ? 0 : hslot + 1;
+        };
+        int r = a_begin;
+        for (; r + 3 <= a_end; r += 3)
+        {
+            row_step(r, std::integral_constant<int, 0>());
+            row_step(r + 1, std::integral_constant<int, 1>());
+            row_step(r + 2, std::integral_constant<int, 2>());
+        }
+        if (r < a_end) row_step(r, std::integral_constant<int, 0>());
+        if (r + 1 < a_end) row_step(r + 1, std::integral_constant<int, 1>());
+#else
+        State5 P0, P1, G0, Fx_lo;
+        {
+            State5 dummy = {};
+            const State5 Pb = prim_bc(a_begin - 1, dummy);
+            const State5 raw0 = load_raw(a_begin), raw1 = load_raw(a_begin + 1);
+            ring_put(0, raw0);
+            ring_put(1, raw1);
+            P0 = prim_of_raw(a_begin, raw0);
+            P1 = prim_bc_raw(a_begin + 1, P0, raw1);
+            G0 = S::plm(Pb, P0, P1, lim);
+            State5 Gb;
+            if (a_begin == 0) Gb = times_zero(G0);                           // extend_zeros on G
+            else              Gb = S::plm(prim_bc(a_begin - 2, dummy), Pb, P0, lim);
+            Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
+        }
+
+        State5 Uahead = load_raw(a_begin + 2);
+        int slot = 0;
+        int hslot = (a_begin - (r0 - 2)) % QSLOTS;      // hand-off slot of row r: (r - (r0 - 2)) mod QSLOTS
+        for (int r = a_begin; r < a_end; ++r)
+        {
+            const State5 Unext = load_raw(r + 3);
+
+            const State5 P2 = prim_bc_raw(r + 2, P1, Uahead);
+            ring_put(slot == 0 ? 2 : slot - 1, Uahead);
+            Uahead = Unext;
+            State5 G1;
+            if (r + 1 == n0) G1 = times_zero(G0);
+            else             G1 = S::plm(P0, P1, P2, lim);
+            const State5 Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
+
+            const State5 Gy = S::plm(dpp_left(P0), P0, dpp_right(P0), lim);          // (a pole lane's lim_polar gives it no weight)
+            const State5 SL = dpp_left(S::plus(P0, Gy, lim_polar));
+            const State5 Fy_lo = S::template hlle<1>(SL, S::minus(P0, Gy, lim_polar), g);
+            const State5 Fy_hi = dpp_right(Fy_lo);
+
+            const State5 U0 = ring_get(slot);
+            __builtin_amdgcn_sched_barrier(0);
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            const State5 Src = S::source(P0, c.rc, c.inv_rc, cot, g);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                hand[hslot][q][lane] = S::update(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
+            cloud_pair_barrier();                            // row r is in the ring
+
+            P0 = P1; P1 = P2;
+            G0 = G1;
+            Fx_lo = Fx_hi;
+            slot = slot == 2 ? 0 : slot + 1;
+            hslot = hslot == QSLOTS - 1 ? 0 : hslot + 1;
+        }
+#endif
+    }
+    else
+    {
+        // ================================================================ CONSUMER: second stage + RK average, rows r0 .. r1 - 1 ========
+        // (cloud.hip's row loop with COMBINE = true, weight 1/2; its loads of the first-stage field are reads of the ring)
+        const int out_lo = pp > 0 ? 2 : QHALO, out_hi = pp < QPAIRS - 1 ? QWAVE - 2 : QWAVE - QHALO;
+        const bool writes = lane >= out_lo && lane < out_hi && col < n1;
+        const unsigned col8 = (unsigned) (writes ? col : 0) * 8u;
+        // the lane of the pair's coordinate system that holds this lane's column (ghost columns: the clamped one, as cloud.hip's loads)
+        const int want = lane + (jc - col);
+        int other = pp, src = want;
+        if (want < 2 && pp > 0) { other = pp - 1; src = want + QPITCH; }
+        else if (want > QWAVE - 3 && pp < QPAIRS - 1) { other = pp + 1; src = want - QPITCH; }
+        if (src < 2 || src > QWAVE - 3) { other = pp; src = min(max(want, 2), QWAVE - 3); }     // no source: a valid neighbour's column (result unused)
+        const double* const hand_flat = &hand_all[0][0][0][0];
+        const int hand_off = other * (QSLOTS * 5 * QWAVE) + src;
+        auto hand_row = [&] (int rr) -> State5
+        {
+            const int slot = (rr - (r0 - 2)) % QSLOTS;
+            State5 U;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) U[q] = hand_flat[hand_off + (slot * 5 + q) * QWAVE];
+            return U;
+        };
+        auto prim_of_raw = [&] (int r, const State5& raw) -> State5
+        {
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            double x[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) x[q] = raw[q];
+            S::to_density(x, c.dv, c.inv_dv);
+            State5 U, P;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) U[q] = x[q];
+            const int st = S::c2p(U, g, tfloor, P);
+            if (__any(st != 0))
+            {
+                if (writes && st != 0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);
+            }
+            return P;
+        };
+        auto prim_bc = [&] (int r, const State5& last) -> State5
+        {
+            if (r < 0) return inflow_row();
+            if (r >= n0) return last;
+            return prim_of_raw(r, hand_row(r));
+        };
+
+        const int fill = min(r0 + 2, a_end) - a_begin;          // barriers until rows a_begin .. min(r0 + 1, a_end - 1) are in the ring
+        for (int k = 0; k < fill; ++k) cloud_pair_barrier();
+
+#if MH_CLOUD_FUSED_RINGS
+        State5 P[3], G[3], Fx[3];
+        {
+            State5 dummy = {};
+            const State5 Pb = prim_bc(r0 - 1, dummy);
+            P[0] = prim_of_raw(r0, hand_row(r0));
+            P[1] = prim_bc(r0 + 1, P[0]);
+            G[0] = S::plm(Pb, P[0], P[1], lim);
+            State5 Gb;
+            if (r0 == 0) Gb = times_zero(G[0]);
+            else         Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P[0], lim);
+            Fx[0] = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P[0], G[0], lim), g);
+        }
+
+        auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
+        {
+            constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
+            if (r + 2 < a_end) cloud_pair_barrier();         // row r + 2 is in the ring
+            P[K2] = prim_bc(r + 2, P[K1]);
+            if (r + 1 == n0) G[K1] = times_zero(G[K0]);
+            else             G[K1] = S::plm(P[K0], P[K1], P[K2], lim);
+            Fx[K1] = S::template hlle<0>(S::plus(P[K0], G[K0], lim), S::minus(P[K1], G[K1], lim), g);
+
+            const State5 Gy = S::plm(dpp_left(P[K0]), P[K0], dpp_right(P[K0]), lim);
+            const State5 SL = dpp_left(S::plus(P[K0], Gy, lim_polar));
+            const State5 Fy_lo = S::template hlle<1>(SL, S::minus(P[K0], Gy, lim_polar), g);
+            const State5 Fy_hi = dpp_right(Fy_lo);
+
+            const State5 U0 = hand_row(r);
+            const State5 Ubase = cloud_load_row(p.u_in + row_off(r), plane, jc8);
+            __builtin_amdgcn_sched_barrier(0);
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            const State5 Src = S::source(P[K0], c.rc, c.inv_rc, cot, g);
+            State5 Un;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+            {
+                const double u1 = S::update(U0[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
+                Un[q] = S::combine(Ubase[q], u1, 0.5);
+            }
+            if (writes) cloud_store_row(p.u_out + row_off(r), plane, col8, Un);
+        };
+        int r = r0;
+        for (; r + 3 <= r1; r += 3)
+        {
+            row_step(r, std::integral_constant<int, 0>());
+            row_step(r + 1, std::integral_constant<int, 1>());
+            row_step(r + 2, std::integral_constant<int, 2>());
+        }
+        if (r < r1) row_step(r, std::integral_constant<int, 0>());
+        if (r + 1 < r1) row_step(r + 1, std::integral_constant<int, 1>());
+#else
+        State5 P0, P1, G0, Fx_lo;
+        {
+            State5 dummy = {};
+            const State5 Pb = prim_bc(r0 - 1, dummy);
+            P0 = prim_of_raw(r0, hand_row(r0));
+            P1 = prim_bc(r0 + 1, P0);
+            G0 = S::plm(Pb, P0, P1, lim);
+            State5 Gb;
+            if (r0 == 0) Gb = times_zero(G0);
+            else         Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, lim);
+            Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
+        }
+
+        for (int r = r0; r < r1; ++r)
+        {
+            if (r + 2 < a_end) cloud_pair_barrier();         // row r + 2 is in the ring
+            const State5 P2 = prim_bc(r + 2, P1);
+            State5 G1;
+            if (r + 1 == n0) G1 = times_zero(G0);
+            else             G1 = S::plm(P0, P1, P2, lim);
+            const State5 Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
+
+            const State5 Gy = S::plm(dpp_left(P0), P0, dpp_right(P0), lim);
+            const State5 SL = dpp_left(S::plus(P0, Gy, lim_polar));
+            const State5 Fy_lo = S::template hlle<1>(SL, S::minus(P0, Gy, lim_polar), g);
+            const State5 Fy_hi = dpp_right(Fy_lo);
+
+            const State5 U0 = hand_row(r);
+            const State5 Ubase = cloud_load_row(p.u_in + row_off(r), plane, jc8);
+            __builtin_amdgcn_sched_barrier(0);
+            const CellGeom c = cell_geometry(p.row_offset + r);
+            const State5 Src = S::source(P0, c.rc, c.inv_rc, cot, g);
+            State5 Un;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+            {
+                const double u1 = S::update(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
+                Un[q] = S::combine(Ubase[q], u1, 0.5);
+            }
+            if (writes) cloud_store_row(p.u_out + row_off(r), plane, col8, Un);
+
+            P0 = P1; P1 = P2;
+            G0 = G1;
+            Fx_lo = Fx_hi;
+        }
+#endif
+    }
+    acc.commit(p.status);
+}
+
+bool cloud_fused_rk2_available(const mh_cloud_desc* d)
+{
+    return d->arith == MH_ARITH_FAST && d->plm_theta >= 0.0 && d->bc_lo0 == MH_BC_INFLOW && d->bc_hi0 == MH_BC_OUTFLOW
+        && d->row_offset == 0 && d->nr == d->nr_global && d->nr >= 4 && d->nq >= 3;
+}
+
+// u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 over the whole field (layout of include/mara_hip.h; the two fields must differ);
+// geom_dev = the block of mh_cloud_pack_geometry, inflow_dev = [5][nq] nozzle primitives at the step-start time
+hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
+                                  double dt, int32_t* status, hipStream_t stream)
+{
+    if (! cloud_fused_rk2_available(d) || u_in == u_out || ! geom_dev || ! inflow_dev) return hipErrorInvalidValue;
+    CloudFusedParams p;
+    p.u_in = u_in; p.u_out = u_out; p.status = status;
+    p.n0 = d->nr; p.n1 = d->nq; p.row_offset = d->row_offset;
+    // geom_dev: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] | rowf[nr_global][8] | colf[nq][8]
+    p.cotq = geom_dev + (d->nr_global + 1) + d->nq + (d->nq + 1);
+    p.rowf = p.cotq + d->nq;
+    p.colf = p.rowf + 8L * d->nr_global;
+    p.inflow = inflow_dev;
+    p.plane_stride = d->nq;
+    p.row_stride = 5L * d->nq;
+    p.nstrips = (p.n1 + QGROUP - 1) / QGROUP;
+    if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
+    else
+    {
+        // as euler2d_fused.hip: a pair pays about eight pipeline-fill rows per chunk, and 256 CUs x MH_CLOUD_FUSED_WAVES workgroups are resident
+        // at a time: the shortest chunk that fills R residency rounds to the brim, for the smallest R that keeps it near 100 rows
+        const int resident = 256 * (4 * MH_CLOUD_FUSED_WAVES) / (2 * QPAIRS);      // workgroups: 768
+        int rounds = 1;
+        auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (p.n0 + nch - 1) / nch; };
+        while (chunk_for(rounds) > 80) ++rounds;      // measured at 4096^2 (gpurun_out/r4b, profiles/r04/ab_cloud_fused_chunks.jsonl): 64 rows (3.0 rounds) 0.993 ms, 98 (1.97) 1.010, 49 (3.9) 1.024, 196 (0.98) 1.037
+        p.chunk_rows = chunk_for(rounds);
+        if (p.chunk_rows < 8) p.chunk_rows = 8;
+    }
+    if (p.chunk_rows > p.n0) p.chunk_rows = p.n0;
+    if (p.chunk_rows < 2) p.chunk_rows = 2;
+    p.nchunks = (p.n0 + p.chunk_rows - 1) / p.chunk_rows;
+    p.gamma = d->gamma; p.theta = d->plm_theta; p.tfloor = d->temperature_floor;
+    p.dt = dt;
+    const dim3 grid(p.nstrips * p.nchunks), block(2 * QWAVE * QPAIRS);
+    hipLaunchKernelGGL(cloud_fused_rk2_kernel, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_cloud_fused)
+
+} // namespace mh

@@ -46,6 +46,7 @@
 #include "launch.hpp"
 #include "status_device.hpp"
 #include "euler2d_rows.hpp"
+#include "row_check.hpp"
 
 namespace mh {
 
@@ -121,7 +122,8 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
 
     const long row_stride = p.row_stride;
     const double* in = p.u_in;                       // row r, plane q lives at (r + 2) * row_stride + q * plane_stride
-    auto row_off = [row_stride] (int r) { return (long) (r + HALO) * row_stride; };
+    const int rows_hi = p.n0 + 1;                     // the rows that exist: -2 .. n0 + 1 (row_check.hpp)
+    auto row_off = [row_stride, rows_hi] (int r) { (void) rows_hi; return (long) (MH_ROW(r, -HALO, rows_hi) + HALO) * row_stride; };
     const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
 
     const double gamma = p.gamma, theta = p.theta;
@@ -448,5 +450,8 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
     }
     return hipErrorInvalidValue;
 }
+
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_euler2d)
 
 } // namespace mh

@@ -37,6 +37,7 @@
 #include "launch.hpp"
 #include "status_device.hpp"
 #include "euler2d_rows.hpp"
+#include "row_check.hpp"
 
 namespace mh {
 
@@ -168,9 +169,14 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         {
             // (the row loop requests rows up to two beyond the last one it uses: EXTERNAL sides stop at the four rows that exist)
             int m = r;
+#ifdef MH_PROBE_FUSED_NO_EXTERNAL_CLAMP      // the round-3 fault, rebuilt for tests/test_gpu_row_range.py (check builds only: MH_ROW holds the access to the rows that exist)
+            if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? r : 0);
+            else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? r : n0 - 1);
+#else
             if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? max(r, -4) : 0);
             else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? min(r, n0 + 3) : n0 - 1);
-            return in + (long) (m + 2) * row_stride;          // (EXTERNAL: rows -4, -3 and n0 + 2, n0 + 3 lie outside the stored ghost rows: the slab stepper allocates them)
+#endif
+            return in + (long) (MH_ROW(m, bc0_lo == 2 ? -4 : -2, bc0_hi == 2 ? n0 + 3 : n0 + 1) + 2) * row_stride;          // (EXTERNAL: rows -4, -3 and n0 + 2, n0 + 3 lie outside the stored ghost rows: the slab stepper allocates them)
         };
         // slot of step-start row x: (x - a0) mod USLOTS
         auto ring_put = [&] (int slot, const State5& raw)
@@ -291,7 +297,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             for (int q = 0; q < 5; ++q) Uq[q] = hand_flat[hand_off + (slot * 5 + q) * FWAVE];
             return Uq;
         };
-        auto row_off = [row_stride] (int r) { return (long) (r + 2) * row_stride; };
+        auto row_off = [row_stride, n0] (int r) { (void) n0; return (long) (MH_ROW(r, -2, n0 + 1) + 2) * row_stride; };
 
         pair_barrier(); pair_barrier(); pair_barrier(); pair_barrier();          // barriers #0..#3: rows r0 - 2 .. r0 + 1 are in the ring
 
@@ -444,5 +450,8 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     }
     return hipGetLastError();
 }
+
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_euler2d_fused)
 
 } // namespace mh

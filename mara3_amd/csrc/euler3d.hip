@@ -98,4 +98,7 @@ hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
     return euler3d_stage_launch_boxes(d, lay, &all, 1, u_in, u_base, u_out, dt, weight, status, stream);
 }
 
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_euler3d)
+
 } // namespace mh

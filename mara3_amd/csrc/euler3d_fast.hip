@@ -21,4 +21,7 @@ hipError_t euler3d_launch_fast(int key, const Stage3dParams& p, int nblocks, hip
     return hipErrorInvalidValue;
 }
 
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_euler3d_fast)
+
 } // namespace mh

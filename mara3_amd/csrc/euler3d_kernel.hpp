@@ -9,6 +9,7 @@
 #include <atomic>
 #include "launch.hpp"
 #include "status_device.hpp"
+#include "row_check.hpp"
 
 namespace mh {
 
@@ -140,7 +141,8 @@ void euler3d_stage_kernel(Stage3dParams p)
     const bool writes = lane >= H3 && lane < W3 - H3 && col < p.n2 && j < p.n1;
 
     const long row_stride = p.row_stride, plane = p.plane_stride;
-    auto row_off = [row_stride] (int r) { return (long) (r + H3) * row_stride; };
+    const int planes_hi = p.n0 + 1;                   // the planes that exist: -2 .. n0 + 1 (row_check.hpp)
+    auto row_off = [row_stride, planes_hi] (int r) { (void) planes_hi; return (long) (MH_ROW(r, -H3, planes_hi) + H3) * row_stride; };
     auto cell_bytes = [&p] (int jj, int kk) { return (unsigned) (((long) (jj + p.g1) * p.pitch2 + (kk + p.g2)) * 8); };
     const unsigned c0 = cell_bytes(jc, kc);
     const unsigned cw = writes ? cell_bytes(j, col) : 0u;

@@ -63,9 +63,24 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
                               const double* u_in, const double* u_base, double* u_out, double dt, double weight,
                               int row_begin, int row_end, int32_t* status, hipStream_t stream);
 
+// both stages of an RK2 step of a whole `cloud` field in one launch (cloud_fused.hip; MH_ARITH_FAST, PLM, both radial sides physical):
+// u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 with the nozzle row of the step-start time in both stages
+bool cloud_fused_rk2_available(const mh_cloud_desc* d);
+hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
+                                  double dt, int32_t* status, hipStream_t stream);
+
 // cloud_diag.hip: make_diagnostic_fields of a device-resident cloud state; fields [5][nr][nq], work [4][nr][nq], columns [15][nq] (device)
 hipError_t cloud_diagnostics_launch(const mh_cloud_desc* d, const double* geom_dev, const double* u, const double units[3],
                                     double* fields, double* work, double* columns, int32_t* status, hipStream_t stream);
+
+// row-range guard (row_check.hpp, -DMH_CHECK_ROWS): {smallest, largest} row index the kernels of a translation unit requested since the last
+// reset; false where the library was built without the guard
+bool rows_requested_euler2d(int32_t out[2], int reset);
+bool rows_requested_euler2d_fused(int32_t out[2], int reset);
+bool rows_requested_cloud(int32_t out[2], int reset);
+bool rows_requested_cloud_fused(int32_t out[2], int reset);
+bool rows_requested_euler3d(int32_t out[2], int reset);
+bool rows_requested_euler3d_fast(int32_t out[2], int reset);
 
 // thread-local error text for the C ABI
 void set_error(const char* fmt, ...);

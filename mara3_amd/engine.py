@@ -160,7 +160,9 @@ class CloudSolver(_StatusMixin):
     cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
 
     def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0,
-                 arith="strict", tail=None):
+                 arith="strict", tail=None, fuse=None):
+        """fuse: the descriptor's fuse_stages - None = where available (one launch per RK2 step: FAST, PLM; csrc/cloud_fused.hip),
+        False = never, True = required."""
         self.lib = L.load_library()
         self.rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
         self.qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
@@ -170,6 +172,7 @@ class CloudSolver(_StatusMixin):
                         arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith], chunk_rows=chunk_rows)
         if tail is not None:
             d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
+        d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
         self.ctx = C.c_void_p()
         L.check(self.lib.mh_create(C.byref(self.ctx), device))
         L.check(self.lib.mh_cloud_configure(self.ctx, C.byref(d), self.rv.ctypes.data_as(C.c_void_p),

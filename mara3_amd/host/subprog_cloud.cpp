@@ -48,6 +48,8 @@ mara::config_t config_template()
     .item("plm_theta", 1.2)
     .item("temperature_floor", 1e-8)
     .item("arith", "strict")         // strict (bit-identical to the reference) | fast (L1 <= 1e-12); not a reference option
+    .item("fuse", 0)                 // the RK2 step as one launch (arith=fast, PLM): 0 = where available, -1 = never, 1 = required; not a reference option
+    .item("chunk_rows", 0)           // rows marched per wave (0 = the library's default); not a reference option
     .item("profile", 0)              // print the average stage-kernel time from HIP events at the end; not a reference option
     .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
     .item("write_inflow", 0)         // also dump the nozzle row of the first step (tests)
@@ -148,6 +150,8 @@ public:
         d.temperature_floor = cfg.get_double("temperature_floor");
         d.bc_lo0 = MH_BC_INFLOW; d.bc_hi0 = MH_BC_OUTFLOW;
         d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
+        d.fuse_stages = int(cfg.get_int("fuse"));
+        d.chunk_rows = int(cfg.get_int("chunk_rows"));
 
         mh_ctx* ctx = nullptr;
         host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");

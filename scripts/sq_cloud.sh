@@ -1,11 +1,11 @@
 #!/bin/bash
 # SQ counters + kernel trace of the cloud stage kernels (dev helper). usage: bash scripts/sq_cloud.sh <tag> [arith]
-TAG=${1:-cloud}; ARITH=${2:-fast}
+TAG=${1:-cloud}; ARITH=${2:-fast}; MORE=$3          # e.g. "fuse=-1" (two launches per RK2 step) or "fuse=1 chunk_rows=64"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 EXE=$PWD/mara3_amd/host/mara_hip
-ARGS="cloud nr=4096 num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 max_steps=6 cpi=0 arith=$ARITH outdir=x"
+ARGS="cloud nr=4096 num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 max_steps=6 cpi=0 arith=$ARITH outdir=x $MORE"
 cd $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $EXE $ARGS > t.log 2> t.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/sq1 -- $EXE $ARGS > b1.log 2> e1.err

@@ -1,0 +1,160 @@
+"""The fused RK2 step of `cloud` (mara3_amd/csrc/cloud_fused.hip: both stages of `s0 * 0.5 + advance(advance(s0)) * 0.5`,
+src/subprog_cloud.cpp:676-697 with `advance` :511-584, in ONE launch - the first-stage field lives in an LDS ring between a producer and
+a consumer wave) against the two launches of cloud_stage_kernel it replaces. Same SrhdFast functions on the same values in the same
+order, so the requirement is BIT-IDENTITY with the two-launch FAST path, which tests/test_gpu_srhd_cloud.py::test_fast_* hold to the
+reference (conserved L1 <= 1e-12 per variable); the reference's RK2 + PLM golden steps are asserted here on the fused launch directly
+too. Covered: the reference's cases (incl. two decades of radius), ragged shapes (strips of 116 columns and chunks that do not divide
+the grid, one-row last chunks, a grid narrower than a pair), chunk lengths down to 2, odd and even step counts (the two fields swap),
+a changing nozzle row, the status contract and the transactional step."""
+import glob
+import os
+import numpy as np
+import pytest
+from conftest import golden, bits_equal, GOLDEN
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+RK2_PLM_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cloud_*_plm_rk2.npz")))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import mara3_amd
+    from mara3_amd import engine
+    assert mara3_amd.load_library().mh_device_count() >= 1
+    return engine
+
+
+def smooth_cloud_state(eng, nr, nq, seed):
+    """a smooth relativistic flow on a logarithmic radial grid from pole to pole: cell-integrated conserved state, nozzle rows, dt"""
+    rng = np.random.default_rng(seed)
+    rv = np.logspace(0.0, 0.6, nr + 1)
+    qv = np.linspace(0.0, np.pi, nq + 1)
+    rc = 0.5 * (rv[1:] + rv[:-1])[:, None]
+    qc = 0.5 * (qv[1:] + qv[:-1])[None, :]
+    k1, k2, k3 = rng.uniform(1.0, 3.0, 3)
+    P = np.zeros((nr, nq, 5))
+    P[..., 0] = (1.0 + 0.3 * np.sin(k1 * qc) * np.cos(k2 * np.log(rc))) / rc ** 2
+    P[..., 1] = 0.8 + 0.5 * np.cos(k3 * qc) * np.sin(2.0 * np.log(rc))
+    P[..., 2] = 0.1 * np.sin(2.0 * qc) * np.cos(k1 * np.log(rc))
+    P[..., 4] = 0.05 * P[..., 0] * (1.0 + 0.5 * np.sin(k2 * qc))
+    U = eng.srhd_to_conserved(P.reshape(-1, 5)).reshape(nr, nq, 5)
+    dmu = -np.cos(qv[1:]) - -np.cos(qv[:-1])
+    dv = ((rv[1:] ** 3 - rv[:-1] ** 3)[:, None] * dmu[None, :] * 2 * np.pi) / 3
+    inflow = np.zeros((8, nq, 5))
+    for n in range(8):                                  # a nozzle that changes from step to step
+        inflow[n, :, 0] = P[0, :, 0] * (1.0 + 0.02 * n)
+        inflow[n, :, 1] = P[0, :, 1] + 0.05 * n * np.exp(-(qc[0] / 0.3) ** 2) + 0.05 * n * np.exp(-((np.pi - qc[0]) / 0.3) ** 2)
+        inflow[n, :, 4] = P[0, :, 4]
+    return rv, qv, U * dv[..., None], inflow, 0.3 * (rv[1] - rv[0])
+
+
+def run(eng, rv, qv, u0, inflow, dt, pieces, fuse, chunk=0, theta=1.2, tfloor=0.0):
+    s = eng.CloudSolver(rv, qv, 2, theta, tfloor, arith="fast", fuse=fuse, chunk_rows=chunk)
+    s.upload(u0)
+    out, k = [], 0
+    for n in pieces:
+        for _ in range(n):
+            s.set_inflow(inflow[k % len(inflow)])
+            s.step(dt, 1)
+            k += 1
+        out.append(s.download())
+    st = s.status_result()
+    s.close()
+    return out, st
+
+
+@pytest.mark.parametrize("chunk", [0, 2, 5, 23])
+@pytest.mark.parametrize("case", RK2_PLM_CASES)
+def test_fused_cloud_step_on_the_reference_cases(eng, case, chunk):
+    """bit-identical to the two FAST launches, and within north_star's tolerance of the reference's own steps (per variable, relative to its mean)"""
+    g = golden(case)
+    n = int(g["nsteps"])
+    two, st2 = run(eng, g["rv"], g["qv"], g["u0"], g["inflow"], float(g["dt"]), (n,), False, chunk, float(g["theta"]), float(g["tfloor"]))
+    one, st1 = run(eng, g["rv"], g["qv"], g["u0"], g["inflow"], float(g["dt"]), (n,), True, chunk, float(g["theta"]), float(g["tfloor"]))
+    assert st1 == (0, None) and st2 == (0, None)
+    assert bits_equal(one[0], two[0]), np.abs(one[0] - two[0]).max()
+    scale = np.abs(g["un"]).reshape(-1, 5).mean(axis=0)
+    scale[1:4] = scale[1:4].max()
+    err = np.abs(one[0] - g["un"]).reshape(-1, 5).mean(axis=0)
+    assert np.all(err <= 1e-12 * scale), err / scale
+
+
+@pytest.mark.parametrize("nr,nq,chunk", [(130, 250, 0), (97, 116, 32), (64, 117, 9), (33, 57, 2), (41, 300, 7), (200, 64, 3), (96, 1000, 0), (12, 3, 0), (5, 40, 4)])
+def test_fused_cloud_step_is_bit_identical_to_the_two_launches(eng, nr, nq, chunk):
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, nr, nq, seed=nr * 1000 + nq)
+    pieces = (1, 2, 3)                       # odd and even step counts: the result lands in either field
+    two, st2 = run(eng, rv, qv, u0, inflow, dt, pieces, False, chunk)
+    one, st1 = run(eng, rv, qv, u0, inflow, dt, pieces, True, chunk)
+    assert st1 == (0, None) and st2 == (0, None), (st1, st2)
+    for a, b, n in zip(one, two, pieces):
+        assert np.isfinite(a).all()
+        assert bits_equal(a, b), (nr, nq, chunk, n, np.abs(a - b).max())
+    assert not bits_equal(one[0], u0)
+
+
+def test_default_is_the_fused_step_where_it_exists_and_never_means_never(eng, monkeypatch):
+    """fuse=None takes the one-launch step (one launch per step between the profile events), fuse=False two"""
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 64, 120, seed=5)
+    counts = {}
+    for fuse in (None, False):
+        s = eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="fast", fuse=fuse)
+        s.upload(u0)
+        s.set_inflow(inflow[0])
+        s.lib.mh_profile_enable(s.ctx, 1)
+        s.step(dt, 3)
+        import ctypes as C
+        ms, n = C.c_double(), C.c_int()
+        assert s.lib.mh_profile_read(s.ctx, C.byref(ms), C.byref(n)) == 0
+        counts[fuse] = n.value
+        s.close()
+    assert counts == {None: 3, False: 6}
+
+
+def test_required_fusion_is_refused_where_it_does_not_exist(eng):
+    import mara3_amd
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 32, 40, seed=1)
+    with pytest.raises(mara3_amd.MaraHipError, match="fuse_stages"):
+        eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="strict", fuse=True)
+    with pytest.raises(mara3_amd.MaraHipError, match="fuse_stages"):
+        eng.CloudSolver(rv, qv, 1, 1.2, 0.0, arith="fast", fuse=True)
+    with pytest.raises(mara3_amd.MaraHipError, match="fuse_stages"):
+        eng.CloudSolver(rv, qv, 2, -1.0, 0.0, arith="fast", fuse=True)          # piecewise constant
+    # STRICT with fuse=None: two launches, bit-identical to the reference as before
+    s = eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="strict")
+    s.upload(u0); s.set_inflow(inflow[0]); s.step(dt, 1)
+    assert s.status() == 0
+    s.close()
+
+
+@pytest.mark.parametrize("where", [(0, 0), (17, 59), (17, 60), (40, 119), (63, 5)])
+def test_status_contract_of_the_fused_cloud_step(eng, where):
+    """a cell the reference's recover_primitive throws on (negative tau): the same status bits and the same first failing cell as the two
+    launches, in the first row, at the seam between the two pairs of a workgroup, at a pole and in the last row. (The first stage's NaNs
+    reach the second stage's recover_primitive in the neighbouring rows, so the FIRST failing cell of the step may lie up to two rows before
+    the poisoned one - in both forms alike.)"""
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 64, 120, seed=9)
+    u = u0.copy()
+    u[where[0], where[1], 4] = -abs(u[where[0], where[1], 4]) * 10.0
+    _, st2 = run(eng, rv, qv, u, inflow, dt, (1,), False, 16)
+    _, st1 = run(eng, rv, qv, u, inflow, dt, (1,), True, 16)
+    assert st2[0] != 0 and st1 == st2, (st1, st2)
+    assert max(where[0] - 2, 0) * 120 <= st1[1] <= where[0] * 120 + where[1]
+
+
+def test_transactional_step_with_the_fused_cloud_launch(eng):
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 48, 130, seed=3)
+    s = eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="fast", fuse=True)
+    s.upload(u0)
+    s.set_inflow(inflow[0])
+    assert s.step_checked(dt) == (0, None)
+    good = s.download()
+    two, _ = run(eng, rv, qv, u0, inflow, dt, (1,), False)
+    assert bits_equal(good, two[0])
+    bad = good.copy()
+    bad[20, 70, 4] = -1.0
+    s.upload(bad)
+    bits, cell = s.step_checked(dt)
+    assert bits != 0 and 18 * 130 <= cell <= 20 * 130 + 70
+    assert bits_equal(s.download(), bad)                 # the previous solution is still in place
+    s.close()
