@@ -112,15 +112,25 @@ def cpu_baseline(n, gamma, theta, riemann, budget_s=15.0):
                       % (steps, n, n, riemann.upper(), cores)}
 
 
-def cpu_reference(gamma, theta):
-    """If the reference-composed driver was prebuilt (oracle/_ref), time Mara3's own lazy-array path (1 thread)."""
+def upstream_threads(cores):
+    """mara::evaluate_on<N>() takes its thread count as a template parameter: the drivers instantiate 1, 2, 4, 8, 16 and 32 - the largest that the
+    usable host cores cover"""
+    return max(t for t in (1, 2, 4, 8, 16, 32) if t <= max(1, cores))
+
+
+def cpu_reference(gamma, theta, n=1024, steps=4):
+    """If the reference-composed driver was prebuilt (oracle/_ref), time Mara3's OWN CPU path on the host cores: its lazy-array composition of the
+    step evaluated as upstream evaluates its `advance` - primitives and result through the threaded evaluator mara::evaluate_on<N>()
+    (src/app_parallel.hpp:72-103; src/subprog_cloud.cpp:525-533, :582), gradients through nd::to_shared() (:566). The one-thread figure of the
+    same composition is reported beside it (the evaluator scales poorly on this composition - that is the reference's behaviour, not this repo's)."""
     import subprocess
     import tempfile
     from mara3_amd import setups
     exe = os.path.join(ROOT, "oracle", "_ref", "euler_cart_ref")
     if not os.path.exists(exe):
         return None
-    n, steps = 512, 4
+    cores = host_cores()
+    threads = upstream_threads(cores)
     u = setups.blast_ic((n, n), gamma)
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
@@ -128,17 +138,22 @@ def cpu_reference(gamma, theta):
         hx = lambda x: float(x).hex()
         args = [exe, "2", str(n), str(n), "1", hx(gamma), hx(theta), "2", "0", hx(setups.baseline_dt(n)),
                 hx(1.0 / n), hx(1.0 / n), hx(1.0)]
-        try:
+
+        def rate(th):
             t0 = time.perf_counter()
-            subprocess.check_call(args + ["0", fin, fout])
+            subprocess.check_call(args + ["0", fin, fout, str(th)])
             tz = time.perf_counter() - t0
             t0 = time.perf_counter()
-            subprocess.check_call(args + [str(steps), fin, fout])
-            t = time.perf_counter() - t0 - tz
+            subprocess.check_call(args + [str(steps), fin, fout, str(th)])
+            return n * n * steps / (time.perf_counter() - t0 - tz) / 1e6
+        try:
+            many = rate(threads)
+            one = rate(1) if threads > 1 else many
         except Exception:
             return None
-    return {"value": n * n * steps / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "reference",
-            "sample": "%d RK2 steps at %dx%d PLM+HLLE, reference headers composed as in oracle/ref_drivers/euler_cart_ref.cpp" % (steps, n, n)}
+    return {"value": many, "unit": "Mcells/s", "cores": threads, "kind": "reference", "one_thread": one, "host_cores": cores,
+            "sample": "%d RK2 steps at %dx%d PLM+HLLE: the reference's headers composed and evaluated as its own `advance` is (lazy arrays, mara::evaluate_on<%d>() "
+                      "where upstream pipes `| evaluate`), oracle/ref_drivers/euler_cart_ref.cpp; results bit-identical to the one-thread run" % (steps, n, n, threads)}
 
 
 def compact(obj, drop=("timing", "traffic_note", "preconditioning", "peak", "unit", "bound", "kernel", "launches", "algorithmic_bytes_per_launch")):
@@ -391,6 +406,7 @@ def main():
                     tf = rec["fp64_flops_per_launch"] / (avg * 1e-3) / 1e12
                     r["fp64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
                                  "valu_busy": rec["valu_busy"], "note": "recorded counters (20-step blast), this run's duration"}
+                    r["bound_measured"] = "fp64 issue (VALU-busy %.2f)" % rec["valu_busy"] if rec["valu_busy"] >= 0.75 else "mixed: VALU-busy %.2f, HBM %.2f of 8 TB/s" % (rec["valu_busy"], r["frac"] or 0.0)
             return r
 
         fused = native and nl1 == 0 and nl2 > 0          # the stepper took the fused step: its one launch is reported in the second-stage slot
@@ -401,9 +417,20 @@ def main():
             # while it moves 80 B per cell (the first-stage field never leaves LDS): `traffic` is then BELOW the algorithmic bytes.
             r = kernel_roofline(BYTES_STEP, avg2, nl2, "euler2d_fused_rk2_kernel<%s> (both RK2 stages, one launch per step)" % riemann,
                                 "fused_%s_%s_bytes_per_launch" % (arith, riemann))
+            # `achieved` / `frac` follow the measurement contract: SURVEY.md 8d's ALGORITHMIC bytes of a zone-update (200 B) over the launch that
+            # performs it. That is a convention, not a utilisation of the memory system - the launch MOVES 80 B per cell - so the hardware
+            # fractions stand beside it: what the launch moves against 8 TB/s, and what bounds it (fp64 issue).
             r["bytes_actually_moved_per_cell"] = 2 * 5 * 8
             r["achieved_actual_traffic"] = cells_launch * 80 / (avg2 * 1e-3) / 1e9 if avg2 > 0 else None
-            r["convention"] = "200 B per zone-update (SURVEY.md 8d) over the step's one launch; the launch reads 40 B and writes 40 B per cell"
+            r["frac_actual_traffic"] = r["achieved_actual_traffic"] / HBM_PEAK_GBS if r["achieved_actual_traffic"] else None
+            if r.get("traffic"):
+                r["achieved_measured_traffic"] = r["traffic"] / (avg2 * 1e-3) / 1e9
+                r["frac_measured_traffic"] = r["achieved_measured_traffic"] / HBM_PEAK_GBS
+            busy = (r.get("fp64") or {}).get("valu_busy")
+            r["bound_measured"] = ("fp64 issue (VALU-busy %.2f, %.2f of the 78.6 TFLOP/s vector peak); HBM carries %.2f of 8 TB/s" % (busy, r["fp64"]["frac"], r["frac_actual_traffic"])
+                                   if busy else "fp64 issue (profiles/r04/kernels_headline.md); HBM carries %.2f of 8 TB/s" % (r["frac_actual_traffic"] or 0.0))
+            r["convention"] = ("frac = 200 B per zone-update (SURVEY.md 8d) over the step's one launch; the launch reads 40 B and writes 40 B per cell: "
+                               "frac_actual_traffic is the fraction of 8 TB/s it really uses")
             res["roofline"] = r
             res["roofline_stage1"] = None
         else:
@@ -507,7 +534,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D Euler Sedov-type blast, %dx%d uniform grid, PLM(theta=%g)+%s, RK2, fp64, fixed dt=0.3*dx/6, outflow BC"
                                    % (n, n, args.theta, args.riemann.upper()),
-                       "decomposition": ("axis-0 slabs x%d (nd::partition_shape formula), %s, %s stepper" % (world, "4-row RCCL halo once per step (fused step across the cuts)" if res["launches_per_step"] == 1 else "2-row RCCL halo per stage", state["stepper"]))
+                       "decomposition": (("one GPU: the whole grid as one slab of the native stepper, no cuts, no exchange" if world == 1 else
+                                          "axis-0 slabs x%d (nd::partition_shape formula), %s, %s stepper" % (world, "4-row RCCL halo once per step (fused step across the cuts)" if res["launches_per_step"] == 1 else "2-row RCCL halo per stage", state["stepper"])))
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
@@ -526,7 +554,8 @@ def main():
         if legs:
             out["legs"] = compact(legs)
             out["legs_note"] = ("each leg: the same measurement as the headline's (fused legs: plain launches, two-launch legs: graph replay; scratch-grid preconditioning, HIP events riding on 5 further steps; "
-                                "roofline = second RK2 stage, roofline_stage1 = first, both against 8000 GB/s and, as fp64, 78.6 TFLOP/s with the recorded counters)")
+                                "two-launch legs: roofline = second RK2 stage, roofline_stage1 = first; fused legs (launches_per_step 1): roofline = the step's one launch at 200 B per zone-update, "
+                                "no roofline_stage1; all against 8000 GB/s and, as fp64, 78.6 TFLOP/s with the recorded counters)")
         if l1 is not None:
             out["l1_fast_vs_strict_after_%d_steps" % nsteps_primary] = l1
         if world == 1 and not args.loopback_slabs:

@@ -107,7 +107,10 @@ def c3_run(args, binary, cfg, n, arith):
     ok = bool(np.isfinite(u).all() and (u[..., 0] > 0).all())
     st = binary.state_as_dict(s.state())
     s.close()
-    bytes_stage = n * n * (80 + 104) / 2          # mean of the two stage kinds of RK2
+    # 120 B per zone-update, 168 B when `initial_conserved_u` is streamed for the buffer term (it is: 24 B per stage) - the figure
+    # `frac` is quoted on. The kernel also streams the per-cell buffer rate (8 B per stage): 184 B, quoted beside it.
+    bytes_stage = n * n * 168 / 2                 # mean of the two stage kinds of RK2 (first: 72 B, second: 96 B)
+    bytes_stage_all = n * n * (80 + 104) / 2      # ... with the buffer-rate array: 80 B and 104 B
     out = {
         "metric": "zone-updates/sec (Mcells/s), subprog_binary 2048^2 (depth=5 block_size=64), PLM+HLLE+viscosity RK2, 1 GPU",
         "value": n * n * args.steps / elapsed / 1e6, "unit": "Mcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -120,6 +123,8 @@ def c3_run(args, binary, cfg, n, arith):
                      "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "binary_stage_kernel + binary_sink_kernel + binary_reduce_kernel (one stage)",
                      "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
+                     "bytes_per_zone_update": 168, "frac_at_184_bytes": bytes_stage_all / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "bytes_note": "168 B per zone-update = SURVEY.md 8d's figure with initial_conserved_u streamed; 184 B adds the 8 B per stage of the buffer-rate array the kernel also reads",
                      "timing": "one pair of HIP events on the launch stream around the 10 stage launches of 5 extra steps after the timed region (gaps between the stages included, the end-of-call fetch not)"},
     }
     return out
@@ -160,7 +165,7 @@ def run_c4(args):
     for arith, p in runs.items():
         res[arith] = c4_parse(args, p.stdout, nr, arith)
     out = res["fast"]
-    out["arith_strict"] = {k: res["strict"][k] for k in ("value", "ms_per_step", "roofline")}
+    out["arith_strict"] = {k: res["strict"][k] for k in ("value", "ms_per_step", "roofline", "roofline_step")}
     out["cpu_baseline"] = None if args.no_cpu_baseline else cloud_cpu_baseline()
     return out
 
@@ -170,25 +175,29 @@ def c4_parse(args, stdout, nr, arith):
         pass
     p.stdout = stdout
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
-    shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches", p.stdout)
-    avg_ms, nl = (float(shape.group(1)), int(shape.group(2))) if shape else (0.0, 0)
+    shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches \((\d+) per step", p.stdout)
+    avg_ms, nl, lps = (float(shape.group(1)), int(shape.group(2)), int(shape.group(3))) if shape else (0.0, 0, 2)
     m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
     vertices = (nr + 1) * (nq + 1)
     ms = [vertices / k for k in kz[args.warmup:]]   # the host prints vertices per ms, like the reference (:858)
     per_step = sum(ms) / len(ms)
     cells = nr * nq
-    bytes_stage = cells * (80 + 120) / 2
+    fused = lps == 1               # the RK2 step as ONE launch (csrc/cloud_fused.hip): charged the whole zone-update's 200 B, moves 120 B per cell
+    bytes_launch = cells * (80 + 120) / lps
+    step_gbs = cells * 200 / (per_step * 1e-3) / 1e9
     return {
         "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, %d GPU" % (nr, nq, args.gpus),
         "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 arith=%s (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % (nr, arith),
-                   "final_state_written": bool(m)},
-        "roofline": {"bound": "hbm", "achieved": bytes_stage / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_stage / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None, "kernel": "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith,
-                     "algorithmic_bytes_per_launch": bytes_stage, "avg_launch_ms": avg_ms, "launches": nl,
-                     "timing": "one pair of HIP events on the launch stream around the two stage launches of each step, inside the timed region"},
+                   "final_state_written": bool(m), "launches_per_step": lps},
+        "roofline": {"bound": "hbm", "achieved": bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None,
+                     "kernel": ("cloud_fused_rk2_kernel (both RK2 stages in one launch per step)" if fused else "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith),
+                     "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms, "launches": nl, "launches_per_step": lps,
+                     "timing": "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"},
+        "roofline_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "note": "200 B per zone-update over the whole host-timed step (nozzle upload and launch gaps included)"},
     }
 
 

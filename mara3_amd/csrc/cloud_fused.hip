@@ -90,6 +90,9 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     }
     const int group = __builtin_amdgcn_readfirstlane(b);
     const int wave_of_group = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+#ifdef MH_CLOUD_FUSED_STAGGER      // probe: the workgroups that share a CU (ids about 256 apart) start a fraction of a row period apart
+    for (int i = 0; i < (int) ((blockIdx.x >> 8) % 3) * MH_CLOUD_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
     const int role = wave_of_group & 1;
     const int pp = wave_of_group >> 1;                  // which pair of the workgroup
     const int lane = threadIdx.x & 63;

@@ -21,6 +21,7 @@
 #include "model_atmosphere.hpp"
 #include "model_jet_nozzle.hpp"
 #include "post_shock_locator.hpp"
+#include "app_parallel.hpp"
 
 namespace cloud_compose {
 
@@ -81,8 +82,11 @@ struct setup_t
     int method = 2;
 };
 
-template<typename U>
-static auto advance(const setup_t& S, U u0, double time, mara::unit_time<double> dt, std::vector<double>* inflow_dump)
+// `evaluate`: nd::to_shared(), or the reference's threaded twin mara::evaluate_on<N>() (app_parallel.hpp:72-103) - upstream pipes
+// `evaluate_on<MARA_PREFERRED_THREAD_COUNT>()` at exactly these six places (:525-533, :582) and keeps nd::to_shared() for the nozzle row and
+// the PLM gradients (:566)
+template<typename U, typename Evaluator>
+static auto advance(const setup_t& S, U u0, double time, mara::unit_time<double> dt, std::vector<double>* inflow_dump, Evaluator evaluate)
 {
     auto source_terms = [] (auto primitive, auto position)
     {
@@ -108,12 +112,12 @@ static auto advance(const setup_t& S, U u0, double time, mara::unit_time<double>
         return inner | nd::concat(array | nd::select_final(1, 0));
     };
 
-    auto rc  = cell_centroids(S.rv, S.qv) | nd::to_shared();
-    auto dv  = cell_volumes(S.rv, S.qv) | nd::to_shared();
-    auto dAr = radial_face_areas(S.rv, S.qv) | nd::to_shared();
-    auto dAq = polar_face_areas(S.rv, S.qv) | nd::to_shared();
+    auto rc  = cell_centroids(S.rv, S.qv) | evaluate;
+    auto dv  = cell_volumes(S.rv, S.qv) | evaluate;
+    auto dAr = radial_face_areas(S.rv, S.qv) | evaluate;
+    auto dAq = polar_face_areas(S.rv, S.qv) | evaluate;
 
-    auto p0 = u0 / dv | nd::map(c2p) | nd::to_shared();
+    auto p0 = u0 / dv | nd::map(c2p) | evaluate;
     auto s0 = nd::zip(p0, rc) | nd::apply(source_terms) | nd::multiply(dv);
 
     auto flux_on = [] (std::size_t axis)
@@ -144,12 +148,36 @@ static auto advance(const setup_t& S, U u0, double time, mara::unit_time<double>
     {
         auto lr = p0 | extend_bc | extrapolate_pcm(0) | flux_on(0)                       | nd::multiply(-dAr) | nd::difference_on_axis(0);
         auto lq = p0 |             extrapolate_pcm(1) | flux_on(1) | nd::extend_zeros(1) | nd::multiply(-dAq) | nd::difference_on_axis(1);
-        return (u0 + (lr + lq + s0) * dt) | nd::to_shared();
+        return (u0 + (lr + lq + s0) * dt) | evaluate;
     }
     auto lr = p0 | extend_bc | extrapolate_plm(0) | flux_on(0)                       | nd::multiply(-dAr) | nd::difference_on_axis(0);
     auto lq = p0 |             extrapolate_plm(1) | flux_on(1) | nd::extend_zeros(1) | nd::multiply(-dAq) | nd::difference_on_axis(1);
-    return (u0 + (lr + lq + s0) * dt) | nd::to_shared();
+    return (u0 + (lr + lq + s0) * dt) | evaluate;
 }
+
+template<typename U>
+static auto advance(const setup_t& S, U u0, double time, mara::unit_time<double> dt, std::vector<double>* inflow_dump)
+{
+    return advance(S, u0, time, dt, inflow_dump, nd::to_shared());
+}
+
+// f(evaluator) with the reference's threaded evaluator on `threads` threads (a template parameter upstream: MARA_PREFERRED_THREAD_COUNT = 12)
+template<class F>
+static auto with_upstream_evaluator(int threads, F f)
+{
+    switch (threads)
+    {
+        case 1:  return f(mara::evaluate_on<1>());
+        case 2:  return f(mara::evaluate_on<2>());
+        case 4:  return f(mara::evaluate_on<4>());
+        case 8:  return f(mara::evaluate_on<8>());
+        case 12: return f(mara::evaluate_on<12>());
+        case 16: return f(mara::evaluate_on<16>());
+        case 32: return f(mara::evaluate_on<32>());
+        default: return f(nd::to_shared());
+    }
+}
+
 
 
 // The sub-program's models, units, vertices and initial state with its option defaults: fills S, returns the cell-integrated conserved

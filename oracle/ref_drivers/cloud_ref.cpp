@@ -24,7 +24,10 @@ using namespace cloud_compose;
 
 int main(int argc, char** argv)
 {
-    if (argc != 8) return 1;
+    if (argc != 8 && argc != 9) return 1;
+    // optional 8th argument: threads = 1, 2, 4, 8, 12, 16 or 32 - the evaluator upstream uses (mara::evaluate_on<threads>(), src/app_parallel.hpp:72-103)
+    // in the place of nd::to_shared(); the bits do not depend on it. bench_configs.py times the reference's own threaded CPU path with it.
+    const int threads = argc == 9 ? std::atoi(argv[8]) : 0;
     int nr = std::atoi(argv[1]);
     double num_decades = std::atof(argv[2]);
     int rk = std::atoi(argv[3]);
@@ -46,16 +49,13 @@ int main(int argc, char** argv)
 
     for (int n = 0; n < nsteps; ++n)
     {
-        if (rk == 1)
+        u = with_upstream_evaluator(threads, [&] (auto evaluate)
         {
-            u = advance(S, u, time, dt, &inflow);
-        }
-        else
-        {
-            auto s1 = advance(S, u, time, dt, &inflow);
-            auto s2 = advance(S, s1, time, dt, nullptr);         // both stages see the step-start time (:468-473, :524)
-            u = (u * 0.5 + s2 * (1 - 0.5)) | nd::to_shared();
-        }
+            if (rk == 1) return advance(S, u, time, dt, &inflow, evaluate);
+            auto s1 = advance(S, u, time, dt, &inflow, evaluate);
+            auto s2 = advance(S, s1, time, dt, nullptr, evaluate);         // both stages see the step-start time (:468-473, :524)
+            return (u * 0.5 + s2 * (1 - 0.5)) | nd::to_shared();
+        });
         time += dt.value;
     }
 

@@ -16,15 +16,19 @@
  * No such sub-program exists upstream; this driver is the
  * oracle for BASELINE configs 2 and 5. Only its OUTPUTS are committed (tests/golden).
  *
- * usage: euler_cart_ref <rank> <n0> <n1> <n2> <gamma> <theta> <rk> <bc> <dt> <d0> <d1> <d2> <nsteps> <in.f64> <out.f64>
+ * usage: euler_cart_ref <rank> <n0> <n1> <n2> <gamma> <theta> <rk> <bc> <dt> <d0> <d1> <d2> <nsteps> <in.f64> <out.f64> [threads]
  *        bc: 0 = zero-gradient (outflow), 1 = periodic; theta<0 => piecewise constant
+ *        threads (PLM, bc 0): 1, 2, 4, 8, 16 or 32 = the step evaluated as upstream evaluates its own (lazy arrays, primitives and result
+ *        through mara::evaluate_on<threads>(), src/app_parallel.hpp:72-103; subprog_cloud.cpp:525-533, :582); -1 = the same composition
+ *        through nd::to_shared(). The bits do not depend on it (tests/test_oracle_golden.py): this is the reference's own CPU path for
+ *        bench.py's cpu_reference.
  *        in/out: row-major AoS [n0][n1][n2][5] doubles (conserved densities)
  */
 #include "euler_cart_compose.hpp"
 using namespace euler_cart;
 
 template<std::size_t Rank>
-static int run(nd::shape_t<Rank> shape, params_t par, int rk, int nsteps, const char* fin, const char* fout)
+static int run(nd::shape_t<Rank> shape, params_t par, int rk, int nsteps, const char* fin, const char* fout, int threads)
 {
     auto u = nd::make_unique_array<cons_t>(shape);
     auto ncell = shape.volume();
@@ -36,6 +40,25 @@ static int run(nd::shape_t<Rank> shape, params_t par, int rk, int nsteps, const 
 
     auto s = cons_array_t<Rank>(std::move(u).shared());
 
+    if (threads != 0)
+    {
+        if (par.theta < 0.0 || par.bc != 0) { std::fprintf(stderr, "threads: PLM with zero-gradient sides only\n"); return 2; }
+        s = with_upstream_evaluator(threads, [&] (auto evaluate)
+        {
+            auto t = s;
+            for (int n = 0; n < nsteps; ++n)
+            {
+                if (rk == 1) t = advance_as_upstream_evaluates<Rank>(t, par, evaluate);
+                else
+                {
+                    auto t2 = advance_as_upstream_evaluates<Rank>(advance_as_upstream_evaluates<Rank>(t, par, evaluate), par, evaluate);
+                    t = (t * 0.5 + t2 * 0.5) | evaluate;          // next_solution, subprog_cloud.cpp:682-695
+                }
+            }
+            return t;
+        });
+        nsteps = 0;
+    }
     for (int n = 0; n < nsteps; ++n)
     {
         if (rk == 1)
@@ -56,7 +79,8 @@ static int run(nd::shape_t<Rank> shape, params_t par, int rk, int nsteps, const 
 
 int main(int argc, char** argv)
 {
-    if (argc != 16) { std::fprintf(stderr, "usage: see header\n"); return 1; }
+    if (argc != 16 && argc != 17) { std::fprintf(stderr, "usage: see header\n"); return 1; }
+    const int threads = argc == 17 ? std::atoi(argv[16]) : 0;
     int rank = std::atoi(argv[1]);
     std::size_t n0 = std::atol(argv[2]), n1 = std::atol(argv[3]), n2 = std::atol(argv[4]);
     params_t par;
@@ -72,9 +96,9 @@ int main(int argc, char** argv)
 
     switch (rank)
     {
-        case 1: return run<1>(nd::make_shape(n0), par, rk, nsteps, argv[14], argv[15]);
-        case 2: return run<2>(nd::make_shape(n0, n1), par, rk, nsteps, argv[14], argv[15]);
-        case 3: return run<3>(nd::make_shape(n0, n1, n2), par, rk, nsteps, argv[14], argv[15]);
+        case 1: return run<1>(nd::make_shape(n0), par, rk, nsteps, argv[14], argv[15], threads);
+        case 2: return run<2>(nd::make_shape(n0, n1), par, rk, nsteps, argv[14], argv[15], threads);
+        case 3: return run<3>(nd::make_shape(n0, n1, n2), par, rk, nsteps, argv[14], argv[15], threads);
     }
     return 1;
 }
