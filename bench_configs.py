@@ -131,19 +131,23 @@ def c3_run(args, binary, cfg, n, arith):
 
 
 def c3_cpu_baseline(binary, cfg):
-    if True:
-        mo = oracle()
-        ocfg = mo.binary_config(depth=4, block_size=64, fixed_dt=1)
-        xv = mo.binary_vertices(ocfg)
-        u0, br, dt = mo.binary_solver_data(ocfg, xv, xv)
-        bodies = binary.two_body_state(binary.initial_elements(cfg), 0.0)
-        t0 = time.perf_counter()
-        u1, _, _ = mo.binary_advance_u(ocfg, xv, xv, u0, u0, br, bodies, dt)
-        mo.binary_advance_u(ocfg, xv, xv, u1, u0, br, bodies, dt)
-        t = time.perf_counter() - t0
-        m = len(xv) - 1
-        return {"value": m * m / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
-                "sample": "one RK2 step (two advance_u stages) at %dx%d (depth=4 block_size=64), oracle/mara_oracle_binary.c, 1 thread" % (m, m)}
+    """the oracle's port of advance_u at the config's FULL size (2048^2, depth=5 block_size=64) on all usable host cores - OpenMP over rows and
+    blocks, the role of the reference's tree.map(fn, pool) (core_tree.hpp:615-625); results independent of the thread count
+    (tests/test_oracle_binary_golden.py)"""
+    from bench import host_cores
+    mo = oracle()
+    cores = host_cores()
+    ocfg = mo.binary_config(depth=5, block_size=64, fixed_dt=1)
+    xv = mo.binary_vertices(ocfg)
+    u0, br, dt = mo.binary_solver_data(ocfg, xv, xv)
+    bodies = binary.two_body_state(binary.initial_elements(cfg), 0.0)
+    t0 = time.perf_counter()
+    u1, _, _ = mo.binary_advance_u(ocfg, xv, xv, u0, u0, br, bodies, dt, nthreads=cores)
+    mo.binary_advance_u(ocfg, xv, xv, u1, u0, br, bodies, dt, nthreads=cores)
+    t = time.perf_counter() - t0
+    m = len(xv) - 1
+    return {"value": m * m / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+            "sample": "one RK2 step (two advance_u stages) at the full %dx%d (depth=5 block_size=64), oracle/mara_oracle_binary.c, %d OpenMP threads" % (m, m, cores)}
 
 
 def run_c4(args):
@@ -151,6 +155,7 @@ def run_c4(args):
     nr = args.grid or 4096
     total = args.warmup + args.steps
     import tempfile
+    identical = None
     with tempfile.TemporaryDirectory() as d:
         runs = {}
         for arith in ("fast", "strict"):
@@ -161,13 +166,32 @@ def run_c4(args):
             runs[arith] = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=1200)
             if runs[arith].returncode != 0:
                 raise SystemExit(runs[arith].stdout[-2000:] + runs[arith].stderr[-2000:])
+        if args.gpus > 1:
+            # the decomposition's own check, as bench.py's for the headline: the slabs' final state against the SAME run on one device (FAST:
+            # two launches per stage and slab against the one-launch step of the whole field) - bit for bit
+            one = subprocess.run([exe, "cloud", "nr=%d" % nr, "num_decades=1", "rk_order=2", "reconstruct_method=2", "plm_theta=1.2", "max_steps=%d" % total,
+                                  "outdir=out_one", "arith=fast"], cwd=d, capture_output=True, text=True, timeout=1200)
+            try:
+                identical = one.returncode == 0 and open(os.path.join(d, "out_one", "final.bin"), "rb").read() == open(os.path.join(d, "out_fast", "final.bin"), "rb").read()
+            except OSError:
+                identical = None
     res = {}
     for arith, p in runs.items():
         res[arith] = c4_parse(args, p.stdout, nr, arith)
     out = res["fast"]
     out["arith_strict"] = {k: res["strict"][k] for k in ("value", "ms_per_step", "roofline", "roofline_step")}
+    if identical is not None:
+        out["slabs_bit_identical_to_one_gpu_run"] = bool(identical)
+        visible = mara_device_count()
+        out["config"]["decomposition"] = ("%d radial slabs (nd::partition_shape), two-row halo per stage, one process driving the devices%s"
+                                          % (args.gpus, "" if visible >= args.gpus else "; REHEARSAL: %d visible device(s), the slabs share them round-robin (peer copies become device-to-device copies)" % visible))
     out["cpu_baseline"] = None if args.no_cpu_baseline else cloud_cpu_baseline()
     return out
+
+
+def mara_device_count():
+    import mara3_amd
+    return mara3_amd.load_library().mh_device_count()
 
 
 def c4_parse(args, stdout, nr, arith):
@@ -209,16 +233,22 @@ def cloud_cpu_baseline():
     exe = os.path.join(ROOT, "oracle", "_ref", "cloud_ref")
     if os.path.exists(exe):
         try:
+            from bench import host_cores, upstream_threads
+            threads = upstream_threads(host_cores())
+            if threads >= 12 and threads < 16:
+                threads = 12                         # upstream's own MARA_PREFERRED_THREAD_COUNT
             nr, few, many = 256, 2, 62
             with tempfile.TemporaryDirectory() as d:
-                def run(nsteps):
+                def run(nsteps, th):
                     t0 = time.perf_counter()
-                    subprocess.run([exe, str(nr), "1", "2", "2", "1.2", str(nsteps), os.path.join(d, "c")], check=True, capture_output=True, timeout=600)
+                    subprocess.run([exe, str(nr), "1", "2", "2", "1.2", str(nsteps), os.path.join(d, "c"), str(th)], check=True, capture_output=True, timeout=600)
                     return time.perf_counter() - t0
-                t = run(many) - run(few)             # set-up, diagnostics and file output cancel
-            return {"value": nr * nr * (many - few) / t / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "reference",
+                t = run(many, threads) - run(few, threads)             # set-up, diagnostics and file output cancel
+                t1 = run(many, 1) - run(few, 1) if threads > 1 else t
+            return {"value": nr * nr * (many - few) / t / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "reference", "one_thread": nr * nr * (many - few) / t1 / 1e6,
                     "sample": "%d RK2 steps of cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 (%d x %d zones), the reference's headers composed as in "
-                              "oracle/ref_drivers/cloud_ref.cpp, 1 thread" % (many - few, nr, nr, nr)}
+                              "oracle/ref_drivers/cloud_ref.cpp through ITS threaded evaluator mara::evaluate_on<%d>() where upstream pipes `| evaluate` "
+                              "(src/subprog_cloud.cpp:525-533, :582); bit-identical to the one-thread run" % (many - few, nr, nr, nr, threads)}
         except Exception:
             pass
     mo = oracle()
@@ -312,6 +342,23 @@ def run_c5_blocks(args):
                                    "timing": "HIP events on the launch stream, 3 extra steps after the timed region"},
                       "messages": {"neighbours": probe.neighbours, "doubles_per_axis": probe.message_doubles}}
         st.close()
+    identical = None
+    if args.loopback_blocks and shape[0] * shape[1] * shape[2] <= 384 ** 3:
+        # the decomposition's own check (as bench.py's for the headline): the union of the blocks against the undivided grid after the same steps
+        from mara3_amd.engine import EulerCartSolver
+        nsteps = 3
+        grp = NativeBlockGroup(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", world=nblocks, device=local_rank, arith="fast")
+        u0 = blast_block(shape, (0, 0, 0), shape, gamma)
+        grp.upload(u0)
+        grp.step(dt, nsteps)
+        grp.synchronize()
+        got = grp.download()
+        grp.close()
+        one = EulerCartSolver(shape, dl, gamma, 1.5, args.riemann, 2, "outflow", arith="fast")
+        one.upload(u0)
+        one.step(dt, nsteps)
+        identical = bool(np.array_equal(got.view(np.uint64), one.download().view(np.uint64)))
+        one.close()
     out = {
         "metric": "zone-updates/sec (Mcells/s), 3D Euler blast %dx%dx%d PLM+%s RK2, (%d,%d,%d) blocks" % (shape + (args.riemann.upper(),) + tuple(B)),
         "value": res["fast"]["value"], "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,6 +370,8 @@ def run_c5_blocks(args):
                    "arith": "fast (headline of this line); strict beside it", "status_word": res["fast"]["status_word"]},
         "roofline": res["fast"]["roofline"], "messages": res["fast"]["messages"], "arith_strict": res["strict"],
     }
+    if identical is not None:
+        out["blocks_bit_identical_to_one_gpu_run"] = identical
     ranks.close()
     return out if rank == 0 else None
 
@@ -377,7 +426,40 @@ def run_c5(args):
         t = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": m ** 3 * 4 / t / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
                                "sample": "4 RK2 steps at %d^3, oracle/mara_oracle.c with %d slab threads" % (m, cores)}
+        ref = c5_cpu_reference(m, gamma)
+        if ref:
+            out["cpu_reference"] = ref
     return out
+
+
+def c5_cpu_reference(m, gamma):
+    """the reference's own lazy-array composition of the 3-D step through its threaded evaluator (oracle/_ref/euler_cart_ref, as bench.py's
+    cpu_reference does for the 2-D headline)"""
+    import tempfile
+    from bench import host_cores, upstream_threads
+    from mara3_amd import setups
+    exe = os.path.join(ROOT, "oracle", "_ref", "euler_cart_ref")
+    if not os.path.exists(exe):
+        return None
+    threads = upstream_threads(host_cores())
+    steps = 2
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+            setups.blast_ic((m, m, m), gamma).tofile(fin)
+            hx = lambda x: float(x).hex()
+            args = [exe, "3", str(m), str(m), str(m), hx(gamma), hx(1.5), "2", "0", hx(setups.baseline_dt(m)), hx(1.0 / m), hx(1.0 / m), hx(1.0 / m)]
+
+            def seconds(nsteps):
+                t0 = time.perf_counter()
+                subprocess.check_call(args + [str(nsteps), fin, fout, str(threads)])
+                return time.perf_counter() - t0
+            t = seconds(steps) - seconds(0)
+    except Exception:
+        return None
+    return {"value": m ** 3 * steps / t / 1e6, "unit": "Mcells/s", "cores": threads, "kind": "reference",
+            "sample": "%d RK2 steps at %d^3 PLM+HLLE, the reference's headers composed and evaluated as its own `advance` is (mara::evaluate_on<%d>()), "
+                      "oracle/ref_drivers/euler_cart_ref.cpp" % (steps, m, threads)}
 
 
 def attach_traffic(out, config):

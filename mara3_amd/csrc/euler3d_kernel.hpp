@@ -71,7 +71,11 @@ struct Tile3d
 {
     double P[2][ROWS3 + 2 * H3][5][W3];
     double U[ROWS3][3][5][W3];             // per-wave private ring: conserved state of planes r, r+1, r+2 (no barrier needed)
+    double F[2][ROWS3][5][W3];             // deferred axis-1 mode only (last member: the other kernels do not allocate it): the flux through the
+                                           // UPPER axis-1 face of each tile row, by plane parity - slot j is written by wave j + 1 (its lower
+                                           // face), slot ROWS3 - 1 by the top wave itself
 };
+template<bool DEFER> constexpr size_t tile3d_bytes() { return DEFER ? sizeof(Tile3d) : sizeof(Tile3d) - sizeof(Tile3d::F); }
 
 __device__ inline void lds_put(double (*dst)[W3], int lane, const State5& s)
 {
@@ -150,8 +154,12 @@ void euler3d_stage_kernel(Stage3dParams p)
     // Rows just outside the tile (two on either side with PLM, one without): the first four waves each fetch one of them
     // per plane and publish its primitives, so that this duty is spread instead of loading the tile's edge waves.
     //   wave 0: row -2   wave 1: row -1   wave 2: row ROWS3   wave 3: row ROWS3 + 1
-    const int eoff = row == 0 ? -2 : (row == 1 ? -1 : (row == 2 ? ROWS3 : ROWS3 + 1));
-    const bool helper = row < 4 && (PLM || row == 1 || row == 2);
+    // (deferred axis-1 mode: waves 0, 1, 2 and 4 - the top wave 7 solves the tile's ninth face, and wave 3 shares its SIMD)
+    constexpr bool DEFER = A::deferred_axis1;
+    static_assert(! DEFER || ! PLM || A::shared_differences, "the deferred axis-1 mode is written for the shared-difference limiter");
+    const int hrow = DEFER ? (row == 3 ? 4 : (row == 4 ? 3 : row)) : row;
+    const int eoff = hrow == 0 ? -2 : (hrow == 1 ? -1 : (hrow == 2 ? ROWS3 : ROWS3 + 1));
+    const bool helper = hrow < 4 && (PLM || hrow == 1 || hrow == 2);
     const unsigned ce = cell_bytes(fold_index(t1 * ROWS3 + eoff, p.n1, p.bc_lo1, p.bc_hi1), kc);
     const int eslot = eoff + H3;
 
@@ -193,6 +201,41 @@ void euler3d_stage_kernel(Stage3dParams p)
         if (writes && !(P[0][4] >= 0.0)) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) r0 * planeu + cellu);
         if (writes && !(P[1][4] >= 0.0) && r0 + 1 < p.n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r0 + 1) * planeu + cellu);
     }
+
+    // ---- deferred axis-1 mode (MH_ARITH_FAST): ONE Riemann problem per axis-1 face. Every wave solves the LOWER face of its row and leaves the
+    // flux in LDS for the wave below it, whose update of that plane then waits one plane step for it: the plane's update is formed up to the
+    // upper-face term (`pending`), and completed behind the NEXT plane's barrier, which makes the neighbour's flux visible. The top wave also
+    // solves the tile's ninth face (it shares its SIMD with wave 3, which has no helper row: the four SIMDs carry 2 x 3 + 1 ... solves).
+    // Same fluxes as the redundant form (it solved each interior face twice on identical inputs); the update adds its terms in another
+    // order - x, z, lower y, upper y - so results differ from that form by rounding, inside MH_ARITH_FAST's tolerance; conservation holds to
+    // rounding as before (both cells of a face take the SAME flux value).
+    // (with the RK average the waiting value is already the weighted sum base (1 - w) + (...) w, and the upper-face term comes in with cy w:
+    // five doubles wait, not ten)
+    State5 pending;
+    const double cy_last = COMBINE ? p.cy * p.weight : p.cy;
+    auto complete_plane = [&] (int rr, int buf) __attribute__((always_inline))
+    {
+        const State5 Fy_hi = lds_get(tile.F[buf][row], lane);
+        State5 Un;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) Un[q] = __builtin_fma(-Fy_hi[q], cy_last, pending[q]);
+        const bool bad_density = writes && !(Un[0] > 0.0);
+        if (__any(bad_density))
+        {
+            if (bad_density) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) rr * planeu + cellu);
+        }
+        if (writes)
+        {
+            store_plane(p.u_out + row_off(rr), plane, cw, Un);
+            if (rr < H3 || rr >= p.n0 - H3)          // keep the physical axis-0 ghost planes of the output current (wave-uniform, cold)
+            {
+                if (p.bc_lo0 == 0 && rr == 0) { store_plane(p.u_out + row_off(-1), plane, cw, Un); store_plane(p.u_out + row_off(-2), plane, cw, Un); }
+                if (p.bc_hi0 == 1 && rr < H3) store_plane(p.u_out + row_off(p.n0 + rr), plane, cw, Un);
+                if (p.bc_hi0 == 0 && rr == p.n0 - 1) { store_plane(p.u_out + row_off(p.n0), plane, cw, Un); store_plane(p.u_out + row_off(p.n0 + 1), plane, cw, Un); }
+                if (p.bc_lo0 == 1 && rr >= p.n0 - H3) store_plane(p.u_out + row_off(rr - p.n0), plane, cw, Un);
+            }
+        }
+    };
 
     // One plane. ONE workgroup barrier: before it every wave publishes the primitives of its row of plane r (and the helper
     // waves those of the outside rows) and does the axis-0 and axis-2 work, which needs no other wave; after it every wave
@@ -248,10 +291,65 @@ void euler3d_stage_kernel(Stage3dParams p)
         }
         Fz_hi = dpp3_right(Fz_lo);
 
+        // deferred axis-1 mode: the update with the axis-0 and axis-2 terms already in it crosses the barrier (5 doubles instead of 4 fluxes)
+        State5 Uxz;
+        if constexpr (DEFER)
+        {
+            const State5 Ucur = lds_get(tile.U[row][K0], lane);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Uxz[q] = __builtin_fma(-(Fz_hi[q] - Fz_lo[q]), p.cz, __builtin_fma(-(Fx[K1][q] - Fx[K0][q]), p.cx, Ucur[q]));
+        }
+
         if (helper) lds_put(tile.P[pb][eslot], lane, A::c2p(Ue, gl));
 #ifndef MH_E3D_NOBARRIER      // diagnostic builds only: wrong results, shows what the barrier costs
         __syncthreads();
 #endif
+        if constexpr (DEFER)
+        {
+            // ---- the plane that has been waiting for its upper-face flux
+            if (r > r0) complete_plane(r - 1, pb ^ 1);
+            State5 Ubase;
+            if constexpr (COMBINE) Ubase = load_plane(p.u_base + row_off(r), plane, c0);
+            // ---- axis 1: the lower face of this row (the top wave: the tile's top face too), handed to the row below through LDS
+            State5 Fy_lo;
+            const State5 Pm1 = lds_get(tile.P[pb][row + H3 - 1], lane);
+            if constexpr (PLM)
+            {
+                const State5 Pp1 = lds_get(tile.P[pb][row + H3 + 1], lane);
+                const State5 Dm = A::difference(Pm1, P[K0]), Dp = A::difference(P[K0], Pp1);
+                const State5 Gy = A::plm_from_differences(Dm, Dp, lim);
+                {
+                    const State5 Pm2 = lds_get(tile.P[pb][row + H3 - 2], lane);
+                    Fy_lo = A::template flux<RIEMANN, 1>(A::plus(Pm1, A::plm_from_differences(A::difference(Pm2, Pm1), Dm, lim), lim), A::minus(P[K0], Gy, lim), gl);
+                }
+                if (row == ROWS3 - 1)
+                {
+                    const State5 Pp2 = lds_get(tile.P[pb][row + H3 + 2], lane);
+                    lds_put(tile.F[pb][ROWS3 - 1], lane,
+                            A::template flux<RIEMANN, 1>(A::plus(P[K0], Gy, lim), A::minus(Pp1, A::plm_from_differences(Dp, A::difference(Pp1, Pp2), lim), lim), gl));
+                }
+            }
+            else
+            {
+                Fy_lo = A::template flux<RIEMANN, 1>(Pm1, P[K0], gl);
+                if (row == ROWS3 - 1) lds_put(tile.F[pb][ROWS3 - 1], lane, A::template flux<RIEMANN, 1>(P[K0], lds_get(tile.P[pb][row + H3 + 1], lane), gl));
+            }
+            if (row > 0) lds_put(tile.F[pb][row - 1], lane, Fy_lo);
+
+            // ---- this plane's update up to the upper-face term
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+            {
+                const double u1 = __builtin_fma(Fy_lo[q], p.cy, Uxz[q]);
+                if constexpr (COMBINE) pending[q] = A::combine(Ubase[q], u1, p.weight);
+                else                   pending[q] = u1;
+            }
+            if (__any(bad_pressure))
+            {
+                if (bad_pressure && r + 2 < p.n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (r + 2) * planeu + cellu);
+            }
+            return;
+        }
         State5 Ubase;
         if constexpr (COMBINE) Ubase = load_plane(p.u_base + row_off(r), plane, c0);
 
@@ -331,6 +429,12 @@ void euler3d_stage_kernel(Stage3dParams p)
     }
     if (r < r1) plane_step(r, std::integral_constant<int, 0>());
     if (r + 1 < r1) plane_step(r + 1, std::integral_constant<int, 1>());
+    if constexpr (DEFER)
+    {
+        // the chunk's last plane: one more barrier makes its upper-face fluxes visible
+        __syncthreads();
+        complete_plane(r1 - 1, (r1 - 1) & 1);
+    }
 
     acc.commit(p.status);
 }
@@ -339,18 +443,18 @@ template<class A, int RIEMANN, bool PLM, bool COMBINE>
 inline hipError_t launch3(const Stage3dParams& p, int nblocks, hipStream_t stream)
 {
     auto kernel = euler3d_stage_kernel<A, RIEMANN, PLM, COMBINE>;
-    // 120 KB of LDS per workgroup: dynamic + opt-in, once per DEVICE (a process may hold contexts on several)
+    // 120 KB of LDS per workgroup (deferred axis-1 mode: all 160 KB): dynamic + opt-in, once per DEVICE (a process may hold contexts on several)
     static std::atomic<uint64_t> attr_set_on(0);
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (! (attr_set_on.load(std::memory_order_acquire) & bit))
     {
-        hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof(Tile3d));
+        hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) tile3d_bytes<A::deferred_axis1>());
         if (e != hipSuccess) return e;
         attr_set_on.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(W3 * ROWS3), sizeof(Tile3d), stream, p);
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(W3 * ROWS3), tile3d_bytes<A::deferred_axis1>(), stream, p);
     return hipGetLastError();
 }
 

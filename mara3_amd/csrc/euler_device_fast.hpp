@@ -58,10 +58,28 @@ __device__ inline double sqrt_fast(double x)
 // - both positive: min(b, min(a, c)); both negative: max(b, max(a, c)); mixed: 0. Same value as the reference's
 // 0.25*|sgn a + sgn b|*(sgn a + sgn c)*min(|a|,|b|,|c|) for finite arguments (the sign of an exact zero may differ); 6 fp64
 // instructions, no selects and no integer sign logic.
+// The six operations are written as the instructions themselves (MH_FAST_ASM_MINMOD, default): v_min_f64 / v_max_f64 are what __builtin_fmin /
+// __builtin_fmax become, but in front of them the compiler canonicalises (v_max_f64 x, x) every operand it cannot prove free of signalling NaNs -
+// each value that reached the lane through a DPP move, 10 of the row loop's ~465 VALU instructions per wave and row in the 2-D kernels. The
+// instructions quiet such operands themselves (IEEE mode), so the result is the same bit for bit.
+#ifndef MH_FAST_ASM_MINMOD
+#define MH_FAST_ASM_MINMOD 1
+#endif
 __device__ inline double minmod_between(double a, double b, double c)
 {
+#if MH_FAST_ASM_MINMOD && defined(__HIP_DEVICE_COMPILE__)
+    double lo, hi, t;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(c));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(c));
+    asm("v_max_f64 %0, %1, 0" : "=v"(lo) : "v"(lo));
+    asm("v_min_f64 %0, %1, 0" : "=v"(hi) : "v"(hi));
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(b), "v"(lo));
+    asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(t), "v"(hi));
+    return t;
+#else
     const double lo = __builtin_fmin(a, c), hi = __builtin_fmax(a, c);
     return __builtin_fmax(__builtin_fmin(b, __builtin_fmax(lo, 0.0)), __builtin_fmin(hi, 0.0));
+#endif
 }
 
 __device__ inline double plm_gradient(double yl, double y0, double yr, double theta)
@@ -252,6 +270,7 @@ struct StrictArith
 {
     static constexpr int min_waves_per_simd = 2;
     static constexpr int min_waves_first_stage = 2;
+    static constexpr bool deferred_axis1 = false;           // (euler3d_kernel.hpp) the update keeps the reference's order of terms
     static constexpr bool shared_differences = false;       // the reference's plm_gradient takes the three values, bit for bit
     static constexpr bool recompute_conserved = false;      // the update starts from the stored conserved state, bit for bit
     static constexpr bool lds_conserved_ring = false;
@@ -299,6 +318,12 @@ struct FastArith
     // and the factor theta / 2 of the half-cell extrapolation rides in the FMA that forms the face state. 1 + 2 + 6 fp64 instructions
     // per variable and axis (the difference, the central term, the limiter) where the three-value form takes 13.
     static constexpr bool shared_differences = true;
+    // euler3d_kernel.hpp: one Riemann problem per axis-1 face, handed to the neighbouring wave through LDS, the update of a plane completed one
+    // plane step later (MH_E3D_DEFER=0 builds the redundant-flux form: two solves per interior face, update in one piece)
+#ifndef MH_E3D_DEFER
+#define MH_E3D_DEFER 1
+#endif
+    static constexpr bool deferred_axis1 = MH_E3D_DEFER != 0;
     // The 2-D stage kernel converts a loaded row to primitives once and keeps only those in its register window (no register-to-register
     // moves in the row loop, 20 VGPRs fewer); the conserved values the update starts from wait in a per-wave LDS ring meanwhile
     // (lds_conserved_ring; euler2d.hip). The first version re-formed them from the primitives instead (p2c, 8 instructions, equal to the

@@ -545,11 +545,13 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
     {
         slabs[r]->peer_lo = slabs[r]->lo >= 0 ? slabs[slabs[r]->lo] : nullptr;
         slabs[r]->peer_hi = slabs[r]->hi >= 0 ? slabs[slabs[r]->hi] : nullptr;
+        // MH_SLAB_TEST_PEER_FAIL=1 (tests on a one-GPU box): take the branch as if a neighbour lived on a device that refuses peer access
+        const bool refuse = getenv("MH_SLAB_TEST_PEER_FAIL") && atoi(getenv("MH_SLAB_TEST_PEER_FAIL")) != 0;
         for (mh_slab* p : {slabs[r]->peer_lo, slabs[r]->peer_hi})
-            if (p && p->device != slabs[r]->device)
+            if (p && (p->device != slabs[r]->device || refuse))
             {
                 hipError_t e = hipSetDevice(slabs[r]->device);
-                if (e == hipSuccess) e = hipDeviceEnablePeerAccess(p->device, 0);
+                if (e == hipSuccess) e = refuse ? hipErrorInvalidDevice : hipDeviceEnablePeerAccess(p->device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
                 {
                     const int rc = hip_fail(e, "hipDeviceEnablePeerAccess");      // the error text before the destructors' own HIP calls

@@ -169,6 +169,8 @@ typedef struct
     int    angmom_form;
 } mo_binary_model;
 /* bodies = (mass, x, y, vx, vy) of body 1 then body 2; fields are [n][n][3] row-major in (Sigma, px, py); returns 1 where validate_u throws */
+/* threads of mo_binary_advance_u (OpenMP over rows / blocks - the role of the reference's tree.map(fn, pool)); results do not depend on it */
+void   mo_binary_set_threads(int n);
 int    mo_binary_advance_u(const mo_binary_params* P, const double* xv, const double* yv, const double* u0, const double* u_init,
                            const double* br, const double bodies[10], double dt, double* u1, double totals[MO_BINARY_NTOTALS]);
 double mo_binary_maximum_timestep(const mo_binary_params* P, const double* xv, const double* yv, const double* u, const double bodies[10]);

@@ -408,6 +408,8 @@ def _binary_lib():
         L.mo_binary_solver_data.restype = C.c_double
         L.mo_binary_diagnostics.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp]
         L.mo_binary_diagnostics.restype = None
+        L.mo_binary_set_threads.argtypes = [C.c_int]
+        L.mo_binary_set_threads.restype = None
         L._binary_ready = True
     return L
 
@@ -429,9 +431,10 @@ def binary_solver_data(cfg, xv, yv):
     return u, br, dt
 
 
-def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False):
-    """-> (u1, totals[18], negative_density)"""
+def binary_advance_u(cfg, xv, yv, u0, u_init, br, bodies, dt, safe_mode=False, nthreads=1):
+    """-> (u1, totals[18], negative_density); nthreads: OpenMP threads over rows / blocks (the results do not depend on it)"""
     P = _binary_params(cfg, safe_mode, xv, yv)
+    _binary_lib().mo_binary_set_threads(int(nthreads))
     u0 = _f64(u0)
     u1 = np.zeros_like(u0)
     tot = np.zeros(BINARY_NTOTALS)

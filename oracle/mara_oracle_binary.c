@@ -121,6 +121,9 @@ static int tree_depth(int n, int bs)
     return depth;
 }
 
+static int binary_threads = 1;
+void mo_binary_set_threads(int n) { binary_threads = n > 0 ? n : 1; }
+
 int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const double* yv, const double* u0, const double* u_init,
     const double* br, const double bodies[10], double dt, double* u1, double totals[MO_BINARY_NTOTALS])
 {
@@ -136,6 +139,10 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
     double* fy = malloc((size_t) N * (N + 1) * 3 * sizeof(double));
     double* blk = calloc((size_t) MO_BINARY_NTOTALS * nb * nb, sizeof(double));
 
+    /* threads (mo_binary_set_threads; 1 by default): every pass below writes disjoint cells / faces / blocks, and the totals are folded from the
+     * per-block values in tree order afterwards, so the results do not depend on the thread count - the role of the reference's
+     * tree.map(fn, pool) over blocks (core_tree.hpp:615-625, core_thread_pool.hpp:47-189) */
+#pragma omp parallel for schedule(static) num_threads(binary_threads)
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
         {
@@ -144,6 +151,7 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
             if (P->angmom_form) mo_iso2d_recover_primitive_angmom(u0 + 3 * n, x, p + 3 * n);
             else                mo_iso2d_recover_primitive(u0 + 3 * n, p + 3 * n);
         }
+#pragma omp parallel for schedule(static) num_threads(binary_threads)
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j)
             for (int q = 0; q < 3; ++q)
@@ -152,6 +160,7 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
                 gy[3 * AT(i, j) + q] = mo_plm_gradient(p[3 * AT(i, j - 1) + q], p[3 * AT(i, j) + q], p[3 * AT(i, j + 1) + q], th) / spacing;
             }
     /* block_fluxes_u :472-516 — a block's outer faces sit at its own vertices, so both sides of the periodic seam are evaluated */
+#pragma omp parallel for schedule(static) num_threads(binary_threads)
     for (int i = 0; i <= N; ++i)
         for (int j = 0; j < N; ++j)
         {
@@ -160,6 +169,7 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
             double dy = yv[j + 1] - yv[j];
             for (int q = 0; q < 3; ++q) fx[((size_t) i * N + j) * 3 + q] = F[q] * dy;
         }
+#pragma omp parallel for schedule(static) num_threads(binary_threads)
     for (int i = 0; i < N; ++i)
         for (int j = 0; j <= N; ++j)
         {
@@ -172,6 +182,7 @@ int mo_binary_advance_u(const mo_binary_params* P, const double* xv, const doubl
     const double rs2 = P->softening_radius * P->softening_radius;
     const double s2 = P->sink_radius * P->sink_radius;
     int negative = 0;
+#pragma omp parallel for collapse(2) schedule(static) reduction(|:negative) num_threads(binary_threads)
     for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj < nb; ++bj)
         {

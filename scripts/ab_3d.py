@@ -7,7 +7,7 @@ import json, sys, time
 sys.path.insert(0, %r)
 from mara3_amd import setups
 from mara3_amd.engine import EulerCartSolver
-n, gamma = 384, 5.0 / 3
+n, gamma = int(%r), 5.0 / 3
 out = {}
 for arith in ("fast", "strict"):
     s = EulerCartSolver((n, n, n), (1.0 / n,) * 3, gamma, 1.5, "hlle", 2, "outflow", arith=arith)
@@ -16,7 +16,7 @@ for arith in ("fast", "strict"):
     t0 = time.perf_counter(); s.step(dt, 10); s.synchronize(); out[arith] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
     s.close()
 print(json.dumps(out))
-''' % ROOT
+''' % (ROOT, os.environ.get('MH_AB_GRID', '384'))
 for rnd in range(2):
     for name in sys.argv[1:]:
         env = dict(os.environ); env["MARA_HIP_LIBRARY"] = os.path.join(ROOT, "build", "variants", name, "libmara_hip.so")

@@ -65,3 +65,38 @@ def test_bench_loopback_rehearsal_of_the_multi_gpu_path(cuts):
     assert d["slabs_bit_identical_to_one_gpu_run"] is True
     assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["status_word"] == 0
     assert ("one exchange per step" in d["config"]["timed_region"]) == (cuts is None)
+
+
+def run_configs(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py")] + extra, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_config4_rehearsal_of_the_four_slab_run_checks_itself():
+    """`bench_configs.py --config c4 --gpus 4` on this one-GPU box: the compiled host drives four radial slabs of the native stepper (the slabs
+    share the device, peer copies become device-to-device copies), incl. the per-step nozzle row that only the slab owning row 0 reads - and
+    the line says whether their union equals the one-device run (whose FAST step is the ONE-launch kernel) bit for bit"""
+    d = run_configs(["--config", "c4", "--gpus", "4", "--grid", "256", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["slabs_bit_identical_to_one_gpu_run"] is True and d["n_gpus"] == 4 and d["value"] > 0
+    assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["launches_per_step"] == 2
+
+
+def test_config5_rehearsal_of_the_eight_block_run_checks_itself():
+    """`bench_configs.py --config c5 --loopback-blocks 8`: the (2,2,2) blocks of propose_block_decomposition<3>(8) as objects of one process,
+    the line carries `blocks_bit_identical_to_one_gpu_run`"""
+    d = run_configs(["--config", "c5", "--loopback-blocks", "8", "--grid", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["blocks_bit_identical_to_one_gpu_run"] is True and d["value"] > 0 and d["arith_strict"]["status_word"] == 0
+
+
+def test_config4_one_gpu_line_reports_the_fused_launch():
+    d = run_configs(["--config", "c4", "--grid", "512", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    r = d["roofline"]
+    assert d["config"]["launches_per_step"] == 1 and "cloud_fused_rk2_kernel" in r["kernel"] and r["launches_per_step"] == 1
+    assert r["algorithmic_bytes_per_launch"] == 200 * 512 * 512 and 0.0 < r["frac"] < 1.0
+    # kernel time <= step time: the profile pass brackets several launches with ONE pair of events
+    assert r["avg_launch_ms"] <= 1.05 * d["ms_per_step"]
+    s = d["arith_strict"]
+    assert s["roofline"]["launches_per_step"] == 2 and s["value"] > 0

@@ -350,3 +350,43 @@ def test_group_fused_step_across_cuts_on_random_shapes(eng, monkeypatch):
             assert bits_equal(grp.download(), ref.download()), (case, shape, world, bc, riemann, chunk, nsteps)
         assert grp.status() == (0, None)
         grp.close(); ref.close()
+
+
+def test_group_create_on_leaves_no_slab_behind_when_a_device_is_missing_or_refuses_peer_access(eng, monkeypatch):
+    """mh_slab_group_create_on (one process driving several GPUs; the reference's thread slabs, src/app_parallel.hpp:75-103) must not leak members
+    when it fails half-way. (i) a device id this box does not have: the members created before it are destroyed, every handle of the caller's
+    array is null, the text names the device. (ii) the branch behind hipDeviceEnablePeerAccess - unreachable with one GPU, so the library takes
+    it on request (MH_SLAB_TEST_PEER_FAIL=1): ALL members are destroyed, the array nulled, and the text is the peer-access failure, not a
+    later destructor's."""
+    import ctypes as C
+    from mara3_amd import _lib as L
+    from mara3_amd.slab import euler_cart_desc
+    lib = L.load_library()
+    world, shape = 3, (48, 40)
+    d = euler_cart_desc(shape, (1.0 / 48, 1.0 / 40), 1.4, 1.5, "hllc", "outflow", 0, "fast")
+    handles = (C.c_void_p * world)(*[C.c_void_p(0xdead)] * world)
+    ids = (C.c_int * world)(0, 0, lib.mh_device_count() + 5)
+    rc = lib.mh_slab_group_create_on(handles, C.byref(d), 2, world, ids)
+    assert rc != 0 and all(not h for h in handles), (rc, list(handles))
+    assert b"device" in lib.mh_last_error(None)
+    monkeypatch.setenv("MH_SLAB_TEST_PEER_FAIL", "1")
+    handles = (C.c_void_p * world)(*[C.c_void_p(0xdead)] * world)
+    ids = (C.c_int * world)(0, 0, 0)
+    rc = lib.mh_slab_group_create_on(handles, C.byref(d), 2, world, ids)
+    assert rc != 0 and all(not h for h in handles), (rc, list(handles))
+    assert b"hipDeviceEnablePeerAccess" in lib.mh_last_error(None), lib.mh_last_error(None)
+    monkeypatch.delenv("MH_SLAB_TEST_PEER_FAIL")
+    # and the library is still usable: the same group without the hook steps as ever
+    g = eng_slab_group(shape, world)
+    g.close()
+
+
+def eng_slab_group(shape, world):
+    from mara3_amd.slab import NativeSlabGroup
+    from mara3_amd import setups
+    g = NativeSlabGroup(shape, (1.0 / shape[0], 1.0 / shape[1]), 1.4, 1.5, "hllc", 2, "outflow", world=world, arith="fast")
+    g.upload(setups.wave_ic(shape, 1.4, seed=2))
+    g.step(2e-4, 2)
+    g.synchronize()
+    assert g.status()[0] == 0
+    return g

@@ -53,3 +53,20 @@ def test_diagnostics_vs_reference_composition(name, oracle):
     mass, lz, fields = oracle.binary_diagnostics(q, g["blocks"], g["xv"], g["u_final"])
     assert mass == g["diag_scalars"][0] and lz == g["diag_scalars"][1]
     assert bits_equal(fields, g["diag_fields"])
+
+
+def test_binary_port_threads_do_not_change_results():
+    """mo_binary_set_threads: OpenMP over rows and blocks (the role of the reference's tree.map(fn, pool), core_tree.hpp:615-625) - field, totals
+    and the negative-density flag are those of the one-thread run, bit for bit (bench_configs.py times the port on all host cores)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import mara_oracle as mo
+    cfg = mo.binary_config(depth=2, block_size=16, fixed_dt=1)
+    xv = mo.binary_vertices(cfg)
+    u0, br, dt = mo.binary_solver_data(cfg, xv, xv)
+    bodies = np.array([0.5, 0.5, 0.0, 0.0, 0.5, 0.5, -0.5, 0.0, 0.0, -0.5])
+    one = mo.binary_advance_u(cfg, xv, xv, u0, u0, br, bodies, dt, nthreads=1)
+    for th in (2, 5, 8):
+        many = mo.binary_advance_u(cfg, xv, xv, u0, u0, br, bodies, dt, nthreads=th)
+        assert np.array_equal(one[0].view(np.uint64), many[0].view(np.uint64)) and np.array_equal(one[1].view(np.uint64), many[1].view(np.uint64)) and one[2] == many[2]
