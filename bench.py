@@ -174,7 +174,8 @@ def extra_configs():
     preconditioning covers (about 25 launches) and the timed region is tens of milliseconds."""
     import subprocess
     out = {}
-    for cfg, steps, warmup in (("c3", 100, 60), ("c4", 20, 10), ("c5", 10, 4)):
+    # (c4 FAST is ONE launch per step since round 4: 30 warm-up steps, where 10 two-launch steps used to cover the ramp)
+    for cfg, steps, warmup in (("c3", 100, 60), ("c4", 30, 30), ("c5", 10, 4)):
         try:
             p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py"), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup)],
                                capture_output=True, text=True, timeout=900)

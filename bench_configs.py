@@ -480,18 +480,20 @@ def attach_traffic(out, config):
                 continue
             tag = "c4s" if (config == "c4" and mode == "Strict") else names[0]
             keys = ["%s:%s" % (tag, n % mode) for n in names[1:]]
-            if config == "c5":
-                continue          # recorded at 384^3, the bench runs 512^3: not comparable per launch
+            if config == "c4" and mode == "Fast" and roof.get("launches_per_step") == 1:
+                keys = ["c4:cloud_fused_rk2_kernel"]           # the RK2 step's one launch
             if all(k in t for k in keys):
-                roof["traffic"] = 0.5 * (t[keys[0]] + t[keys[1]])
+                roof["traffic"] = sum(t[k] for k in keys) / len(keys)
             fk = [k + ":fp64" for k in keys]
             if all(k in t for k in fk):
-                flops = 0.5 * (t[fk[0]]["fp64_flops_per_launch"] + t[fk[1]]["fp64_flops_per_launch"])
+                flops = sum(t[k]["fp64_flops_per_launch"] for k in fk) / len(fk)
                 tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
                 roof["fp64"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                "valu_busy": 0.5 * (t[fk[0]]["valu_busy"] + t[fk[1]]["valu_busy"]),
-                                "note": "recorded SQ counters (profiles/r02/kernels_configs.md), this run's duration"}
+                                "valu_busy": sum(t[k]["valu_busy"] for k in fk) / len(fk),
+                                "note": "recorded SQ counters (profiles/r04/kernels_configs.md), this run's duration"}
                 roof["bound_measured"] = "fp64 issue (VALU-busy %.2f); the HBM figure above is the contract's roofline" % roof["fp64"]["valu_busy"]
+                if roof.get("traffic"):
+                    roof["frac_measured_traffic"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     except Exception:
         pass
     return out

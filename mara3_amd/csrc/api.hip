@@ -31,6 +31,10 @@ void set_error(const char* fmt, ...)
 int hip_fail(hipError_t e, const char* what)
 {
     set_error("HIP error %d (%s) in %s", (int) e, hipGetErrorString(e), what);
+    // the runtime keeps the last error until somebody reads it: a REPORTED failure (e.g. a device id the box does not have) must not come
+    // back out of the hipGetLastError() behind the next, healthy launch of this thread (tests/test_gpu_slab_group.py: a group that failed to
+    // build, then one that steps)
+    (void) hipGetLastError();
     return MH_E_HIP;
 }
 

@@ -52,7 +52,7 @@ def table(tags, part):
              % (ffac, wfac), "=> HBM bytes per launch = %.0f x FETCH_SIZE + %.0f x WRITE_SIZE (KB x 1024)." % (round(ffac), round(wfac)), "",
              "| run | kernel | avg us (kernel trace, ALL launches of the run: cold first ones included) | min us | calls | HBM MB / launch | VALU instr / launch | VALU busy | wait-on-instr | fp64 TFLOP/s | of 78.6 |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
-    if part == "headline" and ROUND == "r03":
+    if part == "headline" and ROUND >= "r03":
         own = {}
         try:
             for l in open(os.path.join(OUT, "fast_hllc_trace.json")):
@@ -61,14 +61,24 @@ def table(tags, part):
         except OSError:
             pass
         tr0 = trace("fast_hllc").get("euler2d_fused_rk2_kernel<1>", (0.0, 0, 0.0))
-        lines[3:3] = ["Kernel traces of the headline variants: `scripts/profile_r3.sh headline_trace` (`bench.py --steps 200`: 283 launches per kernel, so that the cold launches - the first ~25 after",
-                      "an idle period run up to twice as long - do not carry the average; the counters come from the 20-step runs of `headline` / `headline2`). The same command's own bench line is",
+        lines[3:3] = ["Kernel traces of the headline variants: `bench.py --steps 200` under `rocprofv3 --kernel-trace --stats` (283 launches per kernel, so that the cold launches - the first ~25 after",
+                      "an idle period run up to twice as long - do not carry the average; the counters come from 20-step runs). Since round 4 the tracked `kernel_stats_<run>.csv` beside this file ARE these traces",
+                      "(tests/test_profiles_cpu.py holds the table to them). The same command's own bench line is",
                       "`bench_under_rocprof_trace_<run>.json`: for the fused kernel %.3f ms per launch (one pair of events around five launches, gaps included) and %.3f ms per timed step against"
                       % (own.get("roofline", {}).get("avg_launch_ms", 0.0), own.get("ms_per_step", 0.0)),
                       "this trace's %.3f ms average / %.3f ms minimum (same process, same box; boxes differ by 2 - 3 %%)." % (tr0[0] / 1e6, tr0[2] / 1e6), ""]
     traffic, extra = {}, {}
     for tag in tags:
         tr = trace(tag)
+        if ROUND >= "r04":          # the trace this table quotes, tracked beside it
+            for f in glob.glob(os.path.join(OUT, tag + "_trace", "**", "*kernel_stats.csv"), recursive=True):
+                rows = [l for l in open(f) if l.startswith('"Name"') or "mh::" in l]
+                open(os.path.join(DST, "kernel_stats_%s.csv" % tag), "w").write("".join(rows))
+            own_line = os.path.join(OUT, tag + "_trace.json")
+            if os.path.exists(own_line):
+                keep = [l for l in open(own_line) if l.startswith("{")]
+                if keep:
+                    open(os.path.join(DST, "bench_under_rocprof_trace_%s.json" % tag), "w").write(keep[-1])
         fe, _ = counters(tag, "fetch")
         wr, _ = counters(tag, "write")
         sq, _ = counters(tag, "sq")
@@ -120,7 +130,7 @@ if __name__ == "__main__":
         json.dump(out, open(path, "w"), indent=1)
         print(json.dumps(out, indent=1)[:1500])
     else:
-        tr, ex = table(["c3", "c4", "c4s", "c5"], "configs")
+        tr, ex = table(["c3", "c4", "c4two", "c4s", "c5"] if ROUND >= "r04" else ["c3", "c4", "c4s", "c5"], "configs")
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         t = json.load(open(path))
         for (tag, k), v in tr.items():
