@@ -205,6 +205,9 @@ def main():
                          "uploading the initial condition) run up to 25 %% slower while the clocks settle (kernel trace, DESIGN.md §6); 0 = off")
     ap.add_argument("--no-fuse", action="store_true",
                     help="headline leg as two launches per RK2 step instead of the fused one (euler2d_fused.hip; FAST arithmetic, one GPU)")
+    ap.add_argument("--no-planar", action="store_true",
+                    help="headline leg on the GENERAL fused kernel: by default the library verifies at upload that this 2-D field has no third momentum and "
+                         "then skips that component (mh_euler_cart_desc.planar; same bits in the other four)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
@@ -250,8 +253,8 @@ def main():
 
     class GroupAsStepper:
         """--loopback-slabs: the N slab objects of one process behind the stepper interface the timing code uses"""
-        def __init__(self, arith, riemann, bc):
-            self.g = NativeSlabGroup((n, n), dl, gamma, args.theta, riemann, 2, bc, world=nslabs, device=local_rank, chunk_rows=args.chunk_rows, arith=arith)
+        def __init__(self, arith, riemann, bc, planar=None):
+            self.g = NativeSlabGroup((n, n), dl, gamma, args.theta, riemann, 2, bc, world=nslabs, device=local_rank, chunk_rows=args.chunk_rows, arith=arith, planar=planar)
             self.row0, self.row1 = 0, n
             self.member = NativeSlabStepper((n, n), dl, gamma, handle=torch_free_handle(self.g, nslabs // 2))      # profiled member: an inner rank
         def load_slab(self, u): self.g.upload(u)
@@ -259,6 +262,7 @@ def main():
         def synchronize(self): self.g.synchronize()
         def profile(self, on): self.member.profile(on)
         def profile_read(self): return self.member.profile_read()
+        def is_planar(self): return self.member.is_planar()
         def status(self): return self.g.status()[0]
         def slab_host(self): return self.g.download()
         def close(self):
@@ -269,15 +273,19 @@ def main():
         import ctypes
         return ctypes.c_void_p(group.handles[r])
 
-    def make_stepper(arith, riemann, bc, fuse=None):
+    def make_stepper(arith, riemann, bc, fuse=None, planar=None):
+        # planar: None = the library's own check of the uploaded field (one GPU, loopback groups); with ranks in other processes the bench
+        # ASSERTS what it knows of its initial conditions (each rank's upload still verifies its own rows); False = the general kernel
+        if planar is None and world > 1:
+            planar = True
         if args.loopback_slabs:
-            return GroupAsStepper(arith, riemann, bc)
+            return GroupAsStepper(arith, riemann, bc, planar)
         if state["stepper"] == "native":
             st, err = None, None
             try:
                 # without a communicator first: ncclCommInitRank is collective, so every rank must have got this far before any enters it
                 st = NativeSlabStepper((n, n), dl, gamma, args.theta, riemann, 2, bc, rank=rank, world=world,
-                                       comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith, fuse=fuse)
+                                       comm_id=None, device=local_rank, chunk_rows=args.chunk_rows, arith=arith, fuse=fuse, planar=planar)
             except mara3_amd.MaraHipError as e:
                 err = e
             if ranks.agree(st is not None):                       # every rank must take the same path
@@ -308,7 +316,7 @@ def main():
             return setups.blast_ic((n, n), gamma, row_range=(row0, row1))
         return setups.smooth_wave_ic((n, n), gamma, row_range=(row0, row1))
 
-    def run_leg(arith, riemann, workload, nblocks=1, keep_state=False, fuse=None):
+    def run_leg(arith, riemann, workload, nblocks=1, keep_state=False, fuse=None, planar=None):
         """W untimed + K timed steps (+ nblocks - 1 further timed blocks of K) of the whole grid, then a short profiled pass.
         fuse: None = the library's choice (one fused launch per RK2 step where it exists: FAST arithmetic on one GPU), False = two launches."""
         bc = "outflow" if workload == "blast" else "periodic"
@@ -316,15 +324,17 @@ def main():
         native = state["stepper"] == "native" or bool(args.loopback_slabs)
         if native and args.warmup == 0:      # with W >= 1 the warm-up steps do this (and a profile of the run shows the workload's launches only)
             prime(arith, riemann)
-        st = make_stepper(arith, riemann, bc, fuse)
+        st = make_stepper(arith, riemann, bc, fuse, planar)
         native = not isinstance(st, SlabEulerStepper)
         st.load_slab(initial_state(workload, st.row0, st.row1))
+        took_planar = bool(native and st.is_planar())
         if args.precondition > 0:
             # Clock settling, not part of the workload: building and uploading the initial condition leaves the GPU idle for a few hundred
             # ms, and the first ~25 stage launches after an idle period run up to 25 % slower (kernel trace). A scratch grid of
             # this rank's size is stepped right before the W warm-up steps of the real one.
             rows = max(64, min(n, st.row1 - st.row0))
-            scratch = NativeSlabStepper((rows, n), dl, gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith, fuse=fuse)
+            scratch = NativeSlabStepper((rows, n), dl, gamma, args.theta, riemann, 2, "outflow", device=local_rank, arith=arith, fuse=fuse,
+                                        planar=False if planar is False else None)
             scratch.load_slab(setups.blast_ic((rows, n), gamma))
             scratch.step(dt, args.precondition)
             if os.environ.get("MH_BENCH_PRECONDITION_GAP"):      # the first version: the scratch grid is released before the warm-up steps start
@@ -411,18 +421,19 @@ def main():
             return r
 
         fused = native and nl1 == 0 and nl2 > 0          # the stepper took the fused step: its one launch is reported in the second-stage slot
-        res = {"value": value, "ms_per_step": ms, "status_word": st.status(), "launches_per_step": 1 if fused else 2}
+        res = {"value": value, "ms_per_step": ms, "status_word": st.status(), "launches_per_step": 1 if fused else 2, "planar_kernel": took_planar and fused}
         if fused:
             # SURVEY.md section 8d's algorithmic figure for an RK2 zone-update is 200 B (per stage: read U, write U'; the second stage also reads
             # the step-start field). The fused launch advances every cell by a whole step, so by that convention it is charged 200 B per cell -
             # while it moves 80 B per cell (the first-stage field never leaves LDS): `traffic` is then BELOW the algorithmic bytes.
-            r = kernel_roofline(BYTES_STEP, avg2, nl2, "euler2d_fused_rk2_kernel<%s> (both RK2 stages, one launch per step)" % riemann,
-                                "fused_%s_%s_bytes_per_launch" % (arith, riemann))
+            moved = 72 if took_planar else 80          # the planar kernel does not read the third momentum (and writes it as zero)
+            r = kernel_roofline(BYTES_STEP, avg2, nl2, "euler2d_fused_rk2_kernel<%s%s> (both RK2 stages, one launch per step)" % (riemann, ", planar" if took_planar else ""),
+                                "fused%s_%s_%s_bytes_per_launch" % ("_planar" if took_planar else "", arith, riemann))
             # `achieved` / `frac` follow the measurement contract: SURVEY.md 8d's ALGORITHMIC bytes of a zone-update (200 B) over the launch that
             # performs it. That is a convention, not a utilisation of the memory system - the launch MOVES 80 B per cell - so the hardware
             # fractions stand beside it: what the launch moves against 8 TB/s, and what bounds it (fp64 issue).
-            r["bytes_actually_moved_per_cell"] = 2 * 5 * 8
-            r["achieved_actual_traffic"] = cells_launch * 80 / (avg2 * 1e-3) / 1e9 if avg2 > 0 else None
+            r["bytes_actually_moved_per_cell"] = moved
+            r["achieved_actual_traffic"] = cells_launch * moved / (avg2 * 1e-3) / 1e9 if avg2 > 0 else None
             r["frac_actual_traffic"] = r["achieved_actual_traffic"] / HBM_PEAK_GBS if r["achieved_actual_traffic"] else None
             if r.get("traffic"):
                 r["achieved_measured_traffic"] = r["traffic"] / (avg2 * 1e-3) / 1e9
@@ -430,8 +441,8 @@ def main():
             busy = (r.get("fp64") or {}).get("valu_busy")
             r["bound_measured"] = ("fp64 issue (VALU-busy %.2f, %.2f of the 78.6 TFLOP/s vector peak); HBM carries %.2f of 8 TB/s" % (busy, r["fp64"]["frac"], r["frac_actual_traffic"])
                                    if busy else "fp64 issue (profiles/r04/kernels_headline.md); HBM carries %.2f of 8 TB/s" % (r["frac_actual_traffic"] or 0.0))
-            r["convention"] = ("frac = 200 B per zone-update (SURVEY.md 8d) over the step's one launch; the launch reads 40 B and writes 40 B per cell: "
-                               "frac_actual_traffic is the fraction of 8 TB/s it really uses")
+            r["convention"] = ("frac = 200 B per zone-update (SURVEY.md 8d) over the step's one launch; the launch reads %d B and writes 40 B per cell: "
+                               "frac_actual_traffic is the fraction of 8 TB/s it really uses" % (moved - 40))
             res["roofline"] = r
             res["roofline_stage1"] = None
         else:
@@ -489,7 +500,8 @@ def main():
     primary = args.arith
     other = "strict" if primary == "fast" else "fast"
     decomposed = world > 1 or bool(args.loopback_slabs)
-    res, u_primary, nsteps_primary = run_leg(primary, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True, fuse=False if args.no_fuse else None)
+    res, u_primary, nsteps_primary = run_leg(primary, args.riemann, "blast", nblocks=max(1, args.blocks), keep_state=True, fuse=False if args.no_fuse else None,
+                                             planar=False if args.no_planar else None)
     partition_ok = partition_check(primary, args.riemann, u_primary, nsteps_primary) if decomposed and state["stepper"] == "native" else None
 
     arith_note = {"strict": "strict: bit-identical to the reference CPU path (tests/test_gpu_parity.py, golden vectors from reference headers)",
@@ -517,14 +529,19 @@ def main():
         if not decomposed and res["launches_per_step"] == 1:
             # the headline took the fused step: the same workload as the two launches it replaces (bit-identical results), with their per-stage rooflines
             legs["%s_%s_blast_two_launches" % (primary, args.riemann)] = run_leg(primary, args.riemann, "blast", fuse=False)[0]
+        if not decomposed and res.get("planar_kernel"):
+            # ... and took the planar kernel: the same workload on the GENERAL fused kernel (all five components computed; same bits in the other four)
+            legs["%s_%s_blast_general_kernel" % (primary, args.riemann)] = run_leg(primary, args.riemann, "blast", planar=False)[0]
         for key, leg in legs.items():
             a, r, w = key.split("_", 2)
             two = w.endswith("_two_launches")
-            w = w.replace("_two_launches", "")
+            general = w.endswith("_general_kernel")
+            w = w.replace("_two_launches", "").replace("_general_kernel", "")
             leg["note"] = "%s; %s; workload: %s%s" % (arith_note[a], pin_note[r],
                                                       "Sedov-type blast, outflow" if w == "blast" else
                                                       "smooth periodic wave rho = 1 + 0.2 sin(2 pi x) sin(2 pi y), p = rho^gamma, v = (0.5, 0.25) (SURVEY.md §8d)",
-                                                      "; the two launches per step that the fused launch replaces" if two else "")
+                                                      "; the two launches per step that the fused launch replaces" if two else
+                                                      ("; the general fused kernel (planar = -1: the third momentum, identically zero in this field, is read, exchanged and computed)" if general else ""))
     del u_primary
 
     if rank == 0:
@@ -540,6 +557,10 @@ def main():
                                         if not args.loopback_slabs else
                                         ("REHEARSAL on one GPU: %d slab objects of the native stepper exchanging through its loopback backend" % nslabs),
                        "arith": arith_note[primary], "riemann": pin_note[args.riemann], "status_word": res["status_word"],
+                       "planar_kernel": bool(res.get("planar_kernel")),
+                       "planar_note": ("the library verified at upload that this 2-D field carries no third momentum and the fused launch skips that component "
+                                       "(mh_euler_cart_desc.planar; bit-identical in the other four components, tests/test_gpu_planar.py); the same leg on the general "
+                                       "kernel is legs.%s_%s_blast_general_kernel" % (primary, args.riemann)) if res.get("planar_kernel") else "general kernel (all five components computed)",
                        "timed_region": ("one launch per step, issued as it is (a one-node graph replay costs 29 us more per step); two-launch legs: HIP-graph replay of the step" if not decomposed else ("eager two-stream issue, one exchange per step" if res["launches_per_step"] == 1 else "eager two-stream issue, one exchange per stage"))
                                        + (" (ONE fused launch per RK2 step, mara3_amd/csrc/euler2d_fused.hip: results bit-identical to the two launches, tests/test_gpu_fused_rk2.py)"
                                           if res["launches_per_step"] == 1 else " (two launches per RK2 step)"),

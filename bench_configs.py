@@ -201,6 +201,7 @@ def c4_parse(args, stdout, nr, arith):
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
     shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches \((\d+) per step", p.stdout)
     avg_ms, nl, lps = (float(shape.group(1)), int(shape.group(2)), int(shape.group(3))) if shape else (0.0, 0, 2)
+    planar = bool(re.search(r"fused step: planar", p.stdout))
     m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
     vertices = (nr + 1) * (nq + 1)
@@ -215,10 +216,14 @@ def c4_parse(args, stdout, nr, arith):
         "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 arith=%s (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % (nr, arith),
-                   "final_state_written": bool(m), "launches_per_step": lps},
+                   "final_state_written": bool(m), "launches_per_step": lps, "planar_kernel": planar and fused,
+                   "planar_note": ("the library verified at upload / set_inflow that field and nozzle row carry no azimuthal momentum (upstream's problem never has any) and "
+                                   "the fused launch skips that component (mh_cloud_desc.planar; same bits in the other four, tests/test_gpu_cloud_fused.py); "
+                                   "`mara_hip cloud ... planar=-1` runs the general kernel") if planar and fused else "general kernel"},
         "roofline": {"bound": "hbm", "achieved": bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None,
-                     "kernel": ("cloud_fused_rk2_kernel (both RK2 stages in one launch per step)" if fused else "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith),
+                     "kernel": ("cloud_fused_rk2_kernel<%s> (both RK2 stages in one launch per step)" % ("planar" if planar else "general") if fused else "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith),
+                     "bytes_actually_moved_per_cell": (104 if planar else 120) if fused else 100,
                      "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms, "launches": nl, "launches_per_step": lps,
                      "timing": "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"},
         "roofline_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "note": "200 B per zone-update over the whole host-timed step (nozzle upload and launch gaps included)"},
@@ -481,7 +486,7 @@ def attach_traffic(out, config):
             tag = "c4s" if (config == "c4" and mode == "Strict") else names[0]
             keys = ["%s:%s" % (tag, n % mode) for n in names[1:]]
             if config == "c4" and mode == "Fast" and roof.get("launches_per_step") == 1:
-                keys = ["c4:cloud_fused_rk2_kernel"]           # the RK2 step's one launch
+                keys = ["c4:cloud_fused_rk2_kernel<%s>" % ("true" if "planar" in roof.get("kernel", "") else "false")]           # the RK2 step's one launch
             if all(k in t for k in keys):
                 roof["traffic"] = sum(t[k] for k in keys) / len(keys)
             fk = [k + ":fp64" for k in keys]

@@ -127,8 +127,10 @@ def supervise(script, argv, gpus, timeout_s=900, dry=False, retry_with=None):
 
 
 class Deadline:
-    """Per-rank watchdog of a multi-rank run. `phase(name)` says what the rank is about to do; if the deadline passes first, the rank prints the
-    phase it is stuck in and leaves with status 3 (os._exit: a thread blocked inside ncclCommInitRank cannot be interrupted any other way)."""
+    """Per-rank watchdog of a multi-rank run. `phase(name)` says what the rank is about to do; if that phase lasts longer than the deadline
+    (`seconds`, or the phase's own shorter `limit`), the rank prints the phase it is stuck in and leaves with status 3 (os._exit: a thread blocked
+    inside ncclCommInitRank cannot be interrupted any other way). The clock restarts with every phase: a run that keeps moving from phase to
+    phase is never ended for its total length - that bound is the supervisor's `--launch-timeout`."""
 
     def __init__(self, seconds, rank=0, enabled=True):
         self.seconds, self.rank, self.enabled = seconds, rank, enabled and seconds > 0
@@ -139,14 +141,14 @@ class Deadline:
             self.thread.start()
 
     def phase(self, name, limit=None):
-        """enter a phase; `limit` (seconds) bounds this phase alone, on top of the overall deadline"""
-        self.name, self.limit = name, (time.time() + limit if limit else None)
+        """enter a phase: the deadline counts from here; `limit` (seconds) is a shorter bound for this phase alone"""
+        self.name, self.t0, self.limit = name, time.time(), (time.time() + limit if limit else None)
 
     def _watch(self):
         while not self._stop.wait(1.0):
             now = time.time()
             if now - self.t0 > self.seconds or (self.limit is not None and now > self.limit):
-                which = "the run's %d s deadline" % self.seconds if now - self.t0 > self.seconds else "the limit of this phase"
+                which = "the %d s deadline of a phase" % self.seconds if now - self.t0 > self.seconds else "the limit of this phase"
                 print("bench: rank %d is still in phase '%s' after %.0f s - %s has passed; leaving with status 3 instead of waiting in a collective"
                       % (self.rank, self.name, now - self.t0, which), file=sys.stderr, flush=True)
                 os._exit(3)

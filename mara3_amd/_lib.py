@@ -34,6 +34,7 @@ class EulerCartDesc(C.Structure):
         ("tail_rows", C.c_int),
         ("tail_chunk_rows", C.c_int),
         ("fuse_stages", C.c_int),
+        ("planar", C.c_int),
     ]
 
 
@@ -48,7 +49,7 @@ class SedovDesc(C.Structure):
 class CloudDesc(C.Structure):
     _fields_ = [("nr", C.c_int), ("nq", C.c_int), ("nr_global", C.c_int), ("row_offset", C.c_int), ("gamma", C.c_double),
                 ("plm_theta", C.c_double), ("temperature_floor", C.c_double), ("bc_lo0", C.c_int), ("bc_hi0", C.c_int),
-                ("arith", C.c_int), ("chunk_rows", C.c_int), ("tail_rows", C.c_int), ("tail_chunk_rows", C.c_int), ("fuse_stages", C.c_int)]
+                ("arith", C.c_int), ("chunk_rows", C.c_int), ("tail_rows", C.c_int), ("tail_chunk_rows", C.c_int), ("fuse_stages", C.c_int), ("planar", C.c_int)]
 
 
 class BinaryDesc(C.Structure):
@@ -234,6 +235,8 @@ SYMBOLS = [
     ("mh_memcpy_d2h", _i, [_vp, _vp, _sz]),
     ("mh_device_synchronize", _i, []),
     ("mh_debug_row_range", _i, [_i, C.POINTER(C.c_int32), _i]),
+    ("mh_field_is_planar", _i, [_vp]),
+    ("mh_slab_is_planar", _i, [_vp]),
 ]
 
 _lib = None

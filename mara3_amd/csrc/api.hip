@@ -191,6 +191,10 @@ struct mh_ctx
     double* staging = nullptr;               // AoS staging for upload/download
     size_t staging_doubles = 0;
     int32_t* status = nullptr;
+    int32_t* planar_flag = nullptr;          // device word of the planarity check at upload (mh_euler_cart_desc.planar)
+    bool planar_now = false;                 // the resident 2-D Euler field has no third momentum: the fused step takes its planar kernel
+                                             // (cloud: the field has no azimuthal momentum ...
+    bool inflow_planar = false;              //  ... and neither has the nozzle row of the step about to run)
     bool profile = false;
     // profile: ONE pair of events around the stage launches of each mh_step / mh_step_checked call, and how many launches lie between
     // them (events around every launch put two markers between consecutive kernels and read 3 % long on the sub-millisecond ones)
@@ -270,6 +274,8 @@ int mh_create(mh_ctx** out, int device_id)
     e = hipMalloc((void**) &c->status, 2 * sizeof(int32_t));
     if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipMalloc(status)"); }
     hipMemsetAsync(c->status, 0, 2 * sizeof(int32_t), c->stream);
+    e = hipMalloc((void**) &c->planar_flag, sizeof(int32_t));
+    if (e != hipSuccess) { hipFree(c->status); hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipMalloc(planar flag)"); }
     *out = c;
     return MH_OK;
 }
@@ -296,6 +302,7 @@ void mh_destroy(mh_ctx* c)
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     release_fields(c);
     if (c->status) hipFree(c->status);
+    if (c->planar_flag) hipFree(c->planar_flag);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -501,6 +508,14 @@ int mh_cloud_set_inflow(mh_ctx* c, const double* inflow_aos)
     const size_t nq = (size_t) c->cloud.nq;
     std::vector<double> soa(5 * nq);
     for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_aos[5 * j + q];
+    // planarity (mh_cloud_desc.planar): a nozzle row with an azimuthal velocity puts azimuthal momentum into the field - general kernel from here on
+    c->inflow_planar = true;
+    for (size_t j = 0; j < nq; ++j) c->inflow_planar = c->inflow_planar && inflow_aos[5 * j + 3] == 0.0;
+    if (! c->inflow_planar)
+    {
+        if (c->cloud.planar > 0) { set_error("set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return ctx_fail(c, MH_E_INVALID); }
+        c->planar_now = false;
+    }
     // stream-ordered after the stages already queued; the staging vector is consumed before return
     MH_HIP_TRY(hipStreamSynchronize(c->stream));
     MH_HIP_TRY(hipMemcpy(c->inflow, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -538,6 +553,8 @@ static int ensure_staging(mh_ctx* c, size_t doubles)
     return MH_OK;
 }
 
+static bool ctx_can_fuse(const mh_ctx* c);
+
 int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
 {
     if (! c || ! c->configured) { set_error("upload before configure"); return ctx_fail(c, MH_E_STATE); }
@@ -559,6 +576,24 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
     MH_HIP_TRY(hipMemcpyAsync(c->staging, u_aos_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     MH_HIP_TRY(aos_to_soa_launch(c->staging, c->field[0], 5, n0, pitch, c->stream));
     if (! cloud) MH_HIP_TRY(fill_ghost_rows_launch(c->field[0], 5, n0, pitch, d->bc_lo0, d->bc_hi0, c->stream));
+    // planarity (mh_euler_cart_desc.planar): does this 2-D field carry a third momentum at all? One pass here, none per step - the planar
+    // kernel writes that component as zero, so the property holds for as long as this solution is stepped
+    c->planar_now = false;
+    const int planar_request = cloud ? c->cloud.planar : d->planar;
+    if ((cloud || d->rank == 2) && planar_request >= 0 && ctx_can_fuse(c))
+    {
+        int32_t nonzero = 0;
+        MH_HIP_TRY(hipMemsetAsync(c->planar_flag, 0, sizeof(int32_t), c->stream));
+        MH_HIP_TRY(plane_nonzero_launch(c->field[0], 5, 3, n0, pitch, c->planar_flag, c->stream));
+        MH_HIP_TRY(hipMemcpyAsync(&nonzero, c->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP_TRY(hipStreamSynchronize(c->stream));
+        c->planar_now = nonzero == 0;
+        if (planar_request > 0 && ! c->planar_now)
+        {
+            set_error(cloud ? "upload: `planar` was asserted, but the field has an azimuthal momentum" : "upload: `planar` was asserted, but the field has a third momentum");
+            return ctx_fail(c, MH_E_INVALID);
+        }
+    }
     MH_HIP_TRY(hipStreamSynchronize(c->stream));
     c->uploaded = true;
     return MH_OK;
@@ -626,8 +661,15 @@ static bool ctx_can_fuse(const mh_ctx* c)
 static hipError_t timed_fused_step(mh_ctx* c, const double* in, double* out, double dt)
 {
     if (c->profile) ++c->span_launches;
-    if (c->kind == mh_ctx::KIND_CLOUD) return cloud_fused_rk2_launch(&c->cloud, c->geom, c->inflow, in, out, dt, c->status, c->stream);
-    return euler2d_fused_rk2_launch(&c->desc, in, out, dt, c->status, c->stream, LaunchEvents());
+    if (c->kind == mh_ctx::KIND_CLOUD)
+    {
+        mh_cloud_desc d = c->cloud;
+        d.planar = c->planar_now && c->inflow_planar ? 1 : -1;          // what mh_upload and mh_cloud_set_inflow found
+        return cloud_fused_rk2_launch(&d, c->geom, c->inflow, in, out, dt, c->status, c->stream);
+    }
+    mh_euler_cart_desc d = c->desc;
+    d.planar = c->planar_now ? 1 : -1;          // what the upload found (mh_upload)
+    return euler2d_fused_rk2_launch(&d, in, out, dt, c->status, c->stream, LaunchEvents());
 }
 
 int mh_step(mh_ctx* c, double dt, int nsteps)
@@ -776,6 +818,8 @@ int mh_step_checked(mh_ctx* c, double dt, mh_step_result* result)
     else                       std::swap(c->field[0], c->field[1]);
     return MH_OK;
 }
+
+int mh_field_is_planar(const mh_ctx* c) { return c && c->planar_now && (c->kind != mh_ctx::KIND_CLOUD || c->inflow_planar) ? 1 : 0; }
 
 double* mh_field_ptr(mh_ctx* c, int which)
 {

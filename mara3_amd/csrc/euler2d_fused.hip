@@ -86,24 +86,32 @@ struct Fused2dParams
 #ifndef MH_FUSED_XCHG
 #define MH_FUSED_XCHG 0
 #endif
-template<int BIT>
+template<int BIT, bool PLANAR>
 __device__ inline State5 lane_from(const State5& s, int addr_left, int addr_right, bool left)
 {
+    State5 r;
     if constexpr ((MH_FUSED_XCHG & BIT) != 0)
     {
-        State5 r;
         const int addr = left ? addr_left : addr_right;
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
+            if (PLANAR && q == 3) { r[q] = 0.0; continue; }
             const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(s[q]));
             const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(s[q]));
             r[q] = __hiloint2double(hi, lo);
         }
-        return r;
     }
     else
-        return left ? from_left(s) : from_right(s);
+    {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+        {
+            if (PLANAR && q == 3) { r[q] = 0.0; continue; }
+            r[q] = left ? from_left(s[q]) : from_right(s[q]);
+        }
+    }
+    return r;
 }
 
 // LDS-only barrier of the pair: the waves' outstanding global loads and stores are not waited for
@@ -116,13 +124,29 @@ __device__ inline void pair_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template<int RIEMANN>
-__global__ __launch_bounds__(2 * FWAVE * FPAIRS, 2)
+// PLANAR: the field's third momentum is identically zero (a 2-D run of the five-component state: the reference carries it as zeros) - the
+// launcher's choice where the stepper has verified that at upload (mh_euler_cart_desc.planar). The component is neither read nor exchanged
+// nor computed, and is written as zero: 72 instead of 80 B per cell and ~11 % fewer VALU instructions for the same bits in the other four.
+// waves per SIMD the planar kernel is built for: its rings hold four variables (45 KB per workgroup) and it needs 158 - 170 registers, so a third
+// wave per SIMD fits where the general kernel (186 - 208 registers, 56 KB) holds two
+// (measured, profiles/r04/ab_planar.jsonl: at 158 registers and 45 KB the hardware places three workgroups per CU whatever the bound says;
+// what the setting decides is the chunk length below - 64 rows = exactly three residency rounds of 768 workgroups: 0.471 ms per 4096^2 step,
+// 98 rows 0.478, 48 / 80 / 128 rows 0.508 / 0.513 / 0.518)
+#ifndef MH_FUSED_PLANAR_WAVES
+#define MH_FUSED_PLANAR_WAVES 3
+#endif
+static constexpr int fused_waves_per_simd(bool planar) { return planar ? MH_FUSED_PLANAR_WAVES : 2; }
+
+template<int RIEMANN, bool PLANAR>
+__global__ __launch_bounds__(2 * FWAVE * FPAIRS, fused_waves_per_simd(PLANAR))
 void euler2d_fused_rk2_kernel(Fused2dParams p)
 {
-    using A = FastArith;
-    __shared__ double hand_all[FPAIRS][FSLOTS][5][FWAVE];        // first-stage rows on their way from the producer to the consumer
-    __shared__ double start_all[FPAIRS][USLOTS][5][FWAVE];       // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
+    using A = FastArithT<PLANAR>;
+    constexpr auto live = [] (int q) { return ! (PLANAR && q == 3); };
+    constexpr int NV = PLANAR ? 4 : 5;                            // variables held in the rings
+    constexpr auto vi = [] (int q) { return PLANAR && q == 4 ? 3 : q; };
+    __shared__ double hand_all[FPAIRS][FSLOTS][NV][FWAVE];       // first-stage rows on their way from the producer to the consumer
+    __shared__ double start_all[FPAIRS][USLOTS][NV][FWAVE];      // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
 
     int b = (int) blockIdx.x;
     {
@@ -133,8 +157,8 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     const int wave_of_group = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int role = wave_of_group & 1;
     const int pp = wave_of_group >> 1;                  // which pair of the workgroup
-    double (*hand)[5][FWAVE] = hand_all[pp];
-    double (*start_rows)[5][FWAVE] = start_all[pp];
+    double (*hand)[NV][FWAVE] = hand_all[pp];
+    double (*start_rows)[NV][FWAVE] = start_all[pp];
     const int lane = threadIdx.x & 63;
     const int al = ((lane - 1) & 63) * 4, ar = ((lane + 1) & 63) * 4;
     const int chunk_of_launch = pair / p.nstrips;
@@ -182,31 +206,32 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         auto ring_put = [&] (int slot, const State5& raw)
         {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) start_rows[slot][q][lane] = raw[q];
+            for (int q = 0; q < 5; ++q) if (live(q)) start_rows[slot][vi(q)][lane] = raw[q];
         };
         auto ring_get = [&] (int slot) -> State5
         {
             State5 Uq;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Uq[q] = start_rows[slot][q][lane];
+            for (int q = 0; q < 5; ++q) Uq[q] = live(q) ? start_rows[slot][vi(q)][lane] : 0.0;
             return Uq;
         };
         const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
         const int a0 = r0 - 2;
+        const int last_needed = r1 + 3;                 // first-stage rows r0 - 2 .. r1 + 1 need step-start rows r0 - 4 .. r1 + 3
         const bool works = ! MH_FUSED_MASK_HALO || (lane >= 2 && lane < FWAVE - 2);
 
         State5 U[3], P[3], G[3], Fx[3], D[3];
         {
-            const State5 Pa = A::c2p(load_row(row_of(a0 - 2), p.plane_stride, jc8), gl);
-            const State5 Pb = A::c2p(load_row(row_of(a0 - 1), p.plane_stride, jc8), gl);
-            U[0] = load_row(row_of(a0), p.plane_stride, jc8);
-            U[1] = load_row(row_of(a0 + 1), p.plane_stride, jc8);
-            U[2] = load_row(row_of(a0 + 2), p.plane_stride, jc8);
+            const State5 Pa = A::c2p(load_row<PLANAR>(row_of(a0 - 2), p.plane_stride, jc8), gl);
+            const State5 Pb = A::c2p(load_row<PLANAR>(row_of(a0 - 1), p.plane_stride, jc8), gl);
+            U[0] = load_row<PLANAR>(row_of(a0), p.plane_stride, jc8);
+            U[1] = load_row<PLANAR>(row_of(a0 + 1), p.plane_stride, jc8);
+            U[2] = load_row<PLANAR>(row_of(a0 + 2), p.plane_stride, jc8);
             P[0] = A::c2p(U[0], gl);
             P[1] = A::c2p(U[1], gl);
             ring_put(0, U[0]);
             ring_put(1, U[1]);
-            U[0] = load_row(row_of(a0 + 3), p.plane_stride, jc8);
+            U[0] = load_row<PLANAR>(row_of(a0 + 3), p.plane_stride, jc8);
             const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
             D[0] = A::difference(P[0], P[1]);
             const State5 Gb = A::plm_from_differences(Dab, Db0, lim);
@@ -222,7 +247,9 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         auto row_step = [&] (int a, int t, auto k0) __attribute__((always_inline))
         {
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
-            U[K1] = load_row(row_of(a + 4), p.plane_stride, jc8);
+            // (the look-ahead stops at the last row this chunk uses, r1 + 3: the two rows beyond it would be read for nothing - and, for a slab's
+            // interior launch next to a cut, while the exchange on the side stream may still be writing them)
+            U[K1] = load_row<PLANAR>(row_of(min(a + 4, last_needed)), p.plane_stride, jc8);
             P[K2] = A::c2p(U[K2], gl);
             ring_put((t + 2) % USLOTS, U[K2]);
             const bool bad_pressure = !(P[K2][4] >= 0.0);
@@ -230,18 +257,18 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
             if (works) Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
-            const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
-            const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
-            const State5 SL = lane_from<4>(A::plus(P[K0], Gy, lim), al, ar, true);
+            const State5 Dr = A::difference(P[K0], lane_from<1, PLANAR>(P[K0], al, ar, false));
+            const State5 Gy = A::plm_from_differences(lane_from<2, PLANAR>(Dr, al, ar, true), Dr, lim);
+            const State5 SL = lane_from<4, PLANAR>(A::plus(P[K0], Gy, lim), al, ar, true);
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
-            const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
+            const State5 Fy_hi = lane_from<8, PLANAR>(Fy_lo, al, ar, false);
 
             const State5 Uc = ring_get(t % USLOTS);
             State5 Un = Uc;
             if (works)
             {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
+                for (int q = 0; q < 5; ++q) if (live(q)) Un[q] = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
             }
             const bool bad_density = !(Un[0] > 0.0);
             if (__any(bad_pressure || bad_density))
@@ -251,7 +278,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             }
             const int slot = t % FSLOTS;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) hand[slot][q][lane] = Un[q];
+            for (int q = 0; q < 5; ++q) if (live(q)) hand[slot][vi(q)][lane] = Un[q];
             pair_barrier();                                  // barrier #t: row a is in the ring
         };
 
@@ -284,7 +311,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         src_lane = min(max(src_lane, 0), FWAVE - 1);
         // one LDS read per value either way: the lane's offset into the rings of all pairs, [pair][slot][variable][lane] flattened
         const double* const hand_flat = &hand_all[0][0][0][0];
-        const int hand_off = from_other ? other * (FSLOTS * 5 * FWAVE) + src_lane_other : pp * (FSLOTS * 5 * FWAVE) + src_lane;
+        const int hand_off = from_other ? other * (FSLOTS * NV * FWAVE) + src_lane_other : pp * (FSLOTS * NV * FWAVE) + src_lane;
         const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
         // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots (periodic and EXTERNAL: the producer
         // worked on the wrapped row / on the neighbour's rows)
@@ -294,7 +321,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const int slot = (m - (r0 - 2)) % FSLOTS;
             State5 Uq;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) Uq[q] = hand_flat[hand_off + (slot * 5 + q) * FWAVE];
+            for (int q = 0; q < 5; ++q) Uq[q] = live(q) ? hand_flat[hand_off + (slot * NV + vi(q)) * FWAVE] : 0.0;
             return Uq;
         };
         auto row_off = [row_stride, n0] (int r) { (void) n0; return (long) (MH_ROW(r, -2, n0 + 1) + 2) * row_stride; };
@@ -327,7 +354,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             {
                 const int slot = (r - (r0 - 2)) % USLOTS;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) Ubase[q] = start_rows[slot][q][lane];
+                for (int q = 0; q < 5; ++q) Ubase[q] = live(q) ? start_rows[slot][vi(q)][lane] : 0.0;
             }
             P[K2] = A::c2p(hand_row(r + 2), gl);
             const bool bad_pressure = !(P[K2][4] >= 0.0);
@@ -335,18 +362,18 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
             if (works) Fx[K1] = A::template flux<RIEMANN, 0>(A::plus(P[K0], G[K0], lim), A::minus(P[K1], G[K1], lim), gl);
 
-            const State5 Dr = A::difference(P[K0], lane_from<1>(P[K0], al, ar, false));
-            const State5 Gy = A::plm_from_differences(lane_from<2>(Dr, al, ar, true), Dr, lim);
-            const State5 SL = lane_from<4>(A::plus(P[K0], Gy, lim), al, ar, true);
+            const State5 Dr = A::difference(P[K0], lane_from<1, PLANAR>(P[K0], al, ar, false));
+            const State5 Gy = A::plm_from_differences(lane_from<2, PLANAR>(Dr, al, ar, true), Dr, lim);
+            const State5 SL = lane_from<4, PLANAR>(A::plus(P[K0], Gy, lim), al, ar, true);
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
-            const State5 Fy_hi = lane_from<8>(Fy_lo, al, ar, false);
+            const State5 Fy_hi = lane_from<8, PLANAR>(Fy_lo, al, ar, false);
 
             const State5 Uc = hand_row(r);
             State5 Un = Uc;
             if (works)
             {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) Un[q] = A::combine(Ubase[q], A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy), 0.5);
+                for (int q = 0; q < 5; ++q) if (live(q)) Un[q] = A::combine(Ubase[q], A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy), 0.5);
             }
             const bool bad_density = !(Un[0] > 0.0);
             if (__any(bad_pressure || bad_density))
@@ -421,8 +448,9 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
         int rounds = 1;
         // (a slab's interior launch does NOT leave room for its edge launch's pairs: measured slower, 125 against 112 us per step at 512 rows)
-        auto chunk_for = [&] (int r) { const int nch = (1024 / FPAIRS) * r / p.nstrips > 0 ? (1024 / FPAIRS) * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
-        while (chunk_for(rounds) > 112) ++rounds;
+        const int resident = 256 * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);          // workgroups on the chip at a time
+        auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
+        while (chunk_for(rounds) > (d->planar > 0 && MH_FUSED_PLANAR_WAVES >= 3 ? 80 : 112)) ++rounds;
         p.chunk_rows = chunk_for(rounds);
         if (p.chunk_rows < 8) p.chunk_rows = 8;
     }
@@ -438,16 +466,12 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     p.gamma = d->gamma; p.theta = d->plm_theta;
     p.cx = dt / d->dl[0]; p.cy = dt / d->dl[1];
     const dim3 grid(p.nstrips * p.nchunks), block(2 * FWAVE * FPAIRS);
-    if (d->riemann == MH_RIEMANN_HLLC)
-    {
-        if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<1>), grid, block, 0, stream, ev.start, ev.stop, 0, p);
-        else         hipLaunchKernelGGL((euler2d_fused_rk2_kernel<1>), grid, block, 0, stream, p);
-    }
-    else
-    {
-        if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<0>), grid, block, 0, stream, ev.start, ev.stop, 0, p);
-        else         hipLaunchKernelGGL((euler2d_fused_rk2_kernel<0>), grid, block, 0, stream, p);
-    }
+    // d->planar > 0: the caller (a stepper that has verified it at upload) knows the field's third momentum to be identically zero
+#define MH_FUSED_LAUNCH(R, PL) do { if (ev.stop) hipExtLaunchKernelGGL((euler2d_fused_rk2_kernel<R, PL>), grid, block, 0, stream, ev.start, ev.stop, 0, p); \
+                                    else         hipLaunchKernelGGL((euler2d_fused_rk2_kernel<R, PL>), grid, block, 0, stream, p); } while (0)
+    if (d->riemann == MH_RIEMANN_HLLC) { if (d->planar > 0) MH_FUSED_LAUNCH(1, true); else MH_FUSED_LAUNCH(1, false); }
+    else                               { if (d->planar > 0) MH_FUSED_LAUNCH(0, true); else MH_FUSED_LAUNCH(0, false); }
+#undef MH_FUSED_LAUNCH
     return hipGetLastError();
 }
 

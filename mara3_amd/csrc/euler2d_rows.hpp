@@ -42,13 +42,18 @@ __device__ inline State5 from_right(const State5& s)
 // (5 variables x n1 doubles): anything outside returns 0 / is dropped by the hardware range check.
 using b64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
 
+// PLANAR: the fourth variable (third momentum) is identically zero in the field and is not read
+template<bool PLANAR = false>
 __device__ inline State5 load_row(const double* row, long plane_stride, unsigned lane_bytes)
 {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, (int) (5 * plane_stride * 8), 0x00020000);
     State5 U;
 #pragma unroll
     for (int q = 0; q < 5; ++q)
+    {
+        if (PLANAR && q == 3) { U[q] = 0.0; continue; }
         U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * plane_stride * 8), 0));
+    }
     return U;
 }
 __device__ inline void store_row(double* row, long plane_stride, unsigned lane_bytes, const State5& U)

@@ -116,48 +116,55 @@ __device__ inline GammaLawFast make_gamma_law(double gamma)
     return g;
 }
 
+// PLANAR (here and below): the third velocity / momentum is identically zero - a 2-D run of the five-component state, whose out-of-plane
+// momentum the reference carries as zeros (euler2d_fused.hip: chosen where the uploaded field has none). Every term with that component is
+// left out and the component is returned as 0: `x + 0` and `fma(0, 0, x)` are x exactly, so the other four components keep their bits.
+template<bool PLANAR = false>
 __device__ inline State5 recover_primitive(const State5& U, const GammaLawFast& g, double temperature_floor)
 {
     const double rd = rcp_nr(U[0]);
-    const double psq = __builtin_fma(U[3], U[3], __builtin_fma(U[2], U[2], U[1] * U[1]));
+    const double psq2 = __builtin_fma(U[2], U[2], U[1] * U[1]);
+    const double psq = PLANAR ? psq2 : __builtin_fma(U[3], U[3], psq2);
     State5 P;
     P[0] = U[0];
     P[1] = U[1] * rd;
     P[2] = U[2] * rd;
-    P[3] = U[3] * rd;
+    P[3] = PLANAR ? 0.0 : U[3] * rd;
     P[4] = __builtin_fma(-0.5 * psq, rd, U[4]) * g.gm1;
     if (P[4] < 0.0 && temperature_floor > 0.0) P[4] = temperature_floor * U[0];
     return P;
 }
 
 // conserved state, normal velocity, flux and sound speed of one face state
-template<int AXIS>
+template<int AXIS, bool PLANAR = false>
 __device__ inline void face_quantities(const State5& P, const GammaLawFast& g, State5& U, State5& F, double& vn, double& cs)
 {
+    static_assert(! PLANAR || AXIS != 2, "a planar state has no third axis");
     const double d = P[0], p = P[4];
-    const double vsq = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    const double vsq2 = __builtin_fma(P[2], P[2], P[1] * P[1]);
+    const double vsq = PLANAR ? vsq2 : __builtin_fma(P[3], P[3], vsq2);
     U[0] = d;
     U[1] = d * P[1];
     U[2] = d * P[2];
-    U[3] = d * P[3];
+    U[3] = PLANAR ? 0.0 : d * P[3];
     U[4] = __builtin_fma(0.5 * d, vsq, p * g.inv_gm1);
     vn = P[1 + AXIS];
     F[0] = vn * U[0];
     F[1] = AXIS == 0 ? __builtin_fma(vn, U[1], p) : vn * U[1];
     F[2] = AXIS == 1 ? __builtin_fma(vn, U[2], p) : vn * U[2];
-    F[3] = AXIS == 2 ? __builtin_fma(vn, U[3], p) : vn * U[3];
+    F[3] = PLANAR ? 0.0 : (AXIS == 2 ? __builtin_fma(vn, U[3], p) : vn * U[3]);
     F[4] = vn * (U[4] + p);
     // cs = sqrt(gamma p / d) = gamma p / sqrt(gamma p d); p == 0 gives 0 * NaN, which fmax turns into 0
     const double gp = g.gamma * p;
     cs = __builtin_fmax(gp * rsqrt_fast(gp * d), 0.0);
 }
 
-template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const GammaLawFast& g)
+template<int AXIS, bool PLANAR = false> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const GammaLawFast& g)
 {
     State5 Ul, Ur, Fl, Fr;
     double vl, vr, csl, csr;
-    face_quantities<AXIS>(Pl, g, Ul, Fl, vl, csl);
-    face_quantities<AXIS>(Pr, g, Ur, Fr, vr, csr);
+    face_quantities<AXIS, PLANAR>(Pl, g, Ul, Fl, vl, csl);
+    face_quantities<AXIS, PLANAR>(Pr, g, Ur, Fr, vr, csr);
     const double ap = __builtin_fmax(0.0, __builtin_fmax(vl + csl, vr + csr));
     const double am = __builtin_fmin(0.0, __builtin_fmin(vl - csl, vr - csr));
     // (Fl ap - Fr am - (Ul - Ur) ap am) / (ap - am) with the three weights divided once: four instructions per component
@@ -165,7 +172,11 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     const double wl = ap * rden, wr = am * rden, wu = wl * am;
     State5 F;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));
+    for (int q = 0; q < 5; ++q)
+    {
+        if (PLANAR && q == 3) { F[q] = 0.0; continue; }
+        F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));
+    }
     return F;
 }
 
@@ -177,20 +188,21 @@ __device__ inline double sound_speed(const State5& P, const GammaLawFast& g)
 }
 
 // conserved state and flux of one face state (what face_quantities computes besides the sound speed)
-template<int AXIS>
+template<int AXIS, bool PLANAR = false>
 __device__ inline void conserved_and_flux(const State5& P, const GammaLawFast& g, State5& U, State5& F)
 {
     const double d = P[0], p = P[4], vn = P[1 + AXIS];
-    const double vsq = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    const double vsq2 = __builtin_fma(P[2], P[2], P[1] * P[1]);
+    const double vsq = PLANAR ? vsq2 : __builtin_fma(P[3], P[3], vsq2);
     U[0] = d;
     U[1] = d * P[1];
     U[2] = d * P[2];
-    U[3] = d * P[3];
+    U[3] = PLANAR ? 0.0 : d * P[3];
     U[4] = __builtin_fma(0.5 * d, vsq, p * g.inv_gm1);
     F[0] = vn * U[0];
     F[1] = AXIS == 0 ? __builtin_fma(vn, U[1], p) : vn * U[1];
     F[2] = AXIS == 1 ? __builtin_fma(vn, U[2], p) : vn * U[2];
-    F[3] = AXIS == 2 ? __builtin_fma(vn, U[3], p) : vn * U[3];
+    F[3] = PLANAR ? 0.0 : (AXIS == 2 ? __builtin_fma(vn, U[3], p) : vn * U[3]);
     F[4] = vn * (U[4] + p);
 }
 
@@ -210,7 +222,7 @@ __device__ inline State5 to_conserved(const State5& P, const GammaLawFast& g)
 // HLLC (Toro 3rd ed. section 10.4-10.6, pressure-based wave speeds as physics_iso2d.hpp:610-687 generalised to a gamma law). The wave
 // speeds need only (d, u_n, p, a) of the two sides; the conserved state and flux are then formed for the ONE side the
 // sampled region belongs to.
-template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, const GammaLawFast& g)
+template<int AXIS, bool PLANAR = false> __device__ inline State5 riemann_hllc(const State5& Pl, const State5& Pr, const GammaLawFast& g)
 {
     const double ul = Pl[1 + AXIS], ur = Pr[1 + AXIS];
     const double al = sound_speed(Pl, g), ar = sound_speed(Pr, g);
@@ -244,22 +256,22 @@ template<int AXIS> __device__ inline State5 riemann_hllc(const State5& Pl, const
     const bool left = (0.0 <= sstar) | (0.0 <= sl);
     State5 Pk;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) Pk[q] = left ? Pl[q] : Pr[q];
+    for (int q = 0; q < 5; ++q) Pk[q] = (PLANAR && q == 3) ? 0.0 : (left ? Pl[q] : Pr[q]);
     const double sk = left ? sl : sr, mk = left ? ml : mr;
     const bool star = left ? ! (0.0 <= sl) : (0.0 <= sr);
     State5 U, Fk, F;
-    conserved_and_flux<AXIS>(Pk, g, U, Fk);
+    conserved_and_flux<AXIS, PLANAR>(Pk, g, U, Fk);
     const double rinv = rcp_nr(sk - sstar);
     // F = F_K + c (S* U_K - F_K + p* D), c = S_K / (S_K - S*) in the star region and 0 outside it: the same F*_K (subtract F_K from
     // eq. 10.41 over the common denominator) as a blend, two instructions per component and no selects on the five results
     const double pk_star = __builtin_fma(mk, sstar - Pk[1 + AXIS], Pk[4]);
     const double c = star ? sk * rinv : 0.0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(sstar, U[q], -Fk[q]);
+    for (int q = 0; q < 5; ++q) F[q] = (PLANAR && q == 3) ? 0.0 : __builtin_fma(sstar, U[q], -Fk[q]);
     F[1 + AXIS] += pk_star;
     F[4] = __builtin_fma(pk_star, sstar, F[4]);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(c, F[q], Fk[q]);
+    for (int q = 0; q < 5; ++q) F[q] = (PLANAR && q == 3) ? 0.0 : __builtin_fma(c, F[q], Fk[q]);
     return F;
 }
 
@@ -302,8 +314,12 @@ struct StrictArith
     static __device__ inline double combine(double base, double u1, double w) { return base * (1.0 - w) + u1 * w; }
 };
 
-struct FastArith
+// PLANAR: see fast::recover_primitive - the policy of the kernels that advance a field whose third momentum is identically zero
+template<bool PLANAR>
+struct FastArithT
 {
+    static constexpr bool planar = PLANAR;
+    static constexpr bool live(int q) { return ! (PLANAR && q == 3); }
 #ifndef MH_FAST_MIN_WAVES
 #define MH_FAST_MIN_WAVES 2
 #endif
@@ -342,7 +358,7 @@ struct FastArith
     {
         State5 D;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) D[q] = Pnext[q] - P[q];
+        for (int q = 0; q < 5; ++q) D[q] = live(q) ? Pnext[q] - P[q] : 0.0;
         return D;
     }
     // the limited slope in units of theta (see shared_differences): plus / minus below scale it
@@ -350,12 +366,12 @@ struct FastArith
     {
         State5 G;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) G[q] = fast::minmod_between(Dl[q], (Dl[q] + Dr[q]) * lim.central, Dr[q]);
+        for (int q = 0; q < 5; ++q) G[q] = live(q) ? fast::minmod_between(Dl[q], (Dl[q] + Dr[q]) * lim.central, Dr[q]) : 0.0;
         return G;
     }
     using Gamma = fast::GammaLawFast;
     static __device__ inline Gamma gamma_law(double gamma) { return fast::make_gamma_law(gamma); }
-    static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return fast::recover_primitive(U, g, 0.0); }
+    static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return fast::recover_primitive<PLANAR>(U, g, 0.0); }
     static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim)
     {
         return plm_from_differences(difference(l, c), difference(c, r), lim);
@@ -364,21 +380,21 @@ struct FastArith
     {
         State5 S;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], lim.half_theta, P[q]);
+        for (int q = 0; q < 5; ++q) S[q] = live(q) ? __builtin_fma(G[q], lim.half_theta, P[q]) : 0.0;
         return S;
     }
     static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim)
     {
         State5 S;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) S[q] = __builtin_fma(G[q], -lim.half_theta, P[q]);
+        for (int q = 0; q < 5; ++q) S[q] = live(q) ? __builtin_fma(G[q], -lim.half_theta, P[q]) : 0.0;
         return S;
     }
     template<int RIEMANN, int AXIS>
     static __device__ inline State5 flux(const State5& Pl, const State5& Pr, const Gamma& g)
     {
-        if constexpr (RIEMANN == 1) return fast::riemann_hllc<AXIS>(Pl, Pr, g);
-        else                        return fast::riemann_hlle<AXIS>(Pl, Pr, g);
+        if constexpr (RIEMANN == 1) return fast::riemann_hllc<AXIS, PLANAR>(Pl, Pr, g);
+        else                        return fast::riemann_hlle<AXIS, PLANAR>(Pl, Pr, g);
     }
     static __device__ inline double update2(double u, double fxl, double fxh, double fyl, double fyh, double cx, double cy)
     {
@@ -390,5 +406,7 @@ struct FastArith
     }
     static __device__ inline double combine(double base, double u1, double w) { return __builtin_fma(u1, w, base * (1.0 - w)); }
 };
+using FastArith = FastArithT<false>;
+using FastArithPlanar = FastArithT<true>;
 
 } // namespace mh

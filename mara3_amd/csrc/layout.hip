@@ -143,6 +143,29 @@ hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStrea
     return hipGetLastError();
 }
 
+// *flag |= 1 if variable q of any cell of rows [0, n0) is not zero (NaN counts as not zero; -0 as zero): the steppers' check, at upload, that a 2-D
+// field carries no third momentum (mh_euler_cart_desc.planar) / no azimuthal momentum (mh_cloud_desc.planar)
+__global__ void plane_nonzero_kernel(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag)
+{
+    const size_t n = (size_t) n0 * row_pitch;
+    bool any = false;
+    for (size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t) gridDim.x * blockDim.x)
+    {
+        const size_t r = t / row_pitch, j = t - r * row_pitch;
+        const double x = u[((r + HALO) * nq + q) * row_pitch + j];
+        any |= ! (x == 0.0);
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+hipError_t plane_nonzero_launch(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, hipStream_t stream)
+{
+    const size_t n = (size_t) n0 * row_pitch;
+    const unsigned blocks = (unsigned) (n / 256 + 1 < 2048 ? n / 256 + 1 : 2048);
+    hipLaunchKernelGGL(plane_nonzero_kernel, dim3(blocks), dim3(256), 0, stream, u, nq, q, n0, row_pitch, flag);
+    return hipGetLastError();
+}
+
 hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream)
 {
     hipLaunchKernelGGL(fill_ghost_rows_kernel, dim3(grid_for((size_t) nq * HALO * row_pitch)), dim3(256), 0, stream,

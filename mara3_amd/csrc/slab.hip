@@ -120,6 +120,11 @@ struct mh_slab
     size_t pad_doubles = 0;                      // doubles allocated in front of (and behind) each field for rows -4, -3 (n0 + 2, n0 + 3)
     double* fused_src[2] = {nullptr, nullptr};
     hipGraphExec_t fused_exec[2] = {nullptr, nullptr};
+    // planarity of the 2-D Euler field (mh_euler_cart_desc.planar): the caller's request, what this slab's own rows showed at the last upload, and
+    // what the fused launches are told (desc.planar / fused_desc.planar = +1 / -1)
+    int planar_request = 0;
+    bool planar_local = false, planar_now = false;
+    int32_t* planar_flag = nullptr;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];   // bulk launches of stage 1 / stage 2
     std::vector<int> event_launches[2];                          // launches between the two events of each pair
@@ -512,6 +517,12 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     }
     if (hipMalloc((void**) &s->status, 2 * sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     hipMemsetAsync(s->status, 0, 2 * sizeof(int32_t), s->main);
+    if (kind == SLAB_EULER)
+    {
+        s->planar_request = global->planar;
+        s->desc.planar = s->fused_desc.planar = -1;          // until an upload has looked at the field
+        if (hipMalloc((void**) &s->planar_flag, sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
+    }
     if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     if (kind == SLAB_CLOUD)
     {
@@ -566,12 +577,33 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
     return MH_OK;
 }
 
+// what the fused launches of this slab are told about the third momentum from now on; a change makes the captured steps stale
+static void slab_set_planar(mh_slab* s, bool planar)
+{
+    if (planar != s->planar_now)
+        for (auto& e : s->fused_exec) { if (e) hipGraphExecDestroy(e); e = nullptr; }
+    s->planar_now = planar;
+    s->desc.planar = s->fused_desc.planar = planar ? 1 : -1;
+}
+
 static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
 {
     MH_HIP_TRY(hipSetDevice(s->device));
     const size_t ncell = (size_t) s->n0 * s->n1;
     MH_HIP_TRY(hipMemcpyAsync(s->staging, u_aos_slab_host, ncell * 5 * sizeof(double), hipMemcpyHostToDevice, s->main));
     MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
+    // planarity of this slab's own rows (mh_euler_cart_desc.planar): one pass per upload, none per step
+    s->planar_local = false;
+    if (s->kind == SLAB_EULER && s->desc.rank == 2 && s->planar_request >= 0 && (s->fused || s->fused_cut) && s->planar_flag)
+    {
+        int32_t nonzero = 0;
+        MH_HIP_TRY(hipMemsetAsync(s->planar_flag, 0, sizeof(int32_t), s->main));
+        MH_HIP_TRY(plane_nonzero_launch(s->field[0], 5, 3, s->n0, (size_t) s->n1, s->planar_flag, s->main));
+        MH_HIP_TRY(hipMemcpyAsync(&nonzero, s->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, s->main));
+        MH_HIP_TRY(hipStreamSynchronize(s->main));
+        s->planar_local = nonzero == 0;
+        if (s->planar_request > 0 && ! s->planar_local) { set_error("upload: `planar` was asserted, but rows [%d, %d) carry a third momentum", s->row0, s->row1); return MH_E_INVALID; }
+    }
     // physical ghost rows (cloud: none stored - inflow / zero-gradient rows are formed inside the kernel)
     if (s->kind == SLAB_EULER) MH_HIP_TRY(fill_ghost_rows_launch(s->field[0], 5, s->n0, (size_t) s->n1, s->desc.bc_lo0, s->desc.bc_hi0, s->main));
     return MH_OK;
@@ -715,6 +747,7 @@ void mh_slab_destroy(mh_slab* s)
     for (auto& f : s->field) if (f) hipFree(f - s->pad_doubles);
     if (s->staging) hipFree(s->staging);
     if (s->status) hipFree(s->status);
+    if (s->planar_flag) hipFree(s->planar_flag);
     if (s->geom) hipFree(s->geom);
     if (s->inflow) hipFree(s->inflow);
     if (s->ev_edge) hipEventDestroy(s->ev_edge);
@@ -739,6 +772,8 @@ int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
     if (! s || ! u_aos_slab_host) return MH_E_INVALID;
     if (s->backend == EXCHANGE_LOOPBACK) { set_error("mh_slab_upload: member of a loopback group (use mh_slab_group_upload)"); return slab_fail(s, MH_E_STATE); }
     if (int rc = slab_upload_rows(s, u_aos_slab_host)) return slab_fail(s, rc);
+    // alone: what the rows showed; with neighbours in OTHER processes: only what the caller asserted for the whole grid (and these rows confirmed)
+    slab_set_planar(s, s->planar_local && (! has_neighbours(s) || s->backend == EXCHANGE_NONE || s->planar_request > 0));
     if (int rc = slab_exchange(s, s->field[0], s->main, true)) return slab_fail(s, rc);
     if (int rc = slab_reset_chains(s)) return slab_fail(s, rc);
     return MH_OK;
@@ -751,6 +786,11 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
     for (int r = 0; r < n; ++r)
         if (int rc = slab_upload_rows(g[r], u_aos_global_host + (size_t) g[r]->row0 * g[r]->n1 * 5)) return slab_fail(g[r], rc);
     for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); MH_HIP_TRY(hipStreamSynchronize(g[r]->main)); }
+    {
+        bool all = true;          // a loopback group sees every member's rows: planar only if the whole grid is
+        for (int r = 0; r < n; ++r) all = all && g[r]->planar_local;
+        for (int r = 0; r < n; ++r) slab_set_planar(g[r], all);
+    }
     for (int r = 0; r < n; ++r)
     {
         MH_HIP_TRY(hipSetDevice(g[r]->device));
@@ -763,6 +803,8 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
     for (int r = 1; r < n; ++r) g[r]->skew_pending = skew != 0;
     return MH_OK;
 }
+
+int mh_slab_is_planar(const mh_slab* s) { return s && s->planar_now ? 1 : 0; }
 
 int mh_slab_download(mh_slab* s, double* u_aos_slab_host)
 {

@@ -19,11 +19,17 @@ using srhd::Gamma;
 // in cold gas |f| < 1e-10 holds at the first test, so the accepted pressure is ONE Newton step from the start value. Starting from the
 // neighbouring cell's pressure instead (measured: it would save a step or two per cell) lands 1e-9 away in relative terms - closer to
 // the root, but outside the 1e-12 agreement with the reference that this arithmetic mode promises.
+// PLANAR (here and below): the azimuthal four-velocity / momentum is identically zero - the `cloud` problem as upstream sets it up (radial
+// envelope, radial nozzle, 2-D axisymmetric: src/subprog_cloud.cpp:626-660, :466-493), which the reference carries as zeros through every
+// operator. Every term with that component is left out and the component is returned as 0: `x + 0` and `fma(0, 0, x)` are x exactly, so
+// the other four components keep their bits (cloud_fused.hip takes this form where the stepper has verified field and nozzle row).
+template<bool PLANAR = false>
 __device__ inline int recover_primitive(const State5& U, const Gamma& g, double temperature_floor, State5& P)
 {
     const double gm = g.gamma;
     const double D = U[0], tau = U[4];
-    const double SS = __builtin_fma(U[3], U[3], __builtin_fma(U[2], U[2], U[1] * U[1]));
+    const double SS2 = __builtin_fma(U[2], U[2], U[1] * U[1]);
+    const double SS = PLANAR ? SS2 : __builtin_fma(U[3], U[3], SS2);
     const double rD = fast::rcp_nr(D);
     bool solution_found = false;
     int iteration = 0;
@@ -61,7 +67,7 @@ __device__ inline int recover_primitive(const State5& U, const Gamma& g, double 
     P[0] = D * rW0;
     P[1] = s * U[1];
     P[2] = s * U[2];
-    P[3] = s * U[3];
+    P[3] = PLANAR ? 0.0 : s * U[3];
     P[4] = p;
     int status = 0;
     if (! solution_found) status |= MH_STATUS_C2P_FAILED;
@@ -71,10 +77,12 @@ __device__ inline int recover_primitive(const State5& U, const Gamma& g, double 
     return status;
 }
 
-template<int AXIS>
+template<int AXIS, bool PLANAR = false>
 __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, State5& F, double& lam_m, double& lam_p)
 {
-    const double uu = __builtin_fma(P[3], P[3], __builtin_fma(P[2], P[2], P[1] * P[1]));
+    static_assert(! PLANAR || AXIS != 2, "a planar state has no azimuthal axis");
+    const double uu2 = __builtin_fma(P[2], P[2], P[1] * P[1]);
+    const double uu = PLANAR ? uu2 : __builtin_fma(P[3], P[3], uu2);
     const double x1 = 1.0 + uu;
     const double rW = fast::rsqrt_fast(x1);
     const double W = x1 * rW;                      // sqrt(x) = x rsqrt(x), to an ulp or two (x >= 1 here)
@@ -90,13 +98,13 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     U[0] = D;
     U[1] = Dh * P[1];
     U[2] = Dh * P[2];
-    U[3] = Dh * P[3];
+    U[3] = PLANAR ? 0.0 : Dh * P[3];
     U[4] = __builtin_fma(Dh, W, -p) - D;
     const double v = P[1 + AXIS] * rW;
     F[0] = v * U[0];
     F[1] = AXIS == 0 ? __builtin_fma(v, U[1], p) : v * U[1];
     F[2] = AXIS == 1 ? __builtin_fma(v, U[2], p) : v * U[2];
-    F[3] = AXIS == 2 ? __builtin_fma(v, U[3], p) : v * U[3];
+    F[3] = PLANAR ? 0.0 : (AXIS == 2 ? __builtin_fma(v, U[3], p) : v * U[3]);
     F[4] = v * (U[4] + p);
     const double c2 = g.gamma * p * rH;
     const double v2 = v * v;
@@ -111,12 +119,12 @@ __device__ inline void side_fast(const State5& P, const Gamma& g, State5& U, Sta
     lam_p = (a + k0) * rden;
 }
 
-template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const Gamma& g)
+template<int AXIS, bool PLANAR = false> __device__ inline State5 riemann_hlle(const State5& Pl, const State5& Pr, const Gamma& g)
 {
     State5 Ul, Ur, Fl, Fr;
     double alm, alp, arm, arp;
-    side_fast<AXIS>(Pl, g, Ul, Fl, alm, alp);
-    side_fast<AXIS>(Pr, g, Ur, Fr, arm, arp);
+    side_fast<AXIS, PLANAR>(Pl, g, Ul, Fl, alm, alp);
+    side_fast<AXIS, PLANAR>(Pr, g, Ur, Fr, arm, arp);
     const double ap = __builtin_fmax(0.0, __builtin_fmax(alp, arp));
     const double am = __builtin_fmin(0.0, __builtin_fmin(alm, arm));
     const double rden = fast::rcp_nr(ap - am);
@@ -126,20 +134,35 @@ template<int AXIS> __device__ inline State5 riemann_hlle(const State5& Pl, const
     const double wl = ap * rden, wr = am * rden, wu = __builtin_fma(wl, am, poison);       // the three weights divided once (euler_device_fast.hpp)
     State5 F;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));
+    for (int q = 0; q < 5; ++q)
+    {
+        if (PLANAR && q == 3) { F[q] = 0.0; continue; }
+        F[q] = __builtin_fma(Ur[q] - Ul[q], wu, __builtin_fma(-Fr[q], wr, Fl[q] * wl));
+    }
     return F;
 }
 
 // rr = 1 / r (the cloud kernel takes it from the host's per-row table)
+template<bool PLANAR = false>
 __device__ inline State5 source_terms_rinv(const State5& P, double rr, double cotq, const Gamma& g)
 {
     const double ur = P[1], uq = P[2], up = P[3], pg = P[4];
     const double H = __builtin_fma(P[4], g.hfac, P[0]);
     State5 S;
     S[0] = 0.0;
-    S[1] = __builtin_fma(H, __builtin_fma(uq, uq, up * up), 2.0 * pg) * rr;
-    S[2] = __builtin_fma(H, __builtin_fma(up * up, cotq, -ur * uq), cotq * pg) * rr;
-    S[3] = -up * H * __builtin_fma(uq, cotq, ur) * rr;
+    if constexpr (PLANAR)
+    {
+        // (up = 0: fma(uq, uq, 0) = uq uq and fma(0, cotq, -ur uq) = -ur uq to the bit)
+        S[1] = __builtin_fma(H, uq * uq, 2.0 * pg) * rr;
+        S[2] = __builtin_fma(H, -ur * uq, cotq * pg) * rr;
+        S[3] = 0.0;
+    }
+    else
+    {
+        S[1] = __builtin_fma(H, __builtin_fma(uq, uq, up * up), 2.0 * pg) * rr;
+        S[2] = __builtin_fma(H, __builtin_fma(up * up, cotq, -ur * uq), cotq * pg) * rr;
+        S[3] = -up * H * __builtin_fma(uq, cotq, ur) * rr;
+    }
     S[4] = 0.0;
     return S;
 }
@@ -175,23 +198,26 @@ struct SrhdStrict
     static __device__ inline double combine(double base, double u1, double w) { return base * (1.0 - w) + u1 * w; }
 };
 
-struct SrhdFast
+template<bool PLANAR>
+struct SrhdFastT
 {
+    static constexpr bool planar = PLANAR;
+    static constexpr bool live(int q) { return ! (PLANAR && q == 3); }
     static constexpr int min_waves_per_simd = 3;      // hold the allocation at 168 VGPRs
     static constexpr bool table_geometry = true;      // per-row x per-column factors from the host's tables (mh_cloud_pack_geometry)
     static constexpr bool exact_zero_products = false;// pole slopes / fluxes are plain zeros (zero lane constants, cloud.hip: lim_polar)
     static constexpr bool group_own_row_loads = true;
     static constexpr bool lds_row_ring = true;        // ... or wait for it in a per-wave LDS ring
-    static __device__ inline void to_density(double (&x)[5], double, double inv_dv) { for (int q = 0; q < 5; ++q) x[q] *= inv_dv; }
-    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive(U, g, tf, P); }
-    static __device__ inline State5 source(const State5& P, double, double inv_r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms_rinv(P, inv_r, cot, g); }
+    static __device__ inline void to_density(double (&x)[5], double, double inv_dv) { for (int q = 0; q < 5; ++q) if (live(q)) x[q] *= inv_dv; }
+    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd_fast::recover_primitive<PLANAR>(U, g, tf, P); }
+    static __device__ inline State5 source(const State5& P, double, double inv_r, double cot, const srhd::Gamma& g) { return srhd_fast::source_terms_rinv<PLANAR>(P, inv_r, cot, g); }
     // the limiter on unscaled differences, theta / 2 in the face-state FMA (euler_device_fast.hpp: FastArith)
-    using Limiter = FastArith::Limiter;
-    static __device__ inline Limiter limiter(double theta) { return FastArith::limiter(theta); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return FastArith::plm(l, c, r, lim); }
-    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return FastArith::plus(P, G, lim); }
-    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return FastArith::minus(P, G, lim); }
-    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd_fast::riemann_hlle<AXIS>(Pl, Pr, g); }
+    using Limiter = typename FastArithT<PLANAR>::Limiter;
+    static __device__ inline Limiter limiter(double theta) { return FastArithT<PLANAR>::limiter(theta); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return FastArithT<PLANAR>::plm(l, c, r, lim); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return FastArithT<PLANAR>::plus(P, G, lim); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return FastArithT<PLANAR>::minus(P, G, lim); }
+    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd_fast::riemann_hlle<AXIS, PLANAR>(Pl, Pr, g); }
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
     {
         const double lr = __builtin_fma(fxh, nArh, -fxl * nArl);
@@ -200,5 +226,7 @@ struct SrhdFast
     }
     static __device__ inline double combine(double base, double u1, double w) { return __builtin_fma(u1, w, base * (1.0 - w)); }
 };
+using SrhdFast = SrhdFastT<false>;
+using SrhdFastPlanar = SrhdFastT<true>;
 
 } // namespace mh

@@ -31,10 +31,12 @@ class _StatusMixin:
 
 class EulerCartSolver(_StatusMixin):
     def __init__(self, shape, dl, gamma, plm_theta=1.5, riemann="hlle", rk_order=2, bc="outflow",
-                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None, fuse=None):
+                 bc_lo0=None, bc_hi0=None, device=0, chunk_rows=0, arith="strict", tail=None, fuse=None, planar=None):
         """tail = (rows, chunk_rows) forces the graded tail of the stage launch (None: the library's default on large grids).
         fuse: the descriptor's fuse_stages - None = where available (one launch per RK2 step: FAST, PLM, physical sides), False = never,
-        True = required."""
+        True = required.
+        planar: the descriptor's planar - None = the fused step skips the third momentum where the uploaded 2-D field has none (verified at
+        upload), False = never, True = asserted (upload fails on a field that has one)."""
         self.lib = L.load_library()
         self.shape = tuple(int(n) for n in shape)
         rank = len(self.shape)
@@ -55,6 +57,7 @@ class EulerCartSolver(_StatusMixin):
         if tail is not None:
             d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
         d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
+        d.planar = 0 if planar is None else (1 if planar else -1)
         self.desc = d
         self.rk_order = rk_order
         self.ctx = C.c_void_p()
@@ -88,6 +91,10 @@ class EulerCartSolver(_StatusMixin):
 
     def synchronize(self):
         L.check(self.lib.mh_synchronize(self.ctx), self.ctx)
+
+    def is_planar(self):
+        """True while the fused step takes its planar kernel (the uploaded field had no third momentum)"""
+        return bool(self.lib.mh_field_is_planar(self.ctx))
 
     def status(self):
         s = C.c_int32()
@@ -160,9 +167,10 @@ class CloudSolver(_StatusMixin):
     cell-integrated SRHD conserved state, per-step nozzle-inflow row."""
 
     def __init__(self, r_vertices, q_vertices, rk_order=1, plm_theta=1.2, temperature_floor=1e-8, gamma=4.0 / 3, device=0, chunk_rows=0,
-                 arith="strict", tail=None, fuse=None):
+                 arith="strict", tail=None, fuse=None, planar=None):
         """fuse: the descriptor's fuse_stages - None = where available (one launch per RK2 step: FAST, PLM; csrc/cloud_fused.hip),
-        False = never, True = required."""
+        False = never, True = required. planar: the descriptor's planar - None = the fused step skips the azimuthal momentum where field and
+        nozzle row have none (verified at upload / set_inflow), False = never, True = asserted."""
         self.lib = L.load_library()
         self.rv = np.ascontiguousarray(r_vertices, dtype=np.float64)
         self.qv = np.ascontiguousarray(q_vertices, dtype=np.float64)
@@ -173,6 +181,7 @@ class CloudSolver(_StatusMixin):
         if tail is not None:
             d.tail_rows, d.tail_chunk_rows = int(tail[0]), int(tail[1])
         d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
+        d.planar = 0 if planar is None else (1 if planar else -1)
         self.ctx = C.c_void_p()
         L.check(self.lib.mh_create(C.byref(self.ctx), device))
         L.check(self.lib.mh_cloud_configure(self.ctx, C.byref(d), self.rv.ctypes.data_as(C.c_void_p),
@@ -207,6 +216,10 @@ class CloudSolver(_StatusMixin):
 
     def step(self, dt, nsteps=1):
         L.check(self.lib.mh_step(self.ctx, dt, nsteps), self.ctx)
+
+    def is_planar(self):
+        """True while the fused step takes its planar kernel (field and nozzle row without azimuthal momentum)"""
+        return bool(self.lib.mh_field_is_planar(self.ctx))
 
     def status(self):
         s = C.c_int32()

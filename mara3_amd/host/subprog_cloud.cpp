@@ -49,6 +49,7 @@ mara::config_t config_template()
     .item("temperature_floor", 1e-8)
     .item("arith", "strict")         // strict (bit-identical to the reference) | fast (L1 <= 1e-12); not a reference option
     .item("fuse", 0)                 // the RK2 step as one launch (arith=fast, PLM): 0 = where available, -1 = never, 1 = required; not a reference option
+    .item("planar", 0)               // skip the azimuthal momentum where field and nozzle row have none (verified): 0 = auto, -1 = never; not a reference option
     .item("chunk_rows", 0)           // rows marched per wave (0 = the library's default); not a reference option
     .item("profile", 0)              // print the average stage-kernel time from HIP events at the end; not a reference option
     .item("max_steps", 0)            // stop after this many steps (0 = run to tfinal); not a reference option
@@ -152,6 +153,7 @@ public:
         d.arith = cfg.get_string("arith") == "fast" ? MH_ARITH_FAST : MH_ARITH_STRICT;
         d.fuse_stages = int(cfg.get_int("fuse"));
         d.chunk_rows = int(cfg.get_int("chunk_rows"));
+        d.planar = int(cfg.get_int("planar"));
 
         mh_ctx* ctx = nullptr;
         host::check(mh_create(&ctx, cfg.get_int("device")), nullptr, "mh_create");
@@ -347,6 +349,7 @@ public:
             host::dump_state(cfg.get_string("outdir"), "inflow0.bin", {long(nq)}, 5, 0.0, 0, {}, inflow_first);
         if (cfg.get_int("profile") && gpus == 1)
         {
+            std::printf("fused step: %s kernel\n", mh_field_is_planar(ctx) ? "planar (no azimuthal momentum in field and nozzle row: verified)" : "general");
             // after the run and its output: five further steps in ONE call, i.e. between ONE pair of events (events around every step put two markers
             // between consecutive kernels and read long on sub-millisecond launches); the nozzle row stays that of the last step
             const int extra = 5;

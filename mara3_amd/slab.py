@@ -356,7 +356,7 @@ class SlabCloudStepper(SlabEulerStepper):
     def fill_ghosts_physical_only(self, f):
         pass        # inflow / zero-gradient rows are formed inside the kernel from the nozzle row / the last real row
 
-def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=0, arith="strict", fuse=None):
+def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=0, arith="strict", fuse=None, planar=None):
     """mh_euler_cart_desc of a WHOLE uniform-cartesian grid (the form mh_slab_create / mh_slab_group_create take)"""
     rank_ = len(global_shape)
     d = L.EulerCartDesc()
@@ -371,6 +371,7 @@ def euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows=
     d.arith = {"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith]
     d.chunk_rows = chunk_rows
     d.fuse_stages = 0 if fuse is None else (1 if fuse else -1)
+    d.planar = 0 if planar is None else (1 if planar else -1)
     return d
 
 
@@ -380,7 +381,7 @@ class NativeSlabStepper:
     `comm_id` is the 128-byte RCCL unique id every rank must share (see `native_comm_id`)."""
 
     def __init__(self, global_shape, dl, gamma, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow",
-                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict", handle=None, fuse=None):
+                 rank=0, world=1, comm_id=None, self_exchange=False, device=0, chunk_rows=0, arith="strict", handle=None, fuse=None, planar=None):
         """comm_id=None on a rank with neighbours defers the RCCL communicator to connect() (ncclCommInitRank is collective: the host
         first makes sure every rank got this far). handle: wrap a slab created elsewhere (a member of NativeSlabGroup)."""
         import numpy as np
@@ -389,7 +390,7 @@ class NativeSlabStepper:
         if handle is not None:
             self.handle = handle
         else:
-            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith, fuse)
+            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith, fuse, planar)
             self.handle = C.c_void_p()
             idbuf = C.create_string_buffer(bytes(comm_id), 128) if comm_id is not None else None
             L.check(self.lib.mh_slab_create(C.byref(self.handle), C.byref(d), rk_order, rank, world, idbuf,
@@ -412,6 +413,9 @@ class NativeSlabStepper:
         u = self.np.ascontiguousarray(u_aos_slab, dtype=self.np.float64)
         assert u.shape == self.slab_shape, (u.shape, self.slab_shape)
         L.check(self.lib.mh_slab_upload(self.handle, u.ctypes.data_as(C.c_void_p)))
+
+    def is_planar(self):
+        return bool(self.lib.mh_slab_is_planar(self.handle))
 
     def slab_host(self):
         u = self.np.empty(self.slab_shape)
@@ -494,7 +498,7 @@ class NativeSlabGroup:
     mh_slab_group_*). Euler (2-D, 3-D) with global_shape / dl, or the `cloud` grid with r_vertices / q_vertices."""
 
     def __init__(self, global_shape=None, dl=None, gamma=5.0 / 3, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow", world=2,
-                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8, devices=None):
+                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8, devices=None, planar=None):
         """devices: one device id per member (mh_slab_group_create_on: ONE process driving several GPUs, receives as peer copies)"""
         import numpy as np
         self.np = np
@@ -519,7 +523,7 @@ class NativeSlabGroup:
                                                             rk_order, world, device))
             self.global_shape = (nr, nq)
         else:
-            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith)
+            d = euler_cart_desc(global_shape, dl, gamma, plm_theta, riemann, bc, chunk_rows, arith, None, planar)
             if ids is not None:
                 L.check(self.lib.mh_slab_group_create_on(self.handles, C.byref(d), rk_order, world, ids))
             else:

@@ -113,7 +113,7 @@ def table(tags, part):
 if __name__ == "__main__":
     part = sys.argv[1] if len(sys.argv) > 1 else "headline"
     if part == "headline":
-        tags = ["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"] if ROUND == "r02" else ["fast_hllc", "fast_hllc_two", "fast_hlle", "strict_hlle", "strict_hllc"]
+        tags = ["fast_hllc", "strict_hllc", "fast_hlle", "strict_hlle"] if ROUND == "r02" else ["fast_hllc", "fast_hllc_general", "fast_hllc_two", "fast_hlle", "strict_hlle", "strict_hllc"]
         tr, ex = table([t for t in tags if glob.glob(os.path.join(OUT, t + "_trace"))], "headline")
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         out = {"csrc_sha16": csrc_fingerprint(),
@@ -123,7 +123,7 @@ if __name__ == "__main__":
                            "these numbers were measured on."}
         for (tag, k), v in tr.items():
             arith, riemann = tag.split("_")[:2]
-            stage = "fused" if "fused" in k else ("stage2" if k.endswith("true>") else "stage1")
+            stage = ("fused_planar" if k.endswith("true>") else "fused") if "fused" in k else ("stage2" if k.endswith("true>") else "stage1")
             out["%s_%s_%s_bytes_per_launch" % (stage, arith, riemann)] = v
             if (tag, k) in ex:
                 out["%s_%s_%s_fp64" % (stage, arith, riemann)] = ex[(tag, k)]

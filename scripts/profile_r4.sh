@@ -31,6 +31,7 @@ headline_variant () { # tag, bench flags
 }
 if [ $PART = headline ]; then
   headline_variant fast_hllc --arith fast --riemann hllc
+  headline_variant fast_hllc_general --arith fast --riemann hllc --no-planar
   headline_variant fast_hllc_two --arith fast --riemann hllc --no-fuse
   headline_variant strict_hlle --arith strict --riemann hlle
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python3 scripts/calib_fetch.py > $OUT/calib_f.log 2>&1

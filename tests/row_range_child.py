@@ -48,6 +48,18 @@ def euler2d(fused):
                 st = s.status()
                 s.close()
                 report(fam, "%dx%d chunk %d tail %s %s %s %s" % (shape + (chunk, tail, bc, arith, riemann)), shape[0], st)
+    if fused:
+        # the planar kernel (a field without third momentum: the blast) marches the same rows
+        for shape, chunk, bc in (((130, 250), 0, "outflow"), ((67, 200), 7, "periodic")):
+            take(fam)
+            u0 = setups.blast_ic(shape, 1.4, radius=0.3)
+            s = engine.EulerCartSolver(shape, (1.0 / shape[0], 1.0 / shape[1]), 1.4, 1.5, "hllc", 2, bc, arith="fast", chunk_rows=chunk, fuse=True)
+            s.upload(u0)
+            assert s.is_planar()
+            s.step(2e-4, 3)
+            st = s.status()
+            s.close()
+            report(fam, "%dx%d chunk %d %s planar" % (shape + (chunk, bc)), shape[0], st)
     if not fused:
         # PCM and RK1 use the same row loop with fewer rows ahead
         for theta, rk in ((-1.0, 1), (1.5, 1), (-1.0, 2)):

@@ -158,3 +158,59 @@ def test_transactional_step_with_the_fused_cloud_launch(eng):
     assert bits != 0 and 18 * 130 <= cell <= 20 * 130 + 70
     assert bits_equal(s.download(), bad)                 # the previous solution is still in place
     s.close()
+
+
+# ---- the planar kernel (mh_cloud_desc.planar): field and nozzle row without azimuthal momentum - the `cloud` problem as upstream sets it up
+
+def run_planar(eng, rv, qv, u0, inflow, dt, nsteps, planar, fuse=True):
+    s = eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="fast", fuse=fuse, planar=planar)
+    s.upload(u0)
+    took = []
+    for n in range(nsteps):
+        s.set_inflow(inflow[n % len(inflow)])
+        took.append(s.is_planar())
+        s.step(dt, 1)
+    out = s.download()
+    st = s.status_result()
+    s.close()
+    return out, st, took
+
+
+@pytest.mark.parametrize("nr,nq", [(130, 250), (64, 117), (33, 57), (96, 1000)])
+def test_planar_cloud_kernel_keeps_the_bits_of_the_other_four_components(eng, nr, nq):
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, nr, nq, seed=nr + nq)          # (no azimuthal motion anywhere, like upstream's problem)
+    general, st_g, took_g = run_planar(eng, rv, qv, u0, inflow, dt, 4, False)
+    planar, st_p, took_p = run_planar(eng, rv, qv, u0, inflow, dt, 4, None)
+    assert took_g == [False] * 4 and took_p == [True] * 4 and st_g == (0, None) and st_p == (0, None)
+    for q in (0, 1, 2, 4):
+        assert bits_equal(planar[..., q], general[..., q]), (nr, nq, q, np.abs(planar[..., q] - general[..., q]).max())
+    assert np.all(planar[..., 3] == 0.0) and np.all(general[..., 3] == 0.0)
+
+
+def test_azimuthal_motion_in_field_or_nozzle_takes_the_general_cloud_kernel(eng):
+    import mara3_amd
+    nr, nq = 64, 120
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, nr, nq, seed=21)
+    # (i) a field with azimuthal momentum: general kernel from the start, equal to the two launches
+    spun = u0.copy()
+    spun[..., 3] = 0.05 * np.abs(u0[..., 1])
+    one, _, took = run_planar(eng, rv, qv, spun, inflow, dt, 3, None)
+    two, _, _ = run_planar(eng, rv, qv, spun, inflow, dt, 3, None, fuse=False)
+    assert took == [False] * 3 and bits_equal(one, two) and np.abs(one[..., 3]).max() > 0.0
+    # (ii) a nozzle row that starts to rotate at the third step: planar until then, general from then on - as if it had been general throughout
+    rows = inflow[:4].copy()
+    rows[2:, :, 3] = 0.01
+    auto, _, took = run_planar(eng, rv, qv, u0, rows, dt, 4, None)
+    never, _, _ = run_planar(eng, rv, qv, u0, rows, dt, 4, False)
+    assert took == [True, True, False, False]
+    for q in range(5):
+        assert np.array_equal(auto[..., q], never[..., q]), q
+    assert np.abs(auto[..., 3]).max() > 0.0
+    # (iii) asserted planarity refuses both
+    s = eng.CloudSolver(rv, qv, 2, 1.2, 0.0, arith="fast", planar=True)
+    with pytest.raises(mara3_amd.MaraHipError, match="azimuthal"):
+        s.upload(spun)
+    s.upload(u0)
+    with pytest.raises(mara3_amd.MaraHipError, match="azimuthal"):
+        s.set_inflow(rows[3])
+    s.close()

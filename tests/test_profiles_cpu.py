@@ -50,8 +50,10 @@ def test_pmc_traffic_table_is_keyed_and_complete():
     if not os.path.exists(os.path.join(R04, "kernels_headline.md")):
         pytest.skip("profiles/r04 not generated yet")
     cells = 4096 * 4096
-    fused = t["fused_fast_hllc_bytes_per_launch"]
-    assert 80 * cells <= fused <= 1.25 * 80 * cells          # the fused launch reads 40 B and writes 40 B per cell (+ halo re-reads)
-    assert 0.5 < t["fused_fast_hllc_fp64"]["valu_busy"] <= 1.0
+    fused = t["fused_planar_fast_hllc_bytes_per_launch"]
+    assert 72 * cells <= fused <= 1.25 * 72 * cells          # the planar fused launch reads 32 B and writes 40 B per cell (+ halo re-reads)
+    assert 0.5 < t["fused_planar_fast_hllc_fp64"]["valu_busy"] <= 1.0
+    general = t["fused_fast_hllc_bytes_per_launch"]          # ... and the general kernel (bench.py --no-planar) 40 + 40
+    assert 80 * cells <= general <= 1.25 * 80 * cells
     for key in ("stage2_strict_hlle_bytes_per_launch", "stage1_strict_hlle_bytes_per_launch"):
         assert key in t
