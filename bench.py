@@ -369,7 +369,7 @@ def main():
         nprof = 5
         # releasing the scratch grid above idles the GPU for milliseconds, and the first launches after an idle period run slow: `nlead`
         # un-instrumented steps lead straight into the instrumented ones (no synchronisation between them)
-        nlead = 15 if native else 0
+        nlead = 40 if native else 0          # (a fused step is ONE launch: 15 steps used to be 30 launches, which covered the ~25 slow ones after an idle period)
         if native:
             st.step(dt, nlead)
             st.profile(True)

@@ -47,7 +47,8 @@ def test_bench_json_line_contract():
             # one launch per step, charged SURVEY 8d's 200 B per zone-update while it moves 72 or 80 B per cell: the convention's fraction may pass 1
             # (the planar HLLE step does) - the fraction of 8 TB/s the launch really uses stands beside it and cannot
             assert legs[key]["launches_per_step"] == 1 and legs[key]["roofline_stage1"] is None
-            assert 0.0 < legs[key]["roofline"]["frac"] < 2.5 * legs[key]["roofline"]["frac_actual_traffic"] + 1e-9 and 0.0 < legs[key]["roofline"]["frac_actual_traffic"] < 1.0
+            lr = legs[key]["roofline"]
+            assert 0.0 < lr["frac_actual_traffic"] < 1.0 and lr["frac"] == pytest.approx(lr["frac_actual_traffic"] * 200 / lr["bytes_actually_moved_per_cell"], rel=1e-4)
             assert legs[key]["planar_kernel"] is (not key.endswith("general_kernel"))
         else:
             assert 0.0 < legs[key]["roofline"]["frac"] < 1.0
