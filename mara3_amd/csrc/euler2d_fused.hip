@@ -249,7 +249,11 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
             // (the look-ahead stops at the last row this chunk uses, r1 + 3: the two rows beyond it would be read for nothing - and, for a slab's
             // interior launch next to a cut, while the exchange on the side stream may still be writing them)
+#ifdef MH_PROBE_FUSED_NO_EXTERNAL_CLAMP      // round 3's kernel for tests/test_gpu_row_range.py: look-ahead two rows beyond the last one used, no clamp in row_of
+            U[K1] = load_row<PLANAR>(row_of(a + 4), p.plane_stride, jc8);
+#else
             U[K1] = load_row<PLANAR>(row_of(min(a + 4, last_needed)), p.plane_stride, jc8);
+#endif
             P[K2] = A::c2p(U[K2], gl);
             ring_put((t + 2) % USLOTS, U[K2]);
             const bool bad_pressure = !(P[K2][4] >= 0.0);
