@@ -580,11 +580,12 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
     // kernel writes that component as zero, so the property holds for as long as this solution is stepped
     c->planar_now = false;
     const int planar_request = cloud ? c->cloud.planar : d->planar;
-    if ((cloud || d->rank == 2) && planar_request >= 0 && ctx_can_fuse(c))
+    // (cloud: only its one-launch FAST step has a planar form; 2-D Euler: every PLM stage kernel has one, STRICT on the exact bit pattern of +0.0)
+    if ((cloud ? ctx_can_fuse(c) : (d->rank == 2 && d->plm_theta >= 0.0)) && planar_request >= 0)
     {
         int32_t nonzero = 0;
         MH_HIP_TRY(hipMemsetAsync(c->planar_flag, 0, sizeof(int32_t), c->stream));
-        MH_HIP_TRY(plane_nonzero_launch(c->field[0], 5, 3, n0, pitch, c->planar_flag, c->stream));
+        MH_HIP_TRY(plane_nonzero_launch(c->field[0], 5, 3, n0, pitch, c->planar_flag, c->stream, ! cloud && d->arith == MH_ARITH_STRICT));
         MH_HIP_TRY(hipMemcpyAsync(&nonzero, c->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, c->stream));
         MH_HIP_TRY(hipStreamSynchronize(c->stream));
         c->planar_now = nonzero == 0;
@@ -646,9 +647,10 @@ struct ProfileSpan
 static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, double* out, double dt, double w)
 {
     if (c->profile) ++c->span_launches;
-    return c->kind == mh_ctx::KIND_CLOUD
-        ? cloud_stage_launch(&c->cloud, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream)
-        : cart_stage_launch(&c->desc, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
+    if (c->kind == mh_ctx::KIND_CLOUD) return cloud_stage_launch(&c->cloud, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream);
+    mh_euler_cart_desc d = c->desc;
+    d.planar = c->planar_now ? 1 : -1;          // what the upload found (mh_upload)
+    return cart_stage_launch(&d, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);
 }
 
 // a whole-field RK2 step as one launch (the descriptors' fuse_stages; euler2d_fused.hip, cloud_fused.hip)

@@ -126,6 +126,10 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
     auto row_off = [row_stride, rows_hi] (int r) { (void) rows_hi; return (long) (MH_ROW(r, -HALO, rows_hi) + HALO) * row_stride; };
     const unsigned jc8 = (unsigned) jc * 8u, col8 = (unsigned) (writes ? col : 0) * 8u;
 
+    // A::planar (StrictArithT<true>, FastArithT<true>): the field's third momentum is identically zero (+0.0 bit for bit in STRICT) - not read, not
+    // exchanged, not computed, written as +0.0 (mh_euler_cart_desc.planar; euler_device.hpp says why the other four components keep their bits)
+    constexpr bool PL = A::planar;
+    constexpr auto live = [] (int q) { return ! (PL && q == 3); };
     const double gamma = p.gamma, theta = p.theta;
     const typename A::Gamma gl = A::gamma_law(gamma);
     const typename A::Limiter lim = A::limiter(theta);
@@ -141,14 +145,14 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         if constexpr (lds_ring)
         {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) own_rows[wave_in_block][slot][q][lane] = raw[q];
+            for (int q = 0; q < 5; ++q) if (live(q)) own_rows[wave_in_block][slot][q][lane] = raw[q];
         }
     };
     auto ring_get = [&] (int slot) -> State5
     {
         State5 Uq;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) Uq[q] = own_rows[lds_ring ? wave_in_block : 0][slot][q][lane];
+        for (int q = 0; q < 5; ++q) Uq[q] = live(q) ? own_rows[lds_ring ? wave_in_block : 0][slot][q][lane] : 0.0;
         return Uq;
     };
 
@@ -159,18 +163,18 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
     //   D[k]: (FAST) P of row r+1 - P of row r, the limiter's one-sided difference across face r+1/2
     State5 U[3], P[3], G[3], Fx[3], D[3];
     {
-        const State5 Pa = A::c2p(load_row(in + row_off(r0 - 2), p.plane_stride, jc8), gl);
-        const State5 Pb = A::c2p(load_row(in + row_off(r0 - 1), p.plane_stride, jc8), gl);
-        U[0] = load_row(in + row_off(r0), p.plane_stride, jc8);
-        U[1] = load_row(in + row_off(r0 + 1), p.plane_stride, jc8);
-        U[2] = load_row(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
+        const State5 Pa = A::c2p(load_row<PL>(in + row_off(r0 - 2), p.plane_stride, jc8), gl);
+        const State5 Pb = A::c2p(load_row<PL>(in + row_off(r0 - 1), p.plane_stride, jc8), gl);
+        U[0] = load_row<PL>(in + row_off(r0), p.plane_stride, jc8);
+        U[1] = load_row<PL>(in + row_off(r0 + 1), p.plane_stride, jc8);
+        U[2] = load_row<PL>(in + row_off(r0 + 2), p.plane_stride, jc8);   // first prefetch
         P[0] = A::c2p(U[0], gl);
         P[1] = A::c2p(U[1], gl);
         ring_put(0, U[0]);
         ring_put(1, U[1]);
         // (recompute_conserved: U[] is the ring of LOADED rows instead - slot (row - r0) mod 3 holds row r+2, r+3 or r+4 until its
         // conversion; rows r0, r0+1 are converted already and their slots take rows r0+3, r0+4)
-        if constexpr (A::recompute_conserved) U[0] = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
+        if constexpr (A::recompute_conserved) U[0] = load_row<PL>(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
         if constexpr (PLM && A::shared_differences)
         {
             const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
@@ -204,7 +208,7 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
     // Two rows (10 loads of 512 B) in flight per wave keep ~40 KB outstanding per CU, enough to cover HBM latency
     // at this kernel's bandwidth (one row in flight left the first RK stage latency-bound).
     State5 Upre;
-    if constexpr (! A::recompute_conserved) Upre = load_row(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
+    if constexpr (! A::recompute_conserved) Upre = load_row<PL>(in + row_off(min(r0 + 3, p.n0 + 1)), p.plane_stride, jc8);
 
     // one row; K0 = ring slot of row r (compile-time), K1 / K2 = slots of rows r+1 / r+2
     auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
@@ -214,10 +218,10 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         // issue the load of row r+4 (clamped to the stored ghost range; unused past the chunk end)
         const int rp = min(r + 4, p.n0 + 1);
         State5 Unext;
-        if constexpr (A::recompute_conserved) U[K1] = load_row(in + row_off(rp), p.plane_stride, jc8);      // row r+1 was converted a row ago
-        else                                  Unext = load_row(in + row_off(rp), p.plane_stride, jc8);
+        if constexpr (A::recompute_conserved) U[K1] = load_row<PL>(in + row_off(rp), p.plane_stride, jc8);      // row r+1 was converted a row ago
+        else                                  Unext = load_row<PL>(in + row_off(rp), p.plane_stride, jc8);
         State5 Ubase;
-        if constexpr (COMBINE) Ubase = load_row(p.u_base + row_off(r), p.plane_stride, jc8);      // (requesting it a row earlier: no faster, measured)
+        if constexpr (COMBINE) Ubase = load_row<PL>(p.u_base + row_off(r), p.plane_stride, jc8);      // (requesting it a row earlier: no faster, measured)
 
         // ---- axis 0: flux through face r+1/2
         P[K2] = A::c2p(U[K2], gl);
@@ -245,22 +249,22 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM && A::shared_differences)
         {
-            const State5 Dr = A::difference(P[K0], from_right(P[K0]));
-            const State5 Gy = A::plm_from_differences(from_left(Dr), Dr, lim);
-            const State5 SL = from_left(A::plus(P[K0], Gy, lim));
+            const State5 Dr = A::difference(P[K0], from_right_p<PL>(P[K0]));
+            const State5 Gy = A::plm_from_differences(from_left_p<PL>(Dr), Dr, lim);
+            const State5 SL = from_left_p<PL>(A::plus(P[K0], Gy, lim));
             Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
         }
         else if constexpr (PLM)
         {
-            const State5 Gy = A::plm(from_left(P[K0]), P[K0], from_right(P[K0]), lim);
-            const State5 SL = from_left(A::plus(P[K0], Gy, lim));       // left neighbour's right-going face state
+            const State5 Gy = A::plm(from_left_p<PL>(P[K0]), P[K0], from_right_p<PL>(P[K0]), lim);
+            const State5 SL = from_left_p<PL>(A::plus(P[K0], Gy, lim));       // left neighbour's right-going face state
             Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
         }
         else
         {
-            Fy_lo = A::template flux<RIEMANN, 1>(from_left(P[K0]), P[K0], gl);
+            Fy_lo = A::template flux<RIEMANN, 1>(from_left_p<PL>(P[K0]), P[K0], gl);
         }
-        Fy_hi = from_right(Fy_lo);
+        Fy_hi = from_right_p<PL>(Fy_lo);
 
         // ---- conservative update (+ RK combine)
         State5 Un, Uc;
@@ -270,6 +274,7 @@ __device__ __forceinline__ void stage_body(const Stage2dParams& p, int b, const 
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
+            if (! live(q)) { Un[q] = 0.0; continue; }
             const double u1 = A::update2(Uc[q], Fx[K0][q], Fx[K1][q], Fy_lo[q], Fy_hi[q], p.cx, p.cy);
             if constexpr (COMBINE) Un[q] = A::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
@@ -408,9 +413,11 @@ static int build_params(Stage2dParams& p, const mh_euler_cart_desc* d, const dou
     return (p.nstrips * p.nchunks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 }
 
+// d->planar > 0 (a stepper that verified it at upload, or the caller's assertion): the planar instantiations, built for PLM
 static int variant_key(const mh_euler_cart_desc* d, bool combine)
 {
-    return (d->arith == MH_ARITH_FAST ? 8 : 0) | (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (d->plm_theta >= 0.0 ? 2 : 0) | (combine ? 1 : 0);
+    const bool plm = d->plm_theta >= 0.0;
+    return (d->planar > 0 && plm ? 16 : 0) | (d->arith == MH_ARITH_FAST ? 8 : 0) | (d->riemann == MH_RIEMANN_HLLC ? 4 : 0) | (plm ? 2 : 0) | (combine ? 1 : 0);
 }
 
 hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
@@ -447,6 +454,14 @@ hipError_t euler2d_stage_launch2(const mh_euler_cart_desc* d, const double* u_in
         case 13: return launch<FastArith, 1, false, true >(p, stream, ev);
         case 14: return launch<FastArith, 1, true,  false>(p, stream, ev);
         case 15: return launch<FastArith, 1, true,  true >(p, stream, ev);
+        case 18: return launch<StrictArithPlanar, 0, true, false>(p, stream, ev);
+        case 19: return launch<StrictArithPlanar, 0, true, true >(p, stream, ev);
+        case 22: return launch<StrictArithPlanar, 1, true, false>(p, stream, ev);
+        case 23: return launch<StrictArithPlanar, 1, true, true >(p, stream, ev);
+        case 26: return launch<FastArithPlanar, 0, true, false>(p, stream, ev);
+        case 27: return launch<FastArithPlanar, 0, true, true >(p, stream, ev);
+        case 30: return launch<FastArithPlanar, 1, true, false>(p, stream, ev);
+        case 31: return launch<FastArithPlanar, 1, true, true >(p, stream, ev);
     }
     return hipErrorInvalidValue;
 }

@@ -36,6 +36,24 @@ __device__ inline State5 from_right(const State5& s)
     return r;
 }
 
+// PLANAR: the fourth variable (third momentum / velocity) is identically zero and does not travel
+template<bool PLANAR>
+__device__ inline State5 from_left_p(const State5& s)
+{
+    State5 r;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) r[q] = (PLANAR && q == 3) ? 0.0 : from_left(s[q]);
+    return r;
+}
+template<bool PLANAR>
+__device__ inline State5 from_right_p(const State5& s)
+{
+    State5 r;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) r[q] = (PLANAR && q == 3) ? 0.0 : from_right(s[q]);
+    return r;
+}
+
 // One row of one field through a buffer resource: the row pointer is wave-uniform (scalar registers), the lane
 // contributes a 32-bit byte offset and the variable a scalar offset, so a row costs five buffer instructions and
 // no vector address arithmetic (cdna_hip_programming.md T8). The descriptor covers exactly the row block

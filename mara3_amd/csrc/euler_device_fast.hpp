@@ -278,24 +278,32 @@ template<int AXIS, bool PLANAR = false> __device__ inline State5 riemann_hllc(co
 } // namespace fast
 
 // ---- arithmetic policies used by the stage kernels -------------------------
-struct StrictArith
+// PLANAR: see euler_device.hpp (recover_primitive) - the third momentum is +0.0 in every cell, bit for bit
+template<bool PLANAR>
+struct StrictArithT
 {
-    static constexpr int min_waves_per_simd = 2;
-    static constexpr int min_waves_first_stage = 2;
+    static constexpr bool planar = PLANAR;
+    // planar: 170 / 180 registers - a third wave per SIMD is within reach, at 8 - 39 spilled registers. Measured at 4096^2, ms per RK2 step
+    // (profiles/r04/ab_strict_planar.jsonl): HLLE general 0.945, planar at two waves 0.827, at three 0.806; HLLC 0.968 / 0.886 / 0.838
+#ifndef MH_STRICT_PLANAR_WAVES
+#define MH_STRICT_PLANAR_WAVES 3
+#endif
+    static constexpr int min_waves_per_simd = PLANAR ? MH_STRICT_PLANAR_WAVES : 2;
+    static constexpr int min_waves_first_stage = PLANAR ? MH_STRICT_PLANAR_WAVES : 2;
     static constexpr bool deferred_axis1 = false;           // (euler3d_kernel.hpp) the update keeps the reference's order of terms
     static constexpr bool shared_differences = false;       // the reference's plm_gradient takes the three values, bit for bit
     static constexpr bool recompute_conserved = false;      // the update starts from the stored conserved state, bit for bit
     static constexpr bool lds_conserved_ring = false;
     using Gamma = GammaLaw;
     static __device__ inline Gamma gamma_law(double gamma) { return make_gamma_law(gamma); }
-    static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return recover_primitive(U, g.gamma, 0.0); }
+    static __device__ inline State5 c2p(const State5& U, const Gamma& g) { return recover_primitive<PLANAR>(U, g.gamma, 0.0); }
     struct Limiter { double theta; };
     static __device__ inline Limiter limiter(double theta) { return Limiter{theta}; }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return plm_gradient(l, c, r, lim.theta); }
-    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter&) { return face_plus(P, G); }
-    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter&) { return face_minus(P, G); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return plm_gradient<PLANAR>(l, c, r, lim.theta); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter&) { return face_plus<PLANAR>(P, G); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter&) { return face_minus<PLANAR>(P, G); }
     template<int RIEMANN, int AXIS>
-    static __device__ inline State5 flux(const State5& Pl, const State5& Pr, const Gamma& g) { return riemann<RIEMANN, AXIS>(Pl, Pr, g); }
+    static __device__ inline State5 flux(const State5& Pl, const State5& Pr, const Gamma& g) { return riemann<RIEMANN, AXIS, PLANAR>(Pl, Pr, g); }
     // u - ((Fxhi - Fxlo)*cx + (Fyhi - Fylo)*cy)
     static __device__ inline double update2(double u, double fxl, double fxh, double fyl, double fyh, double cx, double cy)
     {
@@ -313,6 +321,8 @@ struct StrictArith
     // src/subprog_cloud.cpp:693: s0*0.5 + s2*0.5
     static __device__ inline double combine(double base, double u1, double w) { return base * (1.0 - w) + u1 * w; }
 };
+using StrictArith = StrictArithT<false>;
+using StrictArithPlanar = StrictArithT<true>;
 
 // PLANAR: see fast::recover_primitive - the policy of the kernels that advance a field whose third momentum is identically zero
 template<bool PLANAR>

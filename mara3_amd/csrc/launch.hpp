@@ -44,7 +44,8 @@ hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3d
                                       int32_t* status, hipStream_t stream);
 
 // *flag |= 1 if variable q of any cell of rows [0, n0) of a field is not zero (the steppers' planarity check at upload)
-hipError_t plane_nonzero_launch(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, hipStream_t stream);
+// (exact_bits: anything but the bit pattern of +0.0 counts - the STRICT kernels' condition; otherwise -0.0 is a zero too)
+hipError_t plane_nonzero_launch(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, hipStream_t stream, bool exact_bits = false);
 hipError_t fill_ghost_rows_launch(double* u, int nq, int n0, size_t row_pitch, int bc_lo0, int bc_hi0, hipStream_t stream);
 hipError_t aos_to_soa_launch(const double* aos, double* soa, int nq, int n0, size_t row_pitch, hipStream_t stream);
 hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStream_t stream);

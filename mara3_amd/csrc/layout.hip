@@ -145,7 +145,7 @@ hipError_t stream_copy_launch(const double* src, double* dst, size_t n, hipStrea
 
 // *flag |= 1 if variable q of any cell of rows [0, n0) is not zero (NaN counts as not zero; -0 as zero): the steppers' check, at upload, that a 2-D
 // field carries no third momentum (mh_euler_cart_desc.planar) / no azimuthal momentum (mh_cloud_desc.planar)
-__global__ void plane_nonzero_kernel(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag)
+__global__ void plane_nonzero_kernel(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, int exact_bits)
 {
     const size_t n = (size_t) n0 * row_pitch;
     bool any = false;
@@ -153,16 +153,16 @@ __global__ void plane_nonzero_kernel(const double* u, int nq, int q, int n0, siz
     {
         const size_t r = t / row_pitch, j = t - r * row_pitch;
         const double x = u[((r + HALO) * nq + q) * row_pitch + j];
-        any |= ! (x == 0.0);
+        any |= exact_bits ? __double_as_longlong(x) != 0 : ! (x == 0.0);          // (STRICT: +0.0 and nothing else - the reference keeps a -0.0 a -0.0)
     }
     if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-hipError_t plane_nonzero_launch(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, hipStream_t stream)
+hipError_t plane_nonzero_launch(const double* u, int nq, int q, int n0, size_t row_pitch, int32_t* flag, hipStream_t stream, bool exact_bits)
 {
     const size_t n = (size_t) n0 * row_pitch;
     const unsigned blocks = (unsigned) (n / 256 + 1 < 2048 ? n / 256 + 1 : 2048);
-    hipLaunchKernelGGL(plane_nonzero_kernel, dim3(blocks), dim3(256), 0, stream, u, nq, q, n0, row_pitch, flag);
+    hipLaunchKernelGGL(plane_nonzero_kernel, dim3(blocks), dim3(256), 0, stream, u, nq, q, n0, row_pitch, flag, exact_bits ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -520,7 +520,7 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     if (kind == SLAB_EULER)
     {
         s->planar_request = global->planar;
-        s->desc.planar = s->fused_desc.planar = -1;          // until an upload has looked at the field
+        s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = -1;          // until an upload has looked at the field
         if (hipMalloc((void**) &s->planar_flag, sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     }
     if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
@@ -581,9 +581,12 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
 static void slab_set_planar(mh_slab* s, bool planar)
 {
     if (planar != s->planar_now)
+    {
         for (auto& e : s->fused_exec) { if (e) hipGraphExecDestroy(e); e = nullptr; }
+        if (s->exec) { hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+    }
     s->planar_now = planar;
-    s->desc.planar = s->fused_desc.planar = planar ? 1 : -1;
+    s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = planar ? 1 : -1;
 }
 
 static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
@@ -594,11 +597,11 @@ static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
     MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
     // planarity of this slab's own rows (mh_euler_cart_desc.planar): one pass per upload, none per step
     s->planar_local = false;
-    if (s->kind == SLAB_EULER && s->desc.rank == 2 && s->planar_request >= 0 && (s->fused || s->fused_cut) && s->planar_flag)
+    if (s->kind == SLAB_EULER && s->desc.rank == 2 && s->desc.plm_theta >= 0.0 && s->planar_request >= 0 && s->planar_flag)
     {
         int32_t nonzero = 0;
         MH_HIP_TRY(hipMemsetAsync(s->planar_flag, 0, sizeof(int32_t), s->main));
-        MH_HIP_TRY(plane_nonzero_launch(s->field[0], 5, 3, s->n0, (size_t) s->n1, s->planar_flag, s->main));
+        MH_HIP_TRY(plane_nonzero_launch(s->field[0], 5, 3, s->n0, (size_t) s->n1, s->planar_flag, s->main, s->desc.arith == MH_ARITH_STRICT));
         MH_HIP_TRY(hipMemcpyAsync(&nonzero, s->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, s->main));
         MH_HIP_TRY(hipStreamSynchronize(s->main));
         s->planar_local = nonzero == 0;

@@ -5,10 +5,10 @@ code = ("import sys, time, json; sys.path.insert(0, %r)\n"
         "from mara3_amd.slab import NativeSlabStepper\n"
         "n, gamma = 4096, 5.0 / 3; out = {}\n"
         "u0 = setups.blast_ic((n, n), gamma)\n"
-        "for arith, riemann, fuse in (('strict', 'hlle', None), ('fast', 'hllc', False)):\n"
-        "    st = NativeSlabStepper((n, n), (1.0 / n, 1.0 / n), gamma, 1.5, riemann, 2, 'outflow', arith=arith, fuse=fuse)\n"
+        "for arith, riemann, fuse, planar in (('strict', 'hlle', None, None), ('strict', 'hlle', None, False), ('strict', 'hllc', None, None), ('fast', 'hllc', False, None), ('fast', 'hllc', False, False)):\n"
+        "    st = NativeSlabStepper((n, n), (1.0 / n, 1.0 / n), gamma, 1.5, riemann, 2, 'outflow', arith=arith, fuse=fuse, planar=planar)\n"
         "    st.load_slab(u0); st.step(setups.baseline_dt(n), 40); st.synchronize()\n"
-        "    t0 = time.perf_counter(); st.step(setups.baseline_dt(n), 60); st.synchronize(); out[arith] = round((time.perf_counter() - t0) / 60 * 1e3, 4)\n"
+        "    t0 = time.perf_counter(); st.step(setups.baseline_dt(n), 60); st.synchronize(); out[arith + '_' + riemann + ('_general' if planar is False else '')] = round((time.perf_counter() - t0) / 60 * 1e3, 4)\n"
         "    st.close()\n"
         "print(json.dumps(out))\n" % ROOT)
 for rnd in range(2):

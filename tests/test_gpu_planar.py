@@ -153,3 +153,64 @@ def test_loopback_group_across_fused_cuts_is_planar_only_if_every_member_is(eng,
         ref = run(eng, shape, "hllc", "periodic", False, u0, nsteps=(4,))[0][0]
         for q in range(5):
             assert np.array_equal(got[..., q], ref[..., q]), (world, q, want_planar)
+
+
+# ---- the two-launch kernels (euler2d.hip): STRICT must keep the REFERENCE's bits, third momentum included
+
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+@pytest.mark.parametrize("riemann", ["hlle", "hllc"])
+@pytest.mark.parametrize("bc", ["outflow", "periodic"])
+def test_two_launch_planar_kernels_are_bit_identical_to_the_general_ones(eng, arith, riemann, bc):
+    """a field whose third momentum is +0.0 in every cell: STRICT every bit of all five components (the reference's operations return +0.0 for
+    the third direction, euler_device.hpp), FAST the bits of the other four"""
+    for shape, chunk in (((130, 250), 0), ((67, 200), 7), ((40, 64), 2)):
+        u0 = planar_state(shape, seed=13)
+        res = {}
+        for planar in (None, False):
+            s = eng.EulerCartSolver(shape, (1.0 / shape[0], 1.0 / shape[1]), 1.4, 1.5, riemann, 2, bc, arith=arith, fuse=False, planar=planar, chunk_rows=chunk)
+            s.upload(u0)
+            assert s.is_planar() is (planar is None)
+            s.step(4e-4, 3)
+            res[planar] = s.download()
+            assert s.status() == 0
+            s.close()
+        if arith == "strict":
+            assert bits_equal(res[None], res[False]), (shape, riemann, bc)
+        else:
+            for q in (0, 1, 2, 4):
+                assert bits_equal(res[None][..., q], res[False][..., q]), (shape, riemann, bc, q)
+            assert np.all(res[None][..., 3] == 0.0)
+
+
+def test_strict_planarity_is_about_the_bit_pattern(eng):
+    """STRICT keeps a -0.0 of the reference a -0.0: a field with a negative zero in its third momentum takes the general kernel"""
+    shape = (64, 80)
+    u0 = planar_state(shape, seed=3)
+    u0[10, 20, 3] = -0.0
+    s = eng.EulerCartSolver(shape, (1.0 / 64, 1.0 / 80), 1.4, 1.5, "hlle", 2, "outflow", arith="strict")
+    s.upload(u0)
+    assert s.is_planar() is False
+    s.close()
+    f = eng.EulerCartSolver(shape, (1.0 / 64, 1.0 / 80), 1.4, 1.5, "hlle", 2, "outflow", arith="fast")
+    f.upload(u0)
+    assert f.is_planar() is True
+    f.close()
+
+
+@pytest.mark.parametrize("case", ["euler2d_blast64_plm15_rk2", "euler2d_blast128_plm15_rk2", "euler2d_wave33x70_plm12_rk2_outflow"])
+def test_strict_planar_kernel_reproduces_the_reference_golden_steps(eng, case):
+    """the reference's own golden steps (its third momentum: identically zero) on the STRICT planar kernel, bit for bit incl. that component"""
+    from conftest import golden
+    g = golden(case)
+    u0 = g["u0"]
+    nsteps = sorted(int(n) for n in g["nsteps"])
+    s = eng.EulerCartSolver(u0.shape[:-1], tuple(g["dl"]), float(g["gamma"]), float(g["theta"]), "hlle", int(g["rk"]), "outflow" if int(g["bc"]) == 0 else "periodic", arith="strict")
+    s.upload(u0)
+    planar = s.is_planar()
+    assert planar is bool(np.all(u0[..., 3].view(np.uint64) == 0))
+    done = 0
+    for n in nsteps:
+        s.step(float(g["dt"]), n - done)
+        done = n
+        assert bits_equal(s.download(), g["u_%d" % n]), (case, n, planar)
+    s.close()
