@@ -201,7 +201,7 @@ def c4_parse(args, stdout, nr, arith):
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
     shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches \((\d+) per step", p.stdout)
     avg_ms, nl, lps = (float(shape.group(1)), int(shape.group(2)), int(shape.group(3))) if shape else (0.0, 0, 2)
-    planar = bool(re.search(r"fused step: planar", p.stdout))
+    planar = bool(re.search(r"step kernels: planar", p.stdout))
     m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
     vertices = (nr + 1) * (nq + 1)
@@ -216,14 +216,15 @@ def c4_parse(args, stdout, nr, arith):
         "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": per_step, "higher_is_better": True, "scaling": "weak" if args.gpus == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "mara_hip cloud nr=%d num_decades=1 rk_order=2 reconstruct_method=2 plm_theta=1.2 arith=%s (compiled host; per-step host nozzle evaluation and its 160 KB upload are inside the timed step)" % (nr, arith),
-                   "final_state_written": bool(m), "launches_per_step": lps, "planar_kernel": planar and fused,
+                   "final_state_written": bool(m), "launches_per_step": lps, "planar_kernel": planar,
                    "planar_note": ("the library verified at upload / set_inflow that field and nozzle row carry no azimuthal momentum (upstream's problem never has any) and "
-                                   "the fused launch skips that component (mh_cloud_desc.planar; same bits in the other four, tests/test_gpu_cloud_fused.py); "
-                                   "`mara_hip cloud ... planar=-1` runs the general kernel") if planar and fused else "general kernel"},
+                                   "the kernels skip that component (mh_cloud_desc.planar; FAST: same bits in the other four, tests/test_gpu_cloud_fused.py; STRICT: "
+                                   "taken on the bit pattern of +0.0, the reference's bits in all five, tests/test_gpu_cloud_planar.py and the golden steps); "
+                                   "`mara_hip cloud ... planar=-1` runs the general kernels") if planar else "general kernels"},
         "roofline": {"bound": "hbm", "achieved": bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None,
-                     "kernel": ("cloud_fused_rk2_kernel<%s> (both RK2 stages in one launch per step)" % ("planar" if planar else "general") if fused else "cloud_stage_kernel<%s,PLM> (mean of both RK2 stages)" % arith),
-                     "bytes_actually_moved_per_cell": (104 if planar else 120) if fused else 100,
+                     "kernel": ("cloud_fused_rk2_kernel<%s> (both RK2 stages in one launch per step)" % ("planar" if planar else "general") if fused else "cloud_stage_kernel<%s%s,PLM> (mean of both RK2 stages)" % (arith, ", planar" if planar else "")),
+                     "bytes_actually_moved_per_cell": (104 if planar else 120) if fused else (88 if planar else 100),
                      "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms, "launches": nl, "launches_per_step": lps,
                      "timing": "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"},
         "roofline_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "note": "200 B per zone-update over the whole host-timed step (nozzle upload and launch gaps included)"},
@@ -478,13 +479,13 @@ def attach_traffic(out, config):
         if t.get("csrc_sha16") != csrc_fingerprint():
             return out
         names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),
-                 "c4": ("c4", "cloud_stage_kernel<Srhd%s, true, false>", "cloud_stage_kernel<Srhd%s, true, true>"),
+                 "c4": ("c4", "cloud_stage_kernel<Srhd%sT<@>, true, false>", "cloud_stage_kernel<Srhd%sT<@>, true, true>"),
                  "c5": ("c5", "euler3d_stage_kernel<%sArith, 0, true, false>", "euler3d_stage_kernel<%sArith, 0, true, true>")}[config]
         for mode, roof in (("Fast", out.get("roofline")), ("Strict", (out.get("arith_strict") or {}).get("roofline"))):
             if not roof or not roof.get("avg_launch_ms"):
                 continue
             tag = "c4s" if (config == "c4" and mode == "Strict") else names[0]
-            keys = ["%s:%s" % (tag, n % mode) for n in names[1:]]
+            keys = ["%s:%s" % (tag, (n % mode).replace("@", "true" if "planar" in roof.get("kernel", "") else "false")) for n in names[1:]]
             if config == "c4" and mode == "Fast" and roof.get("launches_per_step") == 1:
                 keys = ["c4:cloud_fused_rk2_kernel<%s>" % ("true" if "planar" in roof.get("kernel", "") else "false")]           # the RK2 step's one launch
             if all(k in t for k in keys):

@@ -109,9 +109,10 @@ typedef struct
                              * where it is not available). The result is bit-identical to the two launches'. */
     int    planar;          /* rank-2 fields whose THIRD momentum is identically zero - every 2-D run of mara::euler's five-component state, which
                              * the reference carries as zeros through recover_primitive, the slopes, both Riemann problems and the update
-                             * (src/physics_euler.hpp:209-220, :252-263, :555-575). The one-launch FAST step then neither reads nor exchanges nor
-                             * computes that component and writes it as zero: the other four components keep their bits (x + 0 and fma(0, 0, x)
-                             * are x), ~11 % fewer instructions. 0 = where the stepper has VERIFIED it: the context and the slab steppers look at
+                             * (src/physics_euler.hpp:209-220, :252-263, :555-575). The PLM kernels (the one-launch FAST step, and the stage kernels
+                             * of both arithmetic modes) then neither read nor compute that component and write it as zero: the other four
+                             * components keep their bits (x + 0 and fma(0, 0, x) are x), ~11 % fewer instructions. MH_ARITH_STRICT takes it only on
+                             * the BIT PATTERN of +0.0 everywhere, for which the reference's own operations return +0.0: still bit-identical. 0 = where the stepper has VERIFIED it: the context and the slab steppers look at
                              * the uploaded field (one pass at upload, not per step; a field with a third momentum takes the general kernel),
                              * loopback groups at all members' rows; slabs that exchange with OTHER PROCESSES only under > 0 = the caller asserts
                              * it for the whole grid (each rank still verifies its own rows: upload fails otherwise); < 0 = never. */
@@ -204,10 +205,12 @@ typedef struct
                                  * results bit-identical to the two launches), < 0 = never, > 0 = required (configure fails otherwise) */
     int    planar;              /* field and nozzle row without AZIMUTHAL momentum - the `cloud` problem as upstream sets it up (radial envelope and
                                  * nozzle, src/subprog_cloud.cpp:626-660, :466-493), which the reference carries as zeros through every operator. The
-                                 * one-launch step then skips that component (same bits in the other four; cf. mh_euler_cart_desc.planar): 0 = where
-                                 * the context has VERIFIED it (mh_upload looks at the field, mh_cloud_set_inflow at the row; a step whose row has an
-                                 * azimuthal velocity takes the general kernel from then on), < 0 = never, > 0 = asserted (upload / set_inflow fail
-                                 * otherwise) */
+                                 * PLM kernels (one-launch step and stage kernels, both arithmetic modes; MH_ARITH_STRICT on the bit pattern of
+                                 * +0.0, bit-identical to the reference in all five components - csrc/srhd_device.hpp) then skip that component
+                                 * (cf. mh_euler_cart_desc.planar): 0 = where the stepper has VERIFIED it (mh_upload / the slab uploads look at the
+                                 * field, mh_cloud_set_inflow / mh_slab_set_inflow at the row; a step whose row has an azimuthal velocity takes the
+                                 * general kernels from then on; slabs that exchange with other processes only under > 0), < 0 = never,
+                                 * > 0 = asserted (upload / set_inflow fail otherwise) */
 } mh_cloud_desc;
 
 /* doubles of the packed device geometry block: rv[nr_global+1] | dmu[nq] | sinq[nq+1] | cotq[nq] | per-row factors [nr_global][8] |
@@ -250,8 +253,8 @@ int  mh_status(mh_ctx* ctx, mh_step_result* result);
  * exception and retry from the OLD solution (src/subprog_binary.cpp:285-292). Synchronises (one 8-byte read-back per step);
  * mh_step stays the asynchronous in-place form for drivers that, like upstream's cloud / sedov, do not retry. */
 int  mh_step_checked(mh_ctx* ctx, double dt, mh_step_result* result);
-/* 1 if the fused step of this context currently takes its planar kernel (mh_euler_cart_desc.planar: the uploaded 2-D field has no third
- * momentum), else 0 */
+/* 1 if the steps of this context currently take their planar kernels (mh_euler_cart_desc.planar / mh_cloud_desc.planar: the uploaded 2-D
+ * field - and the nozzle row - have no third momentum), else 0 */
 int  mh_field_is_planar(const mh_ctx* ctx);
 /* Raw device pointer of the current solution field (SoA with ghosts) and of the scratch field, for halo exchange. */
 double* mh_field_ptr(mh_ctx* ctx, int which /* 0 = current solution, 1 = stage scratch */);
@@ -321,7 +324,7 @@ int  mh_slab_group_download(mh_slab** slabs, int world, double* u_aos_global_hos
 int  mh_slab_group_step(mh_slab** slabs, int world, double dt, int nsteps);
 void mh_slab_destroy(mh_slab* slab);
 int  mh_slab_rows(const mh_slab* slab, int* row0, int* row1);                 /* this rank's rows [row0, row1) */
-int  mh_slab_is_planar(const mh_slab* slab);                                  /* 1: its fused launches skip the third momentum (mh_euler_cart_desc.planar) */
+int  mh_slab_is_planar(const mh_slab* slab);                                  /* 1: its launches skip the third momentum (the descriptors' planar) */
 int  mh_slab_upload(mh_slab* slab, const double* u_aos_slab_host);            /* host AoS [n0][n1][5] of this rank's rows */
 int  mh_slab_download(mh_slab* slab, double* u_aos_slab_host);
 int  mh_slab_step(mh_slab* slab, double dt, int nsteps, int use_graph);       /* use_graph: replay one captured step (RK2) */

@@ -509,8 +509,9 @@ int mh_cloud_set_inflow(mh_ctx* c, const double* inflow_aos)
     std::vector<double> soa(5 * nq);
     for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_aos[5 * j + q];
     // planarity (mh_cloud_desc.planar): a nozzle row with an azimuthal velocity puts azimuthal momentum into the field - general kernel from here on
+    // (STRICT: the bit pattern of +0.0, as for the field - srhd_device.hpp)
     c->inflow_planar = true;
-    for (size_t j = 0; j < nq; ++j) c->inflow_planar = c->inflow_planar && inflow_aos[5 * j + 3] == 0.0;
+    for (size_t j = 0; j < nq; ++j) c->inflow_planar = c->inflow_planar && inflow_aos[5 * j + 3] == 0.0 && ! (c->cloud.arith == MH_ARITH_STRICT && std::signbit(inflow_aos[5 * j + 3]));
     if (! c->inflow_planar)
     {
         if (c->cloud.planar > 0) { set_error("set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return ctx_fail(c, MH_E_INVALID); }
@@ -580,12 +581,12 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
     // kernel writes that component as zero, so the property holds for as long as this solution is stepped
     c->planar_now = false;
     const int planar_request = cloud ? c->cloud.planar : d->planar;
-    // (cloud: only its one-launch FAST step has a planar form; 2-D Euler: every PLM stage kernel has one, STRICT on the exact bit pattern of +0.0)
-    if ((cloud ? ctx_can_fuse(c) : (d->rank == 2 && d->plm_theta >= 0.0)) && planar_request >= 0)
+    // (every PLM stage kernel of the 2-D Euler and `cloud` steppers has a planar form, STRICT on the exact bit pattern of +0.0)
+    if ((cloud ? c->cloud.plm_theta >= 0.0 : (d->rank == 2 && d->plm_theta >= 0.0)) && planar_request >= 0)
     {
         int32_t nonzero = 0;
         MH_HIP_TRY(hipMemsetAsync(c->planar_flag, 0, sizeof(int32_t), c->stream));
-        MH_HIP_TRY(plane_nonzero_launch(c->field[0], 5, 3, n0, pitch, c->planar_flag, c->stream, ! cloud && d->arith == MH_ARITH_STRICT));
+        MH_HIP_TRY(plane_nonzero_launch(c->field[0], 5, 3, n0, pitch, c->planar_flag, c->stream, (cloud ? c->cloud.arith : d->arith) == MH_ARITH_STRICT));
         MH_HIP_TRY(hipMemcpyAsync(&nonzero, c->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, c->stream));
         MH_HIP_TRY(hipStreamSynchronize(c->stream));
         c->planar_now = nonzero == 0;
@@ -647,7 +648,12 @@ struct ProfileSpan
 static hipError_t timed_stage(mh_ctx* c, const double* in, const double* base, double* out, double dt, double w)
 {
     if (c->profile) ++c->span_launches;
-    if (c->kind == mh_ctx::KIND_CLOUD) return cloud_stage_launch(&c->cloud, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream);
+    if (c->kind == mh_ctx::KIND_CLOUD)
+    {
+        mh_cloud_desc d = c->cloud;
+        d.planar = c->planar_now && c->inflow_planar ? 1 : -1;          // what mh_upload and mh_cloud_set_inflow found
+        return cloud_stage_launch(&d, c->geom, c->inflow, in, base, out, dt, w, 0, c->cloud.nr, c->status, c->stream);
+    }
     mh_euler_cart_desc d = c->desc;
     d.planar = c->planar_now ? 1 : -1;          // what the upload found (mh_upload)
     return cart_stage_launch(&d, in, base, out, dt, w, 0, c->desc.n[0], c->status, c->stream);

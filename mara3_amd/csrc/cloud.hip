@@ -56,6 +56,7 @@ void cloud_stage_kernel(CloudParams p)
     const int w = __builtin_amdgcn_readfirstlane(b * CWAVES_PER_BLOCK + (int) (threadIdx.x >> 6));   // wave-uniform -> scalar registers
     if (w >= p.nstrips * p.nchunks) return;
     const int lane = threadIdx.x & 63;
+    constexpr bool PL = S::planar;                      // no azimuthal component anywhere (the stepper has checked field and nozzle row)
     const int chunk = w / p.nstrips;
     const int strip = w - chunk * p.nstrips;
     int r0 = p.row_begin + chunk * p.chunk_rows;
@@ -134,7 +135,7 @@ void cloud_stage_kernel(CloudParams p)
     auto load_raw = [&] (int r) -> State5
     {
         const int rr = min(max(r, -CHALO), p.n0 + CHALO - 1);
-        return cloud_load_row(in + row_off(rr), plane, jc8);
+        return cloud_load_row<PL>(in + row_off(rr), plane, jc8);
     };
     // MH_ARITH_FAST: the conserved values of rows r, r+1, r+2 wait for their update in a per-wave LDS ring (no barrier: private to the
     // wave) instead of being read a second time - that second read misses in L2 and made the launch's HBM traffic 1.6 x / 1.4 x algorithmic
@@ -145,14 +146,14 @@ void cloud_stage_kernel(CloudParams p)
         if constexpr (S::lds_row_ring)
         {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) own_rows[wave_in_block][slot][q][lane] = raw[q];
+            for (int q = 0; q < 5; ++q) if (S::live(q)) own_rows[wave_in_block][slot][q][lane] = raw[q];
         }
     };
     auto ring_get = [&] (int slot) -> State5
     {
         State5 U;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) U[q] = own_rows[S::lds_row_ring ? wave_in_block : 0][slot][q][lane];
+        for (int q = 0; q < 5; ++q) U[q] = S::live(q) ? own_rows[S::lds_row_ring ? wave_in_block : 0][slot][q][lane] : 0.0;
         return U;
     };
     // primitive of a stored row (real row, or a ghost row received from the neighbouring slab) from its loaded variables
@@ -181,7 +182,7 @@ void cloud_stage_kernel(CloudParams p)
         {
             State5 P;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) P[q] = p.inflow[(long) q * p.n1 + jc];
+            for (int q = 0; q < 5; ++q) P[q] = S::live(q) ? p.inflow[(long) q * p.n1 + jc] : 0.0;
             return P;
         }
         if (r >= p.n0 && p.bc_hi0 != MH_BC_EXTERNAL) return last;
@@ -193,7 +194,7 @@ void cloud_stage_kernel(CloudParams p)
         {
             State5 P;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) P[q] = p.inflow[(long) q * p.n1 + jc];
+            for (int q = 0; q < 5; ++q) P[q] = S::live(q) ? p.inflow[(long) q * p.n1 + jc] : 0.0;
             return P;
         }
         if (r >= p.n0 && p.bc_hi0 != MH_BC_EXTERNAL) return last;     // zero-gradient outer: copy of the last real row
@@ -215,7 +216,7 @@ void cloud_stage_kernel(CloudParams p)
         {
             G0 = S::plm(Pb, P0, P1, lim);
             State5 Gb;
-            if (r0 == 0 && phys_lo) Gb = times_zero(G0);                       // extend_zeros on G
+            if (r0 == 0 && phys_lo) Gb = times_zero_p<PL>(G0);                       // extend_zeros on G
             else                    Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, lim);
             Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
         }
@@ -240,7 +241,7 @@ void cloud_stage_kernel(CloudParams p)
         State5 G1, Fx_hi;
         if constexpr (PLM)
         {
-            if (r + 1 == p.n0 && phys_hi) G1 = times_zero(G0);
+            if (r + 1 == p.n0 && phys_hi) G1 = times_zero_p<PL>(G0);
             else                          G1 = S::plm(P0, P1, P2, lim);
             Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
         }
@@ -253,31 +254,31 @@ void cloud_stage_kernel(CloudParams p)
         State5 Fy_lo, Fy_hi;
         if constexpr (PLM)
         {
-            const State5 Graw = S::plm(dpp_left(P0), P0, dpp_right(P0), lim);
+            const State5 Graw = S::plm(dpp_left_p<PL>(P0), P0, dpp_right_p<PL>(P0), lim);
             State5 Gy;
             if constexpr (S::exact_zero_products)
             {
                 // pole cells: the neighbour's slope times zero (extend_zeros, :563) - NaN and the sign of zero propagate as upstream
-                const State5 Gl = dpp_left(Graw), Gr = dpp_right(Graw);
+                const State5 Gl = dpp_left_p<PL>(Graw), Gr = dpp_right_p<PL>(Graw);
 #pragma unroll
-                for (int q = 0; q < 5; ++q) Gy[q] = pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]);
+                for (int q = 0; q < 5; ++q) Gy[q] = ! S::live(q) ? 0.0 : (pole_lo ? Gr[q] * 0.0 : (pole_hi ? Gl[q] * 0.0 : Graw[q]));
             }
             else
             {
                 Gy = Graw;          // (a pole lane's lim_polar gives it no weight)
             }
-            const State5 SL = dpp_left(S::plus(P0, Gy, lim_polar));
+            const State5 SL = dpp_left_p<PL>(S::plus(P0, Gy, lim_polar));
             Fy_lo = S::template hlle<1>(SL, S::minus(P0, Gy, lim_polar), g);
         }
         else
         {
-            Fy_lo = S::template hlle<1>(dpp_left(P0), P0, g);
+            Fy_lo = S::template hlle<1>(dpp_left_p<PL>(P0), P0, g);
         }
-        Fy_hi = dpp_right(Fy_lo);
+        Fy_hi = dpp_right_p<PL>(Fy_lo);
         if constexpr (S::exact_zero_products)
         {
-            if (pole_lo) Fy_lo = times_zero(Fy_hi);
-            if (pole_hi) Fy_hi = times_zero(Fy_lo);
+            if (pole_lo) Fy_lo = times_zero_p<PL>(Fy_hi);
+            if (pole_hi) Fy_hi = times_zero_p<PL>(Fy_lo);
         }
         // (MH_ARITH_FAST: the pole faces' area factors are zero, see lim_polar above)
 
@@ -290,8 +291,8 @@ void cloud_stage_kernel(CloudParams p)
         auto load_own_row = [&] () __attribute__((always_inline))
         {
             if constexpr (S::lds_row_ring) U0 = ring_get(slot);
-            else                           U0 = cloud_load_row(in + row_off(r), plane, jc8);
-            if constexpr (COMBINE) Ubase = cloud_load_row(p.u_base + row_off(r), plane, jc8);
+            else                           U0 = cloud_load_row<PL>(in + row_off(r), plane, jc8);
+            if constexpr (COMBINE) Ubase = cloud_load_row<PL>(p.u_base + row_off(r), plane, jc8);
         };
         if constexpr (S::group_own_row_loads)
         {
@@ -306,6 +307,7 @@ void cloud_stage_kernel(CloudParams p)
 #pragma unroll
         for (int q = 0; q < 5; ++q)
         {
+            if (! S::live(q)) { Un[q] = 0.0; continue; }      // planar: u0 + ((+0) + (+0) + (+-0)) dt and the combination of two +0 are +0
             const double u1 = S::update(U0[q], Fx_lo[q], Fx_hi[q], Fy_lo[q], Fy_hi[q], c.nAr_lo, c.nAr_hi, c.nAq_lo, c.nAq_hi, Src[q], c.dv, p.dt);
             if constexpr (COMBINE) Un[q] = S::combine(Ubase[q], u1, p.weight);
             else                   Un[q] = u1;
@@ -370,7 +372,19 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
     const int nwaves = p.nstrips * p.nchunks;
     const dim3 grid((nwaves + CWAVES_PER_BLOCK - 1) / CWAVES_PER_BLOCK), block(CWAVE * CWAVES_PER_BLOCK);
     const bool plm = d->plm_theta >= 0.0, combine = weight != 1.0;
-    if (d->arith == MH_ARITH_FAST)
+    // planar (mh_cloud_desc.planar > 0: the stepper has checked the field and the nozzle row - api.hip, slab.hip): the PLM kernels without
+    // the azimuthal component
+    if (d->planar > 0 && plm && d->arith == MH_ARITH_FAST)
+    {
+        if (combine)              hipLaunchKernelGGL((cloud_stage_kernel<SrhdFastPlanar, true, true>), grid, block, 0, stream, p);
+        else                      hipLaunchKernelGGL((cloud_stage_kernel<SrhdFastPlanar, true, false>), grid, block, 0, stream, p);
+    }
+    else if (d->planar > 0 && plm)
+    {
+        if (combine)              hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrictPlanar, true, true>), grid, block, 0, stream, p);
+        else                      hipLaunchKernelGGL((cloud_stage_kernel<SrhdStrictPlanar, true, false>), grid, block, 0, stream, p);
+    }
+    else if (d->arith == MH_ARITH_FAST)
     {
         if (plm && combine)       hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, true, true>), grid, block, 0, stream, p);
         else if (plm)             hipLaunchKernelGGL((cloud_stage_kernel<SrhdFast, true, false>), grid, block, 0, stream, p);

@@ -47,6 +47,10 @@ __device__ inline double dpp_right(double x)
 __device__ inline State5 dpp_left(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp_left(s[q]); return r; }
 __device__ inline State5 dpp_right(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = dpp_right(s[q]); return r; }
 __device__ inline State5 times_zero(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = s[q] * 0.0; return r; }
+// planar states (component 3 is +0.0 in every lane: nothing to move, (+0) * 0.0 = +0)
+template<bool PLANAR> __device__ inline State5 dpp_left_p(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = PLANAR && q == 3 ? 0.0 : dpp_left(s[q]); return r; }
+template<bool PLANAR> __device__ inline State5 dpp_right_p(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = PLANAR && q == 3 ? 0.0 : dpp_right(s[q]); return r; }
+template<bool PLANAR> __device__ inline State5 times_zero_p(const State5& s) { State5 r; for (int q = 0; q < 5; ++q) r[q] = PLANAR && q == 3 ? 0.0 : s[q] * 0.0; return r; }
 
 // wave-uniform radial geometry of global row i
 struct RowGeom
@@ -76,12 +80,18 @@ struct CellGeom { double dv, inv_dv, nAr_lo, nAr_hi, nAq_lo, nAq_hi, rc, inv_rc;
 // the five variables of one stored row through a buffer resource: wave-uniform row pointer (scalar registers), per-lane byte offset,
 // scalar plane offset - five buffer instructions and no vector address arithmetic (as euler2d.hip)
 using cb64_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t(), 0, 0, 0));
+// (PLANAR: the azimuthal plane is known to hold +0.0 - not read; the store still writes it, the output buffer's plane is not known to)
+template<bool PLANAR = false>
 __device__ inline State5 cloud_load_row(const double* row, long plane, unsigned lane_bytes)
 {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(row), 0, (int) (5 * plane * 8), 0x00020000);
     State5 U;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * plane * 8), 0));
+    for (int q = 0; q < 5; ++q)
+    {
+        if (PLANAR && q == 3) U[q] = 0.0;
+        else U[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, (unsigned) (q * plane * 8), 0));
+    }
     return U;
 }
 __device__ inline void cloud_store_row(double* row, long plane, unsigned lane_bytes, const State5& U)

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <dlfcn.h>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,8 +123,9 @@ struct mh_slab
     hipGraphExec_t fused_exec[2] = {nullptr, nullptr};
     // planarity of the 2-D Euler field (mh_euler_cart_desc.planar): the caller's request, what this slab's own rows showed at the last upload, and
     // what the fused launches are told (desc.planar / fused_desc.planar = +1 / -1)
+    // (`cloud`: the same for the azimuthal momentum, mh_cloud_desc.planar; inflow_planar = the nozzle row last handed in has no azimuthal velocity)
     int planar_request = 0;
-    bool planar_local = false, planar_now = false;
+    bool planar_local = false, planar_now = false, inflow_planar = true;
     int32_t* planar_flag = nullptr;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[2];   // bulk launches of stage 1 / stage 2
@@ -517,12 +519,9 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     }
     if (hipMalloc((void**) &s->status, 2 * sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     hipMemsetAsync(s->status, 0, 2 * sizeof(int32_t), s->main);
-    if (kind == SLAB_EULER)
-    {
-        s->planar_request = global->planar;
-        s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = -1;          // until an upload has looked at the field
-        if (hipMalloc((void**) &s->planar_flag, sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
-    }
+    s->planar_request = kind == SLAB_EULER ? global->planar : cglobal->planar;
+    s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = s->cloud.planar = s->cloud_edge.planar = -1;          // until an upload has looked at the field
+    if (hipMalloc((void**) &s->planar_flag, sizeof(int32_t)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     if (kind == SLAB_CLOUD)
     {
@@ -586,7 +585,7 @@ static void slab_set_planar(mh_slab* s, bool planar)
         if (s->exec) { hipGraphExecDestroy(s->exec); s->exec = nullptr; }
     }
     s->planar_now = planar;
-    s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = planar ? 1 : -1;
+    s->desc.planar = s->edge_desc.planar = s->fused_desc.planar = s->cloud.planar = s->cloud_edge.planar = planar ? 1 : -1;
 }
 
 static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
@@ -597,11 +596,12 @@ static int slab_upload_rows(mh_slab* s, const double* u_aos_slab_host)
     MH_HIP_TRY(aos_to_soa_launch(s->staging, s->field[0], 5, s->n0, (size_t) s->n1, s->main));
     // planarity of this slab's own rows (mh_euler_cart_desc.planar): one pass per upload, none per step
     s->planar_local = false;
-    if (s->kind == SLAB_EULER && s->desc.rank == 2 && s->desc.plm_theta >= 0.0 && s->planar_request >= 0 && s->planar_flag)
+    const bool has_planar_kernels = s->kind == SLAB_EULER ? s->desc.rank == 2 && s->desc.plm_theta >= 0.0 : s->cloud.plm_theta >= 0.0;
+    if (has_planar_kernels && s->planar_request >= 0 && s->planar_flag)
     {
         int32_t nonzero = 0;
         MH_HIP_TRY(hipMemsetAsync(s->planar_flag, 0, sizeof(int32_t), s->main));
-        MH_HIP_TRY(plane_nonzero_launch(s->field[0], 5, 3, s->n0, (size_t) s->n1, s->planar_flag, s->main, s->desc.arith == MH_ARITH_STRICT));
+        MH_HIP_TRY(plane_nonzero_launch(s->field[0], 5, 3, s->n0, (size_t) s->n1, s->planar_flag, s->main, (s->kind == SLAB_EULER ? s->desc.arith : s->cloud.arith) == MH_ARITH_STRICT));
         MH_HIP_TRY(hipMemcpyAsync(&nonzero, s->planar_flag, sizeof nonzero, hipMemcpyDeviceToHost, s->main));
         MH_HIP_TRY(hipStreamSynchronize(s->main));
         s->planar_local = nonzero == 0;
@@ -776,7 +776,7 @@ int mh_slab_upload(mh_slab* s, const double* u_aos_slab_host)
     if (s->backend == EXCHANGE_LOOPBACK) { set_error("mh_slab_upload: member of a loopback group (use mh_slab_group_upload)"); return slab_fail(s, MH_E_STATE); }
     if (int rc = slab_upload_rows(s, u_aos_slab_host)) return slab_fail(s, rc);
     // alone: what the rows showed; with neighbours in OTHER processes: only what the caller asserted for the whole grid (and these rows confirmed)
-    slab_set_planar(s, s->planar_local && (! has_neighbours(s) || s->backend == EXCHANGE_NONE || s->planar_request > 0));
+    slab_set_planar(s, s->planar_local && s->inflow_planar && (! has_neighbours(s) || s->backend == EXCHANGE_NONE || s->planar_request > 0));
     if (int rc = slab_exchange(s, s->field[0], s->main, true)) return slab_fail(s, rc);
     if (int rc = slab_reset_chains(s)) return slab_fail(s, rc);
     return MH_OK;
@@ -791,7 +791,7 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
     for (int r = 0; r < n; ++r) { MH_HIP_TRY(hipSetDevice(g[r]->device)); MH_HIP_TRY(hipStreamSynchronize(g[r]->main)); }
     {
         bool all = true;          // a loopback group sees every member's rows: planar only if the whole grid is
-        for (int r = 0; r < n; ++r) all = all && g[r]->planar_local;
+        for (int r = 0; r < n; ++r) all = all && g[r]->planar_local && g[r]->inflow_planar;
         for (int r = 0; r < n; ++r) slab_set_planar(g[r], all);
     }
     for (int r = 0; r < n; ++r)
@@ -832,9 +832,26 @@ int mh_slab_group_download(mh_slab** g, int n, double* u_aos_global_host)
 int mh_slab_set_inflow(mh_slab* s, const double* inflow_prims_aos_host)
 {
     if (! s || s->kind != SLAB_CLOUD || ! inflow_prims_aos_host) { set_error("mh_slab_set_inflow: not a cloud slab"); return MH_E_STATE; }
+    const size_t nq = (size_t) s->n1;
+    // planarity (mh_cloud_desc.planar): every slab is handed the row, so every slab learns of an azimuthal velocity in the same call - and takes
+    // the general kernels until the next upload has looked at the field again (STRICT: the bit pattern of +0.0, srhd_device.hpp)
+    bool row_planar = true;
+    for (size_t j = 0; j < nq; ++j)
+    {
+        const double up = inflow_prims_aos_host[5 * j + 3];
+        row_planar = row_planar && up == 0.0 && ! (s->cloud.arith == MH_ARITH_STRICT && std::signbit(up));
+    }
+    s->inflow_planar = row_planar;
+    if (! row_planar)
+    {
+        if (s->planar_request > 0) { set_error("mh_slab_set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return slab_fail(s, MH_E_INVALID); }
+        MH_HIP_TRY(hipSetDevice(s->device));
+        MH_HIP_TRY(hipStreamSynchronize(s->main));
+        MH_HIP_TRY(hipStreamSynchronize(s->side));
+        slab_set_planar(s, false);
+    }
     if (s->row0 != 0) return MH_OK;              // only the slab that owns the nozzle-side boundary reads the row
     MH_HIP_TRY(hipSetDevice(s->device));
-    const size_t nq = (size_t) s->n1;
     std::vector<double> soa(5 * nq);
     for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_prims_aos_host[5 * j + q];
     // after the stages already queued (they read the previous row); the staging vector is consumed before return

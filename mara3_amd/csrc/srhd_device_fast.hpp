@@ -171,22 +171,39 @@ __device__ inline State5 source_terms(const State5& P, double r, double cotq, co
 } // namespace srhd_fast
 
 // ---- arithmetic policies of the cloud kernel ---------------------------------------------------------------------
-struct SrhdStrict
+// PLANAR: the field and the nozzle row carry no azimuthal component (STRICT: the bit pattern of +0.0; see srhd_device.hpp) - the stage kernel
+// neither loads nor computes it and stores +0.0, which is what the reference's own operations return for it
+template<bool PLANAR>
+struct SrhdStrictT
 {
-    static constexpr int min_waves_per_simd = 2;      // 163-167 VGPRs: three waves fit anyway
+    static constexpr bool planar = PLANAR;
+    static constexpr bool live(int q) { return ! (PLANAR && q == 3); }
+#ifndef MH_CLOUD_STRICT_PLANAR_WAVES
+#define MH_CLOUD_STRICT_PLANAR_WAVES 2
+#endif
+    static constexpr int min_waves_per_simd = PLANAR ? MH_CLOUD_STRICT_PLANAR_WAVES : 2;      // general: 163-167 VGPRs, three waves fit anyway
     static constexpr bool table_geometry = false;     // geometry factors formed per cell in the reference's order
     static constexpr bool exact_zero_products = true; // pole slopes / fluxes as (neighbour's value) * 0, like extend_zeros: NaN and -0 propagate
     static constexpr bool group_own_row_loads = false;// (cloud.hip: where the update's loads of the row's conserved values are requested)
     static constexpr bool lds_row_ring = true;        // the row's conserved values wait for the update in a per-wave LDS ring
-    static __device__ inline void to_density(double (&x)[5], double dv, double) { divide_group<5>(x, make_recip(dv, 1.0)); }
-    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive(U, g, tf, P); }
-    static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms(P, r, cot, g); }
-    using Limiter = StrictArith::Limiter;
-    static __device__ inline Limiter limiter(double theta) { return StrictArith::limiter(theta); }
-    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return StrictArith::plm(l, c, r, lim); }
-    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return StrictArith::plus(P, G, lim); }
-    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return StrictArith::minus(P, G, lim); }
-    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd::riemann_hlle<AXIS>(Pl, Pr, g); }
+    static __device__ inline void to_density(double (&x)[5], double dv, double)
+    {
+        if constexpr (PLANAR)
+        {
+            double y[4] = {x[0], x[1], x[2], x[4]};
+            divide_group<4>(y, make_recip(dv, 1.0));
+            x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; x[3] = 0.0; x[4] = y[3];
+        }
+        else divide_group<5>(x, make_recip(dv, 1.0));
+    }
+    static __device__ inline int c2p(const State5& U, const srhd::Gamma& g, double tf, State5& P) { return srhd::recover_primitive<PLANAR>(U, g, tf, P); }
+    static __device__ inline State5 source(const State5& P, double r, double, double cot, const srhd::Gamma& g) { return srhd::source_terms<PLANAR>(P, r, cot, g); }
+    using Limiter = typename StrictArithT<PLANAR>::Limiter;
+    static __device__ inline Limiter limiter(double theta) { return StrictArithT<PLANAR>::limiter(theta); }
+    static __device__ inline State5 plm(const State5& l, const State5& c, const State5& r, const Limiter& lim) { return StrictArithT<PLANAR>::plm(l, c, r, lim); }
+    static __device__ inline State5 plus(const State5& P, const State5& G, const Limiter& lim) { return StrictArithT<PLANAR>::plus(P, G, lim); }
+    static __device__ inline State5 minus(const State5& P, const State5& G, const Limiter& lim) { return StrictArithT<PLANAR>::minus(P, G, lim); }
+    template<int AXIS> static __device__ inline State5 hlle(const State5& Pl, const State5& Pr, const srhd::Gamma& g) { return srhd::riemann_hlle<AXIS, PLANAR>(Pl, Pr, g); }
     // u0 + ((Fr_hi (-dAr_hi) - Fr_lo (-dAr_lo)) + (Fq_hi (-dAq_hi) - Fq_lo (-dAq_lo)) + S dv) dt     src/subprog_cloud.cpp:572-574
     static __device__ inline double update(double u0, double fxl, double fxh, double fyl, double fyh, double nArl, double nArh, double nAql, double nAqh, double s, double dv, double dt)
     {
@@ -197,6 +214,8 @@ struct SrhdStrict
     }
     static __device__ inline double combine(double base, double u1, double w) { return base * (1.0 - w) + u1 * w; }
 };
+using SrhdStrict = SrhdStrictT<false>;
+using SrhdStrictPlanar = SrhdStrictT<true>;
 
 template<bool PLANAR>
 struct SrhdFastT

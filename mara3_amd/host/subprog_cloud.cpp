@@ -349,7 +349,7 @@ public:
             host::dump_state(cfg.get_string("outdir"), "inflow0.bin", {long(nq)}, 5, 0.0, 0, {}, inflow_first);
         if (cfg.get_int("profile") && gpus == 1)
         {
-            std::printf("fused step: %s kernel\n", mh_field_is_planar(ctx) ? "planar (no azimuthal momentum in field and nozzle row: verified)" : "general");
+            std::printf("step kernels: %s\n", mh_field_is_planar(ctx) ? "planar (no azimuthal momentum in field and nozzle row: verified)" : "general");
             // after the run and its output: five further steps in ONE call, i.e. between ONE pair of events (events around every step put two markers
             // between consecutive kernels and read long on sub-millisecond launches); the nozzle row stays that of the last step
             const int extra = 5;

@@ -514,7 +514,7 @@ class NativeSlabGroup:
             nr, nq = len(rv) - 1, len(qv) - 1
             d = L.CloudDesc(nr=nr, nq=nq, nr_global=nr, row_offset=0, gamma=gamma, plm_theta=plm_theta, temperature_floor=temperature_floor,
                             bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith],
-                            chunk_rows=chunk_rows)
+                            chunk_rows=chunk_rows, planar=0 if planar is None else (1 if planar else -1))
             if ids is not None:
                 L.check(self.lib.mh_slab_cloud_group_create_on(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
                                                                rk_order, world, ids))
@@ -544,6 +544,10 @@ class NativeSlabGroup:
         u = self.np.empty(self.global_shape + (NQ,))
         L.check(self.lib.mh_slab_group_download(self.handles, self.world, u.ctypes.data_as(C.c_void_p)))
         return u
+
+    def is_planar(self):
+        """True while every member's launches take the planar kernels (descriptor field `planar`)"""
+        return all(bool(self.lib.mh_slab_is_planar(C.c_void_p(self.handles[r]))) for r in range(self.world))
 
     def set_inflow(self, inflow_prims):
         p = self.np.ascontiguousarray(inflow_prims, dtype=self.np.float64)
