@@ -33,6 +33,37 @@ void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips)
     *nstrips = (d->n[2] + STRIP3 - 1) / STRIP3;
 }
 
+// Planes per work item of a whole-field launch (descriptor's chunk_rows == 0). A work item occupies a CU (its LDS tile and 256-register waves
+// leave room for one workgroup), so a launch runs in ceil(items / CUs) residency rounds, each as long as a chunk plus the pipeline fill
+// (~1.3 plane-steps: four conversions, two slopes, one Riemann problem before the first update). The chunk with the lowest
+// rounds x (chunk + 1.3) wins; measured at 512^3 FAST (profiles/r04/ab_3d_chunks.jsonl, ms per RK2 step - the model's ratio to the best in
+// brackets): 16 planes 7.99 (1.07), 32: 7.69 (1.03, the fixed default of rounds 1 - 3), 43: 7.65 (1.03), 64: 7.51 (1.01), 86: 7.71 (1.05),
+// 128: 7.46 (1.00), 256: 8.20 (1.10). Results do not depend on the cut (tests/test_gpu_euler3d.py).
+static int euler3d_default_chunk(int planes, long items_per_layer)
+{
+    static int cus = 0;
+    if (cus == 0)
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    int best = planes < 32 ? planes : 32;
+    double best_cost = 0.0;
+    const int longest = planes < 128 ? planes : 128;          // (longer chunks were not measured; they balance worse over CUs whose speeds differ)
+    for (int chunk = 8; chunk <= longest || chunk == 8; ++chunk)
+    {
+        const int c = chunk < longest ? chunk : longest;
+        const long nchunks = (planes + c - 1) / c;
+        if (nchunks > 1 && (planes + nchunks - 1) / nchunks != c) continue;          // only the even cuts
+        const long rounds = (nchunks * items_per_layer + cus - 1) / cus;
+        const double cost = (double) rounds * (c + 1.3);
+        if (best_cost == 0.0 || cost < best_cost * 0.995) { best_cost = cost; best = c; }
+        if (c == longest) break;
+    }
+    return best > 0 ? best : 1;
+}
+
 hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3dLayout& lay, const Euler3dBox* boxes, int nboxes,
                                       const double* u_in, const double* u_base, double* u_out, double dt, double weight,
                                       int32_t* status, hipStream_t stream)
@@ -45,9 +76,11 @@ hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3d
     p.pitch2 = p.n2 + 2 * p.g2;
     p.plane_stride = (long) (p.n1 + 2 * p.g1) * p.pitch2;
     p.row_stride = 5L * p.plane_stride;
-    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     int ntiles1, nstrips;
     euler3d_tiling(d, &ntiles1, &nstrips);
+    p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
+    if (d->chunk_rows == 0 && nboxes == 1 && boxes[0].r1 > boxes[0].r0)          // (a block's shell of several boxes keeps the short chunks)
+        p.chunk_rows = euler3d_default_chunk(boxes[0].r1 - boxes[0].r0, (long) (boxes[0].t1 - boxes[0].t0) * (boxes[0].s1 - boxes[0].s0));
     int nblocks = 0;
     p.nboxes = 0;
     for (int k = 0; k < nboxes; ++k)

@@ -62,6 +62,27 @@ def test_euler3d_fast_within_tolerance(eng):
     assert l1(s.download(), g["u_4"]) <= 1e-12
 
 
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_euler3d_result_does_not_depend_on_the_cut_along_axis_0(eng, arith):
+    """the launcher's own choice of planes per work item (csrc/euler3d.hip: euler3d_default_chunk) against
+    explicit cuts, ragged ones included: bit-identical"""
+    from mara3_amd import setups
+    shape, gamma = (130, 24, 70), 5.0 / 3
+    dl = (1.0 / 130,) * 3
+    u0 = setups.blast_ic(shape, gamma)
+    dt = setups.baseline_dt(130)
+    out = {}
+    for chunk in (0, 32, 7, 130):
+        s = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hlle", 2, "outflow", arith=arith, chunk_rows=chunk)
+        s.upload(u0)
+        s.step(dt, 3)
+        out[chunk] = s.download()
+        assert s.status() == 0
+        s.close()
+    for chunk in (32, 7, 130):
+        assert bits_equal(out[0], out[chunk]), chunk
+
+
 def test_euler3d_blast_128_properties(eng, oracle):
     """A 128^3 blast (config-5 IC at a size one GPU test can hold): conservation, and a sub-block equal to the
     oracle run on that block plus context (domain of dependence), bit for bit."""
