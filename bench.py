@@ -63,7 +63,7 @@ def host_cores():
     return min(cores, int(os.environ.get("MARA_BENCH_CPU_THREADS", "64")))
 
 
-KERNEL_SOURCES = ("euler2d.hip", "euler2d_fused.hip", "euler2d_rows.hpp", "euler3d.hip", "euler3d_fast.hip", "euler3d_kernel.hpp", "cloud.hip", "binary.hip", "binary_fast.hip", "binary_kernel.hpp", "euler_device.hpp", "euler_device_fast.hpp", "srhd_device.hpp",
+KERNEL_SOURCES = ("euler2d.hip", "euler2d_fused.hip", "euler2d_rows.hpp", "euler3d.hip", "euler3d_fast.hip", "euler3d_kernel.hpp", "cloud.hip", "cloud_fused.hip", "cloud_rows.hpp", "row_check.hpp", "binary.hip", "binary_fast.hip", "binary_kernel.hpp", "euler_device.hpp", "euler_device_fast.hpp", "srhd_device.hpp",
                   "srhd_device_fast.hpp", "iso2d_device.hpp", "binary_device.hpp", "status_device.hpp")
 
 

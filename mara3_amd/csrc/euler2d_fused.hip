@@ -218,6 +218,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
         const int a0 = r0 - 2;
         const int last_needed = r1 + 3;                 // first-stage rows r0 - 2 .. r1 + 1 need step-start rows r0 - 4 .. r1 + 3
+        (void) last_needed;                             // (the noclamp probe build does not use it)
         const bool works = ! MH_FUSED_MASK_HALO || (lane >= 2 && lane < FWAVE - 2);
 
         State5 U[3], P[3], G[3], Fx[3], D[3];
