@@ -156,7 +156,7 @@ def cpu_reference(gamma, theta, n=1024, steps=4):
                       "where upstream pipes `| evaluate`), oracle/ref_drivers/euler_cart_ref.cpp; results bit-identical to the one-thread run" % (steps, n, n, threads)}
 
 
-def compact(obj, drop=("timing", "traffic_note", "preconditioning", "peak", "unit", "bound", "kernel", "launches", "algorithmic_bytes_per_launch")):
+def compact(obj, drop=("timing", "traffic_note", "preconditioning", "peak", "unit", "bound", "kernel", "launches")):
     """The legs and the embedded config lines repeat what the headline objects state once (units, peaks, how the events were taken): drop those
     keys there and keep six significant digits, so that the ONE JSON line stays a few kilobytes."""
     if isinstance(obj, dict):

@@ -480,7 +480,7 @@ def attach_traffic(out, config):
             return out
         names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),
                  "c4": ("c4", "cloud_stage_kernel<Srhd%sT<@>, true, false>", "cloud_stage_kernel<Srhd%sT<@>, true, true>"),
-                 "c5": ("c5", "euler3d_stage_kernel<%sArith, 0, true, false>", "euler3d_stage_kernel<%sArith, 0, true, true>")}[config]
+                 "c5": ("c5", "euler3d_stage_kernel<%sArithT<false>, 0, true, false>", "euler3d_stage_kernel<%sArithT<false>, 0, true, true>")}[config]
         for mode, roof in (("Fast", out.get("roofline")), ("Strict", (out.get("arith_strict") or {}).get("roofline"))):
             if not roof or not roof.get("avg_launch_ms"):
                 continue
