@@ -19,7 +19,7 @@ for workload in ("blast", "smooth_wave"):
         for mode in ("alone", "self_exchange"):
             if mode == "self_exchange" and N == 1:
                 continue
-            kw = dict(arith="fast")
+            kw = dict(arith="fast", planar=True)          # (as bench.py: ranks in different processes take the planar kernel on the caller's word)
             if mode == "self_exchange":
                 st = NativeSlabStepper((rows, n), dl, gamma, 1.5, "hllc", 2, "periodic", rank=0, world=1, comm_id=native_comm_id(0, 1, device="cuda"), self_exchange=True, **kw)
             else:
