@@ -105,12 +105,11 @@ struct BinStrict
     static __device__ inline void over_area(double (&l)[3], double dA) { divide_group<3>(l, make_recip(dA, 1.0)); }
 };
 
-// binary_fast.hip is compiled with -ffp-contract=fast, and the compiler then fuses a product into EVERY sum that uses it - also across
-// the inlined function that formed it. A row's primitives and slopes are used in the iteration that forms them and carried to the next
-// two; fused into the first use and rounded in the later ones, a face computed in a chunk's prologue (everything fresh) would differ in
-// the last bit from the same face computed in the row loop (one operand fresh, one carried), i.e. the field would depend on how the rows
-// are cut into chunks and launches. Values that are carried are therefore SETTLED where they are formed: an empty asm the optimiser
-// cannot see through (no instruction).
+// Round 3 compiled binary_fast.hip with -ffp-contract=fast, where the compiler fuses a product into every sum that uses it - also across the
+// inlined function that formed it - so that a value used in the iteration that forms it AND carried to the next would differ in the last bit
+// between a chunk's prologue and the row loop. Values that are carried were therefore SETTLED where they are formed: an empty asm the
+// optimiser cannot see through (no instruction). No file is compiled with contraction any more (Makefile); the marks stay as what they are -
+// the places where a carried value is formed.
 __device__ inline double settled(double x) { asm("" : "+v"(x)); return x; }
 
 struct BinFast

@@ -1,8 +1,9 @@
-// The FAST instantiations of the `binary` stage kernel (binary_kernel.hpp; design notes in binary.hip) as their own translation unit,
-// compiled with -ffp-contract=fast (Makefile). MH_ARITH_FAST promises the reference's formulas to 1e-12 of the field scale, not its
-// operation order: the leaf functions of BinFast are written with explicit FMAs already, this lets the kernel's glue - face states
-// (p +- g h / 2), viscous stress, the six source terms, the eight partial sums, the update and the RK average - contract too. Measured
-// at 2048^2 (profiles/r03/ab_binary_contract.jsonl): the stage kernel's executed VALU instructions and its time.
+// The FAST instantiations of the `binary` stage kernel (binary_kernel.hpp; design notes in binary.hip) as their own translation unit (compile
+// time). MH_ARITH_FAST promises the reference's formulas to 1e-12 of the field scale, not its operation order: the leaf functions of BinFast
+// and the kernel's glue - face states (p +- g h / 2), viscous stress, the source terms, the partial sums, the update and the RK average - are
+// written with explicit FMAs. Round 3 also let the compiler contract what was left (-ffp-contract=fast on this file): 1 % of the loop's
+// instructions, no measurable time (profiles/r04/ab_c3_contract.jsonl) - dropped in round 4, so that the FAST bits do not depend on the
+// compiler's contraction choices (advisor finding, round 3).
 #include "binary_kernel.hpp"
 
 namespace mh {

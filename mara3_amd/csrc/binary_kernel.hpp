@@ -1,7 +1,7 @@
 // The stage kernel of the `binary` path (design notes and citations: binary.hip) as a header, so that the STRICT instantiations
-// (binary.hip, no FMA contraction: reference operation order) and the FAST ones (binary_fast.hip, compiled with -ffp-contract=fast: the
-// scheme's glue - face states, viscous stress, source terms, totals, update - contracts into FMAs like the FAST leaf functions already
-// are) come from one source.
+// (binary.hip: reference operation order) and the FAST ones (binary_fast.hip: the scheme's glue - face states, viscous stress, source
+// terms, totals, update - with gathered factors and explicit FMAs, like the FAST leaf functions) come from one source. No file is compiled
+// with FMA contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -10,7 +10,6 @@ cd $ROOT/mara3_amd/csrc
 repl=""
 for src in "$@"; do
   fl=""
-  [ $src = binary_fast.hip ] && fl="-ffp-contract=fast"
   [ $src = euler3d_fast.hip ] && fl="-mllvm -amdgpu-sched-strategy=max-ilp"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -Wno-unused-value $fl $extra -c $src -o $out/obj/${src%.hip}.o &
   repl="$repl ${src%.hip}.o"

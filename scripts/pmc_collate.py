@@ -4,7 +4,22 @@
                                       FETCH_SIZE tallies 64 B per 128-B request on gfx950, re-calibrated on mh::stream_copy_kernel in the same
                                       script), VALU instructions and utilisation, fp64 FLOP/s from the SQ_INSTS_VALU_*_F64 counters
    profiles/pmc_traffic.json          bytes per launch keyed as bench.py reads them, stamped with the hash of the kernel sources"""
-import csv, glob, json, os, sys, collections
+import csv, glob as _glob, json, os, sys, collections
+
+
+class glob:
+    """one rocprofv3 run per directory is what the tables mean: gpurun MERGES a box's output into gpurun_out/, so a pass that is repeated leaves
+    its files beside the earlier run's (another process id in the name) - only the newest run of a directory is read"""
+    @staticmethod
+    def glob(pattern, recursive=False):
+        files = _glob.glob(pattern, recursive=recursive)
+        newest = {}
+        for f in files:
+            d = os.path.dirname(f)
+            if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+                newest[d] = f
+        return sorted(newest.values()) if files and os.path.isfile(files[0]) else files
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import csrc_fingerprint

@@ -114,7 +114,7 @@ def test_default_tree_through_200_steps_against_the_reference_composition(binary
 def test_uniform_tree_through_both_kernel_families_is_bit_identical(binary):
     """A uniform-depth tree can run through the block kernels (binary_tree.hip) or as one periodic grid (binary.hip): same
     policy arithmetic, so in STRICT mode the two must agree to the last bit. In FAST mode (round 3) the grid kernel gathers the common
-    factors of the scheme's glue and is compiled with FMA contraction (binary_fast.hip), the block kernels are not: the two agree
+    factors of the scheme's glue into FMAs of its own (binary_kernel.hpp), the block kernels keep the generic form: the two agree
     within the mode's own tolerance, 1e-12 of the field scale."""
     for tname, uname in (("binary_tree_d2_b16_uniform", "binary_d2_b16"), ("binary_tree_d2_b16_q_uniform", "binary_d2_b16_q")):
         _both_families(binary, golden(tname), golden(uname))
