@@ -620,8 +620,9 @@ int  mh_device_synchronize(void);
 /* Row-range guard of the row-marching kernels (csrc/row_check.hpp; a library built with -DMH_CHECK_ROWS, `make -C mara3_amd/csrc check`):
  * {smallest, largest} axis-0 row (plane) index the kernels of a family REQUESTED since the last reset - a check build holds every access
  * to the rows that exist and reports which kernel would have left them (the stored rows are -2 .. n0 + 1; -4 .. n0 + 3 on the cut sides of
- * the fused 2-D step). family: */
-enum { MH_ROWS_EULER2D = 0, MH_ROWS_EULER2D_FUSED = 1, MH_ROWS_CLOUD = 2, MH_ROWS_CLOUD_FUSED = 3, MH_ROWS_EULER3D_STRICT = 4, MH_ROWS_EULER3D_FAST = 5 };
+ * the fused 2-D step). family (binary: the stage kernels of the uniform-depth mesh, whole or in bands): */
+enum { MH_ROWS_EULER2D = 0, MH_ROWS_EULER2D_FUSED = 1, MH_ROWS_CLOUD = 2, MH_ROWS_CLOUD_FUSED = 3, MH_ROWS_EULER3D_STRICT = 4, MH_ROWS_EULER3D_FAST = 5,
+       MH_ROWS_BINARY_STRICT = 6, MH_ROWS_BINARY_FAST = 7 };
 /* MH_E_STATE from a product build (no guard compiled in); lo_hi = {INT_MAX, INT_MIN} when nothing was requested */
 int  mh_debug_row_range(int family, int32_t lo_hi[2], int reset);
 

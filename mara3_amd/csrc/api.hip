@@ -1063,6 +1063,8 @@ int mh_debug_row_range(int family, int32_t lo_hi[2], int reset)
         case MH_ROWS_CLOUD_FUSED:    ok = rows_requested_cloud_fused(lo_hi, reset); break;
         case MH_ROWS_EULER3D_STRICT: ok = rows_requested_euler3d(lo_hi, reset); break;
         case MH_ROWS_EULER3D_FAST:   ok = rows_requested_euler3d_fast(lo_hi, reset); break;
+        case MH_ROWS_BINARY_STRICT:  ok = rows_requested_binary(lo_hi, reset); break;
+        case MH_ROWS_BINARY_FAST:    ok = rows_requested_binary_fast(lo_hi, reset); break;
         default: set_error("row range: unknown kernel family %d", family); return MH_E_INVALID;
     }
     if (! ok) { set_error("row range: this library was built without the row-range guard (-DMH_CHECK_ROWS; make -C mara3_amd/csrc check)"); return MH_E_STATE; }

@@ -349,4 +349,7 @@ hipError_t binary_maxw_launch(const mh_binary_desc* d, const double* xv, const d
     return hipGetLastError();
 }
 
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_binary)
+
 } // namespace mh

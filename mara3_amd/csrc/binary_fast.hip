@@ -13,4 +13,7 @@ hipError_t binary_stage_dispatch_fast(const BinaryStageParams& p, dim3 grid, dim
     return binary_stage_dispatch<BinFast>(p, grid, block, stream, combine, qform);
 }
 
+// row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
+MH_ROW_RANGE_READER(rows_requested_binary_fast)
+
 } // namespace mh

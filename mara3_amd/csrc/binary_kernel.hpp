@@ -9,6 +9,7 @@
 #include "launch.hpp"
 #include "binary_device.hpp"
 #include "status_device.hpp"
+#include "row_check.hpp"
 
 namespace mh {
 
@@ -133,7 +134,8 @@ void binary_stage_kernel(BinaryStageParams p)
     const typename A::Ctx k = A::make(c);
     const double theta = p.theta, dt = p.dt;
     const long row_stride = 3L * n;
-    auto row_off = [row_stride] (int r) { return (long) (r + BHALO) * row_stride; };
+    const int rows_hi = n0 + 1;                        // the rows that exist: -2 .. n0 + 1 (row_check.hpp)
+    auto row_off = [row_stride, rows_hi] (int r) { (void) rows_hi; return (long) (MH_ROW(r, -BHALO, rows_hi) + BHALO) * row_stride; };
     const double* in = p.u_in;
 
     // ring slots (index = row mod 3 relative to the chunk start), as in euler2d.hip:

@@ -84,6 +84,8 @@ bool rows_requested_cloud(int32_t out[2], int reset);
 bool rows_requested_cloud_fused(int32_t out[2], int reset);
 bool rows_requested_euler3d(int32_t out[2], int reset);
 bool rows_requested_euler3d_fast(int32_t out[2], int reset);
+bool rows_requested_binary(int32_t out[2], int reset);
+bool rows_requested_binary_fast(int32_t out[2], int reset);
 
 // thread-local error text for the C ABI
 void set_error(const char* fmt, ...);

@@ -2,7 +2,7 @@
 one kernel family over a list of configurations and prints one JSON line per configuration:
     {"family": ..., "config": ..., "n0": rows of the field (the largest member's for slabs / blocks), "cut": the sides are cuts of the fused 2-D step,
      "lo": smallest row index requested, "hi": largest, "status": status word}
-usage: python tests/row_range_child.py <family>      family = euler2d | euler2d_fused | euler2d_fused_cuts | cloud | cloud_fused | euler3d"""
+usage: python tests/row_range_child.py <family>      family = euler2d | euler2d_fused | euler2d_fused_cuts | cloud | cloud_fused | euler3d | binary"""
 import ctypes as C
 import json
 import os
@@ -16,7 +16,7 @@ from mara3_amd import engine, setups
 from mara3_amd import _lib as L
 
 lib = mara3_amd.load_library()
-FAMILY = {"euler2d": 0, "euler2d_fused": 1, "cloud": 2, "cloud_fused": 3, "euler3d_strict": 4, "euler3d_fast": 5}
+FAMILY = {"euler2d": 0, "euler2d_fused": 1, "cloud": 2, "cloud_fused": 3, "euler3d_strict": 4, "euler3d_fast": 5, "binary_strict": 6, "binary_fast": 7}
 
 
 def take(family):
@@ -156,6 +156,31 @@ def euler3d():
             report(fam, "%dx%dx%d in %d blocks" % (shape + (world,)), rows, st)
 
 
+def binary():
+    """the uniform-depth mesh as one periodic grid (its own ghost rows: the periodic images) and as bands of block rows (ghost rows from the
+    neighbours, edges first or not): chunks from 2 rows to the whole band, both forms of the conserved state, RK1 / RK2"""
+    from mara3_amd import binary as B
+    for arith in ("strict", "fast"):
+        fam = "binary_" + arith
+        for overrides, chunk in ((dict(depth=2, block_size=16), 0), (dict(depth=2, block_size=16, fixed_dt=1, rk_order=1), 5), (dict(depth=3, block_size=8), 2),
+                                 (dict(depth=2, block_size=16, conserve_linear_p=0), 7), (dict(depth=2, block_size=32, mass_ratio=0.5, eccentricity=0.3), 64)):
+            take(fam)
+            cfg = B.config(**overrides)
+            s = B.BinarySolver(cfg, arith=arith, chunk_rows=chunk)
+            st = s.next(3)
+            n = B.grid_size(cfg)
+            s.close()
+            report(fam, "%s chunk %d" % (sorted(overrides.items()), chunk), n, st)
+        for world, edge in ((2, None), (3, None), (4, -1)):
+            take(fam)
+            cfg = B.config(depth=2, block_size=16)
+            g = B.BinaryBandGroup(cfg, world=world, arith=arith, edge_rows=edge)
+            st = g.next(3)
+            rows = max(b - a for a, b in g.rows)
+            g.close()
+            report(fam, "64x64 in %d bands, edge_rows %s" % (world, edge), rows, st)
+
+
 if __name__ == "__main__":
-    {"euler2d": lambda: euler2d(False), "euler2d_fused": lambda: euler2d(True), "euler2d_fused_cuts": euler2d_fused_cuts,
+    {"binary": binary, "euler2d": lambda: euler2d(False), "euler2d_fused": lambda: euler2d(True), "euler2d_fused_cuts": euler2d_fused_cuts,
      "cloud": lambda: cloud(False), "cloud_fused": lambda: cloud(True), "euler3d": euler3d}[sys.argv[1]]()
