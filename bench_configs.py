@@ -19,7 +19,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-HBM_PEAK_GBS = 8000.0
+import bench_report
+from bench_report import HBM_PEAK_GBS
 
 
 def oracle():
@@ -208,9 +209,18 @@ def c4_parse(args, stdout, nr, arith):
     ms = [vertices / k for k in kz[args.warmup:]]   # the host prints vertices per ms, like the reference (:858)
     per_step = sum(ms) / len(ms)
     cells = nr * nq
-    fused = lps == 1               # the RK2 step as ONE launch (csrc/cloud_fused.hip): charged the whole zone-update's 200 B, moves 120 B per cell
-    bytes_launch = cells * (80 + 120) / lps
-    step_gbs = cells * 200 / (per_step * 1e-3) / 1e9
+    fused = lps == 1               # the RK2 step as ONE launch (csrc/cloud_fused.hip)
+    timing = "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"
+    if fused:
+        # fp64-issue-bound (VALU-busy 0.85, profiles/r04/cloud_fused.md) and moves 104 (planar) / 120 B per cell: until attach_traffic() finds the
+        # recorded FLOP count the roofline is the bytes the launch moves against 8 TB/s - a hardware fraction either way, never the 200 B convention
+        moved = 104 if planar else 120
+        roof = bench_report.hbm_roofline("cloud_fused_rk2_kernel<%s> (both RK2 stages in one launch per step)" % ("planar" if planar else "general"),
+                                         avg_ms, nl, cells, moved, timing=timing,
+                                         extra={"bytes_moved_per_cell": moved, "launches_per_step": 1, "note": "bytes the launch moves (reads + writes) over 8 TB/s; no FLOP record applied"})
+    else:
+        roof = bench_report.hbm_roofline("cloud_stage_kernel<%s%s,PLM> (mean of both RK2 stages)" % (arith, ", planar" if planar else ""), avg_ms, nl, cells, (80 + 120) / 2,
+                                         timing=timing, extra={"bytes_moved_per_cell": 88 if planar else 100, "launches_per_step": lps})
     return {
         "metric": "zone-updates/sec (Mcells/s), subprog_cloud %dx%d SRHD PLM+HLLE RK2, %d GPU" % (nr, nq, args.gpus),
         "value": cells / per_step / 1e3, "unit": "Mcells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -221,13 +231,8 @@ def c4_parse(args, stdout, nr, arith):
                                    "the kernels skip that component (mh_cloud_desc.planar; FAST: same bits in the other four, tests/test_gpu_cloud_fused.py; STRICT: "
                                    "taken on the bit pattern of +0.0, the reference's bits in all five, tests/test_gpu_cloud_planar.py and the golden steps); "
                                    "`mara_hip cloud ... planar=-1` runs the general kernels") if planar else "general kernels"},
-        "roofline": {"bound": "hbm", "achieved": bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None, "traffic": None,
-                     "kernel": ("cloud_fused_rk2_kernel<%s> (both RK2 stages in one launch per step)" % ("planar" if planar else "general") if fused else "cloud_stage_kernel<%s%s,PLM> (mean of both RK2 stages)" % (arith, ", planar" if planar else "")),
-                     "bytes_actually_moved_per_cell": (104 if planar else 120) if fused else (88 if planar else 100),
-                     "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": avg_ms, "launches": nl, "launches_per_step": lps,
-                     "timing": "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"},
-        "roofline_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "note": "200 B per zone-update over the whole host-timed step (nozzle upload and launch gaps included)"},
+        "roofline": roof,
+        "roofline_step": bench_report.step_equivalents(cells / per_step / 1e3 / max(1, args.gpus), target=None),
     }
 
 
@@ -469,15 +474,15 @@ def c5_cpu_reference(m, gamma):
 
 
 def attach_traffic(out, config):
-    """From the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, keyed by the hash of the kernel sources; reported only while it
-    matches): HBM bytes per launch of the stage kernels (mean of the two RK2 stage kinds, like `achieved`) and the OTHER roofline of these
-    kernels - fp64 issue: FLOP per launch from SQ_INSTS_VALU_*_F64 over this run's average launch duration, against the 78.6 TF vector peak,
-    with the recorded VALU-busy fraction. The configs' stage kernels are issue-bound (VALU-busy 0.65-0.98), so `bound` says so."""
+    """From the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, stamped with the hash of the kernel sources): HBM bytes per launch of the
+    stage kernels (mean of the two RK2 stage kinds, like `achieved`; only for the build they were measured on) and the fp64 side - FLOP per launch
+    from SQ_INSTS_VALU_*_F64 over this run's average launch duration against the 78.6 TF vector peak, with the recorded VALU-busy fraction. The
+    one-launch `cloud` step is fp64-issue-bound and gets that as its roofline (bound "fp64"); the two-launch configs keep bound "hbm" at their
+    algorithmic stage bytes with the fp64 figure beside it."""
     try:
         from bench import csrc_fingerprint
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if t.get("csrc_sha16") != csrc_fingerprint():
-            return out
+        counters = bench_report.Counters(csrc_fingerprint())
+        t = counters.table
         names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),
                  "c4": ("c4", "cloud_stage_kernel<Srhd%sT<@>, true, false>", "cloud_stage_kernel<Srhd%sT<@>, true, true>"),
                  "c5": ("c5", "euler3d_stage_kernel<%sArithT<false>, 0, true, false>", "euler3d_stage_kernel<%sArithT<false>, 0, true, true>")}[config]
@@ -488,20 +493,28 @@ def attach_traffic(out, config):
             keys = ["%s:%s" % (tag, (n % mode).replace("@", "true" if "planar" in roof.get("kernel", "") else "false")) for n in names[1:]]
             if config == "c4" and mode == "Fast" and roof.get("launches_per_step") == 1:
                 keys = ["c4:cloud_fused_rk2_kernel<%s>" % ("true" if "planar" in roof.get("kernel", "") else "false")]           # the RK2 step's one launch
-            if all(k in t for k in keys):
+            if counters.current and all(k in t for k in keys):
                 roof["traffic"] = sum(t[k] for k in keys) / len(keys)
             fk = [k + ":fp64" for k in keys]
-            if all(k in t for k in fk):
-                flops = sum(t[k]["fp64_flops_per_launch"] for k in fk) / len(fk)
-                tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
-                roof["fp64"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                "valu_busy": sum(t[k]["valu_busy"] for k in fk) / len(fk),
-                                "note": "recorded SQ counters (profiles/r04/kernels_configs.md), this run's duration"}
-                roof["bound_measured"] = "fp64 issue (VALU-busy %.2f); the HBM figure above is the contract's roofline" % roof["fp64"]["valu_busy"]
-                if roof.get("traffic"):
-                    roof["frac_measured_traffic"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-    except Exception:
-        pass
+            if not all(k in t for k in fk):
+                continue
+            flops = sum(t[k]["fp64_flops_per_launch"] for k in fk) / len(fk)
+            busy = sum(t[k]["valu_busy"] for k in fk) / len(fk)
+            if roof.get("launches_per_step") == 1 and config == "c4":
+                cells = 4096 * 4096
+                fresh = bench_report.fp64_roofline(roof["kernel"], roof["avg_launch_ms"], roof["launches"], cells, flops / cells, busy,
+                                                   roof["traffic"] / cells if roof.get("traffic") else None, roof["bytes_moved_per_cell"],
+                                                   counters.provenance(), timing=roof.get("timing"))
+                fresh["launches_per_step"] = 1
+                roof.clear()
+                roof.update(fresh)
+                continue
+            tf = flops / (roof["avg_launch_ms"] * 1e-3) / 1e12
+            roof["fp64"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "valu_busy": busy, "counters": counters.provenance()}
+            if roof.get("traffic"):
+                roof["hbm_frac_measured"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    except Exception as e:
+        print("bench_configs.py: counters not attached: %r" % (e,), file=sys.stderr)
     return out
 
 

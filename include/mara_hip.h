@@ -114,7 +114,8 @@ typedef struct
                              * components keep their bits (x + 0 and fma(0, 0, x) are x), ~11 % fewer instructions. MH_ARITH_STRICT takes it only on
                              * the BIT PATTERN of +0.0 everywhere, for which the reference's own operations return +0.0: still bit-identical. 0 = where the stepper has VERIFIED it: the context and the slab steppers look at
                              * the uploaded field (one pass at upload, not per step; a field with a third momentum takes the general kernel),
-                             * loopback groups at all members' rows; slabs that exchange with OTHER PROCESSES only under > 0 = the caller asserts
+                             * loopback groups at all members' rows; slabs that exchange with OTHER PROCESSES - and contexts with an MH_BC_EXTERNAL
+                             * side, whose ghost rows the caller writes through mh_field_ptr - only under > 0 = the caller asserts
                              * it for the whole grid (each rank still verifies its own rows: upload fails otherwise); < 0 = never. */
 } mh_euler_cart_desc;
 

@@ -582,7 +582,11 @@ int mh_upload(mh_ctx* c, const double* u_aos_host, size_t ncell)
     c->planar_now = false;
     const int planar_request = cloud ? c->cloud.planar : d->planar;
     // (every PLM stage kernel of the 2-D Euler and `cloud` steppers has a planar form, STRICT on the exact bit pattern of +0.0)
-    if ((cloud ? c->cloud.plm_theta >= 0.0 : (d->rank == 2 && d->plm_theta >= 0.0)) && planar_request >= 0)
+    // A side of kind MH_BC_EXTERNAL holds ghost rows this context never sees (the caller's halo exchange writes them through mh_field_ptr), so
+    // the look at rows [0, n0) decides nothing there: with such a side only planar > 0 - the caller's word for the WHOLE grid, as for slabs
+    // that exchange with other processes - selects the planar kernels; planar = 0 means the general ones.
+    const bool external_side = (cloud ? c->cloud.bc_lo0 : d->bc_lo0) == MH_BC_EXTERNAL || (cloud ? c->cloud.bc_hi0 : d->bc_hi0) == MH_BC_EXTERNAL;
+    if ((cloud ? c->cloud.plm_theta >= 0.0 : (d->rank == 2 && d->plm_theta >= 0.0)) && planar_request >= 0 && ! (external_side && planar_request == 0))
     {
         int32_t nonzero = 0;
         MH_HIP_TRY(hipMemsetAsync(c->planar_flag, 0, sizeof(int32_t), c->stream));

@@ -155,7 +155,11 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     }
     const int pair = __builtin_amdgcn_readfirstlane(b);
     const int wave_of_group = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+#ifdef MH_FUSED_ROLE_FLIP      // probe: which wave of a pair produces alternates between workgroups (bit MH_FUSED_ROLE_FLIP of the launch's block index)
+    const int role = (wave_of_group ^ (((int) blockIdx.x >> MH_FUSED_ROLE_FLIP) & 1)) & 1;
+#else
     const int role = wave_of_group & 1;
+#endif
     const int pp = wave_of_group >> 1;                  // which pair of the workgroup
     double (*hand)[NV][FWAVE] = hand_all[pp];
     double (*start_rows)[NV][FWAVE] = start_all[pp];
