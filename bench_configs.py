@@ -202,6 +202,10 @@ def c4_parse(args, stdout, nr, arith):
     kz = [float(x) for x in re.findall(r"kzps=([0-9.]+)", p.stdout)]
     shape = re.search(r"profile: stage kernel avg ([0-9.]+) ms over (\d+) launches \((\d+) per step", p.stdout)
     avg_ms, nl, lps = (float(shape.group(1)), int(shape.group(2)), int(shape.group(3))) if shape else (0.0, 0, 2)
+    slab_lps = re.search(r"slab launches per step:((?: \d+)+)", p.stdout)          # gpus > 1: what each radial slab takes (1 = the fused step across its cuts)
+    if slab_lps and not shape:
+        per_slab = [int(x) for x in slab_lps.group(1).split()]
+        lps = max(per_slab)
     planar = bool(re.search(r"step kernels: planar", p.stdout))
     m = re.search(r"write out_%s/final.bin" % arith, p.stdout)
     nq = nr                                          # num_decades=1: nr radial x nr polar zones (subprog_cloud.cpp:233-258)
@@ -211,7 +215,12 @@ def c4_parse(args, stdout, nr, arith):
     cells = nr * nq
     fused = lps == 1               # the RK2 step as ONE launch (csrc/cloud_fused.hip)
     timing = "one pair of HIP events on the launch stream around the launches of 5 further steps after the run (the gaps between the launches included)"
-    if fused:
+    if not avg_ms:
+        # (gpus > 1: the compiled host takes no per-kernel events on the slabs; the line then carries the step figures only)
+        roof = {"bound": "fp64" if fused else "hbm", "achieved": None, "peak": 78.6 if fused else HBM_PEAK_GBS, "unit": "TFLOP/s" if fused else "GB/s", "frac": None, "traffic": None,
+                "kernel": ("cloud_fused_rk2_kernel across radial cuts (one launch per step and slab)" if fused else "cloud_stage_kernel (two launches per step and slab)"),
+                "launches_per_step": lps}
+    elif fused:
         # fp64-issue-bound (VALU-busy 0.85, profiles/r04/cloud_fused.md) and moves 104 (planar) / 120 B per cell: until attach_traffic() finds the
         # recorded FLOP count the roofline is the bytes the launch moves against 8 TB/s - a hardware fraction either way, never the 200 B convention
         moved = 104 if planar else 120

@@ -305,6 +305,13 @@ int  mh_slab_use_comm(mh_slab* slab, mh_comm* comm);
 int  mh_slab_cloud_create(mh_slab** slab, const mh_cloud_desc* global, const double* r_vertices_host, const double* q_vertices_host,
                           int rk_order, int rank, int world, const void* comm_id128, int device_id);
 int  mh_slab_set_inflow(mh_slab* slab, const double* inflow_prims_aos_host);
+/* Planarity contract of the row (mh_cloud_desc.planar): a cloud slab starts out NOT knowing a nozzle row and therefore on the general kernels;
+ * a row with an azimuthal velocity sends the slab it is handed to onto the general kernels until the next upload. A lone slab, or one whose
+ * neighbours live in other processes (there only under planar > 0), re-resolves in mh_slab_set_inflow. The members of a loopback group are
+ * resolved TOGETHER - hand the row to mh_slab_group_set_inflow, which updates every member in one call (the group is planar only if every
+ * member's rows and the row are); through the per-slab call a member can lose its planar kernels but never gain them, so a host that hands
+ * the row to the nozzle-side member only stays correct, on the general kernels. */
+int  mh_slab_group_set_inflow(mh_slab** slabs, int n, const double* inflow_prims_aos_host);
 /* LOOPBACK groups: all `world` slabs of a decomposition as objects of ONE process on one GPU. A "receive" is a stream-ordered
  * device-to-device copy out of the neighbour object's field under the same event protocol; cut, ghost layout, edge / interior
  * split and staggering are the code the RCCL ranks run. (RCCL itself refuses two ranks on one device.) This is how the multi-rank
@@ -326,6 +333,7 @@ int  mh_slab_group_step(mh_slab** slabs, int world, double dt, int nsteps);
 void mh_slab_destroy(mh_slab* slab);
 int  mh_slab_rows(const mh_slab* slab, int* row0, int* row1);                 /* this rank's rows [row0, row1) */
 int  mh_slab_is_planar(const mh_slab* slab);                                  /* 1: its launches skip the third momentum (the descriptors' planar) */
+int  mh_slab_launches_per_step(const mh_slab* slab);                          /* 1: the RK2 step of its rows is ONE fused launch (fuse_stages), else rk_order */
 int  mh_slab_upload(mh_slab* slab, const double* u_aos_slab_host);            /* host AoS [n0][n1][5] of this rank's rows */
 int  mh_slab_download(mh_slab* slab, double* u_aos_slab_host);
 int  mh_slab_step(mh_slab* slab, double dt, int nsteps, int use_graph);       /* use_graph: replay one captured step (RK2) */

@@ -139,7 +139,9 @@ SYMBOLS = [
     ("mh_comm_create", _i, [C.POINTER(_vp), _vp, _i, _i, _i]),
     ("mh_comm_destroy", None, [_vp]),
     ("mh_slab_cloud_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i, _vp, _i]),
+    ("mh_slab_launches_per_step", _i, [_vp]),
     ("mh_slab_set_inflow", _i, [_vp, _vp]),
+    ("mh_slab_group_set_inflow", _i, [C.POINTER(_vp), _i, _vp]),
     ("mh_slab_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
     ("mh_slab_cloud_group_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i]),
     ("mh_slab_group_create_on", _i, [C.POINTER(_vp), _descp, _i, _i, C.POINTER(_i)]),

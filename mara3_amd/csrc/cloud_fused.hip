@@ -66,6 +66,12 @@ struct CloudFusedParams
     long   plane_stride, row_stride;
     int    n0, n1, row_offset;
     int    chunk_rows, nstrips, nchunks;
+    // the rows this launch covers: chunks [0, seg0_chunks) cut rows [seg0_begin, seg0_end), the others [seg1_begin, seg1_end) - a radial slab with
+    // neighbours runs both of its edge strips in one launch and the rest in another (slab.hip); a whole field is one segment
+    int    seg0_begin, seg0_end, seg0_chunks, seg1_begin, seg1_end;
+    int    ext_lo, ext_hi;        // 1: that radial side is a CUT of a slab decomposition (MH_BC_EXTERNAL) - rows -4 .. -1 / n0 .. n0 + 3 of u_in hold the
+                                  // neighbour's step-start rows (four per side: two per stage), the first-stage rows beyond the cut are recomputed here
+                                  // from them, and neither the nozzle rows nor the zero-gradient copy nor the zeroed edge slope apply on that side
     double gamma, theta, tfloor, dt;
 };
 
@@ -103,13 +109,17 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     const int role = wave_of_group & 1;
     const int pp = wave_of_group >> 1;                  // which pair of the workgroup
     const int lane = threadIdx.x & 63;
-    const int chunk = group / p.nstrips;
-    const int strip = group - chunk * p.nstrips;
+    const int chunk_of_launch = group / p.nstrips;
+    const int strip = group - chunk_of_launch * p.nstrips;
     const int n0 = p.n0, n1 = p.n1;
-    const int r0 = chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, n0);
-    // rows of the first-stage field this chunk needs: nothing beyond the grid (physical sides)
-    const int a_begin = max(r0 - 2, 0), a_end = min(r1 + 2, n0);
+    const bool second = chunk_of_launch >= p.seg0_chunks;
+    const int chunk = second ? chunk_of_launch - p.seg0_chunks : chunk_of_launch;
+    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * p.chunk_rows;
+    const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
+    const bool lo_phys = p.ext_lo == 0, hi_phys = p.ext_hi == 0;          // (wave-uniform)
+    // rows of the first-stage field this chunk needs: nothing beyond the grid on a physical side, two rows of the neighbour's beyond a cut
+    const int a_begin = lo_phys ? max(r0 - 2, 0) : r0 - 2, a_end = hi_phys ? min(r1 + 2, n0) : r1 + 2;
+    const int row_min = lo_phys ? 0 : -4, row_max = hi_phys ? n0 - 1 : n0 + 3;      // step-start rows that exist
 
     const int col = strip * QGROUP - QHALO + pp * QPITCH + lane;
     const int jc = min(max(col, 0), n1 - 1);
@@ -145,7 +155,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     };
 
     const long row_stride = p.row_stride, plane = p.plane_stride;
-    auto row_off = [row_stride, n0] (int r) { (void) n0; return (long) (MH_ROW(r, -2, n0 + 1) + 2) * row_stride; };
+    auto row_off = [row_stride, n0, row_min, row_max] (int r) { (void) n0; (void) row_min; (void) row_max; return (long) (MH_ROW(r, min(row_min, -2), max(row_max, n0 + 1)) + 2) * row_stride; };
     const unsigned jc8 = (unsigned) jc * 8u;
     const uint32_t n1u = (uint32_t) n1, colu = (uint32_t) col;
     StatusAcc acc;
@@ -178,10 +188,11 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
         double (*own)[NV][QWAVE] = own_all[pp];
         const double* in = p.u_in;
         const bool real_col = lane >= 2 && lane < QWAVE - 2 && col >= 0 && col < n1;       // a cell of the grid whose first-stage value is valid here
-        // the row loop requests rows up to three beyond the one it updates: held to the rows of the grid (the stored ghost rows hold nothing here)
+        // the row loop requests rows up to three beyond the one it updates: held to the rows that exist (physical side: the rows of the grid -
+        // the stored ghost rows hold nothing there; cut: the four rows of the neighbour)
         auto load_raw = [&] (int r) -> State5
         {
-            const int rr = min(max(r, 0), n0 - 1);
+            const int rr = min(max(r, row_min), row_max);
             return load5(in + row_off(rr));
         };
         auto ring_put = [&] (int slot, const State5& raw)
@@ -209,20 +220,20 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             const int st = S::c2p(U, g, tfloor, P);
             if (__any(st != 0))
             {
-                if (real_col && st != 0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);
+                if (real_col && st != 0 && r >= 0 && r < n0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);      // (a neighbour's row is the neighbour's to report)
             }
             return P;
         };
         auto prim_bc_raw = [&] (int r, const State5& last, const State5& raw) -> State5
         {
-            if (r < 0) return inflow_row();
-            if (r >= n0) return last;                    // zero-gradient outer: copy of the last real row
+            if (lo_phys && r < 0) return inflow_row();
+            if (hi_phys && r >= n0) return last;         // zero-gradient outer: copy of the last real row
             return prim_of_raw(r, raw);
         };
         auto prim_bc = [&] (int r, const State5& last) -> State5
         {
-            if (r < 0) return inflow_row();
-            if (r >= n0) return last;
+            if (lo_phys && r < 0) return inflow_row();
+            if (hi_phys && r >= n0) return last;
             return prim_of_raw(r, load_raw(r));
         };
 
@@ -241,7 +252,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             P[1] = prim_bc_raw(a_begin + 1, P[0], U[1]);
             G[0] = S::plm(Pb, P[0], P[1], lim);
             State5 Gb;
-            if (a_begin == 0) Gb = times_zero(G[0]);                         // extend_zeros on G
+            if (lo_phys && a_begin == 0) Gb = times_zero(G[0]);              // extend_zeros on G
             else              Gb = S::plm(prim_bc(a_begin - 2, dummy), Pb, P[0], lim);
             Fx[0] = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P[0], G[0], lim), g);
         }
@@ -255,7 +266,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
 
             P[K2] = prim_bc_raw(r + 2, P[K1], U[K2]);
             ring_put(K2, U[K2]);
-            if (r + 1 == n0) G[K1] = times_zero(G[K0]);
+            if (hi_phys && r + 1 == n0) G[K1] = times_zero(G[K0]);
             else             G[K1] = S::plm(P[K0], P[K1], P[K2], lim);
             Fx[K1] = S::template hlle<0>(S::plus(P[K0], G[K0], lim), S::minus(P[K1], G[K1], lim), g);
 
@@ -295,7 +306,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             P1 = prim_bc_raw(a_begin + 1, P0, raw1);
             G0 = S::plm(Pb, P0, P1, lim);
             State5 Gb;
-            if (a_begin == 0) Gb = times_zero(G0);                           // extend_zeros on G
+            if (lo_phys && a_begin == 0) Gb = times_zero(G0);                // extend_zeros on G
             else              Gb = S::plm(prim_bc(a_begin - 2, dummy), Pb, P0, lim);
             Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
         }
@@ -311,7 +322,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             ring_put(slot == 0 ? 2 : slot - 1, Uahead);
             Uahead = Unext;
             State5 G1;
-            if (r + 1 == n0) G1 = times_zero(G0);
+            if (hi_phys && r + 1 == n0) G1 = times_zero(G0);
             else             G1 = S::plm(P0, P1, P2, lim);
             const State5 Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
 
@@ -373,14 +384,14 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             const int st = S::c2p(U, g, tfloor, P);
             if (__any(st != 0))
             {
-                if (writes && st != 0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);
+                if (writes && st != 0 && r >= 0 && r < n0) acc.note((uint32_t) st, (uint32_t) r * n1u + colu);
             }
             return P;
         };
         auto prim_bc = [&] (int r, const State5& last) -> State5
         {
-            if (r < 0) return inflow_row();
-            if (r >= n0) return last;
+            if (lo_phys && r < 0) return inflow_row();
+            if (hi_phys && r >= n0) return last;
             return prim_of_raw(r, hand_row(r));
         };
 
@@ -396,7 +407,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             P[1] = prim_bc(r0 + 1, P[0]);
             G[0] = S::plm(Pb, P[0], P[1], lim);
             State5 Gb;
-            if (r0 == 0) Gb = times_zero(G[0]);
+            if (lo_phys && r0 == 0) Gb = times_zero(G[0]);
             else         Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P[0], lim);
             Fx[0] = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P[0], G[0], lim), g);
         }
@@ -406,7 +417,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
             if (r + 2 < a_end) cloud_pair_barrier();         // row r + 2 is in the ring
             P[K2] = prim_bc(r + 2, P[K1]);
-            if (r + 1 == n0) G[K1] = times_zero(G[K0]);
+            if (hi_phys && r + 1 == n0) G[K1] = times_zero(G[K0]);
             else             G[K1] = S::plm(P[K0], P[K1], P[K2], lim);
             Fx[K1] = S::template hlle<0>(S::plus(P[K0], G[K0], lim), S::minus(P[K1], G[K1], lim), g);
 
@@ -448,7 +459,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             P1 = prim_bc(r0 + 1, P0);
             G0 = S::plm(Pb, P0, P1, lim);
             State5 Gb;
-            if (r0 == 0) Gb = times_zero(G0);
+            if (lo_phys && r0 == 0) Gb = times_zero(G0);
             else         Gb = S::plm(prim_bc(r0 - 2, dummy), Pb, P0, lim);
             Fx_lo = S::template hlle<0>(S::plus(Pb, Gb, lim), S::minus(P0, G0, lim), g);
         }
@@ -458,7 +469,7 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
             if (r + 2 < a_end) cloud_pair_barrier();         // row r + 2 is in the ring
             const State5 P2 = prim_bc(r + 2, P1);
             State5 G1;
-            if (r + 1 == n0) G1 = times_zero(G0);
+            if (hi_phys && r + 1 == n0) G1 = times_zero(G0);
             else             G1 = S::plm(P0, P1, P2, lim);
             const State5 Fx_hi = S::template hlle<0>(S::plus(P0, G0, lim), S::minus(P1, G1, lim), g);
 
@@ -491,18 +502,33 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     acc.commit(p.status);
 }
 
-bool cloud_fused_rk2_available(const mh_cloud_desc* d)
+// with_cuts: MH_BC_EXTERNAL radial sides are accepted too (a slab of a radial decomposition: the caller - slab.hip - keeps FOUR rows of the
+// neighbour beyond such a side and exchanges once per step)
+bool cloud_fused_rk2_available(const mh_cloud_desc* d, bool with_cuts)
 {
-    return d->arith == MH_ARITH_FAST && d->plm_theta >= 0.0 && d->bc_lo0 == MH_BC_INFLOW && d->bc_hi0 == MH_BC_OUTFLOW
-        && d->row_offset == 0 && d->nr == d->nr_global && d->nr >= 4 && d->nq >= 3;
+    const bool lo_ok = d->bc_lo0 == MH_BC_INFLOW || (with_cuts && d->bc_lo0 == MH_BC_EXTERNAL);
+    const bool hi_ok = d->bc_hi0 == MH_BC_OUTFLOW || (with_cuts && d->bc_hi0 == MH_BC_EXTERNAL);
+    const bool whole = d->row_offset == 0 && d->nr == d->nr_global;
+    return d->arith == MH_ARITH_FAST && d->plm_theta >= 0.0 && lo_ok && hi_ok && (with_cuts || whole) && d->nr >= 4 && d->nq >= 3
+        && (d->bc_lo0 == MH_BC_INFLOW) == (d->row_offset == 0) && (d->bc_hi0 == MH_BC_OUTFLOW) == (d->row_offset + d->nr == d->nr_global);
 }
 
 // u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 over the whole field (layout of include/mara_hip.h; the two fields must differ);
-// geom_dev = the block of mh_cloud_pack_geometry, inflow_dev = [5][nq] nozzle primitives at the step-start time
+// the nozzle row (inflow_dev, [5][nq] primitives) is that of the step-start time for both stages (src/subprog_cloud.cpp:466-493, :524)
 hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
                                   double dt, int32_t* status, hipStream_t stream)
 {
-    if (! cloud_fused_rk2_available(d) || u_in == u_out || ! geom_dev || ! inflow_dev) return hipErrorInvalidValue;
+    return cloud_fused_rk2_launch_rows(d, geom_dev, inflow_dev, u_in, u_out, dt, 0, d->nr, 0, 0, status, stream, false);
+}
+
+// ... over rows [a, b) and, in the same launch, [a2, b2) (b2 <= a2: none) of the field
+hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
+                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts)
+{
+    if (! cloud_fused_rk2_available(d, with_cuts) || u_in == u_out || ! geom_dev || ! inflow_dev) return hipErrorInvalidValue;
+    if (a < 0 || b > d->nr || b <= a || (b2 > a2 && (a2 < b || b2 > d->nr))) return hipErrorInvalidValue;
+    const int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
+    const int longest = rows0 > rows1 ? rows0 : rows1;
     CloudFusedParams p;
     p.u_in = u_in; p.u_out = u_out; p.status = status;
     p.n0 = d->nr; p.n1 = d->nq; p.row_offset = d->row_offset;
@@ -517,18 +543,23 @@ hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev
     if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
     else
     {
-        // as euler2d_fused.hip: a pair pays about eight pipeline-fill rows per chunk, and 256 CUs x MH_CLOUD_FUSED_WAVES workgroups are resident
+        // as euler2d_fused.hip: a pair pays about eight pipeline-fill rows per chunk, and CUs x MH_CLOUD_FUSED_WAVES workgroups are resident
         // at a time: the shortest chunk that fills R residency rounds to the brim, for the smallest R that keeps it near 100 rows
-        const int resident = 256 * (4 * MH_CLOUD_FUSED_WAVES) / (2 * QPAIRS);      // workgroups: 768
+        const int resident = device_cu_count() * (4 * MH_CLOUD_FUSED_WAVES) / (2 * QPAIRS);      // workgroups: 768 on 256 CUs
         int rounds = 1;
-        auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (p.n0 + nch - 1) / nch; };
+        auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
         while (chunk_for(rounds) > 80) ++rounds;      // measured at 4096^2 (gpurun_out/r4b, profiles/r04/ab_cloud_fused_chunks.jsonl): 64 rows (3.0 rounds) 0.993 ms, 98 (1.97) 1.010, 49 (3.9) 1.024, 196 (0.98) 1.037
         p.chunk_rows = chunk_for(rounds);
         if (p.chunk_rows < 8) p.chunk_rows = 8;
     }
-    if (p.chunk_rows > p.n0) p.chunk_rows = p.n0;
-    if (p.chunk_rows < 2) p.chunk_rows = 2;
-    p.nchunks = (p.n0 + p.chunk_rows - 1) / p.chunk_rows;
+    if (p.chunk_rows > longest) p.chunk_rows = longest;
+    if (p.chunk_rows < 2 && longest >= 2) p.chunk_rows = 2;
+    p.seg0_begin = a; p.seg0_end = b;
+    p.seg0_chunks = (rows0 + p.chunk_rows - 1) / p.chunk_rows;
+    p.seg1_begin = a2; p.seg1_end = rows1 ? b2 : a2;
+    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.chunk_rows - 1) / p.chunk_rows : 0);
+    p.ext_lo = d->bc_lo0 == MH_BC_EXTERNAL ? 1 : 0;
+    p.ext_hi = d->bc_hi0 == MH_BC_EXTERNAL ? 1 : 0;
     p.gamma = d->gamma; p.theta = d->plm_theta; p.tfloor = d->temperature_floor;
     p.dt = dt;
     const dim3 grid(p.nstrips * p.nchunks), block(2 * QWAVE * QPAIRS);

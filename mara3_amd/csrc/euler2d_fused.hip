@@ -457,7 +457,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
         int rounds = 1;
         // (a slab's interior launch does NOT leave room for its edge launch's pairs: measured slower, 125 against 112 us per step at 512 rows)
-        const int resident = 256 * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);          // workgroups on the chip at a time
+        const int resident = device_cu_count() * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);          // workgroups on the chip at a time
         auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
         while (chunk_for(rounds) > (d->planar > 0 && MH_FUSED_PLANAR_WAVES >= 3 ? 80 : 112)) ++rounds;
         p.chunk_rows = chunk_for(rounds);

@@ -41,13 +41,7 @@ void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips)
 // 128: 7.46 (1.00), 256: 8.20 (1.10). Results do not depend on the cut (tests/test_gpu_euler3d.py).
 static int euler3d_default_chunk(int planes, long items_per_layer)
 {
-    static int cus = 0;
-    if (cus == 0)
-    {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
+    const int cus = device_cu_count();
     int best = planes < 32 ? planes : 32;
     double best_cost = 0.0;
     const int longest = planes < 128 ? planes : 128;          // (longer chunks were not measured; they balance worse over CUs whose speeds differ)

@@ -10,6 +10,21 @@ namespace mh {
 // (optional) on its start - no marker packets on the stream. With nothing to launch they are recorded on the stream instead.
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
 
+// compute units of the CURRENT device (256 on an MI355X; a partitioned device or another part has fewer): the launchers size their chunks
+// for whole residency rounds of the chip they run on. Queried once per device.
+inline int device_cu_count()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0)
+    {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 hipError_t euler2d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream,
                                 LaunchEvents ev = LaunchEvents());
@@ -68,9 +83,14 @@ hipError_t cloud_stage_launch(const mh_cloud_desc* d, const double* geom_dev, co
 
 // both stages of an RK2 step of a whole `cloud` field in one launch (cloud_fused.hip; MH_ARITH_FAST, PLM, both radial sides physical):
 // u_out = u_in * 0.5 + advance(advance(u_in)) * 0.5 with the nozzle row of the step-start time in both stages
-bool cloud_fused_rk2_available(const mh_cloud_desc* d);
+// with_cuts: MH_BC_EXTERNAL radial sides too - the field then holds FOUR rows of the neighbour beyond such a side (rows -4 .. -1 / nr .. nr + 3),
+// which the caller allocates and exchanges once per step; the nozzle rows apply on the slab that owns row 0 only
+bool cloud_fused_rk2_available(const mh_cloud_desc* d, bool with_cuts = false);
 hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
                                   double dt, int32_t* status, hipStream_t stream);
+// ... over rows [a, b) and, in the same launch, [a2, b2) (none if b2 <= a2): a radial slab with neighbours runs its two edge strips, then the rest
+hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
+                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts = false);
 
 // cloud_diag.hip: make_diagnostic_fields of a device-resident cloud state; fields [5][nr][nq], work [4][nr][nq], columns [15][nq] (device)
 hipError_t cloud_diagnostics_launch(const mh_cloud_desc* d, const double* geom_dev, const double* u, const double units[3],

@@ -143,6 +143,13 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
     if (s->kind == SLAB_CLOUD)
     {
         const mh_cloud_desc* d = edge ? &s->cloud_edge : &s->cloud;
+        if (s->fused_cut)
+        {
+            // the whole RK2 step of these rows in one launch (cloud_fused.hip across the cuts): `in` is the step-start field, `base` / w unused
+            if (hipError_t e = cloud_fused_rk2_launch_rows(&s->cloud, s->geom, s->inflow, in, out, dt, a, b, a2, b2, s->status, stream, true)) return e;
+            if (ev.stop) return hipEventRecord(ev.stop, stream);
+            return hipSuccess;
+        }
         if (hipError_t e = cloud_stage_launch(d, s->geom, s->inflow, in, base, out, dt, w, a, b, s->status, stream)) return e;
         if (b2 > a2) if (hipError_t e = cloud_stage_launch(d, s->geom, s->inflow, in, base, out, dt, w, a2, b2, s->status, stream)) return e;
     }
@@ -368,10 +375,20 @@ static bool slab_can_fuse(const mh_slab* s)
 // 1024 rows 191 / 179, 512 rows 99 / 92 (with one pair per workgroup the fused form lost below 1536 rows; with two it wins down to the
 // 512 rows of the 8-GPU cut). Thinner slabs were not measured and keep the two launches. MH_SLAB_FUSED_CUTS: 0 never, 1 wherever it can
 // run (12 rows), unset: from 384 rows per slab.
-static bool slab_can_fuse_cut(const mh_slab* s, const mh_euler_cart_desc* global)
+static bool slab_can_fuse_cut(const mh_slab* s, const mh_euler_cart_desc* global, const mh_cloud_desc* cglobal)
 {
     int least = 384;
     if (const char* v = getenv("MH_SLAB_FUSED_CUTS")) { if (atoi(v) == 0) return false; least = 12; }          /* 12: two edge strips of four rows and an interior */
+    if (s->kind == SLAB_CLOUD)
+    {
+        // `cloud` across radial cuts (round 5; BASELINE config 4 is a 4-slab run): both RK stages use the step-start nozzle row
+        // (src/subprog_cloud.cpp:466-493, :524), so the one-launch step of cloud_fused.hip serves a slab as it serves the whole field - four
+        // ghost rows, one exchange per step; the nozzle rows apply on the slab that owns row 0 only. Same threshold as the Euler slabs
+        // (measured: profiles/r05/cloud_fused_cuts.md).
+        mh_cloud_desc d = s->cloud;
+        return s->rk_order == 2 && has_neighbours(s) && cglobal && cglobal->fuse_stages >= 0 && cglobal->nr_global / s->world >= least
+            && s->n0 >= 12 && cloud_fused_rk2_available(&d, true);
+    }
     mh_euler_cart_desc d = s->desc;
     d.n[0] = 8;          // (the member's own row count must not enter: only the thinnest share below does)
     return s->kind == SLAB_EULER && s->rk_order == 2 && has_neighbours(s) && global->fuse_stages >= 0 && global->n[0] / s->world >= least
@@ -481,14 +498,20 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
         }
     }
     s->fused = slab_can_fuse(s);
-    s->fused_cut = kind == SLAB_EULER && slab_can_fuse_cut(s, global);
+    s->fused_cut = slab_can_fuse_cut(s, global, cglobal);
     if (s->fused_cut)
     {
         s->fused_desc = s->desc;
-        s->fused_desc.chunk_rows = global->chunk_rows;
+        if (kind == SLAB_EULER) s->fused_desc.chunk_rows = global->chunk_rows;
         s->pad_doubles = 2 * row_doubles(s);
         s->edge_rows = 4;          // the rows a neighbour needs for both of its stages; every step synchronises both chains (no stagger)
         s->stagger = 0;
+    }
+    if (kind == SLAB_CLOUD && cglobal->fuse_stages > 0 && has_neighbours(s) && ! s->fused_cut)
+    {
+        delete s;
+        set_error("fuse_stages is required, but a fused `cloud` step across radial cuts needs MH_ARITH_FAST, PLM, rk_order 2 and twelve rows per slab");
+        return MH_E_INVALID;
     }
     if (kind == SLAB_EULER && global->fuse_stages > 0 && ! s->fused && ! s->fused_cut)
     {
@@ -525,6 +548,7 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     if (hipMalloc((void**) &s->staging, (size_t) 5 * s->n0 * s->n1 * sizeof(double)) != hipSuccess) { cleanup(); return MH_E_NOMEM; }
     if (kind == SLAB_CLOUD)
     {
+        s->inflow_planar = false;          // no nozzle row seen yet: general kernels until mh_slab_set_inflow / mh_slab_group_set_inflow has looked at one
         std::vector<double> geom(mh_cloud_geometry_doubles(cglobal));
         if (int rc = mh_cloud_pack_geometry(cglobal, rv, qv, geom.data())) { cleanup(); return rc; }
         if (hipMalloc((void**) &s->geom, geom.size() * sizeof(double)) != hipSuccess ||
@@ -555,8 +579,13 @@ static int group_create(mh_slab** slabs, int kind, const mh_euler_cart_desc* glo
     {
         slabs[r]->peer_lo = slabs[r]->lo >= 0 ? slabs[slabs[r]->lo] : nullptr;
         slabs[r]->peer_hi = slabs[r]->hi >= 0 ? slabs[slabs[r]->hi] : nullptr;
-        // MH_SLAB_TEST_PEER_FAIL=1 (tests on a one-GPU box): take the branch as if a neighbour lived on a device that refuses peer access
+        // the branch behind hipDeviceEnablePeerAccess cannot be reached on a one-GPU box: CHECK builds only (-DMH_TEST_HOOKS, libmara_hip_check.so;
+        // the product library reads no such variable) take it on request, as if a neighbour lived on a device that refuses peer access
+#ifdef MH_TEST_HOOKS
         const bool refuse = getenv("MH_SLAB_TEST_PEER_FAIL") && atoi(getenv("MH_SLAB_TEST_PEER_FAIL")) != 0;
+#else
+        const bool refuse = false;
+#endif
         for (mh_slab* p : {slabs[r]->peer_lo, slabs[r]->peer_hi})
             if (p && (p->device != slabs[r]->device || refuse))
             {
@@ -809,6 +838,9 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
 
 int mh_slab_is_planar(const mh_slab* s) { return s && s->planar_now ? 1 : 0; }
 
+// bulk launches per time step: 1 where the RK2 step is one fused launch (lone slabs and, from 384 rows per slab on, slabs across their cuts)
+int mh_slab_launches_per_step(const mh_slab* s) { return ! s ? 0 : ((s->fused || s->fused_cut) ? 1 : s->rk_order); }
+
 int mh_slab_download(mh_slab* s, double* u_aos_slab_host)
 {
     if (! s || ! u_aos_slab_host) return MH_E_INVALID;
@@ -829,35 +861,90 @@ int mh_slab_group_download(mh_slab** g, int n, double* u_aos_global_host)
     return MH_OK;
 }
 
+// does the nozzle row carry an azimuthal velocity? (STRICT: anything but the bit pattern of +0.0 counts, srhd_device.hpp)
+static bool inflow_row_is_planar(const mh_slab* s, const double* row_aos)
+{
+    bool planar = true;
+    for (size_t j = 0; j < (size_t) s->n1; ++j)
+    {
+        const double up = row_aos[5 * j + 3];
+        planar = planar && up == 0.0 && ! (s->cloud.arith == MH_ARITH_STRICT && std::signbit(up));
+    }
+    return planar;
+}
+
+// the row itself, on the slab that owns the nozzle-side boundary (after the stages already queued: they read the previous row)
+static int slab_store_inflow(mh_slab* s, const double* row_aos)
+{
+    if (s->row0 != 0) return MH_OK;
+    const size_t nq = (size_t) s->n1;
+    MH_HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> soa(5 * nq);
+    for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = row_aos[5 * j + q];
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    MH_HIP_TRY(hipMemcpy(s->inflow, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));      // the staging vector is consumed before return
+    return MH_OK;
+}
+
+static int slab_quiesce(mh_slab* s)
+{
+    MH_HIP_TRY(hipSetDevice(s->device));
+    MH_HIP_TRY(hipStreamSynchronize(s->main));
+    MH_HIP_TRY(hipStreamSynchronize(s->side));
+    return MH_OK;
+}
+
 int mh_slab_set_inflow(mh_slab* s, const double* inflow_prims_aos_host)
 {
     if (! s || s->kind != SLAB_CLOUD || ! inflow_prims_aos_host) { set_error("mh_slab_set_inflow: not a cloud slab"); return MH_E_STATE; }
-    const size_t nq = (size_t) s->n1;
-    // planarity (mh_cloud_desc.planar): every slab is handed the row, so every slab learns of an azimuthal velocity in the same call - and takes
-    // the general kernels until the next upload has looked at the field again (STRICT: the bit pattern of +0.0, srhd_device.hpp)
-    bool row_planar = true;
-    for (size_t j = 0; j < nq; ++j)
-    {
-        const double up = inflow_prims_aos_host[5 * j + 3];
-        row_planar = row_planar && up == 0.0 && ! (s->cloud.arith == MH_ARITH_STRICT && std::signbit(up));
-    }
+    // planarity (mh_cloud_desc.planar): a row with an azimuthal velocity sends THIS slab to the general kernels until the next upload has looked
+    // at the field again. A slab learns of the row only through this call, and a cloud slab starts out not knowing one (inflow_planar = false):
+    //  * a lone slab / a slab whose neighbours live in other processes re-resolves here as at upload (the latter only under planar > 0);
+    //  * members of a loopback group are resolved TOGETHER by mh_slab_group_set_inflow - through this per-slab call a member can only lose
+    //    its planar kernels, never gain them, so a host that hands the row to one member only stays correct (on the general kernels).
+    const bool row_planar = inflow_row_is_planar(s, inflow_prims_aos_host);
+    if (! row_planar && s->planar_request > 0) { set_error("mh_slab_set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return slab_fail(s, MH_E_INVALID); }
     s->inflow_planar = row_planar;
-    if (! row_planar)
+    bool want = s->planar_now;
+    if (! row_planar) want = false;
+    else if (s->backend != EXCHANGE_LOOPBACK) want = s->planar_local && (! has_neighbours(s) || s->backend == EXCHANGE_NONE || s->planar_request > 0);
+    if (want != s->planar_now)
     {
-        if (s->planar_request > 0) { set_error("mh_slab_set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return slab_fail(s, MH_E_INVALID); }
-        MH_HIP_TRY(hipSetDevice(s->device));
-        MH_HIP_TRY(hipStreamSynchronize(s->main));
-        MH_HIP_TRY(hipStreamSynchronize(s->side));
-        slab_set_planar(s, false);
+        if (int rc = slab_quiesce(s)) return slab_fail(s, rc);
+        slab_set_planar(s, want);
     }
-    if (s->row0 != 0) return MH_OK;              // only the slab that owns the nozzle-side boundary reads the row
-    MH_HIP_TRY(hipSetDevice(s->device));
-    std::vector<double> soa(5 * nq);
-    for (size_t j = 0; j < nq; ++j) for (int q = 0; q < 5; ++q) soa[q * nq + j] = inflow_prims_aos_host[5 * j + q];
-    // after the stages already queued (they read the previous row); the staging vector is consumed before return
-    MH_HIP_TRY(hipStreamSynchronize(s->main));
-    MH_HIP_TRY(hipStreamSynchronize(s->side));
-    MH_HIP_TRY(hipMemcpy(s->inflow, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (! row_planar && s->backend == EXCHANGE_LOOPBACK)
+    {
+        // a member of a loopback group handed a rotating row on its own: its azimuthal momentum will cross the cuts, so EVERY member leaves the
+        // planar kernels with it (radial slabs form an open chain: walk it both ways)
+        for (int dir = 0; dir < 2; ++dir)
+            for (mh_slab* p = dir ? s->peer_hi : s->peer_lo; p && p != s; p = dir ? p->peer_hi : p->peer_lo)
+            {
+                p->inflow_planar = false;
+                if (p->planar_now) { if (int rc = slab_quiesce(p)) return slab_fail(s, rc); slab_set_planar(p, false); }
+            }
+    }
+    if (int rc = slab_store_inflow(s, inflow_prims_aos_host)) return slab_fail(s, rc);
+    return MH_OK;
+}
+
+int mh_slab_group_set_inflow(mh_slab** g, int n, const double* inflow_prims_aos_host)
+{
+    if (int rc = check_group(g, n)) return rc;
+    if (g[0]->kind != SLAB_CLOUD || ! inflow_prims_aos_host) { set_error("mh_slab_group_set_inflow: not a group of cloud slabs"); return MH_E_STATE; }
+    // every member learns of the row in ONE call: the group is planar only if every member's rows AND the row are (mh_slab_group_upload's rule)
+    const bool row_planar = inflow_row_is_planar(g[0], inflow_prims_aos_host);
+    if (! row_planar && g[0]->planar_request > 0) { set_error("mh_slab_group_set_inflow: `planar` was asserted, but the nozzle row has an azimuthal velocity"); return slab_fail(g[0], MH_E_INVALID); }
+    bool all = row_planar, change = false;
+    for (int r = 0; r < n; ++r) { g[r]->inflow_planar = row_planar; all = all && g[r]->planar_local; }
+    for (int r = 0; r < n; ++r) change = change || g[r]->planar_now != all;
+    if (change)
+    {
+        for (int r = 0; r < n; ++r) if (int rc = slab_quiesce(g[r])) return slab_fail(g[r], rc);
+        for (int r = 0; r < n; ++r) slab_set_planar(g[r], all);
+    }
+    for (int r = 0; r < n; ++r) if (int rc = slab_store_inflow(g[r], inflow_prims_aos_host)) return slab_fail(g[r], rc);
     return MH_OK;
 }
 

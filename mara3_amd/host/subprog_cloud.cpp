@@ -171,6 +171,10 @@ public:
             if (visible < gpus) std::printf("gpus=%d on %d visible device(s): slabs share devices round-robin\n", gpus, visible);
             if (mh_slab_cloud_group_create_on(slabs.data(), &d, rv.data(), qv.data(), int(cfg.get_int("rk_order")), gpus, ids.data()) != MH_OK)
                 throw std::runtime_error(std::string("mh_slab_cloud_group_create_on: ") + mh_last_error(nullptr));
+            // (1: the one-launch RK2 step across the radial cuts - four ghost rows, one exchange per step; round 5)
+            std::printf("slab launches per step:");
+            for (mh_slab* sl : slabs) std::printf(" %d", mh_slab_launches_per_step(sl));
+            std::printf("\n");
         }
         auto group_check = [] (int rc, const char* what) { if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(nullptr)); };
         auto upload_solution = [&] ()
@@ -303,7 +307,7 @@ public:
             const double ms = host::time_ms([&] {
                 if (gpus > 1)
                 {
-                    for (mh_slab* sl : slabs) group_check(mh_slab_set_inflow(sl, inflow.data()), "mh_slab_set_inflow");
+                    group_check(mh_slab_group_set_inflow(slabs.data(), gpus, inflow.data()), "mh_slab_group_set_inflow");
                     group_check(mh_slab_group_step(slabs.data(), gpus, dt, 1), "mh_slab_group_step");
                     for (mh_slab* sl : slabs) group_check(mh_slab_synchronize(sl), "mh_slab_synchronize");
                 }
@@ -347,6 +351,10 @@ public:
         host::dump_state(cfg.get_string("outdir"), "final.bin", {long(nr), long(nq)}, 5, time, iteration, vertices, u);
         if (cfg.get_int("write_inflow"))
             host::dump_state(cfg.get_string("outdir"), "inflow0.bin", {long(nq)}, 5, 0.0, 0, {}, inflow_first);
+        // upstream's closing `run_tasks_on_next(state)` (:935): one more step whose only visible effect is a task that falls due on it.
+        // final.bin above is the state the loop ended with; a run cut short by max_steps (not upstream) ends there.
+        if (max_steps == 0 && tasks_on) advance(false);
+        // (profile = 1 steps the live solution further: only now, after every task of the run - the closing one included - has seen its state)
         if (cfg.get_int("profile") && gpus == 1)
         {
             std::printf("step kernels: %s\n", mh_field_is_planar(ctx) ? "planar (no azimuthal momentum in field and nozzle row: verified)" : "general");
@@ -365,9 +373,6 @@ public:
             int32_t word = 0;
             host::check(mh_status_word(ctx, &word), ctx, "mh_status_word");       // (cleared: these steps are not part of the run)
         }
-        // upstream's closing `run_tasks_on_next(state)` (:935): one more step whose only visible effect is a task that falls due on it.
-        // final.bin above is the state the loop ended with; a run cut short by max_steps (not upstream) ends there.
-        if (max_steps == 0 && tasks_on) advance(false);
         for (mh_slab* sl : slabs) mh_slab_destroy(sl);
         mh_destroy(ctx);
         return 0;

@@ -498,8 +498,10 @@ class NativeSlabGroup:
     mh_slab_group_*). Euler (2-D, 3-D) with global_shape / dl, or the `cloud` grid with r_vertices / q_vertices."""
 
     def __init__(self, global_shape=None, dl=None, gamma=5.0 / 3, plm_theta=1.5, riemann="hllc", rk_order=2, bc="outflow", world=2,
-                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8, devices=None, planar=None):
-        """devices: one device id per member (mh_slab_group_create_on: ONE process driving several GPUs, receives as peer copies)"""
+                 device=0, chunk_rows=0, arith="strict", r_vertices=None, q_vertices=None, temperature_floor=1e-8, devices=None, planar=None, fuse=None):
+        """devices: one device id per member (mh_slab_group_create_on: ONE process driving several GPUs, receives as peer copies)
+        fuse (`cloud`): mh_cloud_desc.fuse_stages - None = the one-launch RK2 step across the radial cuts where available (FAST, PLM, from 384
+        rows per slab on), False = never, True = required"""
         import numpy as np
         self.np = np
         self.lib = L.load_library()
@@ -514,7 +516,8 @@ class NativeSlabGroup:
             nr, nq = len(rv) - 1, len(qv) - 1
             d = L.CloudDesc(nr=nr, nq=nq, nr_global=nr, row_offset=0, gamma=gamma, plm_theta=plm_theta, temperature_floor=temperature_floor,
                             bc_lo0=L.BC_INFLOW, bc_hi0=L.BC_OUTFLOW, arith={"strict": L.ARITH_STRICT, "fast": L.ARITH_FAST}[arith],
-                            chunk_rows=chunk_rows, planar=0 if planar is None else (1 if planar else -1))
+                            chunk_rows=chunk_rows, planar=0 if planar is None else (1 if planar else -1),
+                            fuse_stages=0 if fuse is None else (1 if fuse else -1))
             if ids is not None:
                 L.check(self.lib.mh_slab_cloud_group_create_on(self.handles, C.byref(d), rv.ctypes.data_as(C.c_void_p), qv.ctypes.data_as(C.c_void_p),
                                                                rk_order, world, ids))
@@ -545,6 +548,10 @@ class NativeSlabGroup:
         L.check(self.lib.mh_slab_group_download(self.handles, self.world, u.ctypes.data_as(C.c_void_p)))
         return u
 
+    def launches_per_step(self):
+        """per member: 1 where its RK2 step is one fused launch (across its cuts), else the number of RK stages"""
+        return [int(self.lib.mh_slab_launches_per_step(C.c_void_p(self.handles[r]))) for r in range(self.world)]
+
     def is_planar(self):
         """True while every member's launches take the planar kernels (descriptor field `planar`)"""
         return all(bool(self.lib.mh_slab_is_planar(C.c_void_p(self.handles[r]))) for r in range(self.world))
@@ -552,8 +559,8 @@ class NativeSlabGroup:
     def set_inflow(self, inflow_prims):
         p = self.np.ascontiguousarray(inflow_prims, dtype=self.np.float64)
         assert p.shape == (self.global_shape[1], NQ)
-        for r in range(self.world):
-            L.check(self.lib.mh_slab_set_inflow(C.c_void_p(self.handles[r]), p.ctypes.data_as(C.c_void_p)))
+        # every member learns of the row in one call (the group's planarity is resolved over all members' rows and the row together)
+        L.check(self.lib.mh_slab_group_set_inflow(self.handles, self.world, p.ctypes.data_as(C.c_void_p)))
 
     def step(self, dt, nsteps=1):
         L.check(self.lib.mh_slab_group_step(self.handles, self.world, dt, nsteps))

@@ -214,3 +214,85 @@ def test_azimuthal_motion_in_field_or_nozzle_takes_the_general_cloud_kernel(eng)
     with pytest.raises(mara3_amd.MaraHipError, match="azimuthal"):
         s.set_inflow(rows[3])
     s.close()
+
+
+# ---- round 5: the one-launch step across RADIAL CUTS (BASELINE config 4 is a 4-slab run) -------------------------------------------------
+# Both RK stages use the step-start nozzle row (src/subprog_cloud.cpp:466-493, :524), so a radial slab takes the fused launch as the whole
+# field does: four rows of each neighbour, ONE exchange per step, the neighbours' first-stage rows recomputed inside the launch; the nozzle
+# rows apply on the slab that owns row 0, the zero-gradient copy and the zeroed edge slope (:563) on the one that owns the last row.
+
+def run_slabs(rv, qv, u0, inflow, dt, pieces, world, fuse, chunk=0, planar=None):
+    from mara3_amd.slab import NativeSlabGroup
+    g = NativeSlabGroup(world=world, rk_order=2, plm_theta=1.2, gamma=4.0 / 3, arith="fast", r_vertices=rv, q_vertices=qv, temperature_floor=0.0,
+                        fuse=fuse, chunk_rows=chunk, planar=planar)
+    lps, rows = g.launches_per_step(), list(g.rows)
+    g.upload(u0)
+    out, k = [], 0
+    for n in pieces:
+        for _ in range(n):
+            g.set_inflow(inflow[k % len(inflow)])
+            g.step(dt, 1)
+            k += 1
+        g.synchronize()
+        out.append(g.download())
+    st = g.status()
+    g.close()
+    return out, st, lps, rows
+
+
+@pytest.mark.parametrize("nr,nq,world,chunk", [(96, 130, 2, 0), (97, 250, 3, 0), (130, 117, 4, 0), (61, 64, 4, 5), (50, 300, 3, 2), (200, 57, 4, 23), (48, 40, 4, 0)])
+def test_fused_cloud_step_across_radial_cuts_is_the_whole_field_run(eng, nr, nq, world, chunk, monkeypatch):
+    """2 - 4 radial slabs (uneven cuts where world does not divide nr: nd::partition_shape), slabs down to twelve rows, chunk lengths that do not
+    divide the segments, a nozzle row that changes every step, odd and even step counts - bit-identical to the ONE-launch step of the whole
+    field, and (therefore) to the two FAST launches per slab that MH_SLAB_FUSED_CUTS=0 keeps"""
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")          # (default: from 384 rows per slab on)
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, nr, nq, seed=nr + 7 * nq + world)
+    pieces = (1, 2, 3)
+    whole, st_w = run(eng, rv, qv, u0, inflow, dt, pieces, True, chunk)
+    cut, st_c, lps, rows = run_slabs(rv, qv, u0, inflow, dt, pieces, world, None, chunk)
+    assert lps == [1] * world, lps                        # EVERY slab takes the fused launch
+    assert rows[0][0] == 0 and rows[-1][1] == nr and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert st_w == (0, None) and st_c == (0, None)
+    for a, b, n in zip(cut, whole, pieces):
+        assert bits_equal(a, b), (nr, nq, world, chunk, n, np.abs(a - b).max())
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "0")
+    two, st_t, lps2, _ = run_slabs(rv, qv, u0, inflow, dt, pieces, world, None, chunk)
+    assert lps2 == [2] * world and st_t == (0, None)
+    for a, b in zip(two, whole):
+        assert bits_equal(a, b)
+
+
+def test_fused_cuts_are_the_default_from_384_rows_per_slab_and_can_be_refused_or_required(eng, monkeypatch):
+    import mara3_amd
+    monkeypatch.delenv("MH_SLAB_FUSED_CUTS", raising=False)
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 800, 64, seed=3)
+    cut, st, lps, _ = run_slabs(rv, qv, u0, inflow, dt, (2,), 2, None)
+    whole, _ = run(eng, rv, qv, u0, inflow, dt, (2,), True)
+    assert lps == [1, 1] and st == (0, None) and bits_equal(cut[0], whole[0])
+    assert run_slabs(rv, qv, u0, inflow, dt, (1,), 4, None)[2] == [2] * 4          # 200 rows per slab: the two launches
+    assert run_slabs(rv, qv, u0, inflow, dt, (1,), 2, False)[2] == [2, 2]           # fuse_stages < 0: never
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 40, 64, seed=3)
+    with pytest.raises(mara3_amd.MaraHipError, match="fuse_stages is required"):
+        run_slabs(rv, qv, u0, inflow, dt, (1,), 4, True)                            # ten rows per slab: cannot
+
+
+def test_fused_cuts_general_kernel_with_azimuthal_motion_and_the_status_contract(eng, monkeypatch):
+    """a field WITH azimuthal momentum takes the general fused kernel on every slab (same bits as the whole field); a cell that fails
+    recover_primitive is reported once, with its GLOBAL flat index, by the slab that owns it - not by the neighbour that recomputes its row"""
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    nr, nq, world = 90, 70, 3
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, nr, nq, seed=12)
+    rng = np.random.default_rng(4)
+    spin = u0.copy()
+    spin[..., 3] = 0.05 * spin[..., 0] * rng.uniform(-1.0, 1.0, (nr, nq))
+    whole, st_w = run(eng, rv, qv, spin, inflow, dt, (3,), True)
+    cut, st_c, lps, rows = run_slabs(rv, qv, spin, inflow, dt, (3,), world, None)
+    assert lps == [1] * world and st_w == (0, None) and st_c == (0, None)
+    assert bits_equal(cut[0], whole[0]) and np.abs(cut[0][..., 3]).max() > 0.0
+    bad = u0.copy()
+    i, j = rows[1][0], 33                               # the first row of the middle slab: slab 0 recomputes it as a first-stage ghost row
+    bad[i, j, 4] = -abs(bad[i, j, 4])                   # negative energy: recover_primitive fails there
+    _, st_w = run(eng, rv, qv, bad, inflow, dt, (1,), True)
+    _, st_c, _, _ = run_slabs(rv, qv, bad, inflow, dt, (1,), world, None)
+    # (the failure may spread to the cells around it within the step: what is pinned is that slabs and whole field report the SAME bits and first cell)
+    assert st_w[0] != 0 and st_c == st_w and st_w[1] <= i * nq + j and st_w[1] >= (i - 3) * nq, (st_w, st_c)

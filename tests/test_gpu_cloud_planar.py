@@ -152,9 +152,10 @@ def test_slab_group_takes_the_planar_stages_and_matches_the_whole_field_run(eng,
     assert took == [True] * 4 and st == (0, None)
     g = slab.NativeSlabGroup(world=world, rk_order=2, plm_theta=1.2, gamma=4.0 / 3, arith=arith, r_vertices=rv, q_vertices=qv, temperature_floor=0.0)
     g.upload(u0)
-    assert g.is_planar()
+    assert not g.is_planar()                                  # (round 5: a cloud slab knows no nozzle row until it is handed one)
     for n in range(4):
         g.set_inflow(inflow[n])
+        assert g.is_planar()
         g.step(dt, 1)
     g.synchronize()
     assert g.status() == (0, None)
@@ -172,4 +173,22 @@ def test_slab_group_takes_the_planar_stages_and_matches_the_whole_field_run(eng,
     g.synchronize()
     ref, _, took = run(eng, rv, qv, u0, rows, dt, 2, None, arith)
     assert took == [True, False] and bits_equal(g.download(), ref)
+    # advisor finding, round 4: a host that hands the rotating row to the nozzle-side member ONLY (the per-slab call) must not leave the other
+    # members on their planar kernels: they all go general with it, and the result is the whole-field run's
+    import ctypes as C
+    from mara3_amd import _lib as L
+    g.upload(u0)
+    g.set_inflow(rows[0])
+    assert g.is_planar()
+    g.step(dt, 1)
+    p = np.ascontiguousarray(rows[1])
+    L.check(g.lib.mh_slab_set_inflow(C.c_void_p(g.handles[0]), p.ctypes.data_as(C.c_void_p)))
+    assert not any(bool(g.lib.mh_slab_is_planar(C.c_void_p(h))) for h in g.handles)
+    g.step(dt, 1)
+    g.synchronize()
+    assert bits_equal(g.download(), ref)
+    # ... and through the per-slab call with a planar row no member GAINS the planar kernels (the group call resolves them together)
+    g.upload(u0)
+    L.check(g.lib.mh_slab_set_inflow(C.c_void_p(g.handles[0]), np.ascontiguousarray(rows[0]).ctypes.data_as(C.c_void_p)))
+    assert not g.is_planar()
     g.close()

@@ -220,38 +220,39 @@ def test_strict_planar_kernel_reproduces_the_reference_golden_steps(eng, case):
 def test_context_with_an_external_side_does_not_go_planar_on_its_own_rows(eng, arith):
     """advisor finding, round 4: a context with an MH_BC_EXTERNAL side sees only its own rows at mh_upload - its ghost rows are the caller's
     (mh_field_ptr) and may carry a third momentum. planar = 0 must then mean the GENERAL kernels (as for slabs that exchange with other
-    processes); planar > 0 is the caller's word for the whole grid. Lower half of a grid whose upper half has a third momentum, RK1, one
-    step: bit-identical to the same rows of the whole-grid run - which the planar kernel (it never reads component 3 of the ghost rows) is not."""
+    processes); planar > 0 is the caller's word for the whole grid. UPPER half of a grid whose lower half has a third momentum (the flow
+    of wave_ic runs towards higher rows, so that momentum crosses the cut), RK1, one step: bit-identical to the same rows of the whole-grid
+    run - which the planar kernel (it never reads component 3 of the ghost rows) is not."""
     import ctypes as C
     from mara3_amd import _lib as L
     n0, n1 = 64, 96
     whole = planar_state((2 * n0, n1), seed=21)
-    upper = planar_state((2 * n0, n1), seed=21, third=0.4)
-    whole[n0:] = upper[n0:]                                            # rows [0, n0) planar, rows [n0, 2 n0) with a third momentum
+    tilted = planar_state((2 * n0, n1), seed=21, third=0.4)
+    whole[:n0] = tilted[:n0]                                           # rows [0, n0) with a third momentum, rows [n0, 2 n0) planar
     dl = (1.0 / (2 * n0), 1.0 / n1)
     ref = eng.EulerCartSolver((2 * n0, n1), dl, 1.4, 1.5, "hllc", 1, "outflow", arith=arith, planar=False)
     ref.upload(whole)
     ref.step(4e-4, 1)
-    want = ref.download()[:n0]
+    want = ref.download()[n0:]
     ref.close()
+    assert np.abs(want[:2, :, 3]).max() > 0.0                              # the lower half's third momentum does cross the cut within the step
 
-    def lower_half(planar):
-        s = eng.EulerCartSolver((n0, n1), dl, 1.4, 1.5, "hllc", 1, "outflow", bc_hi0="external", arith=arith, planar=planar)
-        s.upload(whole[:n0])
+    def upper_half(planar):
+        s = eng.EulerCartSolver((n0, n1), dl, 1.4, 1.5, "hllc", 1, "outflow", bc_lo0="external", arith=arith, planar=planar)
+        s.upload(whole[n0:])
         took = s.is_planar()
-        # the two ghost rows above row n0 - 1: rows n0, n0 + 1 of the whole grid, in the device layout ((i + 2) * 5 + q) * pitch + t
-        ghost = np.ascontiguousarray(np.transpose(whole[n0:n0 + 2], (0, 2, 1)))        # [row][q][t]
+        # the two ghost rows below row 0: rows n0 - 2, n0 - 1 of the whole grid, in the device layout ((i + 2) * 5 + q) * pitch + t, i = -2, -1
+        ghost = np.ascontiguousarray(np.transpose(whole[n0 - 2:n0], (0, 2, 1)))        # [row][q][t]
         lib = L.load_library()
         lib.mh_field_ptr.restype = C.c_void_p
         base = lib.mh_field_ptr(s.ctx, 0)
-        L.check(lib.mh_memcpy_h2d(C.c_void_p(base + (n0 + 2) * 5 * n1 * 8), ghost.ctypes.data_as(C.c_void_p), ghost.nbytes))
+        L.check(lib.mh_memcpy_h2d(C.c_void_p(base), ghost.ctypes.data_as(C.c_void_p), ghost.nbytes))
         s.step(4e-4, 1)
         got = s.download()
         s.close()
         return took, got
 
-    took, got = lower_half(None)
+    took, got = upper_half(None)
     assert took is False and bits_equal(got, want)
-    assert np.abs(got[n0 - 2:, :, 3]).max() > 0.0                          # the neighbour's third momentum did arrive
-    took_asserted, got_asserted = lower_half(True)                        # the caller's (here: wrong) word is taken
+    took_asserted, got_asserted = upper_half(True)                        # the caller's (here: wrong) word is taken
     assert took_asserted is True and not bits_equal(got_asserted, want)

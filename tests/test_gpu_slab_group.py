@@ -369,16 +369,32 @@ def test_group_create_on_leaves_no_slab_behind_when_a_device_is_missing_or_refus
     rc = lib.mh_slab_group_create_on(handles, C.byref(d), 2, world, ids)
     assert rc != 0 and all(not h for h in handles), (rc, list(handles))
     assert b"device" in lib.mh_last_error(None)
+    # the PRODUCT library has no such hook (advisor finding, round 4): with the variable set its groups are created as ever
     monkeypatch.setenv("MH_SLAB_TEST_PEER_FAIL", "1")
-    handles = (C.c_void_p * world)(*[C.c_void_p(0xdead)] * world)
-    ids = (C.c_int * world)(0, 0, 0)
-    rc = lib.mh_slab_group_create_on(handles, C.byref(d), 2, world, ids)
-    assert rc != 0 and all(not h for h in handles), (rc, list(handles))
-    assert b"hipDeviceEnablePeerAccess" in lib.mh_last_error(None), lib.mh_last_error(None)
-    monkeypatch.delenv("MH_SLAB_TEST_PEER_FAIL")
-    # and the library is still usable: the same group without the hook steps as ever
     g = eng_slab_group(shape, world)
     g.close()
+    monkeypatch.delenv("MH_SLAB_TEST_PEER_FAIL")
+    # the CHECK library (-DMH_TEST_HOOKS) takes the branch on request, in a child process of its own
+    import os, subprocess, sys
+    from conftest import ROOT
+    check = os.path.join(ROOT, "mara3_amd", "libmara_hip_check.so")
+    assert os.path.exists(check), "build the check libraries: make -C mara3_amd/csrc check (__graft_entry__.build() does)"
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from mara3_amd import _lib as L\n"
+            "from mara3_amd.slab import euler_cart_desc, NativeSlabGroup\n"
+            "lib = L.load_library(); world, shape = 3, (48, 40)\n"
+            "d = euler_cart_desc(shape, (1.0 / 48, 1.0 / 40), 1.4, 1.5, 'hllc', 'outflow', 0, 'fast')\n"
+            "handles = (C.c_void_p * world)(*[C.c_void_p(0xdead)] * world)\n"
+            "ids = (C.c_int * world)(0, 0, 0)\n"
+            "rc = lib.mh_slab_group_create_on(handles, C.byref(d), 2, world, ids)\n"
+            "assert rc != 0 and all(not h for h in handles), (rc, list(handles))\n"
+            "assert b'hipDeviceEnablePeerAccess' in lib.mh_last_error(None), lib.mh_last_error(None)\n"
+            "import os; del os.environ['MH_SLAB_TEST_PEER_FAIL']\n"
+            "g = NativeSlabGroup(shape, (1.0 / 48, 1.0 / 40), 1.4, 1.5, 'hllc', 2, 'outflow', world=world, arith='fast'); g.close()\n"      # still usable
+            "print('peer-fail branch ok')\n" % ROOT)
+    env = dict(os.environ, MARA_HIP_LIBRARY=check, MH_SLAB_TEST_PEER_FAIL="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "peer-fail branch ok" in p.stdout, (p.stdout[-800:], p.stderr[-1500:])
 
 
 def eng_slab_group(shape, world):
