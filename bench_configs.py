@@ -184,8 +184,9 @@ def run_c4(args):
     if identical is not None:
         out["slabs_bit_identical_to_one_gpu_run"] = bool(identical)
         visible = mara_device_count()
-        out["config"]["decomposition"] = ("%d radial slabs (nd::partition_shape), two-row halo per stage, one process driving the devices%s"
-                                          % (args.gpus, "" if visible >= args.gpus else "; REHEARSAL: %d visible device(s), the slabs share them round-robin (peer copies become device-to-device copies)" % visible))
+        out["config"]["decomposition"] = ("%d radial slabs (nd::partition_shape), %s, one process driving the devices%s"
+                                          % (args.gpus, "four-row halo, one exchange per step (the one-launch RK2 step across the cuts)" if out["config"].get("launches_per_step") == 1 else "two-row halo per stage",
+                                             "" if visible >= args.gpus else "; REHEARSAL: %d visible device(s), the slabs share them round-robin (peer copies become device-to-device copies)" % visible))
     out["cpu_baseline"] = None if args.no_cpu_baseline else cloud_cpu_baseline()
     return out
 

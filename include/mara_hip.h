@@ -332,6 +332,20 @@ int  mh_slab_group_download(mh_slab** slabs, int world, double* u_aos_global_hos
 int  mh_slab_group_step(mh_slab** slabs, int world, double dt, int nsteps);
 void mh_slab_destroy(mh_slab* slab);
 int  mh_slab_rows(const mh_slab* slab, int* row0, int* row1);                 /* this rank's rows [row0, row1) */
+/* The decisions of a slab decomposition that touch no device, in ONE place (csrc/slab_plan.hpp) - pure host code, callable without a GPU: the
+ * rows of a rank (nd::partition_shape, src/core_ndarray.hpp:820-836), its neighbours, the ghost rows that travel (2 per stage, or 4 once per
+ * step under the one-launch RK2 step across the cuts), the edge rows stepped first, and the messages of one exchange IN ISSUE ORDER (rows are
+ * local: ghost rows are negative / >= row1 - row0). The native stepper issues exactly these; mara3_amd/slab.py's torch.distributed stepper
+ * (bench.py's fallback, the gloo tests on CPU) reads them here instead of restating them. */
+typedef struct
+{
+    int row0, row1, lo, hi;               /* rows [row0, row1) of the global grid; neighbour ranks, -1 = physical side */
+    int ghost_rows, edge_rows, exchanges_per_step;
+    int nmsg;
+    struct { int send, peer, first_row, rows; } msg[4];
+} mh_slab_plan;
+int  mh_slab_plan_make(int nrows_global, int world, int rank, int periodic, int self_exchange, int rk_order, int fused_cut, mh_slab_plan* plan);
+int  mh_slab_plan_of(const mh_slab* slab, mh_slab_plan* plan);                 /* the plan this slab was created with */
 int  mh_slab_is_planar(const mh_slab* slab);                                  /* 1: its launches skip the third momentum (the descriptors' planar) */
 int  mh_slab_launches_per_step(const mh_slab* slab);                          /* 1: the RK2 step of its rows is ONE fused launch (fuse_stages), else rk_order */
 int  mh_slab_upload(mh_slab* slab, const double* u_aos_slab_host);            /* host AoS [n0][n1][5] of this rank's rows */
@@ -620,6 +634,7 @@ int  mh_binary_tree_owned_blocks(const mh_binary* b, int32_t* ids, int* count);
 
 /* device utilities used by bench / tests without torch */
 int  mh_device_count(void);
+int  mh_device_cu_count(void);         /* compute units of the current HIP device (256 on an MI355X): the launchers size their chunks for whole residency rounds of it */
 int  mh_malloc(void** ptr, size_t bytes);
 int  mh_free(void* ptr);
 int  mh_memcpy_h2d(void* dst, const void* src, size_t bytes);

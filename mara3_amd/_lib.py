@@ -52,6 +52,16 @@ class CloudDesc(C.Structure):
                 ("arith", C.c_int), ("chunk_rows", C.c_int), ("tail_rows", C.c_int), ("tail_chunk_rows", C.c_int), ("fuse_stages", C.c_int), ("planar", C.c_int)]
 
 
+class SlabPlanMsg(C.Structure):
+    _fields_ = [("send", C.c_int), ("peer", C.c_int), ("first_row", C.c_int), ("rows", C.c_int)]
+
+
+class SlabPlan(C.Structure):
+    """mh_slab_plan (include/mara_hip.h): the device-free decisions of a slab decomposition, made in csrc/slab_plan.hpp"""
+    _fields_ = [("row0", C.c_int), ("row1", C.c_int), ("lo", C.c_int), ("hi", C.c_int), ("ghost_rows", C.c_int), ("edge_rows", C.c_int),
+                ("exchanges_per_step", C.c_int), ("nmsg", C.c_int), ("msg", SlabPlanMsg * 4)]
+
+
 class BinaryDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("block_size", C.c_int32), ("domain_radius", C.c_double), ("mach_number", C.c_double),
                 ("alpha", C.c_double), ("nu", C.c_double), ("alpha_cutoff_radius", C.c_double), ("sink_rate", C.c_double),
@@ -140,6 +150,8 @@ SYMBOLS = [
     ("mh_comm_destroy", None, [_vp]),
     ("mh_slab_cloud_create", _i, [C.POINTER(_vp), C.POINTER(CloudDesc), _vp, _vp, _i, _i, _i, _vp, _i]),
     ("mh_slab_launches_per_step", _i, [_vp]),
+    ("mh_slab_plan_make", _i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(SlabPlan)]),
+    ("mh_slab_plan_of", _i, [_vp, C.POINTER(SlabPlan)]),
     ("mh_slab_set_inflow", _i, [_vp, _vp]),
     ("mh_slab_group_set_inflow", _i, [C.POINTER(_vp), _i, _vp]),
     ("mh_slab_group_create", _i, [C.POINTER(_vp), _descp, _i, _i, _i]),
@@ -231,6 +243,7 @@ SYMBOLS = [
     ("mh_binary_disk_totals", _i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     ("mh_binary_diagnostic_fields", _i, [_vp, _vp, _vp, _vp]),
     ("mh_device_count", _i, []),
+    ("mh_device_cu_count", _i, []),
     ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
     ("mh_free", _i, [_vp]),
     ("mh_memcpy_h2d", _i, [_vp, _vp, _sz]),

@@ -1049,6 +1049,7 @@ int mh_block_layout(const int global_n[3], int world, int rank, int blocks_per_a
 
 // ---- device utilities -------------------------------------------------------
 int mh_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+int mh_device_cu_count(void) { return device_cu_count(); }          // compute units of the current device: what the launchers size their chunks for
 int mh_malloc(void** ptr, size_t bytes) { MH_HIP_TRY(hipMalloc(ptr, bytes)); return MH_OK; }
 int mh_free(void* ptr) { MH_HIP_TRY(hipFree(ptr)); return MH_OK; }
 int mh_memcpy_h2d(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return MH_OK; }

@@ -225,6 +225,7 @@ BinaryConsts binary_make_consts(const mh_binary_desc* d, const double bodies[10]
     c.axisym = d->axisymmetric_cs2;
     c.rd = d->domain_radius;
     c.sr2 = d->gst_suppr_radius * d->gst_suppr_radius;
+    binary_set_theta(c, d->plm_theta);
     for (int k = 0; k < 10; ++k) c.body[k] = bodies[k];
     return c;
 }
@@ -297,6 +298,7 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     p.dt = dt;
     p.weight = weight;
     p.c = binary_make_consts(d, bodies);
+    binary_set_theta(p.c, theta);          // the STAGE's theta (safe mode steps with theta = 0, subprog_binary.cpp:285-292)
     const int launch_waves = p.nstrips * p.nchunks;
     const int nwaves = p.wave_base + launch_waves;          // of the whole stage, once its last part is issued
     p.partials = scratch;

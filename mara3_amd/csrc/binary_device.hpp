@@ -36,7 +36,10 @@ struct BinaryConsts
     double rd;                // domain radius (the angular-momentum flux through x, y = +-rd is set to zero, scheme.cpp:208-209)
     double sr2;               // gst_suppr_radius^2: range of the ramp on advance_q's geometrical source term (:421, :440)
     double body[10];          // (mass, x, y, vx, vy) x 2
+    double plm_theta, plm_central;   // theta and 1 / (2 theta) (host division): MH_ARITH_FAST limits the unscaled one-sided differences and scales once
 };
+// theta = 0 (the safe mode's piecewise-constant step): minmod(dl, 0, dr) * 0 - zero slopes without a division by zero
+inline void binary_set_theta(BinaryConsts& c, double theta) { c.plm_theta = theta; c.plm_central = theta > 0.0 ? 0.5 / theta : 0.0; }
 
 
 // ---- arithmetic policies ----------------------------------------------------------------------------------------------
@@ -112,20 +115,26 @@ struct BinStrict
 // the places where a carried value is formed.
 __device__ inline double settled(double x) { asm("" : "+v"(x)); return x; }
 
-struct BinFast
+// DISK (round 5): the sub-program's default disk - two-body sound speed (axisymmetric_cs2 = 0), alpha viscosity (nu = 0) without the tanh cut-off
+// (alpha_cutoff_radius = 0) - with those three run-time-uniform switches pinned at COMPILE time. The generic kernel keeps them as scalar
+// branches inside the row loop: six per cell-row around ~380 instructions of device-libm tanh and the axisymmetric forms that a default run
+// never executes (profiles/r05/binary_instruction_classes.md) - the loop body is then 845 VALU instructions per row where 447 run. Same
+// formulas, same bits (the launcher picks the instantiation from the constants: binary_fast.hip).
+template<bool DISK>
+struct BinFastT
 {
     static constexpr int arith = MH_ARITH_FAST;
     static __device__ inline double carried(double x) { return settled(x); }
-    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2, half_h, inv_h2; };
+    struct Ctx { double inv_mach, inv_mach2, inv_h, inv_2s2, half_h, inv_h2, slope_scale, central; };
     static __device__ inline Ctx make(const BinaryConsts& c)
     {
         const double im = fast::rcp_nr(c.mach), ih = fast::rcp_nr(c.h);
-        return {im, im * im, ih, fast::rcp_nr(2.0 * c.s2), 0.5 * c.h, ih * ih};
+        return {im, im * im, ih, fast::rcp_nr(2.0 * c.s2), 0.5 * c.h, ih * ih, c.plm_theta * ih, c.plm_central};
     }
     static __device__ inline double rsqrt(double x) { return fast::rsqrt_fast(x); }
     static __device__ inline double cs2(const BinaryConsts& c, const Ctx& k, double x, double y)
     {
-        if (c.axisym) return rsqrt(__builtin_fma(x, x, y * y)) * k.inv_mach2;
+        if constexpr (! DISK) { if (c.axisym) return rsqrt(__builtin_fma(x, x, y * y)) * k.inv_mach2; }
         const double d0 = x - c.body[1], d1 = y - c.body[2];
         const double e0 = x - c.body[6], e1 = y - c.body[7];
         const double r1 = rsqrt(__builtin_fma(d0, d0, __builtin_fma(d1, d1, c.rs2)));
@@ -137,11 +146,14 @@ struct BinFast
     static __device__ inline double nu(const BinaryConsts& c, const Ctx& k, double x, double y, double cs2v)
     {
         const double radius = root(__builtin_fma(x, x, y * y));
+        if constexpr (DISK) return 1.0 * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);      // (profile = 1.0: the product keeps its bits)
         const double profile = c.rc_cut > 0.0 ? 0.5 * (1.0 + tanh(3.0 * (radius - c.rc_cut))) : 1.0;
         if (c.nu > 0.0)
             return profile * c.nu;
         return profile * c.alpha * fast::sqrt_fast(cs2v) * (radius * k.inv_mach);      // the same root as hlle's sound speed: formed once
     }
+    // the constants this instantiation is valid for
+    static inline bool serves(const BinaryConsts& c) { return ! DISK || (c.axisym == 0 && !(c.rc_cut > 0.0) && !(c.nu > 0.0)); }
     // iso2d::riemann_hlle physics_iso2d.hpp:488-506 with one sound speed for both sides (the scheme passes cs2 twice, :288)
     template<int AXIS> static __device__ inline State3 hlle(const State3& pl, const State3& pr, double cs2v)
     {
@@ -174,7 +186,14 @@ struct BinFast
     {
         State3 g;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) g[q] = settled(fast::plm_gradient(l[q], m[q], r[q], theta) * k.inv_h);
+        for (int q = 0; q < 3; ++q)
+        {
+            // minmod(theta dl, (dl + dr) / 2, theta dr) / h = (theta / h) minmod(dl, (dl + dr) / (2 theta), dr): the limiter on the unscaled
+            // one-sided differences, one scaling (round 5: 11 instead of 13 instructions per variable and axis)
+            const double dl = m[q] - l[q], dr = r[q] - m[q];
+            g[q] = settled(fast::minmod_between(dl, (dl + dr) * k.central, dr) * k.slope_scale);
+        }
+        (void) theta;
         return g;
     }
     template<bool QFORM> static __device__ inline State3 c2p(const State3& U, double xc, double yc)
@@ -206,6 +225,8 @@ struct BinFast
     static __device__ inline double sink_a2(const BinaryConsts& c, double d0, double d1) { return __builtin_fma(d0, d0, d1 * d1) * fast::rcp_nr(2.0 * c.s2); }
     static __device__ inline void over_area(double (&l)[3], double dA) { const double r = fast::rcp_nr(dA); for (int q = 0; q < 3; ++q) l[q] *= r; }
 };
+using BinFast = BinFastT<false>;
+using BinFastDisk = BinFastT<true>;
 
 // strict helpers used by the small kernels (sink sums, maximum wavespeed)
 __device__ inline double binary_cs2(const BinaryConsts& c, const Recip& rmach, double x, double y)

@@ -470,6 +470,7 @@ hipError_t binary_tree_stage_launch(const mh_binary_desc* d, const TreeGeom& g, 
                                     const TreeRun* part)
 {
     BinaryConsts c = binary_make_consts(d, bodies);
+    binary_set_theta(c, theta);            // the STAGE's theta (safe mode: 0)
     BinaryConsts cn = bodies_next ? binary_make_consts(d, bodies_next) : c;
     const dim3 blk(256);
     const bool fast = d->arith == MH_ARITH_FAST, combine = weight != 1.0, q = d->angmom_form != 0, maxw = bodies_next != nullptr;

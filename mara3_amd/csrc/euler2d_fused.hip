@@ -187,26 +187,32 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     const uint32_t n1u = (uint32_t) n1, colu = (uint32_t) col;
     StatusAcc acc;
 
-    if (role == 0)
+    // ================================================================ FIRST STAGE over rows a0 .. a0 + T - 1 of a strip ==========================
+    // The row loop of euler2d.hip on the step-start field; each row of u1 goes to the hand-off ring instead of memory. Run by the PRODUCER over
+    // rows r0 - 2 .. r1 + 1 with a barrier per row - or (round 5 probe, MH_FUSED_SPLIT_LEAD = 1) over r0 .. r1 + 1, with the CONSUMER forming
+    // the two rows r0 - 2, r0 - 1 itself before it joins the barriers (same functions on the same values: same bits; not taken, see below).
+    // slot0: ring slot of row a0 (rows are numbered from r0 - 2 in both rings); BARRIERS: the producer's form.
+    // step-start rows beyond the field: the periodic image, or (outflow) the edge row - what the stored ghost rows hold, two rows
+    // further out than they reach
+    const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
+    auto row_of = [in, row_stride, n0, bc0_lo, bc0_hi] (int r)
     {
-        // ================================================================ PRODUCER: first stage, rows r0 - 2 .. r1 + 1 ================
-        // step-start rows beyond the field: the periodic image, or (outflow) the edge row - what the stored ghost rows hold, two rows
-        // further out than they reach
-        const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
-        auto row_of = [in, row_stride, n0, bc0_lo, bc0_hi] (int r)
-        {
-            // (the row loop requests rows up to two beyond the last one it uses: EXTERNAL sides stop at the four rows that exist)
-            int m = r;
+        // (the row loop requests rows up to two beyond the last one it uses: EXTERNAL sides stop at the four rows that exist)
+        int m = r;
 #ifdef MH_PROBE_FUSED_NO_EXTERNAL_CLAMP      // the round-3 fault, rebuilt for tests/test_gpu_row_range.py (check builds only: MH_ROW holds the access to the rows that exist)
-            if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? r : 0);
-            else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? r : n0 - 1);
+        if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? r : 0);
+        else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? r : n0 - 1);
 #else
-            if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? max(r, -4) : 0);
-            else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? min(r, n0 + 3) : n0 - 1);
+        if (r < 0)        m = bc0_lo == 1 ? r + n0 : (bc0_lo == 2 ? max(r, -4) : 0);
+        else if (r >= n0) m = bc0_hi == 1 ? r - n0 : (bc0_hi == 2 ? min(r, n0 + 3) : n0 - 1);
 #endif
-            return in + (long) (MH_ROW(m, bc0_lo == 2 ? -4 : -2, bc0_hi == 2 ? n0 + 3 : n0 + 1) + 2) * row_stride;          // (EXTERNAL: rows -4, -3 and n0 + 2, n0 + 3 lie outside the stored ghost rows: the slab stepper allocates them)
-        };
-        // slot of step-start row x: (x - a0) mod USLOTS
+        return in + (long) (MH_ROW(m, bc0_lo == 2 ? -4 : -2, bc0_hi == 2 ? n0 + 3 : n0 + 1) + 2) * row_stride;          // (EXTERNAL: rows -4, -3 and n0 + 2, n0 + 3 lie outside the stored ghost rows: the slab stepper allocates them)
+    };
+    auto first_stage = [&] (const int a0, const int T, const int slot0, const int last_needed, auto barriers) __attribute__((always_inline))
+    {
+        constexpr bool BARRIERS = decltype(barriers)::value;
+        (void) last_needed;                             // (the noclamp probe build does not use it)
+        // slot of step-start row x: (x - (r0 - 2)) mod USLOTS
         auto ring_put = [&] (int slot, const State5& raw)
         {
 #pragma unroll
@@ -220,9 +226,6 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             return Uq;
         };
         const bool real_col = lane >= 2 && lane < FWAVE - 2 && col >= 0 && col < n1;     // a cell of the grid whose first-stage value is valid here
-        const int a0 = r0 - 2;
-        const int last_needed = r1 + 3;                 // first-stage rows r0 - 2 .. r1 + 1 need step-start rows r0 - 4 .. r1 + 3
-        (void) last_needed;                             // (the noclamp probe build does not use it)
         const bool works = ! MH_FUSED_MASK_HALO || (lane >= 2 && lane < FWAVE - 2);
 
         State5 U[3], P[3], G[3], Fx[3], D[3];
@@ -231,12 +234,12 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const State5 Pb = A::c2p(load_row<PLANAR>(row_of(a0 - 1), p.plane_stride, jc8), gl);
             U[0] = load_row<PLANAR>(row_of(a0), p.plane_stride, jc8);
             U[1] = load_row<PLANAR>(row_of(a0 + 1), p.plane_stride, jc8);
-            U[2] = load_row<PLANAR>(row_of(a0 + 2), p.plane_stride, jc8);
+            U[2] = load_row<PLANAR>(row_of(min(a0 + 2, last_needed)), p.plane_stride, jc8);
             P[0] = A::c2p(U[0], gl);
             P[1] = A::c2p(U[1], gl);
-            ring_put(0, U[0]);
-            ring_put(1, U[1]);
-            U[0] = load_row<PLANAR>(row_of(a0 + 3), p.plane_stride, jc8);
+            ring_put(slot0 % USLOTS, U[0]);
+            ring_put((slot0 + 1) % USLOTS, U[1]);
+            U[0] = load_row<PLANAR>(row_of(min(a0 + 3, last_needed)), p.plane_stride, jc8);
             const State5 Dab = A::difference(Pa, Pb), Db0 = A::difference(Pb, P[0]);
             D[0] = A::difference(P[0], P[1]);
             const State5 Gb = A::plm_from_differences(Dab, Db0, lim);
@@ -245,14 +248,14 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         }
         if (__any(!(P[0][4] >= 0.0) || !(P[1][4] >= 0.0)))
         {
-            if (real_col && !(P[0][4] >= 0.0) && a0 >= 0) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) a0 * n1u + colu);
+            if (real_col && !(P[0][4] >= 0.0) && a0 >= 0 && a0 < n0) acc.note_value(P[0][4], MH_STATUS_NEG_PRESSURE, (uint32_t) a0 * n1u + colu);
             if (real_col && !(P[1][4] >= 0.0) && a0 + 1 >= 0 && a0 + 1 < n0) acc.note_value(P[1][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a0 + 1) * n1u + colu);
         }
 
         auto row_step = [&] (int a, int t, auto k0) __attribute__((always_inline))
         {
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
-            // (the look-ahead stops at the last row this chunk uses, r1 + 3: the two rows beyond it would be read for nothing - and, for a slab's
+            // (the look-ahead stops at the last row this run uses: the rows beyond it would be read for nothing - and, for a slab's
             // interior launch next to a cut, while the exchange on the side stream may still be writing them)
 #ifdef MH_PROBE_FUSED_NO_EXTERNAL_CLAMP      // round 3's kernel for tests/test_gpu_row_range.py: look-ahead two rows beyond the last one used, no clamp in row_of
             U[K1] = load_row<PLANAR>(row_of(a + 4), p.plane_stride, jc8);
@@ -260,7 +263,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             U[K1] = load_row<PLANAR>(row_of(min(a + 4, last_needed)), p.plane_stride, jc8);
 #endif
             P[K2] = A::c2p(U[K2], gl);
-            ring_put((t + 2) % USLOTS, U[K2]);
+            if constexpr (BARRIERS) ring_put((slot0 + t + 2) % USLOTS, U[K2]);          // (the consumer's two rows wait in the slots its prologue filled)
             const bool bad_pressure = !(P[K2][4] >= 0.0);
             D[K1] = A::difference(P[K1], P[K2]);
             G[K1] = A::plm_from_differences(D[K0], D[K1], lim);
@@ -272,7 +275,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const State5 Fy_lo = A::template flux<RIEMANN, 1>(SL, A::minus(P[K0], Gy, lim), gl);
             const State5 Fy_hi = lane_from<8, PLANAR>(Fy_lo, al, ar, false);
 
-            const State5 Uc = ring_get(t % USLOTS);
+            const State5 Uc = ring_get((slot0 + t) % USLOTS);
             State5 Un = Uc;
             if (works)
             {
@@ -282,16 +285,15 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
             const bool bad_density = !(Un[0] > 0.0);
             if (__any(bad_pressure || bad_density))
             {
-                if (real_col && bad_pressure && a + 2 >= 0 && a + 2 < n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a + 2) * n1u + colu);
+                if (real_col && bad_pressure && BARRIERS && a + 2 >= 0 && a + 2 < n0) acc.note_value(P[K2][4], MH_STATUS_NEG_PRESSURE, (uint32_t) (a + 2) * n1u + colu);
                 if (real_col && bad_density && a >= 0 && a < n0) acc.note_value(Un[0], MH_STATUS_NEG_DENSITY, (uint32_t) a * n1u + colu);
             }
-            const int slot = t % FSLOTS;
+            const int slot = (slot0 + t) % FSLOTS;
 #pragma unroll
             for (int q = 0; q < 5; ++q) if (live(q)) hand[slot][vi(q)][lane] = Un[q];
-            pair_barrier();                                  // barrier #t: row a is in the ring
+            if constexpr (BARRIERS) pair_barrier();          // barrier #t: row a is in the ring
         };
 
-        const int T = nrows + 4;
         int t = 0;
         for (; t + 3 <= T; t += 3)
         {
@@ -301,6 +303,22 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         }
         if (t < T) row_step(a0 + t, t, std::integral_constant<int, 0>());
         if (t + 1 < T) row_step(a0 + t + 1, t + 1, std::integral_constant<int, 1>());
+    };
+    // MH_FUSED_SPLIT_LEAD = 1: the consumer forms first-stage rows r0 - 2, r0 - 1 itself; 0 (default): the producer forms all of r0 - 2 .. r1 + 1.
+    // Built, bit-identical (tests/test_gpu_fused_rk2.py ran green on it) and NOT taken: 76.6 / 140.1 / 530.8 against 76.4 / 138.9 / 532.5 us per
+    // step at 512 / 1024 / 4096 rows (profiles/r05/ab_split_lead.jsonl). The chunk's fill is WORK, not a wave waiting: the hardware already
+    // places producers and consumers of different workgroups on one SIMD (scripts/probes/wave_placement.hip: every SIMD holds one or two
+    // producers of its three waves), so the lead rows run in the issue slots the waiting consumers leave - splitting them moves nothing.
+#ifndef MH_FUSED_SPLIT_LEAD
+#define MH_FUSED_SPLIT_LEAD 0
+#endif
+    constexpr int LEAD = MH_FUSED_SPLIT_LEAD ? 2 : 4;      // barriers the consumer passes before its prologue = rows the producer forms ahead of it
+
+    if (role == 0)
+    {
+        // ================================================================ PRODUCER: first stage, rows r1 + 2 - (nrows + LEAD) .. r1 + 1 =========
+        // (first-stage rows r0 - 2 .. r1 + 1 need step-start rows r0 - 4 .. r1 + 3)
+        first_stage(r0 - 2 + (4 - LEAD), nrows + LEAD, 4 - LEAD, r1 + 3, std::true_type());
     }
     else
     {
@@ -321,7 +339,6 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         // one LDS read per value either way: the lane's offset into the rings of all pairs, [pair][slot][variable][lane] flattened
         const double* const hand_flat = &hand_all[0][0][0][0];
         const int hand_off = from_other ? other * (FSLOTS * NV * FWAVE) + src_lane_other : pp * (FSLOTS * NV * FWAVE) + src_lane;
-        const int bc0_lo = p.bc0_lo, bc0_hi = p.bc0_hi;
         // first-stage row rr as the producer left it; outflow ghost rows are the edge rows' slots (periodic and EXTERNAL: the producer
         // worked on the wrapped row / on the neighbour's rows)
         auto hand_row = [&] (int rr) -> State5
@@ -335,7 +352,17 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         };
         auto row_off = [row_stride, n0] (int r) { (void) n0; return (long) (MH_ROW(r, -2, n0 + 1) + 2) * row_stride; };
 
-        pair_barrier(); pair_barrier(); pair_barrier(); pair_barrier();          // barriers #0..#3: rows r0 - 2 .. r0 + 1 are in the ring
+        if constexpr (LEAD == 2)
+        {
+            // first-stage rows r0 - 2, r0 - 1 by this wave (slots 0, 1 of both rings; the producer starts at row r0, slot 2), from step-start rows
+            // r0 - 4 .. r0 + 1; then the producer's rows r0, r0 + 1
+            first_stage(r0 - 2, 2, 0, r0 + 1, std::false_type());
+            pair_barrier(); pair_barrier();                                          // barriers #0, #1: rows r0, r0 + 1 are in the ring
+        }
+        else
+        {
+            pair_barrier(); pair_barrier(); pair_barrier(); pair_barrier();          // barriers #0..#3: rows r0 - 2 .. r0 + 1 are in the ring
+        }
 
         State5 P[3], G[3], Fx[3], D[3];
         {
@@ -358,7 +385,7 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
         auto row_step = [&] (int r, auto k0) __attribute__((always_inline))
         {
             constexpr int K0 = decltype(k0)::value, K1 = (K0 + 1) % 3, K2 = (K0 + 2) % 3;
-            pair_barrier();                                  // barrier #(r - r0 + 4): row r + 2 is in the ring
+            pair_barrier();                                  // barrier #(r - r0 + LEAD): row r + 2 is in the ring
             State5 Ubase;                                    // the step-start row, for the average: the producer kept it (slot of row r)
             {
                 const int slot = (r - (r0 - 2)) % USLOTS;

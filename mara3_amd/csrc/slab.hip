@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 #include "launch.hpp"
+#include "slab_plan.hpp"
 #include "rccl_api.hpp"
 
 namespace mh {
@@ -95,6 +96,7 @@ struct mh_slab
     int test_delay = 0;               // MH_SLAB_TEST_DELAY, see slab_test_delay_kernel
     bool event_on_launch = true;      // the stage kernels signal the cross-stream events themselves (hipExtLaunchKernel's stopEvent)
     mh_euler_cart_desc desc, edge_desc;
+    mh_slab_plan plan = {};                      // rows, neighbours, ghost rows and the messages of an exchange in issue order (slab_plan.hpp)
     mh_cloud_desc cloud, cloud_edge;             // SLAB_CLOUD: this rank's rows of the global radial grid
     double* geom = nullptr;                      // SLAB_CLOUD: packed geometry of the GLOBAL grid (mh_cloud_pack_geometry)
     double* inflow = nullptr;                    // SLAB_CLOUD: [5][nq] nozzle primitives (read by the rank that owns row 0)
@@ -167,7 +169,7 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
 }
 static bool launch_carries_events(const mh_slab* s) { return s->kind == SLAB_EULER && s->desc.rank == 2; }
 
-static int ghost_rows(const mh_slab* s) { return s->fused_cut ? 4 : 2; }
+static int ghost_rows(const mh_slab* s) { return s->plan.ghost_rows; }
 static size_t row_doubles(const mh_slab* s) { return (size_t) 5 * s->n1; }
 // row r of a field (r = -2: its first stored ghost row; a fused slab with neighbours also owns rows -4, -3 and n0 + 2, n0 + 3)
 static double* row_ptr(const mh_slab* s, double* f, long r) { return f + (r + 2) * (long) row_doubles(s); }
@@ -177,14 +179,16 @@ static int exchange_rccl(mh_slab* s, double* f, hipStream_t stream)
 {
     RcclApi* a = rccl();
     if (! a || ! s->comm) { set_error("mh_slab: neighbours exist but the RCCL communicator was not connected (mh_slab_connect)"); return MH_E_STATE; }
-    const size_t blk = ghost_block_doubles(s);
-    const int G = ghost_rows(s);
+    // the messages of the plan, in its order (slab_plan.hpp: sends first, receives mirroring the neighbours' send order - matters when lo == hi),
+    // one contiguous block of all variables per neighbour and direction, all in one RCCL group
     MH_RCCL_TRY(a->GroupStart());
-    if (s->lo >= 0) MH_RCCL_TRY(a->Send(row_ptr(s, f, 0), blk, ncclDouble, s->lo, s->comm, stream));                    // rows 0 .. G-1
-    if (s->hi >= 0) MH_RCCL_TRY(a->Send(row_ptr(s, f, s->n0 - G), blk, ncclDouble, s->hi, s->comm, stream));            // rows n0-G .. n0-1
-    // receive order mirrors the neighbours' send order (low rows first): matters when lo == hi
-    if (s->hi >= 0) MH_RCCL_TRY(a->Recv(row_ptr(s, f, s->n0), blk, ncclDouble, s->hi, s->comm, stream));                // ghosts n0 .. n0+G-1
-    if (s->lo >= 0) MH_RCCL_TRY(a->Recv(row_ptr(s, f, -G), blk, ncclDouble, s->lo, s->comm, stream));                   // ghosts -G .. -1
+    for (int k = 0; k < s->plan.nmsg; ++k)
+    {
+        const auto& m = s->plan.msg[k];
+        const size_t count = (size_t) m.rows * row_doubles(s);
+        if (m.send) MH_RCCL_TRY(a->Send(row_ptr(s, f, m.first_row), count, ncclDouble, m.peer, s->comm, stream));
+        else        MH_RCCL_TRY(a->Recv(row_ptr(s, f, m.first_row), count, ncclDouble, m.peer, s->comm, stream));
+    }
     MH_RCCL_TRY(a->GroupEnd());
     return MH_OK;
 }
@@ -441,12 +445,12 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     mh_slab* s = new mh_slab();
     s->kind = kind;
     s->device = device_id; s->rank = rank; s->world = world; s->rk_order = rk_order;
-    size_t a, b;
-    mh_partition_rows((size_t) nrows_global, (size_t) world, (size_t) rank, &a, &b);
-    s->row0 = (int) a; s->row1 = (int) b; s->n0 = s->row1 - s->row0;
-    const bool wrap = periodic && (world > 1 || self_exchange);
-    s->lo = rank > 0 ? rank - 1 : (wrap ? world - 1 : -1);
-    s->hi = rank < world - 1 ? rank + 1 : (wrap ? 0 : -1);
+    // rows, neighbours and message order: slab_plan.hpp decides, for this stepper and for the torch.distributed one alike (ghost rows and
+    // exchanges per step are settled below, once it is known whether the slab takes the one-launch step across its cuts)
+    if (slab_plan_make(nrows_global, world, rank, periodic ? 1 : 0, self_exchange, rk_order, 0, &s->plan) != MH_OK)
+    { delete s; set_error("mh_slab: %d rows cannot be cut into %d slabs", nrows_global, world); return MH_E_INVALID; }
+    s->row0 = s->plan.row0; s->row1 = s->plan.row1; s->n0 = s->row1 - s->row0;
+    s->lo = s->plan.lo; s->hi = s->plan.hi;
     s->backend = has_neighbours(s) ? backend : EXCHANGE_NONE;
     int edge = 2;
     if (kind == SLAB_EULER)
@@ -460,7 +464,8 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
         // launch sits on the stage's critical chain (exchange(k-1) -> edge(k) -> exchange(k)) while it shares the SIMDs with the interior
         // launch, so its latency - rows per wave - is what matters: 8-row strips took 35 us per stage at 512 x 4096 per rank and made the
         // side chain, not the interior, set the step time (rocprofv3 kernel trace, scripts/slab_trace.py); 2-row strips take ~15 us.
-        edge = global->rank == 2 ? 2 : 8;
+        edge = global->rank == 2 ? s->plan.edge_rows : 8;          // (2-D: the plan's two; 3-D: planes are marched in chunks of eight)
+        if (edge < 2) edge = 2;
         s->edge_desc = s->desc;
         s->edge_desc.chunk_rows = edge;
         s->edge_desc.tail_rows = -1;
@@ -499,12 +504,13 @@ static int slab_create_common(mh_slab** out, int kind, const mh_euler_cart_desc*
     }
     s->fused = slab_can_fuse(s);
     s->fused_cut = slab_can_fuse_cut(s, global, cglobal);
+    slab_plan_make(nrows_global, world, rank, periodic ? 1 : 0, self_exchange, rk_order, s->fused_cut ? 1 : 0, &s->plan);      // four ghost rows once per step, or two per stage
     if (s->fused_cut)
     {
         s->fused_desc = s->desc;
         if (kind == SLAB_EULER) s->fused_desc.chunk_rows = global->chunk_rows;
         s->pad_doubles = 2 * row_doubles(s);
-        s->edge_rows = 4;          // the rows a neighbour needs for both of its stages; every step synchronises both chains (no stagger)
+        s->edge_rows = s->plan.edge_rows;          // 4: the rows a neighbour needs for both of its stages; every step synchronises both chains (no stagger)
         s->stagger = 0;
     }
     if (kind == SLAB_CLOUD && cglobal->fuse_stages > 0 && has_neighbours(s) && ! s->fused_cut)
@@ -837,6 +843,15 @@ int mh_slab_group_upload(mh_slab** g, int n, const double* u_aos_global_host)
 }
 
 int mh_slab_is_planar(const mh_slab* s) { return s && s->planar_now ? 1 : 0; }
+
+int mh_slab_plan_make(int nrows_global, int world, int rank, int periodic, int self_exchange, int rk_order, int fused_cut, mh_slab_plan* plan)
+{
+    const int rc = slab_plan_make(nrows_global, world, rank, periodic, self_exchange, rk_order, fused_cut, plan);
+    if (rc != MH_OK) set_error("mh_slab_plan_make: %d rows, rank %d of %d, rk_order %d", nrows_global, rank, world, rk_order);
+    return rc;
+}
+// the plan a slab was created with (its ghost rows and exchanges per step say whether it takes the one-launch step across its cuts)
+int mh_slab_plan_of(const mh_slab* s, mh_slab_plan* plan) { if (! s || ! plan) return MH_E_INVALID; *plan = s->plan; return MH_OK; }
 
 // bulk launches per time step: 1 where the RK2 step is one fused launch (lone slabs and, from 384 rows per slab on, slabs across their cuts)
 int mh_slab_launches_per_step(const mh_slab* s) { return ! s ? 0 : ((s->fused || s->fused_cut) ? 1 : s->rk_order); }

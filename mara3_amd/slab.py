@@ -57,30 +57,44 @@ class HipStage:
                                                       C.c_void_p(self.status.data_ptr()), stream))
 
 
+def slab_plan(nrows_global, world, rank, periodic, self_exchange=False, rk_order=2, fused_cut=False):
+    """mh_slab_plan_make (csrc/slab_plan.hpp, host code - callable without a GPU): the ONE place that decides a rank's rows, its neighbours,
+    the ghost rows that travel and the messages of an exchange in issue order - for the native stepper and for this module alike."""
+    p = L.SlabPlan()
+    L.check(L.load_library().mh_slab_plan_make(int(nrows_global), int(world), int(rank), 1 if periodic else 0, 1 if self_exchange else 0,
+                                              int(rk_order), 1 if fused_cut else 0, C.byref(p)))
+    return p
+
+
 class TorchDistExchange:
-    """Ghost-row exchange with the axis-0 neighbours over torch.distributed (nccl = RCCL on GPUs, gloo on CPU)."""
+    """Ghost-row exchange with the axis-0 neighbours over torch.distributed (nccl = RCCL on GPUs, gloo on CPU): the messages of the native
+    plan, in its order - the same pairing the library's exchange_rccl issues (csrc/slab.hip)."""
 
     def __init__(self, rank, world, periodic, group=None, self_exchange=False):
         """self_exchange: with a periodic domain on ONE rank, wrap around by sending to oneself instead of letting the
         kernel copy the rows locally - exercises the whole send/recv + overlap machinery on a single GPU."""
         self.rank, self.world, self.group = rank, world, group
-        wrap = periodic and (world > 1 or self_exchange)
-        self.lo = rank - 1 if rank > 0 else (world - 1 if wrap else None)
-        self.hi = rank + 1 if rank < world - 1 else (0 if wrap else None)
+        self.periodic, self.self_exchange = bool(periodic), bool(self_exchange)
+        self.bind(4 * world, 2)          # neighbours are known at once; the rows of the messages once the stepper has bound the grid
+
+    def bind(self, nrows_global, rk_order):
+        """the plan of THIS grid: rows, neighbours and the messages of an exchange in issue order, as csrc/slab_plan.hpp decides them"""
+        self.plan = slab_plan(nrows_global, self.world, self.rank, self.periodic, self.self_exchange, rk_order, False)
+        self.lo = self.plan.lo if self.plan.lo >= 0 else None
+        self.hi = self.plan.hi if self.plan.hi >= 0 else None
+        return self.plan
 
     def start(self, field, n0):
-        """Post the sends of the two edge row-blocks and the receives into the two ghost row-blocks."""
+        """Post the plan's sends of the edge row-blocks and receives into the ghost row-blocks (rows of the plan are local: row r of the slab is
+        field[r + HALO]; ghost rows are negative / >= n0)."""
         ops = []
-        # field: [n0 + 4, NQ, pitch]; row-blocks are contiguous: one message per neighbour
-        if self.lo is not None:
-            ops.append(dist.P2POp(dist.isend, field[HALO:2 * HALO], self.lo, self.group, tag=1))
-        if self.hi is not None:
-            ops.append(dist.P2POp(dist.isend, field[n0:n0 + HALO], self.hi, self.group, tag=2))
-        # receive order mirrors the neighbours' send order (low rows first), which matters when lo == hi
-        if self.hi is not None:
-            ops.append(dist.P2POp(dist.irecv, field[n0 + HALO:n0 + 2 * HALO], self.hi, self.group, tag=1))
-        if self.lo is not None:
-            ops.append(dist.P2POp(dist.irecv, field[0:HALO], self.lo, self.group, tag=2))
+        # field: [n0 + 4, NQ, pitch]; row-blocks are contiguous: one message per neighbour and direction. Tags pair the two messages that
+        # one pair of ranks may exchange in a step (lo == hi on a periodic axis of two ranks): a block of LOW rows always lands in HIGH ghosts.
+        for k in range(self.plan.nmsg):
+            m = self.plan.msg[k]
+            block = field[m.first_row + HALO:m.first_row + HALO + m.rows]
+            low = m.first_row == 0 if m.send else m.first_row >= n0
+            ops.append(dist.P2POp(dist.isend if m.send else dist.irecv, block, m.peer, self.group, tag=1 if low else 2))
         return dist.batch_isend_irecv(ops) if ops else []
 
     @staticmethod
@@ -101,14 +115,19 @@ class SlabEulerStepper:
                  edge_chunk_rows=8, arith="strict"):
         self.global_shape = tuple(global_shape)
         self.rank, self.world = rank, world
-        self.row0, self.row1 = partition_rows(global_shape[0], world, rank)
+        periodic = bc == "periodic"
+        # rows, neighbours, message order: the native plan (two launches per stage here: two ghost rows after every stage)
+        if exchange is None:
+            exchange = TorchDistExchange(rank, world, periodic)
+        self.plan = exchange.bind(global_shape[0], rk_order) if hasattr(exchange, "bind") else slab_plan(global_shape[0], world, rank, periodic, False, rk_order, False)
+        assert self.plan.ghost_rows == HALO
+        self.row0, self.row1 = self.plan.row0, self.plan.row1
         self.n0, self.n1 = self.row1 - self.row0, global_shape[1]
         if self.n0 < 2 * HALO and world > 1:
             raise ValueError("slab of %d rows is thinner than two ghost layers" % self.n0)
         self.rk_order = rk_order
         self.device = torch.device(device)
-        periodic = bc == "periodic"
-        self.exchange = exchange if exchange is not None else TorchDistExchange(rank, world, periodic)
+        self.exchange = exchange
         has_lo = getattr(self.exchange, "lo", None) is not None
         has_hi = getattr(self.exchange, "hi", None) is not None
 
@@ -304,13 +323,16 @@ class SlabCloudStepper(SlabEulerStepper):
         nr, nq = len(rv) - 1, len(qv) - 1
         self.global_shape = (nr, nq)
         self.rank, self.world = rank, world
-        self.row0, self.row1 = partition_rows(nr, world, rank)
+        if exchange is None:
+            exchange = TorchDistExchange(rank, world, False)
+        self.plan = exchange.bind(nr, rk_order) if hasattr(exchange, "bind") else slab_plan(nr, world, rank, False, False, rk_order, False)
+        self.row0, self.row1 = self.plan.row0, self.plan.row1
         self.n0, self.n1 = self.row1 - self.row0, nq
         if self.n0 < 2 * HALO and world > 1:
             raise ValueError("slab of %d rows is thinner than two ghost layers" % self.n0)
         self.rk_order = rk_order
         self.device = torch.device(device)
-        self.exchange = exchange if exchange is not None else TorchDistExchange(rank, world, False)
+        self.exchange = exchange
         has_lo = getattr(self.exchange, "lo", None) is not None
         has_hi = getattr(self.exchange, "hi", None) is not None
         d = L.CloudDesc(nr=self.n0, nq=nq, nr_global=nr, row_offset=self.row0, gamma=gamma, plm_theta=plm_theta,

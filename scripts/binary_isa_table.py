@@ -106,34 +106,39 @@ for combine in (False, True):
         ("face: nu at position, given cs2 (2 faces)", (net("piece_cs2_nu", minus=("piece_cs2",)), 2)),
         ("face: HLLE, given cs2 (axis 0)", (net("piece_hlle0"), 1)),
         ("face: HLLE (axis 1)", (net("piece_hlle1"), 1)),
-        ("face: states + viscous stress (axis 0)", (net("piece_face0", minus=("piece_cs2_nu", "piece_hlle0")), 1)),
+        ("face: states + viscous stress, and what nu and HLLE share (axis 0)", (net("piece_face0", minus=("piece_cs2_nu", "piece_hlle0")), 1)),
         ("face: states + viscous stress (axis 1)", (net("piece_face1", minus=("piece_cs2_nu", "piece_hlle1")), 1)),
         ("gravity of both bodies (1)", (net("piece_gravity2"), 1)),
-        ("sink rates of both bodies (1; `exp` skipped by a wave out of range)", (net("piece_sink2"), 1)),
-        ("buffer, floor, totals, update%s (1)" % (" + RK average" if combine else ""), (net(su, minus=("piece_gravity2", "piece_sink2")), 1))])
+        ("sink ranges of both bodies, wave out of range (1)", (net("piece_sink2_far"), 1)),
+        ("buffer, floor, totals, update%s (1)" % (" + RK average" if combine else ""), (net(su, minus=("piece_gravity2", "piece_sink2_far")), 1))])
     print("### %s RK2 stage (`COMBINE = %s`)\n" % ("second" if combine else "first", "true" if combine else "false"))
     tot = print_table(per_row, "")
     flops = 2 * tot["fp64 fma"] + tot["fp64 mul"] + tot["fp64 add / sub"] + tot["v_rcp_f64 (quarter rate)"] + tot["v_rsq_f64 (quarter rate)"]
     s = sum(tot.values())
-    print("**%d VALU instructions per cell-row = %d fma + %d mul + %d add + %d rcp + %d rsq + %d min / max + %d DPP + %d other; %d flop, %.2f flop per issue slot.** "
-          "Quarter-rate instructions: %d (%d issue cycles of a full-rate instruction each).\n"
+    print("**%d VALU instructions per cell-row = %d fma + %d mul + %d add + %d rcp + %d rsq + %d min / max + %d DPP + %d other; %d flop, %.2f flop per issue slot.**\n"
           % (s, tot["fp64 fma"], tot["fp64 mul"], tot["fp64 add / sub"], tot["v_rcp_f64 (quarter rate)"], tot["v_rsq_f64 (quarter rate)"], tot["v_min / v_max f64"], tot["DPP moves (v_mov_b32_dpp)"],
              s - tot["fp64 fma"] - tot["fp64 mul"] - tot["fp64 add / sub"] - tot["v_rcp_f64 (quarter rate)"] - tot["v_rsq_f64 (quarter rate)"] - tot["v_min / v_max f64"] - tot["DPP moves (v_mov_b32_dpp)"],
-             flops, flops / s, tot["v_rcp_f64 (quarter rate)"] + tot["v_rsq_f64 (quarter rate)"], 4))
+             flops, flops / s))
+near = sum(net("piece_sink2_near").values()) - sum(net("piece_sink2_far").values())
+print("A wave with a lane within 38 sink radii of a body also evaluates `exp` (device libm): **+%d** VALU instructions per body and cell-row (counted statically: both bodies %d).\n"
+      % (near // 2, near))
 
 # ---- (2) the kernel's own loop
 print("## 2. The kernel's own row loop (`binary_fast.hip` compiled to assembly: the loop of three row steps, per row)\n")
 ktxt = asm(os.path.join(ROOT, "mara3_amd", "csrc", "binary_fast.hip"))
-print("| kernel | VGPRs | SGPRs | spilled SGPRs / VGPRs | scratch bytes | loop: VALU per row | of them fma / mul / add | rcp + rsq | min / max | DPP | v_readlane + v_writelane | moves | integer | other VALU | SALU per row | s_load per row | vector loads / stores per row | s_waitcnt per row |")
-print("|---|---:|---:|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---|---:|")
-for m in re.finditer(r"\n(_ZN2mh19binary_stage_kernelINS_7BinFastELb([01])ELb0EEEvNS_17BinaryStageParamsE):[^\n]*\n(.*?)\.Lfunc_end", ktxt, flags=re.S):
-    body = m.group(3)
+print("| kernel | VGPRs | SGPRs | spilled SGPRs / VGPRs | scratch bytes | loop, hot path: VALU per row | cold blocks per row (tanh, exp, status) | of them fma / mul / add | rcp + rsq | min / max | DPP | v_readlane + v_writelane | moves | integer | other VALU | SALU per row | s_load per row | vector loads / stores per row | s_waitcnt per row |")
+print("|---|---:|---:|---|---:|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---|---:|")
+for m in re.finditer(r"\n(_ZN2mh19binary_stage_kernelINS_8BinFastTILb([01])EEELb([01])ELb0EEEvNS_17BinaryStageParamsE):[^\n]*\n(.*?)\.Lfunc_end", ktxt, flags=re.S):
+    body = m.group(4)
+    disk, comb = m.group(2) == "1", m.group(3) == "1"
     meta = ktxt[m.end():m.end() + 6000]
     g = lambda pat: (re.search(pat, meta) or [None, "?"])[1]
     vg, sg = g(r"; NumVgprs: (\d+)"), g(r"; NumSgprs: (\d+)")
-    ss, vs = g(r"; SGPRSpillCount: (\d+)|sgpr_spill_count: (\d+)"), g(r"; VGPRSpillCount: (\d+)|vgpr_spill_count: (\d+)")
+    amd = re.search(r"\.name:\s+%s\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)" % re.escape(m.group(1)), ktxt)
+    ss, vs = (amd.group(1), amd.group(2)) if amd else ("?", "?")
     scratch = g(r"; ScratchSize: (\d+)")
-    # basic blocks; the row loop is the block (or run of blocks) closed by a backward branch with the most VALU instructions
+    # the row loop: from the header of the innermost loop with the most VALU instructions to its back edge; inside it, basic blocks that hold device
+    # libm code (exp of a sink in range, tanh of the viscosity cut-off: v_rndne_f64) or a status report (atomics) are COLD in C3 and counted apart
     lines = body.split("\n")
     labels = {}
     for i, l in enumerate(lines):
@@ -142,17 +147,27 @@ for m in re.finditer(r"\n(_ZN2mh19binary_stage_kernelINS_7BinFastELb([01])ELb0EE
             labels[mm.group(1)] = i
     best = None
     for i, l in enumerate(lines):
-        mm = re.match(r"\s+s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        mm = re.match(r"\s+s_c?branch\w* (\.LBB\d+_\d+)", l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
             seg = lines[labels[mm.group(1)]:i + 1]
             n = sum(classify(seg).values())
             if best is None or n > best[0]:
                 best = (n, seg)
-    n, seg = best
+    blocks = [[]]
+    for l in best[1]:
+        if re.match(r"\.LBB\d+_\d+:", l):
+            blocks.append([])
+        blocks[-1].append(l)
+        if re.match(r"\s+s_c?branch", l):
+            blocks.append([])
+    seg, cold = [], []
+    for b in blocks:
+        (cold if re.search(r"v_rndne_f64|atomic", "\n".join(b)) else seg).extend(b)
+    n, ncold = sum(classify(seg).values()), sum(classify(cold).values())
     c, o = classify(seg), other(seg)
     per = lambda x: "%.1f" % (x / 3.0)
-    print("| `<BinFast, %s, false>` | %s | %s | %s / %s | %s | **%s** | %s / %s / %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s / %s | %s |"
-          % ("true" if m.group(2) == "1" else "false", vg, sg, ss, vs, scratch, per(n), per(c["fp64 fma"]), per(c["fp64 mul"]), per(c["fp64 add / sub"]),
+    print("| `<%s, %s, false>` | %s | %s | %s / %s | %s | **%s** | %s | %s / %s / %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s / %s | %s |"
+          % ("BinFastT<DISK = true>" if disk else "BinFastT<false> (generic)", "true" if comb else "false", vg, sg, ss, vs, scratch, per(n), per(ncold), per(c["fp64 fma"]), per(c["fp64 mul"]), per(c["fp64 add / sub"]),
              per(c["v_rcp_f64 (quarter rate)"] + c["v_rsq_f64 (quarter rate)"]), per(c["v_min / v_max f64"]), per(c["DPP moves (v_mov_b32_dpp)"]),
              per(c["lane reads / writes (v_readlane, v_writelane, v_readfirstlane)"]), per(c["plain moves"]), per(c["integer / address"]),
              per(c["other VALU"] + c["compares"] + c["selects (v_cndmask_b32)"] + c["sign / bit logic (v_bfi, v_and, v_or, v_xor)"] + c["other transcendental / exp pieces (v_exp, v_ldexp, v_frexp, v_rndne, v_cvt)"]),

@@ -7,33 +7,42 @@ using namespace mh;
 using A = BinFast;
 #define LOAD(i) State3 s##i; for (int q = 0; q < 3; ++q) s##i[q] = in[(i * 3 + q) * n + t];
 #define STORE(x) for (int q = 0; q < 3; ++q) out[q * n + t] = x[q];
-#define HEAD int t = threadIdx.x; LOAD(0) LOAD(1) LOAD(2) LOAD(3) LOAD(4) LOAD(5) const A::Ctx k = A::make(c); const double xf = in[18 * n + t], yf = in[19 * n + t];
+// C3's run-time-uniform switches are pinned at compile time (alpha viscosity without tanh cut-off, two-body sound speed), so that the static count
+// of a piece is what a wave executes; the per-launch constants A::Ctx arrive as an argument, as the kernel forms them once per wave, not per row
+#define HEAD int t = threadIdx.x; LOAD(0) LOAD(1) LOAD(2) LOAD(3) LOAD(4) LOAD(5) BinaryConsts c = c_in; c.axisym = 0; c.rc_cut = 0.0; c.nu = 0.0; \
+             const double xf = in[18 * n + t], yf = in[19 * n + t];
 #define TAIL(r) STORE(r) out[3 * n + t] = s0[0] + s1[0] + s2[0] + s3[0] + s4[0] + s5[0] + xf + yf;
 // every probe loads six states and two positions and adds them up at the end (so that no load is dropped): the baseline is that alone
-extern "C" __global__ void piece_baseline(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = s0; TAIL(r) }
-extern "C" __global__ void piece_c2p(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = A::c2p<false>(s0, xf, yf); TAIL(r) }
-extern "C" __global__ void piece_plm(const double* in, double* out, int n, BinaryConsts c, double theta) { HEAD State3 r = A::plm_per_length(s0, s1, s2, theta, k); TAIL(r) }
-extern "C" __global__ void piece_dpp3(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = bdpp_left(s0); TAIL(r) }
-extern "C" __global__ void piece_cs2(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = s0; r[0] = A::cs2(c, k, xf, yf); TAIL(r) }
-extern "C" __global__ void piece_cs2_nu(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = s0; const double cs2 = A::cs2(c, k, xf, yf); r[0] = cs2; r[1] = A::nu(c, k, xf, yf, cs2); TAIL(r) }
-extern "C" __global__ void piece_hlle0(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = A::hlle<0>(s0, s1, xf); TAIL(r) }
-extern "C" __global__ void piece_hlle1(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = A::hlle<1>(s0, s1, xf); TAIL(r) }
-extern "C" __global__ void piece_face0(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = binary_face_flux<A, 0, false>(c, k, xf, yf, s0, s1, s2, s3, s4, s5); TAIL(r) }
-extern "C" __global__ void piece_face1(const double* in, double* out, int n, BinaryConsts c) { HEAD State3 r = binary_face_flux<A, 1, false>(c, k, xf, yf, s0, s1, s2, s3, s4, s5); TAIL(r) }
-extern "C" __global__ void piece_gravity2(const double* in, double* out, int n, BinaryConsts c)
+extern "C" __global__ void piece_baseline(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = s0; TAIL(r) }
+extern "C" __global__ void piece_c2p(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = A::c2p<false>(s0, xf, yf); TAIL(r) }
+extern "C" __global__ void piece_plm(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k, double theta) { HEAD State3 r = A::plm_per_length(s0, s1, s2, theta, k); TAIL(r) }
+extern "C" __global__ void piece_dpp3(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = bdpp_left(s0); TAIL(r) }
+extern "C" __global__ void piece_cs2(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = s0; r[0] = A::cs2(c, k, xf, yf); TAIL(r) }
+extern "C" __global__ void piece_cs2_nu(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = s0; const double cs2 = A::cs2(c, k, xf, yf); r[0] = cs2; r[1] = A::nu(c, k, xf, yf, cs2); TAIL(r) }
+extern "C" __global__ void piece_hlle0(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = A::hlle<0>(s0, s1, xf); TAIL(r) }
+extern "C" __global__ void piece_hlle1(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = A::hlle<1>(s0, s1, xf); TAIL(r) }
+extern "C" __global__ void piece_face0(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = binary_face_flux<A, 0, false>(c, k, xf, yf, s0, s1, s2, s3, s4, s5); TAIL(r) }
+extern "C" __global__ void piece_face1(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k) { HEAD State3 r = binary_face_flux<A, 1, false>(c, k, xf, yf, s0, s1, s2, s3, s4, s5); TAIL(r) }
+extern "C" __global__ void piece_gravity2(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k)
 {
     HEAD State3 r = s0; double fg[2][2];
     for (int b = 0; b < 2; ++b) A::gravity(c, b, xf - c.body[5 * b + 1], yf - c.body[5 * b + 2], s0[0], fg[b]);
     r[1] = fg[0][0] + fg[1][0]; r[2] = fg[0][1] + fg[1][1]; TAIL(r)
 }
-extern "C" __global__ void piece_sink2(const double* in, double* out, int n, BinaryConsts c)
+extern "C" __global__ void piece_sink2_near(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k)
 {
     HEAD State3 r = s0; double rate = 0.0;
     for (int b = 0; b < 2; ++b) rate += binary_sink_rate<A>(c, xf - c.body[5 * b + 1], yf - c.body[5 * b + 2]);
     r[0] = rate; TAIL(r)
 }
+extern "C" __global__ void piece_sink2_far(const double* in, double* out, int n, BinaryConsts c_in, A::Ctx k)
+{
+    HEAD State3 r = s0; double rate = 0.0;
+    for (int b = 0; b < 2; ++b) rate += __any(A::sink_a2(c, xf - c.body[5 * b + 1], yf - c.body[5 * b + 2]) < 750.0) ? 1.0 : 0.0;
+    r[0] = rate; TAIL(r)
+}
 // the FAST source terms and update of the kernel as they stand there (gravity, sinks, buffer, floor, totals, update; COMBINE): fluxes are s1 .. s4
-template<bool COMBINE> __device__ inline void sources_update(const double* in, double* out, int n, const BinaryConsts& c, double dt, double weight, double brate, bool writes)
+template<bool COMBINE, bool NEAR> __device__ inline void sources_update(const double* in, double* out, int n, const BinaryConsts& c_in, const A::Ctx& k, double dt, double weight, double brate, bool writes)
 {
     HEAD
     const State3 u0 = s0, Uinit = s5;
@@ -46,7 +55,8 @@ template<bool COMBINE> __device__ inline void sources_update(const double* in, d
     {
         const double d0 = xc - c.body[5 * bdy + 1], d1 = yc - c.body[5 * bdy + 2];
         A::gravity(c, bdy, d0, d1, u0[0], fg[bdy]);
-        rate += binary_sink_rate<A>(c, d0, d1);
+        if constexpr (NEAR) rate += binary_sink_rate<A>(c, d0, d1);
+        else                rate += __any(A::sink_a2(c, d0, d1) < 750.0) ? 1.0 : 0.0;          // a wave out of range of the sink: the test alone
     }
     const double w0 = __builtin_fma(-rate, dt, u0[0] < c.floor_sigma ? 1e-2 : 0.0);
     const double bw = brate * dt;
@@ -78,5 +88,6 @@ template<bool COMBINE> __device__ inline void sources_update(const double* in, d
     for (int i = 0; i < NPART; ++i) out[(4 + i) * n + t] = part[i];
     TAIL(Un)
 }
-extern "C" __global__ void piece_sources_update(const double* in, double* out, int n, BinaryConsts c, double dt, double w, double brate, int writes) { sources_update<false>(in, out, n, c, dt, w, brate, writes != 0); }
-extern "C" __global__ void piece_sources_update_combine(const double* in, double* out, int n, BinaryConsts c, double dt, double w, double brate, int writes) { sources_update<true>(in, out, n, c, dt, w, brate, writes != 0); }
+extern "C" __global__ void piece_sources_update(const double* in, double* out, int n, BinaryConsts c, A::Ctx k, double dt, double w, double brate, int writes) { sources_update<false, false>(in, out, n, c, k, dt, w, brate, writes != 0); }
+extern "C" __global__ void piece_sources_update_combine(const double* in, double* out, int n, BinaryConsts c, A::Ctx k, double dt, double w, double brate, int writes) { sources_update<true, false>(in, out, n, c, k, dt, w, brate, writes != 0); }
+extern "C" __global__ void piece_sources_update_near(const double* in, double* out, int n, BinaryConsts c, A::Ctx k, double dt, double w, double brate, int writes) { sources_update<false, true>(in, out, n, c, k, dt, w, brate, writes != 0); }

@@ -23,7 +23,7 @@ code = ("import sys, time, json; sys.path.insert(0, %r)\n"
         "        st = NativeSlabStepper((rows, n), (1.0 / n, 1.0 / n), gamma, 1.5, 'hllc', 2, 'periodic', rank=0, world=1, comm_id=native_comm_id(0, 1, device='cuda'), self_exchange=True, **kw)\n"
         "    else:\n"
         "        st = NativeSlabStepper((rows, n), (1.0 / n, 1.0 / n), gamma, 1.5, 'hllc', 2, 'periodic', **kw)\n"
-        "    st.load_slab(np.ascontiguousarray(full[:rows])); st.step(setups.baseline_dt(n), 80); st.synchronize()\n"
+        "    st.load_slab(np.ascontiguousarray(full[:rows])); st.step(setups.baseline_dt(n), max(80, int(3e5 / rows))); st.synchronize()          # (>= ~0.1 s: the first configuration of a process ran during the clock ramp after RCCL's start-up)\n"
         "    best = 1e9\n"
         "    for rep in range(3):\n"
         "        t0 = time.perf_counter(); st.step(setups.baseline_dt(n), 200); st.synchronize(); best = min(best, (time.perf_counter() - t0) / 200 * 1e6)\n"

@@ -2,7 +2,7 @@
 one kernel family over a list of configurations and prints one JSON line per configuration:
     {"family": ..., "config": ..., "n0": rows of the field (the largest member's for slabs / blocks), "cut": the sides are cuts of the fused 2-D step,
      "lo": smallest row index requested, "hi": largest, "status": status word}
-usage: python tests/row_range_child.py <family>      family = euler2d | euler2d_fused | euler2d_fused_cuts | cloud | cloud_fused | euler3d | binary"""
+usage: python tests/row_range_child.py <family>      family = euler2d | euler2d_fused | euler2d_fused_cuts | cloud | cloud_fused | cloud_fused_cuts | euler3d | binary"""
 import ctypes as C
 import json
 import os
@@ -130,6 +130,28 @@ def cloud(fused):
             report(fam, "70x90 in %d radial slabs" % world, rows, st)
 
 
+def cloud_fused_cuts():
+    """round 5: the one-launch `cloud` step across radial cuts - MH_BC_EXTERNAL radial sides with FOUR stored rows of the neighbour, two row
+    segments per edge launch, the nozzle rows on the slab that owns row 0 only (cloud_fused.hip, slab.hip)"""
+    from mara3_amd.slab import NativeSlabGroup
+    os.environ["MH_SLAB_FUSED_CUTS"] = "1"
+    for nr, nq, world, chunk in ((70, 90, 2, 0), (97, 250, 3, 0), (61, 64, 4, 5), (50, 300, 3, 2), (48, 40, 4, 0)):
+        take("cloud_fused")
+        take("cloud")
+        rv, qv, u0, inflow, dt = cloud_state(nr, nq)
+        g = NativeSlabGroup(r_vertices=rv, q_vertices=qv, rk_order=2, plm_theta=1.2, world=world, arith="fast", temperature_floor=0.0, chunk_rows=chunk)
+        assert g.launches_per_step() == [1] * world
+        g.upload(u0)
+        for n in range(3):
+            g.set_inflow(inflow[n])
+            g.step(dt, 1)
+        g.synchronize()
+        st = g.status()[0]
+        rows = max(b - a for a, b in g.rows)
+        g.close()
+        report("cloud_fused_cuts", "%dx%d in %d radial slabs chunk %d" % (nr, nq, world, chunk), rows, st, cut=True, read="cloud_fused")
+
+
 def euler3d():
     from mara3_amd.block import NativeBlockGroup
     for arith in ("strict", "fast"):
@@ -183,4 +205,4 @@ def binary():
 
 if __name__ == "__main__":
     {"binary": binary, "euler2d": lambda: euler2d(False), "euler2d_fused": lambda: euler2d(True), "euler2d_fused_cuts": euler2d_fused_cuts,
-     "cloud": lambda: cloud(False), "cloud_fused": lambda: cloud(True), "euler3d": euler3d}[sys.argv[1]]()
+     "cloud": lambda: cloud(False), "cloud_fused": lambda: cloud(True), "cloud_fused_cuts": cloud_fused_cuts, "euler3d": euler3d}[sys.argv[1]]()

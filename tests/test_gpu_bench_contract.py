@@ -84,8 +84,9 @@ def test_bench_loopback_rehearsal_of_the_multi_gpu_path(cuts):
     assert ("one exchange per step" in d["config"]["timed_region"]) == (cuts is None)
 
 
-def run_configs(extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py")] + extra, cwd=ROOT, capture_output=True, text=True, timeout=280)
+def run_configs(extra, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py")] + extra, cwd=ROOT, capture_output=True, text=True, timeout=280,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -98,7 +99,12 @@ def test_config4_rehearsal_of_the_four_slab_run_checks_itself():
     the line says whether their union equals the one-device run (whose FAST step is the ONE-launch kernel) bit for bit"""
     d = run_configs(["--config", "c4", "--gpus", "4", "--grid", "256", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
     assert d["slabs_bit_identical_to_one_gpu_run"] is True and d["n_gpus"] == 4 and d["value"] > 0
-    assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["launches_per_step"] == 2
+    assert "REHEARSAL" in d["config"]["decomposition"] and d["config"]["launches_per_step"] == 2          # 64 rows per slab: the two launches
+    # round 5: from 384 rows per slab on (the 4096-row config: 1024) - here on request - every slab takes the ONE-launch step across its cuts
+    d = run_configs(["--config", "c4", "--gpus", "4", "--grid", "256", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], env={"MH_SLAB_FUSED_CUTS": "1"})
+    assert d["slabs_bit_identical_to_one_gpu_run"] is True and d["config"]["launches_per_step"] == 1 and "one exchange per step" in d["config"]["decomposition"]
+    d = run_configs(["--config", "c4", "--gpus", "2", "--grid", "800", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["slabs_bit_identical_to_one_gpu_run"] is True and d["config"]["launches_per_step"] == 1          # 400 rows per slab: by default
 
 
 def test_config5_rehearsal_of_the_eight_block_run_checks_itself():

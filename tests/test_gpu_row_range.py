@@ -30,7 +30,7 @@ def run_child(family, library):
     return rows
 
 
-@pytest.mark.parametrize("family", ["euler2d", "euler2d_fused", "euler2d_fused_cuts", "cloud", "cloud_fused", "euler3d", "binary"])
+@pytest.mark.parametrize("family", ["euler2d", "euler2d_fused", "euler2d_fused_cuts", "cloud", "cloud_fused", "cloud_fused_cuts", "euler3d", "binary"])
 def test_no_row_request_leaves_the_stored_rows(family):
     for r in run_child(family, CHECK):
         ghost = 4 if r["cut"] else 2

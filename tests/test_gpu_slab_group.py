@@ -406,3 +406,27 @@ def eng_slab_group(shape, world):
     g.synchronize()
     assert g.status()[0] == 0
     return g
+
+
+@pytest.mark.parametrize("cuts", ["1", "0"])
+def test_native_slabs_carry_the_plan_the_torch_stepper_reads(eng, cuts, monkeypatch):
+    """round 5: ONE place decides rows, neighbours, ghost rows and message order (csrc/slab_plan.hpp). Every member of a native group holds
+    exactly mh_slab_plan_make's plan - four ghost rows once per step where it takes the one-launch step across its cuts, two per stage otherwise -
+    and mara3_amd.slab's torch.distributed stepper (the gloo tests, bench.py's fallback) binds the same function."""
+    import ctypes as C
+    from mara3_amd import _lib as L
+    from mara3_amd.slab import NativeSlabGroup, slab_plan
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", cuts)
+    shape, world = (97, 61), 4
+    for bc in ("outflow", "periodic"):
+        g = NativeSlabGroup(shape, (1.0 / shape[0], 1.0 / shape[1]), 1.4, 1.5, "hllc", 2, bc, world=world, arith="fast")
+        fused = g.launches_per_step() == [1] * world
+        assert fused == (cuts == "1")
+        for r in range(world):
+            have = L.SlabPlan()
+            L.check(g.lib.mh_slab_plan_of(C.c_void_p(g.handles[r]), C.byref(have)))
+            want = slab_plan(shape[0], world, r, bc == "periodic", False, 2, fused)
+            assert bytes(have) == bytes(want), (bc, r)
+            assert have.ghost_rows == (4 if fused else 2) and have.exchanges_per_step == (1 if fused else 2)
+            assert (have.row0, have.row1) == g.rows[r]
+        g.close()
