@@ -493,14 +493,14 @@ def attach_traffic(out, config):
         from bench import csrc_fingerprint
         counters = bench_report.Counters(csrc_fingerprint())
         t = counters.table
-        names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),
+        names = {"c3": ("c3", "binary_stage_kernel<Bin%s, false, false>", "binary_stage_kernel<Bin%s, true, false>"),          # (Fast: BinFastT<true>, the default disk's instantiation)
                  "c4": ("c4", "cloud_stage_kernel<Srhd%sT<@>, true, false>", "cloud_stage_kernel<Srhd%sT<@>, true, true>"),
                  "c5": ("c5", "euler3d_stage_kernel<%sArithT<false>, 0, true, false>", "euler3d_stage_kernel<%sArithT<false>, 0, true, true>")}[config]
         for mode, roof in (("Fast", out.get("roofline")), ("Strict", (out.get("arith_strict") or {}).get("roofline"))):
             if not roof or not roof.get("avg_launch_ms"):
                 continue
             tag = "c4s" if (config == "c4" and mode == "Strict") else names[0]
-            keys = ["%s:%s" % (tag, (n % mode).replace("@", "true" if "planar" in roof.get("kernel", "") else "false")) for n in names[1:]]
+            keys = ["%s:%s" % (tag, (n % ("FastT<true>" if (config == "c3" and mode == "Fast") else mode)).replace("@", "true" if "planar" in roof.get("kernel", "") else "false")) for n in names[1:]]
             if config == "c4" and mode == "Fast" and roof.get("launches_per_step") == 1:
                 keys = ["c4:cloud_fused_rk2_kernel<%s>" % ("true" if "planar" in roof.get("kernel", "") else "false")]           # the RK2 step's one launch
             if counters.current and all(k in t for k in keys):

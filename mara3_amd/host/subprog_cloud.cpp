@@ -195,6 +195,8 @@ public:
         double time = 0.0;
         long iteration = 0;
         std::vector<double> inflow(std::size_t(5) * nq, 0.0), inflow_first;
+        double timed_ms = 0.0;               // profile = 1: the steps after the first 30 (the GPU's clocks settle over the first ~25 launches)
+        long timed_steps = 0;
         h5io::schedule_t schedule;
         if (restart.empty())
         {
@@ -343,6 +345,7 @@ public:
             }
             else host::throw_on_status(ctx, MH_SYSTEM_SRHD);
             if (verbose) std::printf("[%04ld] t=%3.7lf kzps=%3.2lf\n", iteration, time, double(nrv) * nqv / ms);    // vertices, like the reference (:858)
+            if (iteration > 30) { timed_ms += ms; timed_steps += 1; }
         };
         while (time < tfinal && (max_steps == 0 || iteration < max_steps)) advance(true);
         download_solution();
@@ -354,6 +357,14 @@ public:
         // upstream's closing `run_tasks_on_next(state)` (:935): one more step whose only visible effect is a task that falls due on it.
         // final.bin above is the state the loop ended with; a run cut short by max_steps (not upstream) ends there.
         if (max_steps == 0 && tasks_on) advance(false);
+        if (cfg.get_int("profile") && timed_steps > 0)
+        {
+            // one JSON line of this process's own timing (kept beside the rocprofv3 trace of the same run: profiles/r05, tests/test_profiles_cpu.py)
+            int lps = gpus > 1 ? mh_slab_launches_per_step(slabs[0]) : 0;
+            std::printf("{\"run\": \"mara_hip cloud nr=%d gpus=%d arith=%s\", \"ms_per_step\": %.6f, \"steps_timed\": %ld, \"zones\": %ld, \"value\": %.3f, \"unit\": \"Mcells/s\", "
+                        "\"slab_launches_per_step\": %d, \"note\": \"host-timed steps 31.. (nozzle row evaluated on the host and uploaded, step, synchronise)\"}\n",
+                        nr, gpus, cfg.get_string("arith").c_str(), timed_ms / timed_steps, timed_steps, long(nr) * nq, double(nr) * nq / (timed_ms / timed_steps) / 1e3, lps);
+        }
         // (profile = 1 steps the live solution further: only now, after every task of the run - the closing one included - has seen its state)
         if (cfg.get_int("profile") && gpus == 1)
         {

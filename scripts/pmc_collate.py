@@ -76,7 +76,8 @@ def table(tags, part):
         except OSError:
             pass
         tr0 = ([v for k, v in trace("fast_hllc").items() if k.startswith("euler2d_fused_rk2_kernel<1")] or [(0.0, 0, 0.0)])[0]
-        lines[3:3] = ["Kernel traces of the headline variants: `bench.py --steps 200` under `rocprofv3 --kernel-trace --stats` (about 300 launches per kernel, so that the cold launches - the first ~25 after",
+        steps, launches = ("1000", "1100") if ROUND >= "r05" else ("200", "300")
+        lines[3:3] = ["Kernel traces of the headline variants: `bench.py --steps %s` under `rocprofv3 --kernel-trace --stats` (about %s launches per kernel, so that the cold launches - the first ~25 after" % (steps, launches),
                       "an idle period run up to twice as long - do not carry the average; the counters come from 20-step runs). Since round 4 the tracked `kernel_stats_<run>.csv` beside this file ARE these traces",
                       "(tests/test_profiles_cpu.py holds the table to them). The same command's own bench line is",
                       "`bench_under_rocprof_trace_<run>.json`: for the fused kernel %.3f ms per launch (one pair of events around five launches, gaps included) and %.3f ms per timed step against"
