@@ -1,5 +1,6 @@
 // Both stages of an RK2 step of the `cloud` sub-program (2-D axisymmetric spherical-polar SRHD, BASELINE config 4) in ONE launch
-// (gfx950 / MI355X), MH_ARITH_FAST + PLM, both radial sides physical (nozzle inflow inside, zero gradient outside).
+// (gfx950 / MI355X), MH_ARITH_FAST + PLM: the whole field (nozzle inflow inside, zero gradient outside) and, since round 5, a radial SLAB of
+// it whose cut sides are MH_BC_EXTERNAL (four stored rows of the neighbour per cut side, one exchange per step: slab.hip).
 //
 // What it replaces: `s0 * 0.5 + advance(advance(s0)) * 0.5` (src/subprog_cloud.cpp:676-697, `advance` :511-584) as two launches of
 // cloud_stage_kernel (cloud.hip). Both stages use the nozzle row of the step-START time (:466-493, :524) and the same geometry, so the
@@ -14,6 +15,9 @@
 //     producer cannot form, from the neighbouring pair's ring - 116 output columns per workgroup.
 // Physical radial sides cost no first-stage ghost rows: the inner ghost rows of BOTH stages are the nozzle primitives, the outer ones a copy of
 // the last row's primitives, so the producer covers rows max(r0 - 2, 0) .. min(r1 + 2, nr) - 1 of a chunk [r0, r1) and nothing beyond the grid.
+// Beyond a CUT the producer forms the neighbour's first-stage rows (two per side) from its four step-start rows, with the neighbour's geometry
+// (row factors are indexed by GLOBAL row), so that every cell sees the bits of the one-domain run; a neighbour's cell that fails
+// recover_primitive is the neighbour's to report.
 // Every lane of the consumer converts a valid cell (ghost and out-of-range columns read the clamped column, lanes without a source a neighbour's):
 // recover_primitive iterates, and one lane on garbage would hold its wave for fifty Newton steps.
 //
