@@ -120,6 +120,8 @@ def config_summary(line):
 
 def build_summary(details):
     s = {"headline": leg_summary(details), "n_gpus": details.get("n_gpus")}
+    if details.get("stepper"):
+        s["stepper"] = details["stepper"]
     for key, leg in (details.get("legs") or {}).items():
         s[key] = leg_summary(leg)
     for cfg, line in (details.get("extra_configs") or {}).items():
@@ -177,7 +179,7 @@ def final_line(details, limit=LINE_LIMIT, details_file="bench_details.json"):
         out.pop(victim, None)
         text = json.dumps(out)
     if len(text) > limit:
-        keep = ("headline", "n_gpus", "note")
+        keep = ("headline", "n_gpus", "note", "stepper")
         out["summary"] = {k: v for k, v in out["summary"].items() if k in keep or not isinstance(v, list) or k.startswith("c")}
         text = json.dumps(out)
     if len(text) > limit:

@@ -310,7 +310,8 @@ int  mh_slab_set_inflow(mh_slab* slab, const double* inflow_prims_aos_host);
  * neighbours live in other processes (there only under planar > 0), re-resolves in mh_slab_set_inflow. The members of a loopback group are
  * resolved TOGETHER - hand the row to mh_slab_group_set_inflow, which updates every member in one call (the group is planar only if every
  * member's rows and the row are); through the per-slab call a member can lose its planar kernels but never gain them, so a host that hands
- * the row to the nozzle-side member only stays correct, on the general kernels. */
+ * the row to the nozzle-side member only stays correct, on the general kernels. Likewise a rank of a multi-process run that is never
+ * handed a row (only the rank owning row 0 READS it) stays on the general kernels: correct, slower - hand the row to every rank. */
 int  mh_slab_group_set_inflow(mh_slab** slabs, int n, const double* inflow_prims_aos_host);
 /* LOOPBACK groups: all `world` slabs of a decomposition as objects of ONE process on one GPU. A "receive" is a stream-ordered
  * device-to-device copy out of the neighbour object's field under the same event protocol; cut, ghost layout, edge / interior

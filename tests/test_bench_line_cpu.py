@@ -96,3 +96,13 @@ def test_recorded_driver_style_line_of_this_round():
                 assert d["summary"][key][0] == pytest.approx(leg["value"], rel=1e-5)
                 r = leg["roofline"]
                 assert 0.0 < r["frac"] < 1.0, (key, r)
+
+
+def test_counters_are_stamped_with_the_code_of_this_tree():
+    """profiles/pmc_traffic.json is stamped with a hash of the kernel sources' CODE (comments and white space aside): the counters the bench line
+    quotes were taken on the kernels of this tree - a kernel edit without a new profile pass (scripts/profile_r5.sh, scripts/pmc_collate.py) fails here"""
+    import bench
+    assert bench.code_only("a = 1; // note\n/* block\n comment */ b  =\t2;\n") == "a = 1; b = 2;"
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert t["csrc_sha16"] == bench.csrc_fingerprint(), "kernel sources changed since the PMC passes: re-run scripts/profile_r5.sh and scripts/pmc_collate.py"
+    assert bench_report.Counters(bench.csrc_fingerprint()).current

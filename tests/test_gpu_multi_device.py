@@ -78,3 +78,27 @@ def test_block_and_band_configs_start_from_a_plain_command():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["status_word"] == 0
     out, _ = run_bench("bench_configs.py", ["--config", "c3", "--gpus", "2", "--steps", "5", "--warmup", "2"])
     assert out["n_gpus"] == 2 and out["value"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cloud_one_launch_step_across_radial_cuts_on_distinct_devices(world, monkeypatch):
+    """round 5: `cloud`'s fused RK2 step across radial cuts (four ghost rows, one exchange per step) with member r on device r - peer copies of the
+    four-row blocks, the nozzle row through mh_slab_group_set_inflow - equals the one-launch step of the whole field bit for bit"""
+    need(world)
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    from mara3_amd import engine
+    from mara3_amd.slab import NativeSlabGroup
+    from test_gpu_cloud_fused import smooth_cloud_state, run
+    rv, qv, u0, inflow, dt = smooth_cloud_state(engine, 130, 117, seed=world)
+    whole, st = run(engine, rv, qv, u0, inflow, dt, (3,), True)
+    g = NativeSlabGroup(world=world, rk_order=2, plm_theta=1.2, gamma=4.0 / 3, arith="fast", r_vertices=rv, q_vertices=qv, temperature_floor=0.0,
+                        devices=list(range(world)))
+    assert g.launches_per_step() == [1] * world
+    g.upload(u0)
+    for n in range(3):
+        g.set_inflow(inflow[n])
+        g.step(dt, 1)
+    g.synchronize()
+    assert st == (0, None) and g.status() == (0, None)
+    assert bits_equal(g.download(), whole[0])
+    g.close()
