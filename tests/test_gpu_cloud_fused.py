@@ -296,3 +296,14 @@ def test_fused_cuts_general_kernel_with_azimuthal_motion_and_the_status_contract
     _, st_c, _, _ = run_slabs(rv, qv, bad, inflow, dt, (1,), world, None)
     # (the failure may spread to the cells around it within the step: what is pinned is that slabs and whole field report the SAME bits and first cell)
     assert st_w[0] != 0 and st_c == st_w and st_w[1] <= i * nq + j and st_w[1] >= (i - 3) * nq, (st_w, st_c)
+
+
+def test_fused_cuts_stay_bit_identical_through_a_long_run(eng, monkeypatch):
+    """400 steps of a 512 x 256 grid over four slabs of 128 rows (the exchange's four-row blocks, the recomputed first-stage rows and the nozzle row
+    that changes every step, 400 times over): the slabs' final state is the whole-field run's, bit for bit, and so are the status words"""
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 512, 256, seed=77)
+    whole, st_w = run(eng, rv, qv, u0, inflow, 0.5 * dt, (400,), True)
+    cut, st_c, lps, _ = run_slabs(rv, qv, u0, inflow, 0.5 * dt, (400,), 4, None)
+    assert lps == [1] * 4 and st_w == st_c
+    assert bits_equal(cut[0], whole[0]) and np.isfinite(whole[0]).all()
