@@ -305,8 +305,11 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     const int nblocks = (launch_waves + BWAVES_PER_BLOCK - 1) / BWAVES_PER_BLOCK;
     const dim3 grid(nblocks), block(BWAVE * BWAVES_PER_BLOCK);
     const bool combine = weight != 1.0;
-    hipError_t e = d->arith == MH_ARITH_FAST ? binary_stage_dispatch_fast(p, grid, block, stream, combine, d->angmom_form != 0)
-                                             : binary_stage_dispatch<BinStrict>(p, grid, block, stream, combine, d->angmom_form != 0);
+    // the stage's completion event for the totals stream rides on the launch itself (no marker packet between two stage kernels)
+    static const bool event_on_launch = ! (getenv("MH_BIN_EVENT_ON_LAUNCH") && atoi(getenv("MH_BIN_EVENT_ON_LAUNCH")) == 0);
+    const hipEvent_t done = (overlap && part != BIN_ROWS_EDGES && event_on_launch) ? overlap->stage_done : nullptr;
+    hipError_t e = d->arith == MH_ARITH_FAST ? binary_stage_dispatch_fast(p, grid, block, stream, combine, d->angmom_form != 0, done)
+                                             : binary_stage_dispatch<BinStrict>(p, grid, block, stream, combine, d->angmom_form != 0, done);
     if (e != hipSuccess) return e;
     if (part == BIN_ROWS_EDGES) return hipSuccess;          // the totals follow the interior
 
@@ -318,7 +321,7 @@ hipError_t binary_stage_launch(const mh_binary_desc* d, const double* xv, const 
     if (overlap)
     {
         tstream = overlap->stream;
-        if ((e = hipEventRecord(overlap->stage_done, stream)) != hipSuccess) return e;
+        if (! done && (e = hipEventRecord(overlap->stage_done, stream)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(tstream, overlap->input_ready, 0)) != hipSuccess) return e;
     }
     BinarySinkParams s;

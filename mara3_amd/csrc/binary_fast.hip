@@ -8,12 +8,12 @@
 
 namespace mh {
 
-hipError_t binary_stage_dispatch_fast(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform)
+hipError_t binary_stage_dispatch_fast(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform, hipEvent_t done)
 {
     // the default disk (two-body sound speed, alpha viscosity, no cut-off) has its own instantiation: its row loop carries neither the branches
     // nor the code of the other forms (BinFastT<DISK>, binary_device.hpp) - same formulas, same bits
-    if (BinFastDisk::serves(p.c)) return binary_stage_dispatch<BinFastDisk>(p, grid, block, stream, combine, qform);
-    return binary_stage_dispatch<BinFast>(p, grid, block, stream, combine, qform);
+    if (BinFastDisk::serves(p.c)) return binary_stage_dispatch<BinFastDisk>(p, grid, block, stream, combine, qform, done);
+    return binary_stage_dispatch<BinFast>(p, grid, block, stream, combine, qform, done);
 }
 
 // row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds

@@ -4,6 +4,7 @@
 // with FMA contraction.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 #include "launch.hpp"
@@ -399,18 +400,25 @@ void binary_stage_kernel(BinaryStageParams p)
 }
 
 // launches the instantiation (COMBINE, QFORM) of arithmetic A; the FAST ones live in binary_fast.hip
+// done (or null): an event that fires when THIS launch completes. It rides on the dispatch packet's own completion signal (hipExtLaunchKernel,
+// as the 2-D slab stepper's launches do) instead of being recorded behind the launch, where it is a marker packet between two stage kernels of
+// the main stream. Measured at 2048^2 (round 5, profiles/r05/ab_c3_event_on_launch.txt; MH_BIN_EVENT_ON_LAUNCH=0 records it as before): FAST
+// 21.3 - 21.5 Gzones/s either way (the 6.7 us between stage kernels in a rocprofv3 trace are the tracer's), STRICT 11.27 against 11.05.
 template<class A>
-inline hipError_t binary_stage_dispatch(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform)
+inline hipError_t binary_stage_dispatch(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform, hipEvent_t done = nullptr)
 {
+#define MH_BIN_LAUNCH(C, Q) do { if (done) hipExtLaunchKernelGGL((binary_stage_kernel<A, C, Q>), grid, block, 0, stream, nullptr, done, 0, p); \
+                                 else      hipLaunchKernelGGL((binary_stage_kernel<A, C, Q>), grid, block, 0, stream, p); } while (0)
     switch ((qform ? 2 : 0) | (combine ? 1 : 0))
     {
-        case 0: hipLaunchKernelGGL((binary_stage_kernel<A, false, false>), grid, block, 0, stream, p); break;
-        case 1: hipLaunchKernelGGL((binary_stage_kernel<A, true,  false>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((binary_stage_kernel<A, false, true >), grid, block, 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((binary_stage_kernel<A, true,  true >), grid, block, 0, stream, p); break;
+        case 0: MH_BIN_LAUNCH(false, false); break;
+        case 1: MH_BIN_LAUNCH(true,  false); break;
+        case 2: MH_BIN_LAUNCH(false, true ); break;
+        case 3: MH_BIN_LAUNCH(true,  true ); break;
     }
+#undef MH_BIN_LAUNCH
     return hipGetLastError();
 }
-hipError_t binary_stage_dispatch_fast(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform);
+hipError_t binary_stage_dispatch_fast(const BinaryStageParams& p, dim3 grid, dim3 block, hipStream_t stream, bool combine, bool qform, hipEvent_t done = nullptr);
 
 } // namespace mh
