@@ -106,3 +106,21 @@ def test_counters_are_stamped_with_the_code_of_this_tree():
     t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert t["csrc_sha16"] == bench.csrc_fingerprint(), "kernel sources changed since the PMC passes: re-run scripts/profile_r5.sh and scripts/pmc_collate.py"
     assert bench_report.Counters(bench.csrc_fingerprint()).current
+
+
+@pytest.mark.parametrize("config,kernel,lps", [("c3", "binary_stage_kernel + binary_sink_kernel + binary_reduce_kernel (one stage)", 2),
+                                               ("c5", "euler3d_stage_kernel<fast,hlle,PLM> (mean of both RK2 stages)", 2),
+                                               ("c4", "cloud_fused_rk2_kernel<planar> (both RK2 stages in one launch per step)", 1)])
+def test_config_lines_find_their_counters(config, kernel, lps):
+    """bench_configs.attach_traffic maps a config's kernels to the rows of profiles/pmc_traffic.json (the C3 FAST kernel is BinFastT<true> since
+    round 5): with a current stamp every config gets its fp64 figure and its PMC bytes; the one-launch `cloud` step becomes bound fp64"""
+    import bench_configs
+    roof = bench_report.hbm_roofline(kernel, 0.9 if config == "c4" else (3.7 if config == "c5" else 0.1), 10, 4096 * 4096, 104 if config == "c4" else 100,
+                                     extra={"bytes_moved_per_cell": 104, "launches_per_step": lps})
+    out = bench_configs.attach_traffic({"roofline": roof, "arith_strict": {"roofline": dict(roof, kernel=kernel.replace("fast", "strict"), launches_per_step=2)}}, config)
+    r = out["roofline"]
+    if config == "c4":
+        assert r["bound"] == "fp64" and 0.0 < r["frac"] < 1.0 and r["traffic"] > 0 and 0.5 < r["valu_busy"] <= 1.0
+    else:
+        assert r["bound"] == "hbm" and r["traffic"] > 0 and 0.0 < r["fp64"]["frac"] < 1.0 and 0.3 < r["fp64"]["valu_busy"] <= 1.0
+        assert out["arith_strict"]["roofline"]["fp64"]["valu_busy"] > 0.3
