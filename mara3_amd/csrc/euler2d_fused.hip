@@ -73,6 +73,8 @@ struct Fused2dParams
     // the rows this launch covers: chunks [0, seg0_chunks) cut rows [seg0_begin, seg0_end), the others [seg1_begin, seg1_end) - a slab with
     // neighbours runs both of its edge strips in one launch and the rest in another (slab.hip); a whole field is one segment
     int    seg0_begin, seg0_end, seg0_chunks, seg1_begin, seg1_end;
+    int    seg1_chunk_rows;       // rows per chunk of the second segment (= chunk_rows unless the launcher tapers the launch: the interior of a slab
+                                  // with neighbours ends in SHORTER chunks, whose workgroups start late - behind the edge launch's - and must not end late)
     int    bc0_lo, bc0_hi;        // axis 0, per side: 0 outflow, 1 periodic (both sides then), 2 EXTERNAL - a cut of a slab decomposition: rows
                                   // -4 .. -1 / n0 .. n0 + 3 of u_in hold the neighbour's rows (four per side: two per stage), nothing is
                                   // clamped or wrapped there, and the result's ghost rows on that side are the next exchange's to fill
@@ -148,9 +150,13 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     __shared__ double hand_all[FPAIRS][FSLOTS][NV][FWAVE];       // first-stage rows on their way from the producer to the consumer
     __shared__ double start_all[FPAIRS][USLOTS][NV][FWAVE];      // step-start rows: they wait for the producer's update (as euler2d.hip's ring) and for the consumer's average
 
-    int b = (int) blockIdx.x;
+    // the blocks of the first segment come first IN LAUNCH ORDER (the hardware starts workgroups in the order of their ids: what is launched last
+    // starts last), the XCD-aware order applies within each segment
+    const int seg0_blocks = p.seg0_chunks * p.nstrips;
+    const bool second = (int) blockIdx.x >= seg0_blocks;
+    int b = second ? (int) blockIdx.x - seg0_blocks : (int) blockIdx.x;
     {
-        const int per_xcd = (int) gridDim.x >> 3;
+        const int per_xcd = (second ? (int) gridDim.x - seg0_blocks : seg0_blocks) >> 3;
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);      // neighbouring strips and chunks on one XCD (halo re-reads hit its L2)
     }
     const int pair = __builtin_amdgcn_readfirstlane(b);
@@ -165,13 +171,12 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     double (*start_rows)[NV][FWAVE] = start_all[pp];
     const int lane = threadIdx.x & 63;
     const int al = ((lane - 1) & 63) * 4, ar = ((lane + 1) & 63) * 4;
-    const int chunk_of_launch = pair / p.nstrips;
-    const int strip = pair - chunk_of_launch * p.nstrips;
+    const int chunk = pair / p.nstrips;                 // within its segment
+    const int strip = pair - chunk * p.nstrips;
     const int n0 = p.n0, n1 = p.n1;
-    const bool second = chunk_of_launch >= p.seg0_chunks;
-    const int chunk = second ? chunk_of_launch - p.seg0_chunks : chunk_of_launch;
-    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
+    const int chunk_rows = second ? p.seg1_chunk_rows : p.chunk_rows;
+    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * chunk_rows;
+    const int r1 = min(r0 + chunk_rows, second ? p.seg1_end : p.seg0_end);
     const int nrows = r1 - r0;                         // >= 1 by construction of the grid
 
     const int col = strip * FGROUP - FHALO + pp * FPITCH + lane;
@@ -457,16 +462,17 @@ bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d, bool with_cuts)
 hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
                                     LaunchEvents ev, bool with_cuts)
 {
-    return euler2d_fused_rk2_launch_rows(d, u_in, u_out, dt, 0, d->n[0], 0, 0, status, stream, ev, with_cuts);
+    return euler2d_fused_rk2_launch_rows(d, u_in, u_out, dt, 0, d->n[0], 0, 0, status, stream, ev, with_cuts, 0);
 }
 
 // ... over rows [a, b) and, in the same launch, [a2, b2) (b2 <= a2: none) of the field
+// late_blocks: workgroups of ANOTHER launch that hold slots of the chip when this one starts (a slab's edge launch beside its interior), see below
 hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int a, int b, int a2, int b2,
-                                         int32_t* status, hipStream_t stream, LaunchEvents ev, bool with_cuts)
+                                         int32_t* status, hipStream_t stream, LaunchEvents ev, bool with_cuts, int late_blocks)
 {
     if (! euler2d_fused_rk2_available(d, with_cuts) || u_in == u_out) return hipErrorInvalidValue;
     if (a < 0 || b > d->n[0] || b <= a || (b2 > a2 && (a2 < b || b2 > d->n[0]))) return hipErrorInvalidValue;
-    const int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
+    int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
     const int longest = rows0 > rows1 ? rows0 : rows1;
     Fused2dParams p;
     p.u_in = u_in; p.u_out = u_out; p.status = status;
@@ -491,10 +497,41 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         if (p.chunk_rows < 8) p.chunk_rows = 8;
     }
     if (p.chunk_rows > longest) p.chunk_rows = longest;
+    p.seg1_chunk_rows = p.chunk_rows;
+    // TAPER (round 5): a one-round launch fills the chip's workgroup slots to the brim, so when `late_blocks` slots are held by another launch at
+    // its start (the edge strips of a slab, issued first on the high-priority stream), as many of THIS launch's workgroups - the ones launched
+    // last - start only when those end, `taper` row-times later, and end that much after all the others: 156.6 instead of 134.8 us per step
+    // for a 1024-row slab with neighbours (profiles/r05/thin_slab_scaling.md). The rows are therefore cut into long chunks, launched first, and
+    // ceil(late_blocks / nstrips) SHORTER chunks per strip, launched last: c_short = c_long - taper, so that all end together. Results do
+    // not depend on the cut (tests/test_gpu_fused_rk2.py, tests/test_gpu_slab_group.py). MH_FUSED_TAPER_ROWS: the head start lost, in rows
+    // (default 8 = an edge chunk's four rows and its fill; 0 = off).
+    static const int taper = [] { const char* v = getenv("MH_FUSED_TAPER_ROWS"); return v ? atoi(v) : 8; } ();
+    if (late_blocks > 0 && taper > 0 && rows1 == 0 && d->chunk_rows <= 0)
+    {
+        const int resident = device_cu_count() * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);
+        const int nch = resident / p.nstrips;                                  // chunks per strip of one residency round
+        const int nshort = (late_blocks + p.nstrips - 1) / p.nstrips;
+        const int clong = nch > 0 ? (rows0 + nshort * taper + nch - 1) / nch : 0;
+        // one round, and chunks long enough for the taper to pay: measured with the exchange to self (profiles/r05/ab_taper.txt, us per step, taper
+        // 0 / 6 / 8 / 10 / 12 rows): 1024 rows (50-row chunks) 154.5 - 156.9 / 146.8 - 149.4 / 147.0 - 150.7 / 145.3 - 150.1 / 145.7 - 149.7;
+        // 512 rows (24-row chunks, which fit the 21 chunks per strip exactly) 80.4 - 82.0 / 81.3 - 81.9 / 81.8 - 82.9 / 81.2 - 82.1 / 83.8 - 84.3: not there
+        if (nch > nshort && clong - taper >= 24 && clong <= (d->planar > 0 && MH_FUSED_PLANAR_WAVES >= 3 ? 80 : 112))
+        {
+            const int long_rows = (nch - nshort) * clong;
+            if (long_rows < rows0)
+            {
+                p.chunk_rows = clong;
+                p.seg1_chunk_rows = clong - taper;
+                a2 = a + long_rows; b2 = b;                                    // the short chunks take the END of the range
+                b = a2;
+                rows0 = long_rows; rows1 = b2 - a2;
+            }
+        }
+    }
     p.seg0_begin = a; p.seg0_end = b;
     p.seg0_chunks = (rows0 + p.chunk_rows - 1) / p.chunk_rows;
     p.seg1_begin = a2; p.seg1_end = rows1 ? b2 : a2;
-    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.chunk_rows - 1) / p.chunk_rows : 0);
+    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.seg1_chunk_rows - 1) / p.seg1_chunk_rows : 0);
     auto side = [] (int bc) { return bc == MH_BC_PERIODIC ? 1 : (bc == MH_BC_EXTERNAL ? 2 : 0); };
     p.bc0_lo = side(d->bc_lo0);
     p.bc0_hi = side(d->bc_hi0);
@@ -510,6 +547,8 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
 #undef MH_FUSED_LAUNCH
     return hipGetLastError();
 }
+
+int euler2d_fused_rk2_blocks_per_chunk(const mh_euler_cart_desc* d) { return (d->n[1] + FGROUP - 1) / FGROUP; }
 
 // row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
 MH_ROW_RANGE_READER(rows_requested_euler2d_fused)

@@ -41,8 +41,11 @@ bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d, bool with_cuts = f
 hipError_t euler2d_fused_rk2_launch(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int32_t* status, hipStream_t stream,
                                     LaunchEvents ev = LaunchEvents(), bool with_cuts = false);
 // ... over rows [a, b) and, in the same launch, [a2, b2) (none if b2 <= a2): a slab with neighbours runs its two edge strips, then the rest
+// late_blocks: workgroups of another launch that hold slots when this one starts (the slab's edge launch): the launch then ends in shorter
+// chunks, launched last, so that the workgroups that start late do not end late (euler2d_fused.hip: TAPER)
 hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const double* u_in, double* u_out, double dt, int a, int b, int a2, int b2,
-                                         int32_t* status, hipStream_t stream, LaunchEvents ev = LaunchEvents(), bool with_cuts = false);
+                                         int32_t* status, hipStream_t stream, LaunchEvents ev = LaunchEvents(), bool with_cuts = false, int late_blocks = 0);
+int euler2d_fused_rk2_blocks_per_chunk(const mh_euler_cart_desc* d);          // workgroups per chunk of rows (strips of 116 columns)
 
 hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in, const double* u_base, double* u_out,
                                 double dt, double weight, int row_begin, int row_end, int32_t* status, hipStream_t stream);

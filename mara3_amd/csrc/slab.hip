@@ -158,7 +158,10 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
     else
     {
         const mh_euler_cart_desc* d = edge ? &s->edge_desc : &s->desc;
-        if (s->fused_cut) return euler2d_fused_rk2_launch_rows(&s->fused_desc, in, out, dt, a, b, a2, b2, s->status, stream, ev, true);
+        // (the interior launch of a slab with neighbours is told how many workgroups its edge launch - two segments of one chunk each, issued
+        // first on the high-priority stream - holds when it starts: it then ends in shorter chunks, euler2d_fused.hip: TAPER)
+        if (s->fused_cut) return euler2d_fused_rk2_launch_rows(&s->fused_desc, in, out, dt, a, b, a2, b2, s->status, stream, ev, true,
+                                                               edge ? 0 : 2 * euler2d_fused_rk2_blocks_per_chunk(&s->fused_desc));
         if (d->rank == 2) return euler2d_stage_launch2(d, in, base, out, dt, w, a, b, a2, b2, s->status, stream, ev);
         if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a, b, s->status, stream)) return e;
         if (b2 > a2) if (hipError_t e = euler3d_stage_launch(d, in, base, out, dt, w, a2, b2, s->status, stream)) return e;
