@@ -649,6 +649,9 @@ int  mh_device_synchronize(void);
 enum { MH_ROWS_EULER2D = 0, MH_ROWS_EULER2D_FUSED = 1, MH_ROWS_CLOUD = 2, MH_ROWS_CLOUD_FUSED = 3, MH_ROWS_EULER3D_STRICT = 4, MH_ROWS_EULER3D_FAST = 5,
        MH_ROWS_BINARY_STRICT = 6, MH_ROWS_BINARY_FAST = 7 };
 /* MH_E_STATE from a product build (no guard compiled in); lo_hi = {INT_MAX, INT_MIN} when nothing was requested */
+/* {chunk rows, chunk rows of the second segment, chunks of the first segment, chunks} of the LAST one-launch RK2 step this process issued
+ * (family 1: 2-D Euler, 3: cloud): the tests of the tapered interior launch (a slab with neighbours: csrc/euler2d_fused.hip, TAPER) read it */
+int  mh_debug_last_fused_cut(int family, int32_t out[4]);
 int  mh_debug_row_range(int family, int32_t lo_hi[2], int reset);
 
 #ifdef __cplusplus

@@ -244,6 +244,7 @@ SYMBOLS = [
     ("mh_binary_diagnostic_fields", _i, [_vp, _vp, _vp, _vp]),
     ("mh_device_count", _i, []),
     ("mh_device_cu_count", _i, []),
+    ("mh_debug_last_fused_cut", _i, [_i, C.POINTER(C.c_int32)]),
     ("mh_malloc", _i, [C.POINTER(_vp), _sz]),
     ("mh_free", _i, [_vp]),
     ("mh_memcpy_h2d", _i, [_vp, _vp, _sz]),

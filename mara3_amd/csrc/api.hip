@@ -1056,6 +1056,16 @@ int mh_memcpy_h2d(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemc
 int mh_memcpy_d2h(void* dst, const void* src, size_t bytes) { MH_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return MH_OK; }
 int mh_device_synchronize(void) { MH_HIP_TRY(hipDeviceSynchronize()); return MH_OK; }
 
+// how the last one-launch RK2 step of this process cut its rows (family 1: 2-D Euler, 3: cloud - the row-range guard's numbering)
+int mh_debug_last_fused_cut(int family, int32_t out[4])
+{
+    if (! out || (family != 1 && family != 3)) { set_error("mh_debug_last_fused_cut: family 1 (euler2d fused) or 3 (cloud fused)"); return MH_E_INVALID; }
+    int v[4];
+    if (family == 1) euler2d_fused_last_cut(v); else cloud_fused_last_cut(v);
+    for (int k = 0; k < 4; ++k) out[k] = v[k];
+    return MH_OK;
+}
+
 int mh_debug_row_range(int family, int32_t lo_hi[2], int reset)
 {
     if (! lo_hi) { set_error("row range: null argument"); return MH_E_INVALID; }

@@ -73,6 +73,7 @@ struct CloudFusedParams
     // the rows this launch covers: chunks [0, seg0_chunks) cut rows [seg0_begin, seg0_end), the others [seg1_begin, seg1_end) - a radial slab with
     // neighbours runs both of its edge strips in one launch and the rest in another (slab.hip); a whole field is one segment
     int    seg0_begin, seg0_end, seg0_chunks, seg1_begin, seg1_end;
+    int    seg1_chunk_rows;       // rows per chunk of the second segment (= chunk_rows unless the launcher tapers the launch, see the launcher)
     int    ext_lo, ext_hi;        // 1: that radial side is a CUT of a slab decomposition (MH_BC_EXTERNAL) - rows -4 .. -1 / n0 .. n0 + 3 of u_in hold the
                                   // neighbour's step-start rows (four per side: two per stage), the first-stage rows beyond the cut are recomputed here
                                   // from them, and neither the nozzle rows nor the zero-gradient copy nor the zeroed edge slope apply on that side
@@ -100,9 +101,12 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     __shared__ double hand_all[QPAIRS][QSLOTS][NV][QWAVE];       // first-stage rows on their way from the producer to the consumer
     __shared__ double own_all[QPAIRS][OSLOTS][NV][QWAVE];        // step-start rows waiting for the producer's update
 
-    int b = (int) blockIdx.x;
+    // the blocks of the first segment come first in launch order (what is launched last starts last); the XCD-aware order applies within a segment
+    const int seg0_blocks = p.seg0_chunks * p.nstrips;
+    const bool second = (int) blockIdx.x >= seg0_blocks;
+    int b = second ? (int) blockIdx.x - seg0_blocks : (int) blockIdx.x;
     {
-        const int per_xcd = (int) gridDim.x >> 3;
+        const int per_xcd = (second ? (int) gridDim.x - seg0_blocks : seg0_blocks) >> 3;
         if (b < per_xcd * 8) b = (b & 7) * per_xcd + (b >> 3);      // neighbouring strips and chunks on one XCD
     }
     const int group = __builtin_amdgcn_readfirstlane(b);
@@ -113,13 +117,12 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     const int role = wave_of_group & 1;
     const int pp = wave_of_group >> 1;                  // which pair of the workgroup
     const int lane = threadIdx.x & 63;
-    const int chunk_of_launch = group / p.nstrips;
-    const int strip = group - chunk_of_launch * p.nstrips;
+    const int chunk = group / p.nstrips;                // within its segment
+    const int strip = group - chunk * p.nstrips;
     const int n0 = p.n0, n1 = p.n1;
-    const bool second = chunk_of_launch >= p.seg0_chunks;
-    const int chunk = second ? chunk_of_launch - p.seg0_chunks : chunk_of_launch;
-    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * p.chunk_rows;
-    const int r1 = min(r0 + p.chunk_rows, second ? p.seg1_end : p.seg0_end);
+    const int chunk_rows = second ? p.seg1_chunk_rows : p.chunk_rows;
+    const int r0 = (second ? p.seg1_begin : p.seg0_begin) + chunk * chunk_rows;
+    const int r1 = min(r0 + chunk_rows, second ? p.seg1_end : p.seg0_end);
     const bool lo_phys = p.ext_lo == 0, hi_phys = p.ext_hi == 0;          // (wave-uniform)
     // rows of the first-stage field this chunk needs: nothing beyond the grid on a physical side, two rows of the neighbour's beyond a cut
     const int a_begin = lo_phys ? max(r0 - 2, 0) : r0 - 2, a_end = hi_phys ? min(r1 + 2, n0) : r1 + 2;
@@ -506,6 +509,10 @@ void cloud_fused_rk2_kernel(CloudFusedParams p)
     acc.commit(p.status);
 }
 
+// how the last launch of this translation unit cut its rows: {chunk rows, chunk rows of the second segment, chunks of the first, chunks} (tests)
+static int last_cut[4] = {0, 0, 0, 0};
+void cloud_fused_last_cut(int out[4]) { for (int k = 0; k < 4; ++k) out[k] = last_cut[k]; }
+
 // with_cuts: MH_BC_EXTERNAL radial sides are accepted too (a slab of a radial decomposition: the caller - slab.hip - keeps FOUR rows of the
 // neighbour beyond such a side and exchanges once per step)
 bool cloud_fused_rk2_available(const mh_cloud_desc* d, bool with_cuts)
@@ -522,16 +529,16 @@ bool cloud_fused_rk2_available(const mh_cloud_desc* d, bool with_cuts)
 hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
                                   double dt, int32_t* status, hipStream_t stream)
 {
-    return cloud_fused_rk2_launch_rows(d, geom_dev, inflow_dev, u_in, u_out, dt, 0, d->nr, 0, 0, status, stream, false);
+    return cloud_fused_rk2_launch_rows(d, geom_dev, inflow_dev, u_in, u_out, dt, 0, d->nr, 0, 0, status, stream, false, 0);
 }
 
 // ... over rows [a, b) and, in the same launch, [a2, b2) (b2 <= a2: none) of the field
 hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
-                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts)
+                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts, int late_blocks)
 {
     if (! cloud_fused_rk2_available(d, with_cuts) || u_in == u_out || ! geom_dev || ! inflow_dev) return hipErrorInvalidValue;
     if (a < 0 || b > d->nr || b <= a || (b2 > a2 && (a2 < b || b2 > d->nr))) return hipErrorInvalidValue;
-    const int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
+    int rows0 = b - a, rows1 = b2 > a2 ? b2 - a2 : 0;
     const int longest = rows0 > rows1 ? rows0 : rows1;
     CloudFusedParams p;
     p.u_in = u_in; p.u_out = u_out; p.status = status;
@@ -558,10 +565,40 @@ hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geo
     }
     if (p.chunk_rows > longest) p.chunk_rows = longest;
     if (p.chunk_rows < 2 && longest >= 2) p.chunk_rows = 2;
+    p.seg1_chunk_rows = p.chunk_rows;
+    // TAPER, as euler2d_fused.hip's (where it is measured: the same 36 strips, 768 resident workgroups and 72 edge workgroups make the 4-GPU cut of
+    // a 4096-row grid end 5 % sooner): the interior launch of a radial slab with neighbours - `late_blocks` slots are held by its edge launch when
+    // it starts - ends in shorter chunks, launched last, so that the workgroups that start late do not end late. Config 4's four 1024-row slabs
+    // are this case; on ONE GPU, where the four slabs share the device, it cannot be measured (profiles/r05/cloud_fused_cuts.md).
+    // MH_FUSED_TAPER_ROWS as there (default 8 rows, 0 = off); from 24-row short chunks on.
+    // (read per launch, not cached: tests/test_gpu_slab_group.py and test_gpu_cloud_fused.py exercise the tapered cut on small grids with
+    // MH_FUSED_TAPER_MIN - the shortest short chunk for which the taper applies, default 24 rows)
+    const int taper = [] { const char* v = getenv("MH_FUSED_TAPER_ROWS"); return v ? atoi(v) : 8; } ();
+    const int taper_min = [] { const char* v = getenv("MH_FUSED_TAPER_MIN"); return v ? atoi(v) : 24; } ();
+    if (late_blocks > 0 && taper > 0 && rows1 == 0 && d->chunk_rows <= 0)
+    {
+        const int resident = device_cu_count() * (4 * MH_CLOUD_FUSED_WAVES) / (2 * QPAIRS);
+        const int nch = resident / p.nstrips;
+        const int nshort = (late_blocks + p.nstrips - 1) / p.nstrips;
+        const int clong = nch > 0 ? (rows0 + nshort * taper + nch - 1) / nch : 0;
+        if (nch > nshort && clong - taper >= taper_min && clong <= 80)
+        {
+            const int long_rows = (nch - nshort) * clong;
+            if (long_rows < rows0)
+            {
+                p.chunk_rows = clong;
+                p.seg1_chunk_rows = clong - taper;
+                a2 = a + long_rows; b2 = b;
+                b = a2;
+                rows0 = long_rows; rows1 = b2 - a2;
+            }
+        }
+    }
     p.seg0_begin = a; p.seg0_end = b;
     p.seg0_chunks = (rows0 + p.chunk_rows - 1) / p.chunk_rows;
     p.seg1_begin = a2; p.seg1_end = rows1 ? b2 : a2;
-    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.chunk_rows - 1) / p.chunk_rows : 0);
+    p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.seg1_chunk_rows - 1) / p.seg1_chunk_rows : 0);
+    last_cut[0] = p.chunk_rows; last_cut[1] = p.seg1_chunk_rows; last_cut[2] = p.seg0_chunks; last_cut[3] = p.nchunks;          // (mh_debug_last_fused_cut: tests)
     p.ext_lo = d->bc_lo0 == MH_BC_EXTERNAL ? 1 : 0;
     p.ext_hi = d->bc_hi0 == MH_BC_EXTERNAL ? 1 : 0;
     p.gamma = d->gamma; p.theta = d->plm_theta; p.tfloor = d->temperature_floor;
@@ -572,6 +609,8 @@ hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geo
     else               hipLaunchKernelGGL(cloud_fused_rk2_kernel<false>, grid, block, 0, stream, p);
     return hipGetLastError();
 }
+
+int cloud_fused_rk2_blocks_per_chunk(const mh_cloud_desc* d) { return (d->nq + QGROUP - 1) / QGROUP; }
 
 // row-range guard (row_check.hpp): what this translation unit's kernels asked for; false in product builds
 MH_ROW_RANGE_READER(rows_requested_cloud_fused)

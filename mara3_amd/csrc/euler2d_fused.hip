@@ -448,6 +448,10 @@ void euler2d_fused_rk2_kernel(Fused2dParams p)
     acc.commit(p.status);
 }
 
+// how the last launch of this translation unit cut its rows: {chunk rows, chunk rows of the second segment, chunks of the first, chunks} (tests)
+static int last_cut[4] = {0, 0, 0, 0};
+void euler2d_fused_last_cut(int out[4]) { for (int k = 0; k < 4; ++k) out[k] = last_cut[k]; }
+
 // with_cuts: MH_BC_EXTERNAL sides are accepted too - the caller (slab.hip) keeps FOUR rows of the neighbour beyond such a side
 bool euler2d_fused_rk2_available(const mh_euler_cart_desc* d, bool with_cuts)
 {
@@ -505,7 +509,10 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     // ceil(late_blocks / nstrips) SHORTER chunks per strip, launched last: c_short = c_long - taper, so that all end together. Results do
     // not depend on the cut (tests/test_gpu_fused_rk2.py, tests/test_gpu_slab_group.py). MH_FUSED_TAPER_ROWS: the head start lost, in rows
     // (default 8 = an edge chunk's four rows and its fill; 0 = off).
-    static const int taper = [] { const char* v = getenv("MH_FUSED_TAPER_ROWS"); return v ? atoi(v) : 8; } ();
+    // (read per launch, not cached: tests/test_gpu_slab_group.py and test_gpu_cloud_fused.py exercise the tapered cut on small grids with
+    // MH_FUSED_TAPER_MIN - the shortest short chunk for which the taper applies, default 24 rows)
+    const int taper = [] { const char* v = getenv("MH_FUSED_TAPER_ROWS"); return v ? atoi(v) : 8; } ();
+    const int taper_min = [] { const char* v = getenv("MH_FUSED_TAPER_MIN"); return v ? atoi(v) : 24; } ();
     if (late_blocks > 0 && taper > 0 && rows1 == 0 && d->chunk_rows <= 0)
     {
         const int resident = device_cu_count() * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);
@@ -515,7 +522,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         // one round, and chunks long enough for the taper to pay: measured with the exchange to self (profiles/r05/ab_taper.txt, us per step, taper
         // 0 / 6 / 8 / 10 / 12 rows): 1024 rows (50-row chunks) 154.5 - 156.9 / 146.8 - 149.4 / 147.0 - 150.7 / 145.3 - 150.1 / 145.7 - 149.7;
         // 512 rows (24-row chunks, which fit the 21 chunks per strip exactly) 80.4 - 82.0 / 81.3 - 81.9 / 81.8 - 82.9 / 81.2 - 82.1 / 83.8 - 84.3: not there
-        if (nch > nshort && clong - taper >= 24 && clong <= (d->planar > 0 && MH_FUSED_PLANAR_WAVES >= 3 ? 80 : 112))
+        if (nch > nshort && clong - taper >= taper_min && clong <= (d->planar > 0 && MH_FUSED_PLANAR_WAVES >= 3 ? 80 : 112))
         {
             const int long_rows = (nch - nshort) * clong;
             if (long_rows < rows0)
@@ -532,6 +539,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     p.seg0_chunks = (rows0 + p.chunk_rows - 1) / p.chunk_rows;
     p.seg1_begin = a2; p.seg1_end = rows1 ? b2 : a2;
     p.nchunks = p.seg0_chunks + (rows1 ? (rows1 + p.seg1_chunk_rows - 1) / p.seg1_chunk_rows : 0);
+    last_cut[0] = p.chunk_rows; last_cut[1] = p.seg1_chunk_rows; last_cut[2] = p.seg0_chunks; last_cut[3] = p.nchunks;          // (mh_debug_last_fused_cut: tests)
     auto side = [] (int bc) { return bc == MH_BC_PERIODIC ? 1 : (bc == MH_BC_EXTERNAL ? 2 : 0); };
     p.bc0_lo = side(d->bc_lo0);
     p.bc0_hi = side(d->bc_hi0);

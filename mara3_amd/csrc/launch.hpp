@@ -93,7 +93,10 @@ hipError_t cloud_fused_rk2_launch(const mh_cloud_desc* d, const double* geom_dev
                                   double dt, int32_t* status, hipStream_t stream);
 // ... over rows [a, b) and, in the same launch, [a2, b2) (none if b2 <= a2): a radial slab with neighbours runs its two edge strips, then the rest
 hipError_t cloud_fused_rk2_launch_rows(const mh_cloud_desc* d, const double* geom_dev, const double* inflow_dev, const double* u_in, double* u_out,
-                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts = false);
+                                       double dt, int a, int b, int a2, int b2, int32_t* status, hipStream_t stream, bool with_cuts = false, int late_blocks = 0);
+int cloud_fused_rk2_blocks_per_chunk(const mh_cloud_desc* d);
+void euler2d_fused_last_cut(int out[4]);          // {chunk rows, chunk rows of the second segment, chunks of the first segment, chunks} of the last launch (tests)
+void cloud_fused_last_cut(int out[4]);
 
 // cloud_diag.hip: make_diagnostic_fields of a device-resident cloud state; fields [5][nr][nq], work [4][nr][nq], columns [15][nq] (device)
 hipError_t cloud_diagnostics_launch(const mh_cloud_desc* d, const double* geom_dev, const double* u, const double units[3],

@@ -148,7 +148,8 @@ static hipError_t stage_launch(mh_slab* s, bool edge, const double* in, const do
         if (s->fused_cut)
         {
             // the whole RK2 step of these rows in one launch (cloud_fused.hip across the cuts): `in` is the step-start field, `base` / w unused
-            if (hipError_t e = cloud_fused_rk2_launch_rows(&s->cloud, s->geom, s->inflow, in, out, dt, a, b, a2, b2, s->status, stream, true)) return e;
+            if (hipError_t e = cloud_fused_rk2_launch_rows(&s->cloud, s->geom, s->inflow, in, out, dt, a, b, a2, b2, s->status, stream, true,
+                                                           edge ? 0 : 2 * cloud_fused_rk2_blocks_per_chunk(&s->cloud))) return e;
             if (ev.stop) return hipEventRecord(ev.stop, stream);
             return hipSuccess;
         }

@@ -307,3 +307,27 @@ def test_fused_cuts_stay_bit_identical_through_a_long_run(eng, monkeypatch):
     cut, st_c, lps, _ = run_slabs(rv, qv, u0, inflow, 0.5 * dt, (400,), 4, None)
     assert lps == [1] * 4 and st_w == st_c
     assert bits_equal(cut[0], whole[0]) and np.isfinite(whole[0]).all()
+
+
+def test_tapered_interior_launch_of_cloud_slabs_is_the_same_step(eng, monkeypatch):
+    """cloud_fused.hip carries euler2d_fused.hip's TAPER (the interior launch of a radial slab with neighbours ends in shorter chunks, launched
+    last): on request on a small grid - by default it applies from 24-row short chunks on, i.e. to config 4's 1024-row slabs - the launch does cut
+    its rows that way and the slabs' state is the whole-field run's, bit for bit"""
+    import ctypes as C
+    import mara3_amd
+    lib = mara3_amd.load_library()
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    rv, qv, u0, inflow, dt = smooth_cloud_state(eng, 594, 1400, seed=41)          # 13 strips: 59 chunks per strip and round
+    whole, st_w = run(eng, rv, qv, u0, inflow, dt, (3,), True)
+    for taper, least, cut in (("3", "2", (5, 2)), ("0", "24", None)):
+        monkeypatch.setenv("MH_FUSED_TAPER_ROWS", taper)
+        monkeypatch.setenv("MH_FUSED_TAPER_MIN", least)
+        got_cut, st_c, lps, _ = run_slabs(rv, qv, u0, inflow, dt, (3,), 2, None)
+        out = (C.c_int32 * 4)()
+        assert lib.mh_debug_last_fused_cut(3, out) == 0
+        if cut is not None:
+            assert tuple(out)[:2] == cut and out[3] > out[2] > 0, tuple(out)
+        else:
+            assert out[0] == out[1], tuple(out)
+        assert lps == [1, 1] and st_c == st_w == (0, None)
+        assert bits_equal(got_cut[0], whole[0]), (taper, least)

@@ -430,3 +430,44 @@ def test_native_slabs_carry_the_plan_the_torch_stepper_reads(eng, cuts, monkeypa
             assert have.ghost_rows == (4 if fused else 2) and have.exchanges_per_step == (1 if fused else 2)
             assert (have.row0, have.row1) == g.rows[r]
         g.close()
+
+
+def last_fused_cut(lib, family):
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    assert lib.mh_debug_last_fused_cut(family, out) == 0
+    return tuple(out)
+
+
+@pytest.mark.parametrize("world,n0,bc", [(2, 620, "outflow"), (3, 930, "periodic")])
+def test_tapered_interior_launch_is_the_same_step(eng, world, n0, bc, monkeypatch):
+    """round 5 (euler2d_fused.hip: TAPER): the interior launch of a slab with neighbours ends in SHORTER chunks, launched last (a chunk length per
+    segment, segments in launch order) - by default from 24-row short chunks on, here on request on a grid whose 13 strips make 39 chunks per strip
+    and residency round. The launch does cut its rows that way (mh_debug_last_fused_cut), and whatever the cut, the step is the one-domain step."""
+    from mara3_amd import setups
+    from mara3_amd.slab import NativeSlabGroup
+    monkeypatch.setenv("MH_SLAB_FUSED_CUTS", "1")
+    shape, gamma = (n0, 1400), 1.4
+    dl = (1.0 / shape[0], 1.0 / shape[1])
+    u0 = setups.wave_ic(shape, gamma, seed=31)
+    ref = eng.EulerCartSolver(shape, dl, gamma, 1.5, "hllc", 2, bc, arith="fast")
+    ref.upload(u0)
+    ref.step(3e-4, 3)
+    want = ref.download()
+    ref.close()
+    for taper, least, cut in (("3", "2", (8, 5)), ("5", "1", (8, 3)), ("0", "24", None)):
+        monkeypatch.setenv("MH_FUSED_TAPER_ROWS", taper)
+        monkeypatch.setenv("MH_FUSED_TAPER_MIN", least)
+        grp = NativeSlabGroup(shape, dl, gamma, 1.5, "hllc", 2, bc, world=world, arith="fast")
+        assert grp.launches_per_step() == [1] * world
+        grp.upload(u0)
+        grp.step(3e-4, 3)
+        grp.synchronize()
+        got = last_fused_cut(grp.lib, 1)          # the last launch issued: the last member's interior
+        if cut is not None:
+            assert got[:2] == cut and got[3] > got[2] > 0, got          # long chunks, then shorter ones
+        else:
+            assert got[0] == got[1], got
+        assert grp.status() == (0, None)
+        assert bits_equal(grp.download(), want), (world, bc, taper, least)
+        grp.close()
