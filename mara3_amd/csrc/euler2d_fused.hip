@@ -484,6 +484,7 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     p.plane_stride = p.n1;
     p.row_stride = 5L * p.n1;
     p.nstrips = (p.n1 + FGROUP - 1) / FGROUP;
+    int rounds = 1;          // residency rounds of the launch at the default chunk length
     if (d->chunk_rows > 0) p.chunk_rows = d->chunk_rows;
     else
     {
@@ -492,7 +493,6 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
         // to the brim, for the smallest R that keeps it near 100 rows. Measured at 4096^2, 74 strips (profiles/r03/ab_fused_chunks.jsonl):
         // 100 rows (41 chunks, 2.96 rounds) 0.631-0.638 ms per step; 106 rows (2.82 rounds) 0.658; 75-79 rows (3.8-4 rounds) 0.645;
         // 64 rows 0.669; 152 rows (1.95 rounds) 0.651; 316 rows (one round) 0.680; two launches 0.669-0.697 on the same boxes.
-        int rounds = 1;
         // (a slab's interior launch does NOT leave room for its edge launch's pairs: measured slower, 125 against 112 us per step at 512 rows)
         const int resident = device_cu_count() * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);          // workgroups on the chip at a time
         auto chunk_for = [&] (int r) { const int nch = resident * r / p.nstrips > 0 ? resident * r / p.nstrips : 1; return (rows0 + rows1 + nch - 1) / nch; };
@@ -516,7 +516,8 @@ hipError_t euler2d_fused_rk2_launch_rows(const mh_euler_cart_desc* d, const doub
     if (late_blocks > 0 && taper > 0 && rows1 == 0 && d->chunk_rows <= 0)
     {
         const int resident = device_cu_count() * 4 * fused_waves_per_simd(d->planar > 0) / (2 * FPAIRS);
-        const int nch = resident / p.nstrips;                                  // chunks per strip of one residency round
+        const int nch = resident * rounds / p.nstrips;                         // chunks per strip of the launch's residency rounds (the workgroups launched
+                                                                               // last are the last round's late starters whatever the number of rounds)
         const int nshort = (late_blocks + p.nstrips - 1) / p.nstrips;
         const int clong = nch > 0 ? (rows0 + nshort * taper + nch - 1) / nch : 0;
         // one round, and chunks long enough for the taper to pay: measured with the exchange to self (profiles/r05/ab_taper.txt, us per step, taper
