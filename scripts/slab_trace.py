@@ -8,10 +8,11 @@ from mara3_amd.slab import NativeSlabStepper, native_comm_id
 n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 mode = sys.argv[2] if len(sys.argv) > 2 else "self-exchange"
 n1, gamma = 4096, 5.0 / 3
-u0 = setups.wave_ic((n0, n1), gamma, seed=1)
-kw = dict(comm_id=native_comm_id(0, 1), self_exchange=True) if mode == "self-exchange" else {}
-st = NativeSlabStepper((n0, n1), (1.0 / 4096, 1.0 / 4096), gamma, 1.5, "hllc", 2, "periodic", arith="fast", **kw)
+import numpy as np
+u0 = np.ascontiguousarray(setups.smooth_wave_ic((4096, n1), gamma)[:n0])          # planar rows (no third momentum), as bench.py's slabs
+kw = dict(comm_id=native_comm_id(0, 1, device="cuda"), self_exchange=True) if mode == "self-exchange" else {}
+st = NativeSlabStepper((n0, n1), (1.0 / 4096, 1.0 / 4096), gamma, 1.5, "hllc", 2, "periodic", arith="fast", planar=True, **kw)
 st.load_slab(u0)
-st.step(1e-5, 60, graph=False)
+st.step(setups.baseline_dt(4096), 400, graph=False)
 st.synchronize()
 st.close()
