@@ -187,3 +187,21 @@ def test_readme_first_screen_quotes_the_recorded_line():
     assert abs(d["value"] - full["value"]) <= 1e-5 * full["value"]
     for v in (full["value"], full["legs"]["fast_hlle_blast"]["value"], full["legs"]["strict_hlle_blast"]["value"], full["legs"]["fast_hllc_blast_general_kernel"]["value"]):
         assert fmt(v) in text, fmt(v)
+
+
+def test_config5_block_proxy_record_is_the_ratio_of_its_own_lines():
+    """profiles/r05/c5_block_scaling_one_gpu.jsonl: the eight (2,2,2) blocks on one GPU against one undivided grid of a block's size (same box, same
+    call); the proxy quoted in DESIGN.md section 7 and README is the ratio of the two rates of the 512^3 row, and both runs ended with a clean status"""
+    path = os.path.join(R05, "c5_block_scaling_one_gpu.jsonl")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r05/c5_block_scaling_one_gpu.jsonl not recorded")
+    rows = {r["cells_per_block_edge"]: r for r in map(json.loads, open(path))}
+    assert set(rows) >= {256, 512}
+    for n, r in rows.items():
+        assert r["single"]["status_word"] == 0 and r["blocks8"]["status_word"] == 0
+        assert "(2,2,2)" in r["blocks8"]["workload"] and ("%d^3 cells per block" % n) in r["blocks8"]["workload"]
+        assert r["weak_scaling_proxy_fast"] == pytest.approx(r["blocks8"]["value"] / r["single"]["value"])
+        # eight blocks step in about eight times a block-sized grid's step: the decomposition is no free lunch and no cliff
+        assert 0.7 < r["weak_scaling_proxy_fast"] < 1.02 and 8 * r["single"]["ms_per_step"] * 0.98 < r["blocks8"]["ms_per_step"]
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert ("%.2f" % rows[512]["weak_scaling_proxy_fast"]) in text and "{:,}".format(int(round(rows[512]["blocks8"]["value"]))).replace(",", " ") in text
