@@ -205,3 +205,29 @@ def test_config5_block_proxy_record_is_the_ratio_of_its_own_lines():
         assert 0.7 < r["weak_scaling_proxy_fast"] < 1.02 and 8 * r["single"]["ms_per_step"] * 0.98 < r["blocks8"]["ms_per_step"]
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     assert ("%.2f" % rows[512]["weak_scaling_proxy_fast"]) in text and "{:,}".format(int(round(rows[512]["blocks8"]["value"]))).replace(",", " ") in text
+
+
+def test_clock_record_factors_multiply_to_the_fraction():
+    """profiles/r05/clock_under_load.jsonl + profiles/pmc_traffic.json: frac = (flop per VALU lane-slot / 2) x (instructions x 4 cycles / 1024 SIMDs / cycles)
+    x (sclk / 2.4 GHz) for every workload of the record, the board at its power limit in each, and the table of clock_under_load.md quotes those lines"""
+    path = os.path.join(R05, "clock_under_load.jsonl")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r05/clock_under_load.jsonl not recorded")
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    md = open(os.path.join(R05, "clock_under_load.md")).read()
+    seen = 0
+    for d in map(json.loads, open(path)):
+        if d["workload"] not in ("blast", "wave"):
+            continue
+        clk = [v for k, v in d["sensors"].items() if k.endswith(":sclk")][0]["mean"]
+        watts = [v for k, v in d["sensors"].items() if "power" in k][0]["mean"]
+        rec = t["fused_planar_fast_%s_fp64" % d["riemann"]]
+        T = d["us_per_step"] * 1e-6
+        frac = rec["fp64_flops_per_launch"] / T / 78.6e12
+        mix = rec["fp64_flops_per_launch"] / (rec["valu_instructions_per_launch"] * 64) / 2
+        util = rec["valu_instructions_per_launch"] * 4 / 1024 / (T * clk * 1e6)
+        assert frac == pytest.approx(mix * util * clk / 2400.0, rel=2e-3)         # (78.6 TFLOP/s is 2.4 GHz x 32768 flop per cycle, rounded)
+        assert d["planar"] and 1300 < watts < 1420 and 2000 < clk < 2400 and 0.7 < util < rec["valu_busy"]
+        assert ("| %s | %s | %.1f |" % (d["riemann"].upper(), d["workload"], d["us_per_step"])) in md and ("**%.0f**" % clk) in md and ("| %.3f | %.3f | %.3f |" % (frac, mix, util)) in md
+        seen += 1
+    assert seen == 4
