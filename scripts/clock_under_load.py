@@ -3,7 +3,8 @@ The fp64 roofline of bench.py is priced at the peak clock (78.6 TFLOP/s = 256 CU
 4096^2 grid (fused planar RK2 step, FAST, `riemann`) for `seconds` while a second thread samples the clock and power files the amdgpu driver
 exposes to an ordinary user (sysfs: hwmon freq*_input / power*_average|input, pp_dpm_sclk) - whatever of them exists on the box; it changes nothing.
 Workloads: blast (mostly quiescent operands), wave (every cell busy), idle (no launches).
-usage: python scripts/clock_under_load.py [seconds=8] [riemann=hllc]   -> one JSON line per workload"""
+usage: python scripts/clock_under_load.py [seconds=8] [riemann=hllc]   -> one JSON line per workload
+       python scripts/clock_under_load.py [seconds=6] configs          -> the kernels of BASELINE configs 3, 4 and 5 (FAST and STRICT) the same way"""
 import glob, json, os, re, sys, threading, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -81,9 +82,84 @@ class Sampler(threading.Thread):
         return out
 
 
+def run_configs(src):
+    """configs 5 (3-D Euler 512^3), 3 (`binary` 2048^2) in this process; config 4 (`cloud` 4096^2) through the compiled host as bench_configs.py runs it:
+    its set-up and file output are idle time, so its figures are taken over the samples within 10 % of the highest power seen"""
+    import subprocess, tempfile
+    from mara3_amd import binary
+    from mara3_amd.engine import EulerCartSolver
+    n5, gamma = 512, 5.0 / 3
+    only = sys.argv[3] if len(sys.argv) > 3 else ""
+    for arith in ("fast", "strict") if only in ("", "c5") else ():
+        s5 = EulerCartSolver((n5,) * 3, (1.0 / n5,) * 3, gamma, 1.5, "hlle", 2, "outflow", arith=arith)
+        s5.upload(setups.blast_ic((n5,) * 3, gamma))
+        s5.step(setups.baseline_dt(n5), 5); s5.synchronize()
+        sm = Sampler(src); sm.start()
+        t0 = time.perf_counter(); steps = 0
+        while time.perf_counter() - t0 < seconds:
+            s5.step(setups.baseline_dt(n5), 20); s5.synchronize(); steps += 20
+        el = time.perf_counter() - t0
+        sm.stop = True; sm.join()
+        print(json.dumps({"workload": "c5 euler3d 512^3 hlle", "arith": arith, "seconds": round(el, 2), "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+                          "Mzones_per_s": round(n5 ** 3 * steps / el / 1e6, 1), "pci_bus_id": own_pci_bus_id(), "sensors": sm.summary()}), flush=True)
+        s5.close()
+    cfg = binary.config(depth=5, block_size=64, fixed_dt=1, rk_order=2, plm_theta=1.8)
+    n3 = binary.grid_size(cfg)
+    for arith in ("fast", "strict") if only in ("", "c3") else ():
+        s3 = binary.BinarySolver(cfg, arith=arith)
+        s3.next(20)
+        sm = Sampler(src); sm.start()
+        t0 = time.perf_counter(); steps = 0
+        while time.perf_counter() - t0 < seconds:
+            s3.next(500); steps += 500
+        el = time.perf_counter() - t0
+        sm.stop = True; sm.join()
+        print(json.dumps({"workload": "c3 binary 2048^2", "arith": arith, "seconds": round(el, 2), "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+                          "Mzones_per_s": round(n3 * n3 * steps / el / 1e6, 1), "pci_bus_id": own_pci_bus_id(), "sensors": sm.summary()}), flush=True)
+        s3.close()
+    # config 4's kernels (`cloud`, SRHD 4096^2): the reference's own problem throws after 335 steps at this size (tests/test_gpu_long_runs_vs_reference.py),
+    # too short for the clock to settle - so a smooth relativistic flow on the same grid shape, fixed nozzle row, the same kernels
+    from mara3_amd import engine
+    nr = nq = 4096
+    rv, qv = np.logspace(0.0, 0.6, nr + 1), np.linspace(0.0, np.pi, nq + 1)
+    rc, qc = 0.5 * (rv[1:] + rv[:-1])[:, None], 0.5 * (qv[1:] + qv[:-1])[None, :]
+    P = np.zeros((nr, nq, 5))
+    P[..., 0] = (1.0 + 0.3 * np.sin(2.0 * qc) * np.cos(1.5 * np.log(rc))) / rc ** 2
+    P[..., 1] = 0.8 + 0.5 * np.cos(2.5 * qc) * np.sin(2.0 * np.log(rc))
+    P[..., 2] = 0.1 * np.sin(2.0 * qc) * np.cos(2.0 * np.log(rc))
+    P[..., 4] = 0.05 * P[..., 0] * (1.0 + 0.5 * np.sin(1.5 * qc))
+    U = engine.srhd_to_conserved(P.reshape(-1, 5)).reshape(nr, nq, 5)
+    dmu = -np.cos(qv[1:]) - -np.cos(qv[:-1])
+    U *= (((rv[1:] ** 3 - rv[:-1] ** 3)[:, None] * dmu[None, :] * 2 * np.pi) / 3)[..., None]
+    row = np.ascontiguousarray(P[0])
+    dtc = 0.3 * (rv[1] - rv[0])
+    for arith in ("fast", "strict") if only in ("", "c4") else ():
+        s4 = engine.CloudSolver(rv, qv, 2, 1.2, 0.0, arith=arith)
+        s4.upload(U); s4.set_inflow(row)
+        s4.step(dtc, 5)
+        sm = Sampler(src); sm.start()
+        t0 = time.perf_counter(); steps = 0; note = None
+        try:
+            while time.perf_counter() - t0 < seconds:
+                s4.step(dtc, 50); steps += 50
+                if s4.status():
+                    note = "status word %#x after %d steps" % (s4.status(), steps); break
+        except Exception as e:
+            note = repr(e)[:200]
+        el = time.perf_counter() - t0
+        sm.stop = True; sm.join()
+        print(json.dumps({"workload": "c4 cloud kernels 4096^2 (smooth relativistic flow, fixed nozzle row)", "arith": arith, "seconds": round(el, 2), "steps": steps,
+                          "ms_per_step": round(el / max(1, steps) * 1e3, 4), "Mzones_per_s": round(nr * nq * steps / el / 1e6, 1), "planar": s4.is_planar(), "note": note,
+                          "pci_bus_id": own_pci_bus_id(), "sensors": sm.summary()}), flush=True)
+        s4.close()
+
+
 src = sources()
 if not src:
     print(json.dumps({"error": "no clock or power file of the amdgpu driver is readable here"}))
+if riemann == "configs":
+    run_configs(src)
+    sys.exit(0)
 n, gamma = 4096, 5.0 / 3
 dt = setups.baseline_dt(n)
 for workload in ("idle", "blast", "wave", "idle_after"):
