@@ -15,7 +15,7 @@
 // exchanged: the scheme is dimension-by-dimension (a cell reads i +- 2 along each axis separately).
 //
 // Overlap. A stage is two launches of the same kernel over lists of boxes (launch.hpp: Euler3dBox): the boundary SHELL - every
-// cell within the kernel's tile granularity (8 planes / one 8-row tile / one 60-column strip) of a cut side - on the side stream,
+// cell within the kernel's tile granularity (8 planes / one tile of 4 or 8 rows / one 60-column strip) of a cut side - on the side stream,
 // followed by pack -> exchange -> unpack, and the INTERIOR on the main stream. The interior reads no ghost cell, so the exchange
 // has the whole interior launch to hide behind (512^3 per rank: ~21 MB per face, ~0.15 ms over xGMI, against ~6 ms of interior).
 // Event protocol as the slab stepper's non-staggered one: main waits for the previous shell, side for the previous interior.
@@ -279,10 +279,10 @@ static int block_create_common(mh_block** out, const mh_euler_cart_desc* global,
     b->face_doubles[2] = (size_t) b->n[0] * 5 * b->n[1] * 2;
     euler3d_tiling(&b->desc, &b->ntiles1, &b->nstrips);
 
-    // boundary shell / interior in the kernel's work-item granularity: 8 planes (one short chunk), 8-row tiles, 60-column strips
+    // boundary shell / interior in the kernel's work-item granularity: 8 planes (one short chunk), tiles of 4 (STRICT) or 8 (FAST) rows, 60-column strips
     int r_lo, r_hi, r_n, t_lo, t_hi, t_n, s_lo, s_hi, s_n;
     shell_range(b->n[0], 1, b->nbr[0][0] >= 0, b->nbr[0][1] >= 0, 8, &r_lo, &r_hi, &r_n);
-    shell_range(b->n[1], 8, b->nbr[1][0] >= 0, b->nbr[1][1] >= 0, 2, &t_lo, &t_hi, &t_n);
+    shell_range(b->n[1], euler3d_tile_rows(&b->desc), b->nbr[1][0] >= 0, b->nbr[1][1] >= 0, 2, &t_lo, &t_hi, &t_n);
     shell_range(b->n[2], 60, b->nbr[2][0] >= 0, b->nbr[2][1] >= 0, 2, &s_lo, &s_hi, &s_n);
     const Euler3dBox boxes[6] = {
         {0, r_lo, 0, t_n, 0, s_n}, {r_n - r_hi, r_n, 0, t_n, 0, s_n},

@@ -6,7 +6,8 @@
 // src/subprog_cloud.cpp:511-584; RK combine :682-695).
 //
 // 2.5-D plane marching. A workgroup of 8 wavefronts owns a tile of 8 axis-1
-// rows x 60 axis-2 columns and marches along axis 0:
+// rows x 60 axis-2 columns and marches along axis 0 (STRICT since round 5: 4 wavefronts,
+// 4 rows - two independent workgroups per CU, A::tile_rows):
 //   * axis 0 (march): primitives of planes i..i+2, the slope of plane i and the
 //     flux through face i-1/2 live in registers (three-slot rings, loop unrolled
 //     x3); each flux is computed once;
@@ -27,9 +28,13 @@
 
 namespace mh {
 
+// axis-1 rows of a work item's tile: the arithmetic's choice (euler_device_fast.hpp: STRICT four - two workgroups per CU -, FAST eight)
+int euler3d_tile_rows(const mh_euler_cart_desc* d) { return d->arith == MH_ARITH_FAST ? FastArith::tile_rows : StrictArith::tile_rows; }
+
 void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips)
 {
-    *ntiles1 = (d->n[1] + ROWS3 - 1) / ROWS3;
+    const int rows = euler3d_tile_rows(d);
+    *ntiles1 = (d->n[1] + rows - 1) / rows;
     *nstrips = (d->n[2] + STRIP3 - 1) / STRIP3;
 }
 
@@ -39,9 +44,9 @@ void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips)
 // rounds x (chunk + 1.3) wins; measured at 512^3 FAST (profiles/r04/ab_3d_chunks.jsonl, ms per RK2 step - the model's ratio to the best in
 // brackets): 16 planes 7.99 (1.07), 32: 7.69 (1.03, the fixed default of rounds 1 - 3), 43: 7.65 (1.03), 64: 7.51 (1.01), 86: 7.71 (1.05),
 // 128: 7.46 (1.00), 256: 8.20 (1.10). Results do not depend on the cut (tests/test_gpu_euler3d.py).
-static int euler3d_default_chunk(int planes, long items_per_layer)
+static int euler3d_default_chunk(int planes, long items_per_layer, int tile_rows)
 {
-    const int cus = device_cu_count();
+    const int cus = device_cu_count() * (tile_rows == 4 ? 2 : 1);          // resident work items: two four-row workgroups share a CU
     int best = planes < 32 ? planes : 32;
     double best_cost = 0.0;
     const int longest = planes < 128 ? planes : 128;          // (longer chunks were not measured; they balance worse over CUs whose speeds differ)
@@ -74,7 +79,7 @@ hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3d
     euler3d_tiling(d, &ntiles1, &nstrips);
     p.chunk_rows = d->chunk_rows > 0 ? d->chunk_rows : 32;
     if (d->chunk_rows == 0 && nboxes == 1 && boxes[0].r1 > boxes[0].r0)          // (a block's shell of several boxes keeps the short chunks)
-        p.chunk_rows = euler3d_default_chunk(boxes[0].r1 - boxes[0].r0, (long) (boxes[0].t1 - boxes[0].t0) * (boxes[0].s1 - boxes[0].s0));
+        p.chunk_rows = euler3d_default_chunk(boxes[0].r1 - boxes[0].r0, (long) (boxes[0].t1 - boxes[0].t0) * (boxes[0].s1 - boxes[0].s0), euler3d_tile_rows(d));
     int nblocks = 0;
     p.nboxes = 0;
     for (int k = 0; k < nboxes; ++k)

@@ -16,7 +16,7 @@ namespace mh {
 static constexpr int W3 = 64;                  // lanes
 static constexpr int H3 = 2;                   // halo
 static constexpr int STRIP3 = W3 - 2 * H3;     // 60 output columns per wave
-static constexpr int ROWS3 = 8;                // axis-1 rows per workgroup (= waves)
+// axis-1 rows per workgroup (= waves): A::tile_rows (euler_device_fast.hpp) - 8: one workgroup per CU; 4: two independent workgroups per CU
 static constexpr int MAX_BOXES = 8;
 
 struct Stage3dParams
@@ -67,7 +67,8 @@ __device__ inline int fold_index(int j, int n, int bc_lo, int bc_hi)
 
 // LDS exchange buffer: primitives of one axis-0 plane for the tile's rows and two rows on either side, double-buffered by
 // the parity of the plane index: [parity][slot = tile row + 2][variable][lane]
-struct Tile3d
+template<int ROWS3>
+struct Tile3dT
 {
     double P[2][ROWS3 + 2 * H3][5][W3];
     double U[ROWS3][3][5][W3];             // per-wave private ring: conserved state of planes r, r+1, r+2 (no barrier needed)
@@ -75,7 +76,11 @@ struct Tile3d
                                            // UPPER axis-1 face of each tile row, by plane parity - slot j is written by wave j + 1 (its lower
                                            // face), slot ROWS3 - 1 by the top wave itself
 };
-template<bool DEFER> constexpr size_t tile3d_bytes() { return DEFER ? sizeof(Tile3d) : sizeof(Tile3d) - sizeof(Tile3d::F); }
+template<class A> constexpr size_t tile3d_bytes()
+{
+    using T = Tile3dT<A::tile_rows>;
+    return A::deferred_axis1 ? sizeof(T) : sizeof(T) - sizeof(T::F);
+}
 
 __device__ inline void lds_put(double (*dst)[W3], int lane, const State5& s)
 {
@@ -112,11 +117,12 @@ __device__ inline void store_plane(double* plane_ptr, long plane_doubles, unsign
 }
 
 template<class A, int RIEMANN, bool PLM, bool COMBINE>
-__global__ __launch_bounds__(W3 * ROWS3, 2)
+__global__ __launch_bounds__(W3 * A::tile_rows, 2)
 void euler3d_stage_kernel(Stage3dParams p)
 {
     extern __shared__ double lds_raw[];
-    Tile3d& tile = *reinterpret_cast<Tile3d*>(lds_raw);
+    constexpr int ROWS3 = A::tile_rows;
+    Tile3dT<ROWS3>& tile = *reinterpret_cast<Tile3dT<ROWS3>*>(lds_raw);
 
     // work item -> (chunk along axis 0, tile along axis 1, strip along axis 2); neighbouring items share an XCD
     int b = blockIdx.x;
@@ -157,7 +163,8 @@ void euler3d_stage_kernel(Stage3dParams p)
     // (deferred axis-1 mode: waves 0, 1, 2 and 4 - the top wave 7 solves the tile's ninth face, and wave 3 shares its SIMD)
     constexpr bool DEFER = A::deferred_axis1;
     static_assert(! DEFER || ! PLM || A::shared_differences, "the deferred axis-1 mode is written for the shared-difference limiter");
-    const int hrow = DEFER ? (row == 3 ? 4 : (row == 4 ? 3 : row)) : row;
+    static_assert(ROWS3 == 8 || (ROWS3 == 4 && ! DEFER), "tiles of eight rows, or of four without the deferred axis-1 faces");
+    const int hrow = DEFER ? (row == 3 ? 4 : (row == 4 ? 3 : row)) : row;          // (four-row tiles: every wave fetches one outside row)
     const int eoff = hrow == 0 ? -2 : (hrow == 1 ? -1 : (hrow == 2 ? ROWS3 : ROWS3 + 1));
     const bool helper = hrow < 4 && (PLM || hrow == 1 || hrow == 2);
     const unsigned ce = cell_bytes(fold_index(t1 * ROWS3 + eoff, p.n1, p.bc_lo1, p.bc_hi1), kc);
@@ -450,11 +457,11 @@ inline hipError_t launch3(const Stage3dParams& p, int nblocks, hipStream_t strea
     const uint64_t bit = 1ull << (dev & 63);
     if (! (attr_set_on.load(std::memory_order_acquire) & bit))
     {
-        hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) tile3d_bytes<A::deferred_axis1>());
+        hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) tile3d_bytes<A>());
         if (e != hipSuccess) return e;
         attr_set_on.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(W3 * ROWS3), tile3d_bytes<A::deferred_axis1>(), stream, p);
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(W3 * A::tile_rows), tile3d_bytes<A>(), stream, p);
     return hipGetLastError();
 }
 

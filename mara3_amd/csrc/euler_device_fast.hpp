@@ -291,6 +291,14 @@ struct StrictArithT
     static constexpr int min_waves_per_simd = PLANAR ? MH_STRICT_PLANAR_WAVES : 2;
     static constexpr int min_waves_first_stage = PLANAR ? MH_STRICT_PLANAR_WAVES : 2;
     static constexpr bool deferred_axis1 = false;           // (euler3d_kernel.hpp) the update keeps the reference's order of terms
+    // (euler3d_kernel.hpp) rows of a 3-D tile = waves of a workgroup. Four: the tile's LDS (70 KB) lets TWO workgroups share a CU, each with its own
+    // barrier per plane, so one runs while the other waits for its slowest wave, an LDS read or a load - measured at 512^3 (profiles/r05/
+    // ab_3d_four_row_tiles.json): STRICT 8.82 -> 9.35 Gzones/s. (FAST loses 6 % on four rows - every wave then fetches an outside row, five
+    // axis-1 faces per four rows instead of nine per eight, and the kernel is within 6 % of the board's power limit already - and keeps eight.)
+#ifndef MH_E3D_STRICT_ROWS
+#define MH_E3D_STRICT_ROWS 4
+#endif
+    static constexpr int tile_rows = MH_E3D_STRICT_ROWS;
     static constexpr bool shared_differences = false;       // the reference's plm_gradient takes the three values, bit for bit
     static constexpr bool recompute_conserved = false;      // the update starts from the stored conserved state, bit for bit
     static constexpr bool lds_conserved_ring = false;
@@ -350,6 +358,7 @@ struct FastArithT
 #define MH_E3D_DEFER 1
 #endif
     static constexpr bool deferred_axis1 = MH_E3D_DEFER != 0;
+    static constexpr int tile_rows = 8;                      // (the deferred axis-1 faces are written for eight rows: one workgroup per CU)
     // The 2-D stage kernel converts a loaded row to primitives once and keeps only those in its register window (no register-to-register
     // moves in the row loop, 20 VGPRs fewer); the conserved values the update starts from wait in a per-wave LDS ring meanwhile
     // (lds_conserved_ring; euler2d.hip). The first version re-formed them from the primitives instead (p2c, 8 instructions, equal to the

@@ -54,9 +54,10 @@ hipError_t euler3d_stage_launch(const mh_euler_cart_desc* d, const double* u_in,
 // Layout: plane_stride = (n1 + 2 g1) * (n2 + 2 g2); cell (i, j, k), variable q at ((i + 2) * 5 + q) * plane_stride + (j + g1) * (n2 + 2 g2) + (k + g2).
 // Each transverse side has its own boundary kind; MH_BC_EXTERNAL sides read the stored ghost cells.
 struct Euler3dLayout { int g1 = 0, g2 = 0; int bc_lo1 = 0, bc_hi1 = 0, bc_lo2 = 0, bc_hi2 = 0; };
-// rows [r0, r1) of axis 0 x tiles [t0, t1) of 8 axis-1 rows x strips [s0, s1) of 60 axis-2 columns (the kernel's work items)
+// rows [r0, r1) of axis 0 x tiles [t0, t1) of euler3d_tile_rows() axis-1 rows x strips [s0, s1) of 60 axis-2 columns (the kernel's work items)
 struct Euler3dBox { int r0, r1, t0, t1, s0, s1; };
 void euler3d_tiling(const mh_euler_cart_desc* d, int* ntiles1, int* nstrips);
+int euler3d_tile_rows(const mh_euler_cart_desc* d);          // axis-1 rows of a tile: 4 (STRICT) or 8 (FAST)
 hipError_t euler3d_stage_launch_boxes(const mh_euler_cart_desc* d, const Euler3dLayout& lay, const Euler3dBox* boxes, int nboxes,
                                       const double* u_in, const double* u_base, double* u_out, double dt, double weight,
                                       int32_t* status, hipStream_t stream);
